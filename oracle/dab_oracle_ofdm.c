@@ -1,0 +1,548 @@
+/*
+ * dab_oracle_ofdm.c -- CPU ORACLE (test infrastructure, NOT product code): OFDM half.
+ * See dab_oracle.h for the scope statement and the arithmetic contract.
+ * Paths cited are relative to /root/reference.
+ */
+#include "dab_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+/* same arithmetic, two code paths: hardware vfmadd when the CPU has it, libm fmaf otherwise */
+#define DAB_HOT __attribute__((target_clones("arch=haswell", "default")))
+#else
+#define DAB_HOT
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* constant tables                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/ofdm/dab_mapper_ref.cpp:10-51 */
+void dab_get_mapper(int *carrier_map) {
+    const int N = DAB_NB_FFT, K = N / 4, nb = DAB_NB_DATA_CARRIERS;
+    const int dc = N / 2, lo = dc - nb / 2, hi = dc + nb / 2;
+    int pi = 0, k = 0;
+    for (int i = 0; i < N; i++) {
+        if (i > 0) pi = (13 * pi + K - 1) % N;              /* :24 */
+        if (pi < lo || pi > hi || pi == dc) continue;       /* :39 */
+        carrier_map[k++] = (pi < dc) ? (pi - lo) : (pi - lo - 1);  /* :43-49 */
+    }
+}
+
+/* ETSI EN 300 401 table 23/24 as transcribed in src/ofdm/dab_prs_ref.cpp:24-75 (Mode I rows) and :125-130 */
+static const signed char PRS_I_IDX[48] = {
+    0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,
+    0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 };
+static const signed char PRS_I_N[48] = {
+    1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,
+    3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 };
+static const signed char PRS_H[4][32] = {
+    {0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1,0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1},
+    {0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0,0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0},
+    {0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3,0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3},
+    {0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2,0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2},
+};
+
+/* src/ofdm/dab_prs_ref.cpp:140-195 */
+void dab_get_prs_fft(dab_cf32 *prs) {
+    for (int i = 0; i < DAB_NB_FFT; i++) { prs[i].re = 0.0f; prs[i].im = 0.0f; }
+    for (int row = 0; row < 48; row++) {
+        /* rows 0..23 cover k = -768..-1, rows 24..47 cover k = +1..+768, 32 carriers each */
+        const int k_min = (row < 24) ? (-768 + 32 * row) : (1 + 32 * (row - 24));
+        for (int j = 0; j < 32; j++) {
+            const int k = k_min + j;
+            const int h = PRS_H[(int)PRS_I_IDX[row]][j];
+            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_I_N[row]);   /* :167,:184 */
+            dab_cf32 v; v.re = cosf(phi); v.im = sinf(phi);
+            prs[(k < 0) ? (DAB_NB_FFT + k) : k] = v;
+        }
+    }
+}
+
+void dab_get_twiddles(dab_cf32 *tw) {
+    for (int m = 0; m < DAB_NB_FFT; m++) {
+        const double a = 2.0 * M_PI * (double)m / (double)DAB_NB_FFT;
+        tw[m].re = (float)cos(a);
+        tw[m].im = (float)(-sin(a));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DSP primitives                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/ofdm/dsp/chebyshev_sine.h:13-20 */
+static const float CH_A0 = -25.13274193f, CH_A1 = 64.83583069f, CH_A2 = -67.07687378f,
+                   CH_A3 = 38.50016403f,  CH_A4 = -14.07150173f, CH_A5 = 3.20396066f;
+
+/* src/ofdm/dsp/chebyshev_sine.h:22-41 */
+float dab_chebyshev_sine(float x) {
+    const float z = x * x;
+    const float b4 = CH_A5 * z + CH_A4;
+    const float b3 = b4 * z + CH_A3;
+    const float b2 = b3 * z + CH_A2;
+    const float b1 = b2 * z + CH_A1;
+    const float b0 = b1 * z + CH_A0;
+    return b0 * (z - 0.25f) * x;
+}
+
+/* src/ofdm/dsp/chebyshev_sine.h:82-107 with __FMA__ */
+static inline float cheb_fma(float x) {
+    const float z = x * x;
+    const float b4 = fmaf(CH_A5, z, CH_A4);
+    const float b3 = fmaf(b4, z, CH_A3);
+    const float b2 = fmaf(b3, z, CH_A2);
+    const float b1 = fmaf(b2, z, CH_A1);
+    const float b0 = fmaf(b1, z, CH_A0);
+    const float c0 = z - 0.25f;
+    return (b0 * c0) * x;
+}
+float dab_chebyshev_sine_fma(float x) { return cheb_fma(x); }
+
+/* src/ofdm/dsp/apply_pll.cpp:12-30 ; std::complex product without contraction */
+void dab_apply_pll_scalar(const dab_cf32 *x, dab_cf32 *y, size_t n, float freq_norm, float dt_norm) {
+    for (size_t i = 0; i < n; i++) {
+        float dt_sin = dt_norm + (float)i * freq_norm;
+        float dt_cos = dt_sin + 0.25f;
+        dt_sin = dt_sin - roundf(dt_sin);
+        dt_cos = dt_cos - roundf(dt_cos);
+        const float c = dab_chebyshev_sine(dt_cos);
+        const float s = dab_chebyshev_sine(dt_sin);
+        const float xr = x[i].re, xi = x[i].im;
+        y[i].re = xr * c - xi * s;
+        y[i].im = xr * s + xi * c;
+    }
+}
+
+/* one sample of apply_pll_avx (apply_pll.cpp:81-117) + c32_mul_avx with __FMA__ (x86/c32_mul.h:9-38):
+ * i4 = index of the 4-sample group start, k = lane in the group */
+static inline dab_cf32 pll_sample(dab_cf32 v, size_t i4, int k, float f, float dt_norm) {
+    const float step_sin = (float)k * f;                 /* :95-99 */
+    const float step_cos = step_sin + 0.25f;
+    const float base = dt_norm + (float)i4 * f;          /* :103 */
+    float dc = base + step_cos;                          /* :104 */
+    float ds = base + step_sin;
+    dc = dc - rintf(dc);                                 /* :107 round-to-nearest-even */
+    ds = ds - rintf(ds);
+    const float c = cheb_fma(dc), s = cheb_fma(ds);
+    /* c32_mul_avx(X, pll): b0 = [s*xi, s*xr]; y = fmaddsub([c,c],[xr,xi],b0) */
+    const float b0r = s * v.im, b0i = s * v.re;
+    dab_cf32 y;
+    y.re = fmaf(c, v.re, -b0r);
+    y.im = fmaf(c, v.im, b0i);
+    return y;
+}
+
+DAB_HOT
+void dab_apply_pll(const dab_cf32 *x, dab_cf32 *y, size_t n, float freq_norm, float dt_norm) {
+    const size_t nv = (n / 4) * 4;
+    for (size_t i = 0; i < nv; i += 4)
+        for (int k = 0; k < 4; k++)
+            y[i + k] = pll_sample(x[i + k], i, k, freq_norm, dt_norm);
+    if (nv < n) {                                        /* apply_pll.cpp:115-116 */
+        const float dt_scalar = dt_norm + (float)nv * freq_norm;
+        dab_apply_pll_scalar(x + nv, y + nv, n - nv, freq_norm, dt_scalar);
+    }
+}
+
+/* element of c32_conj_mul_avx with __FMA__ (x86/c32_conj_mul.h:12-44): x0*conj(x1) */
+static inline dab_cf32 conj_mul(dab_cf32 x0, dab_cf32 x1) {
+    const float a = x0.re, b = x0.im, c = x1.re, d = x1.im;
+    dab_cf32 y;
+    y.re = fmaf(b, d, a * c);        /* bd + ac */
+    y.im = fmaf(b, c, -(a * d));     /* bc - ad */
+    return y;
+}
+dab_cf32 dab_conj_mul(dab_cf32 x0, dab_cf32 x1) { return conj_mul(x0, x1); }
+
+/* fixed reduction tree used for every 256-leaf sum in the contract:
+ * per 64-leaf group halve with strides 32..1, then (g0+g1)+(g2+g3). */
+static inline float tree256(float *a) {
+    for (int w = 0; w < 4; w++)
+        for (int h = 32; h >= 1; h >>= 1)
+            for (int i = 0; i < h; i++) a[64 * w + i] += a[64 * w + i + h];
+    return (a[0] + a[64]) + (a[128] + a[192]);
+}
+
+/* ofdm_demodulator.cpp:768-775 */
+DAB_HOT
+dab_cf32 dab_cp_correlation(const dab_cf32 *sym) {
+    float pr[256], pi[256];
+    for (int t = 0; t < 256; t++) {
+        if (t < 4) { pr[t] = 0.0f; pi[t] = 0.0f; continue; }
+        const int n = 2 * (t - 4);
+        const dab_cf32 p0 = conj_mul(sym[DAB_NB_FFT + n],     sym[n]);
+        const dab_cf32 p1 = conj_mul(sym[DAB_NB_FFT + n + 1], sym[n + 1]);
+        pr[t] = p0.re + p1.re;
+        pi[t] = p0.im + p1.im;
+    }
+    dab_cf32 r; r.re = tree256(pr); r.im = tree256(pi);
+    return r;
+}
+
+/* deterministic atan2 (range reduction + odd minimax polynomial, Cephes atanf constants) */
+float dab_atan2f(float y, float x) {
+    const float PI_F = 3.14159274101257324f, PIO2_F = 1.57079637050628662f, PIO4_F = 0.785398185253143311f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = (ax > ay) ? ax : ay;
+    const float mn = (ax > ay) ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float base = 0.0f;
+    if (a > 0.4142135679721832f) { base = PIO4_F; a = (a - 1.0f) / (a + 1.0f); }
+    const float z = a * a;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    float r = fmaf(p * z, a, a);
+    r = base + r;
+    if (ay > ax) r = PIO2_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+float dab_cabsf(dab_cf32 v) { return sqrtf(fmaf(v.re, v.re, v.im * v.im)); }
+
+/* 20*log10(m): exponent split + Cephes logf polynomial on [sqrt(.5), sqrt(2)) */
+float dab_db20f(float m) {
+    if (!(m > 0.0f)) return -INFINITY;
+    union { float f; uint32_t u; } b;
+    float e_adj = 0.0f;
+    if (m < 1.17549435e-38f) { m = m * 16777216.0f; e_adj = -24.0f; }
+    b.f = m;
+    int e = (int)((b.u >> 23) & 0xFF) - 126;                 /* m = f * 2^e, f in [0.5,1) */
+    b.u = (b.u & 0x007FFFFFu) | 0x3F000000u;
+    float f = b.f;
+    if (f < 0.707106769084930420f) { e -= 1; f = f + f; }    /* f in [sqrt(.5), sqrt(2)) */
+    const float x = f - 1.0f;
+    const float z = x * x;
+    float p = fmaf(7.0376836292e-2f, x, -1.1514610310e-1f);
+    p = fmaf(p, x, 1.1676998740e-1f);
+    p = fmaf(p, x, -1.2420140846e-1f);
+    p = fmaf(p, x, 1.4249322787e-1f);
+    p = fmaf(p, x, -1.6668057665e-1f);
+    p = fmaf(p, x, 2.0000714765e-1f);
+    p = fmaf(p, x, -2.4999993993e-1f);
+    p = fmaf(p, x, 3.3333331174e-1f);
+    float y = (p * x) * z;
+    y = fmaf(-0.5f, z, y);
+    const float fe = (float)e + e_adj;
+    const float ln = fmaf(fe, 0.693147182464599609f, x + y);
+    return ln * 8.68588924407958984f;                        /* 20/ln(10) */
+}
+
+/* 10^(db/20) = 2^(db*log2(10)/20), Cephes exp2f polynomial */
+float dab_undb20f(float db) {
+    float x = db * 0.166096404194831848f;
+    if (x > 127.0f) return INFINITY;
+    if (!(x > -149.0f)) return 0.0f;
+    float n = floorf(x);
+    x = x - n;
+    if (x > 0.5f) { n += 1.0f; x -= 1.0f; }
+    float p = fmaf(1.535336188319500e-4f, x, 1.339887440266574e-3f);
+    p = fmaf(p, x, 9.618437357674640e-3f);
+    p = fmaf(p, x, 5.550332471162809e-2f);
+    p = fmaf(p, x, 2.402264791363012e-1f);
+    p = fmaf(p, x, 6.931472028550421e-1f);
+    p = fmaf(p, x, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FFT contract: Stockham autosort, 2048 = 4 x 8 x 8 x 8, decimation in frequency               */
+/* ------------------------------------------------------------------------------------------ */
+
+static dab_cf32 g_tw[DAB_NB_FFT];
+static int g_tw_ready = 0;
+static void ensure_tw(void) { if (!g_tw_ready) { dab_get_twiddles(g_tw); g_tw_ready = 1; } }
+
+static inline dab_cf32 cadd(dab_cf32 a, dab_cf32 b) { dab_cf32 r = { a.re + b.re, a.im + b.im }; return r; }
+static inline dab_cf32 csub(dab_cf32 a, dab_cf32 b) { dab_cf32 r = { a.re - b.re, a.im - b.im }; return r; }
+static inline dab_cf32 mul_mi(dab_cf32 a) { dab_cf32 r = { a.im, -a.re }; return r; }       /* * (-i) */
+/* b*w : re = fma(b.re, w.re, -(b.im*w.im)), im = fma(b.re, w.im, b.im*w.re) */
+static inline dab_cf32 cmul(dab_cf32 b, dab_cf32 w) {
+    const float t0 = b.im * w.im, t1 = b.im * w.re;
+    dab_cf32 r; r.re = fmaf(b.re, w.re, -t0); r.im = fmaf(b.re, w.im, t1);
+    return r;
+}
+#define SQRT_HALF 0.707106769084930420f
+/* * (1-i)/sqrt2 and * (-1-i)/sqrt2 */
+static inline dab_cf32 mul_w8_1(dab_cf32 a) { dab_cf32 r = { (a.re + a.im) * SQRT_HALF, (a.im - a.re) * SQRT_HALF }; return r; }
+static inline dab_cf32 mul_w8_3(dab_cf32 a) { dab_cf32 r = { (a.im - a.re) * SQRT_HALF, -((a.re + a.im) * SQRT_HALF) }; return r; }
+
+static inline void dft4(const dab_cf32 *a, dab_cf32 *b) {
+    const dab_cf32 s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+    const dab_cf32 s13 = cadd(a[1], a[3]), d13 = mul_mi(csub(a[1], a[3]));
+    b[0] = cadd(s02, s13); b[1] = cadd(d02, d13);
+    b[2] = csub(s02, s13); b[3] = csub(d02, d13);
+}
+
+static inline void dft8(const dab_cf32 *a, dab_cf32 *b) {
+    const dab_cf32 c0 = cadd(a[0], a[4]), c1 = csub(a[0], a[4]);
+    const dab_cf32 c2 = cadd(a[2], a[6]), c3 = mul_mi(csub(a[2], a[6]));
+    const dab_cf32 c4 = cadd(a[1], a[5]), c5 = csub(a[1], a[5]);
+    const dab_cf32 c6 = cadd(a[3], a[7]), c7 = mul_mi(csub(a[3], a[7]));
+    const dab_cf32 d0 = cadd(c0, c2), d2 = csub(c0, c2);
+    const dab_cf32 d1 = cadd(c1, c3), d3 = csub(c1, c3);
+    const dab_cf32 d4 = cadd(c4, c6), d6 = mul_mi(csub(c4, c6));
+    const dab_cf32 d5 = mul_w8_1(cadd(c5, c7)), d7 = mul_w8_3(csub(c5, c7));
+    b[0] = cadd(d0, d4); b[4] = csub(d0, d4);
+    b[1] = cadd(d1, d5); b[5] = csub(d1, d5);
+    b[2] = cadd(d2, d6); b[6] = csub(d2, d6);
+    b[3] = cadd(d3, d7); b[7] = csub(d3, d7);
+}
+
+DAB_HOT
+static void fft2048_core(const dab_cf32 *in, dab_cf32 *out, int conj_io) {
+    dab_cf32 x[DAB_NB_FFT], y[DAB_NB_FFT];
+    dab_cf32 a[8], b[8];
+    /* pass 1: radix 4, n=2048, s=1 */
+    for (int p = 0; p < 512; p++) {
+        for (int j = 0; j < 4; j++) {
+            a[j] = in[p + 512 * j];
+            if (conj_io) a[j].im = -a[j].im;
+        }
+        dft4(a, b);
+        y[4 * p] = b[0];
+        for (int k = 1; k < 4; k++) y[4 * p + k] = cmul(b[k], g_tw[p * k]);
+    }
+    /* pass 2: radix 8, n=512, s=4 */
+    for (int p = 0; p < 64; p++)
+        for (int q = 0; q < 4; q++) {
+            for (int j = 0; j < 8; j++) a[j] = y[q + 4 * (p + 64 * j)];
+            dft8(a, b);
+            x[q + 4 * (8 * p)] = b[0];
+            for (int k = 1; k < 8; k++) x[q + 4 * (8 * p + k)] = cmul(b[k], g_tw[4 * p * k]);
+        }
+    /* pass 3: radix 8, n=64, s=32 */
+    for (int p = 0; p < 8; p++)
+        for (int q = 0; q < 32; q++) {
+            for (int j = 0; j < 8; j++) a[j] = x[q + 32 * (p + 8 * j)];
+            dft8(a, b);
+            y[q + 32 * (8 * p)] = b[0];
+            for (int k = 1; k < 8; k++) y[q + 32 * (8 * p + k)] = cmul(b[k], g_tw[32 * p * k]);
+        }
+    /* pass 4: radix 8, n=8, s=256 */
+    for (int q = 0; q < 256; q++) {
+        for (int j = 0; j < 8; j++) a[j] = y[q + 256 * j];
+        dft8(a, b);
+        for (int k = 0; k < 8; k++) {
+            dab_cf32 v = b[k];
+            if (conj_io) v.im = -v.im;
+            out[q + 256 * k] = v;
+        }
+    }
+}
+
+void dab_fft2048(const dab_cf32 *in, dab_cf32 *out)  { ensure_tw(); fft2048_core(in, out, 0); }
+/* IFFT(x) = conj(FFT(conj(x))), unnormalised like FFTW_BACKWARD */
+void dab_ifft2048(const dab_cf32 *in, dab_cf32 *out) { ensure_tw(); fft2048_core(in, out, 1); }
+
+void dab_dft_naive(const dab_cf32 *in, double *out_re, double *out_im, int n, int inverse) {
+    const double sgn = inverse ? 1.0 : -1.0;
+    for (int k = 0; k < n; k++) {
+        double sr = 0.0, si = 0.0;
+        for (int j = 0; j < n; j++) {
+            const double a = sgn * 2.0 * M_PI * (double)(((long)j * k) % n) / (double)n;
+            const double c = cos(a), s = sin(a);
+            sr += in[j].re * c - in[j].im * s;
+            si += in[j].re * s + in[j].im * c;
+        }
+        out_re[k] = sr; out_im[k] = si;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-frame demodulation                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* convert_to_viterbi_bit ofdm_demodulator.cpp:57-72 ; float->int8 truncation, NaN -> 0 (x86 cvttss2si low byte) */
+static inline int8_t to_vbit(float x) {
+    const float v = -x * 127.0f;
+    if (v != v) return 0;
+    return (int8_t)(int)v;
+}
+
+/* ofdm_demodulator.cpp:842-889 */
+DAB_HOT
+void dab_dqpsk_demap(const dab_cf32 *fft_i, const dab_cf32 *fft_ip1, const int *mapper, int8_t *bits) {
+    const int N = DAB_NB_DATA_CARRIERS, M = N / 2;
+    for (int i = 0; i < N; i++) {
+        const int c = mapper[i];                                   /* :874 */
+        const int k = (c < M) ? (c - M) : (c - M + 1);             /* carrier -768..-1,1..768 (:853-864) */
+        const int bin = (DAB_NB_FFT + k) % DAB_NB_FFT;
+        const dab_cf32 d = conj_mul(fft_i[bin], fft_ip1[bin]);     /* in1*conj(in0) :861, in1 = symbol i */
+        const float ar = fabsf(d.re), ai = fabsf(d.im);
+        const float A = (ar < ai) ? ai : ar;                       /* std::max :882 */
+        const float nr = d.re / A, ni = d.im / A;                  /* :883 */
+        bits[i]     = to_vbit(+nr);                                /* :886 */
+        bits[i + N] = to_vbit(-ni);                                /* :887 */
+    }
+}
+
+/* ofdm_demodulator.cpp:650-766 (single pipeline thread order) */
+float dab_demod_frame(const dab_cf32 *frame, float f, const int *mapper,
+                      int8_t *bits, dab_cf32 *cp_corr, float *cp_phase, dab_cf32 *fft_out) {
+    ensure_tw();
+    static __thread dab_cf32 sym[DAB_NB_SYMBOL_PERIOD];
+    static __thread dab_cf32 X[2][DAB_NB_FFT];
+    float total = 0.0f;
+    for (int i = 0; i <= DAB_NB_FRAME_SYMBOLS; i++) {
+        const dab_cf32 *src = frame + (size_t)i * DAB_NB_SYMBOL_PERIOD;     /* ofdm_frame_buffer.h:87-99 */
+        const float dt0 = (float)(i * DAB_NB_SYMBOL_PERIOD) * f;            /* :675-676 */
+        dab_apply_pll(src, sym, DAB_NB_SYMBOL_PERIOD, f, dt0);              /* :677 */
+        if (i < DAB_NB_FRAME_SYMBOLS) {                                     /* :686-690 */
+            const dab_cf32 c = dab_cp_correlation(sym);
+            const float ph = dab_atan2f(c.im, c.re);
+            if (cp_corr) cp_corr[i] = c;
+            if (cp_phase) cp_phase[i] = ph;
+            total += ph;
+        }
+        if (i == DAB_NB_FRAME_SYMBOLS && !fft_out) break;                   /* NULL FFT is display-only */
+        dab_cf32 *cur = X[i & 1];
+        fft2048_core(sym + DAB_NB_CYCLIC_PREFIX, cur, 0);                   /* :701-709 */
+        if (fft_out) memcpy(fft_out + (size_t)i * DAB_NB_FFT, cur, sizeof(dab_cf32) * DAB_NB_FFT);
+        if (i >= 1 && i < DAB_NB_FRAME_SYMBOLS)                             /* :728-739 */
+            dab_dqpsk_demap(X[(i - 1) & 1], cur, mapper, bits + (size_t)(i - 1) * DAB_NB_SYM_BITS);
+    }
+    return total;
+}
+
+/* ofdm_demodulator.cpp:829-840 */
+float dab_fine_freq_add(float fine, float delta) {
+    const float spacing = 1.0f / (float)DAB_NB_FFT;
+    const float wrap = 0.5f * spacing * 1.01f;
+    fine += delta;
+    return fmodf(fine, wrap);
+}
+
+/* ofdm_demodulator.cpp:606-618 + :779-824 */
+float dab_update_fine_freq(float fine, float total_phase_error) {
+    const float TWO_PI = (float)M_PI * 2.0f;
+    const float avg = total_phase_error / (float)DAB_NB_FRAME_SYMBOLS;
+    const float spacing = 1.0f / (float)DAB_NB_FFT;
+    const float err = spacing * avg / TWO_PI;
+    const float delta = -0.9f * err;
+    return dab_fine_freq_add(fine, delta);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sync                                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+void dab_sync_cfg_default(dab_sync_cfg *c) {         /* ofdm_demodulator.h:34-44 */
+    c->fine_freq_update_beta = 0.9f;
+    c->is_coarse_freq_correction = 1;
+    c->max_coarse_freq_correction_norm = 0.5f;
+    c->coarse_freq_slow_beta = 0.1f;
+    c->impulse_peak_threshold_db = 20.0f;
+    c->impulse_peak_distance_probability = 0.15f;
+}
+
+/* ofdm_demodulator.cpp:901-909 ; conj(in[i]) * in[i+1] == in[i+1] * conj(in[i]) */
+static void relative_phase(const dab_cf32 *in, dab_cf32 *out) {
+    for (int i = 0; i < DAB_NB_FFT - 1; i++) out[i] = conj_mul(in[i + 1], in[i]);
+    out[DAB_NB_FFT - 1].re = 0.0f; out[DAB_NB_FFT - 1].im = 0.0f;
+}
+
+/* ofdm_demodulator.cpp:128-140 */
+void dab_sync_refs(const dab_cf32 *prs_fft, dab_cf32 *prs_fft_conj, dab_cf32 *prs_time_ref) {
+    dab_cf32 tmp[DAB_NB_FFT];
+    for (int i = 0; i < DAB_NB_FFT; i++) { prs_fft_conj[i].re = prs_fft[i].re; prs_fft_conj[i].im = -prs_fft[i].im; }
+    relative_phase(prs_fft, tmp);
+    dab_ifft2048(tmp, prs_time_ref);
+    for (int i = 0; i < DAB_NB_FFT; i++) prs_time_ref[i].im = -prs_time_ref[i].im;
+}
+
+/* 2048 values: leaf t sums elements t, t+256, ... sequentially, then the 256-leaf tree */
+static float tree_sum_2048(const float *v) {
+    float a[256];
+    for (int t = 0; t < 256; t++) {
+        float s = v[t];
+        for (int j = 1; j < 8; j++) s += v[t + 256 * j];
+        a[t] = s;
+    }
+    return tree256(a);
+}
+
+/* ofdm_demodulator.cpp:360-471 */
+void dab_coarse_freq_sync(const dab_cf32 *prs_sym, const dab_cf32 *prs_time_ref, const dab_sync_cfg *cfg,
+                          dab_sync_state *st, float *freq_response) {
+    if (!cfg->is_coarse_freq_correction) { st->freq_coarse = 0.0f; return; }     /* :363-367 */
+    const int N = DAB_NB_FFT, M = N / 2;
+    dab_cf32 A[DAB_NB_FFT], B[DAB_NB_FFT];
+    float resp[DAB_NB_FFT];
+    dab_fft2048(prs_sym, A);                                    /* :377 */
+    relative_phase(A, B);                                       /* :380 (out of place, same values) */
+    dab_ifft2048(B, A);                                         /* :383 */
+    for (int i = 0; i < N; i++) A[i] = cmul(A[i], prs_time_ref[i]);   /* :387-389 */
+    dab_fft2048(A, B);                                          /* :392 */
+    for (int i = 0; i < N; i++) resp[i] = dab_db20f(dab_cabsf(B[(i + M) % N]));  /* :911-920 */
+    if (freq_response) memcpy(freq_response, resp, sizeof(resp));
+
+    int max_off = (int)(cfg->max_coarse_freq_correction_norm * (float)N);        /* :399-402 */
+    if (max_off < 0) max_off = 0;
+    if (max_off > M) max_off = M;
+    int max_index = -max_off;
+    float max_value = resp[max_index + M];
+    for (int i = -max_off; i <= max_off; i++) {                 /* :405-413 */
+        const int idx = i + M;
+        if (idx == N) continue;
+        if (resp[idx] > max_value) { max_value = resp[idx]; max_index = i; }
+    }
+    int pidx[3]; float pmag[3];
+    for (int j = 0; j < 3; j++) {                               /* :423-434 */
+        int index = max_index - 1 + j;
+        if (index < -max_off) index = -max_off;
+        if (index > max_off) index = max_off;
+        int fi = index + M;
+        if (fi >= N) fi = N - 1;
+        pidx[j] = fi - M;
+        pmag[j] = dab_undb20f(resp[fi]);
+    }
+    float peak_sum = 0.0f, lerp = 0.0f;
+    for (int j = 0; j < 3; j++) peak_sum += pmag[j];
+    for (int j = 0; j < 3; j++) lerp += (float)pidx[j] * pmag[j] / peak_sum;     /* :438 */
+    const float predicted = -lerp / (float)N;
+    const float error = predicted - st->freq_coarse;
+    const float large_thresh = 1.5f / (float)N;
+    const int is_large = fabsf(error) > large_thresh;
+    const int is_fast = is_large || !st->is_found_coarse;
+    const float beta = is_fast ? 1.0f : cfg->coarse_freq_slow_beta;
+    const float delta = beta * error;
+    st->freq_coarse += delta;                                   /* :461 */
+    st->is_found_coarse = 1;
+    st->freq_fine = dab_fine_freq_add(st->freq_fine, -delta);   /* :467 */
+}
+
+/* ofdm_demodulator.cpp:473-548 (numeric part) */
+int dab_fine_time_sync(const dab_cf32 *prs_sym, const dab_cf32 *prs_fft_conj, const dab_sync_cfg *cfg,
+                       float freq_offset, int *offset, float *impulse_response) {
+    const int N = DAB_NB_FFT;
+    dab_cf32 A[DAB_NB_FFT], B[DAB_NB_FFT];
+    float ir[DAB_NB_FFT];
+    dab_apply_pll(prs_sym, A, N, freq_offset, 0.0f);            /* :481-482 */
+    dab_fft2048(A, B);                                          /* :487 */
+    for (int i = 0; i < N; i++) B[i] = cmul(B[i], prs_fft_conj[i]);   /* :488-490 */
+    dab_ifft2048(B, A);                                         /* :493 */
+    for (int i = 0; i < N; i++) ir[i] = dab_db20f(dab_cabsf(A[i]));   /* :494-498 */
+    if (impulse_response) memcpy(impulse_response, ir, sizeof(ir));
+
+    float max_value = ir[0];
+    int max_index = 0;
+    const float decay = 1.0f - cfg->impulse_peak_distance_probability;           /* :515 */
+    for (int i = 0; i < N; i++) {                               /* :505-524 */
+        const int dist = abs(DAB_NB_CYCLIC_PREFIX - i);
+        const float norm_dist = (float)dist / (float)DAB_NB_SYMBOL_PERIOD;
+        const float prob = 1.0f - decay * norm_dist;
+        const float w = prob * ir[i];
+        if (w > max_value) { max_value = w; max_index = i; }
+    }
+    const float avg = tree_sum_2048(ir) / (float)N;            /* :519,:525 ; summation order = contract tree */
+    if ((max_value - avg) < cfg->impulse_peak_threshold_db) return 0;            /* :529 */
+    *offset = max_index - DAB_NB_CYCLIC_PREFIX;                 /* :536 */
+    return 1;
+}

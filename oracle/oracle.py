@@ -1,0 +1,459 @@
+"""ctypes bindings for the CPU oracle (oracle/libdab_oracle.so) and, when built, the reference
+objects (oracle/_ref/libdab_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Nothing under dab-radio_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(_HERE, "libdab_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libdab_ref.so")
+
+NB_FRAME_SYMBOLS = 76
+NB_SYMBOL_PERIOD = 2552
+NB_NULL_PERIOD = 2656
+NB_FFT = 2048
+NB_CP = 504
+NB_CARRIERS = 1536
+NB_FRAME_SAMPLES = 196608
+NB_SYM_BITS = 3072
+NB_FRAME_BITS = 230400
+NB_FIC_BITS = 9216
+NB_FIB_GROUP_BITS = 2304
+NB_CIF_BITS = 55296
+
+
+def build(force=False):
+    """Compile the oracle (and _ref when /root/reference exists). Building the checker is not using it."""
+    if force or not os.path.exists(_ORACLE_SO) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_ORACLE_SO)
+        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle.h")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libdab_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class SubChannel(C.Structure):
+    _fields_ = [("start_address", C.c_int), ("length", C.c_int), ("is_uep", C.c_int),
+                ("uep_prot_index", C.c_int), ("eep_prot_level", C.c_int), ("eep_type", C.c_int)]
+
+
+class SyncCfg(C.Structure):
+    _fields_ = [("fine_freq_update_beta", C.c_float), ("is_coarse_freq_correction", C.c_int),
+                ("max_coarse_freq_correction_norm", C.c_float), ("coarse_freq_slow_beta", C.c_float),
+                ("impulse_peak_threshold_db", C.c_float), ("impulse_peak_distance_probability", C.c_float)]
+
+
+class SyncState(C.Structure):
+    _fields_ = [("freq_coarse", C.c_float), ("freq_fine", C.c_float), ("is_found_coarse", C.c_int),
+                ("fine_time_offset", C.c_int), ("total_frames_read", C.c_int), ("total_frames_desync", C.c_int)]
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        L.dab_chebyshev_sine.restype = C.c_float
+        L.dab_chebyshev_sine.argtypes = [C.c_float]
+        L.dab_chebyshev_sine_fma.restype = C.c_float
+        L.dab_chebyshev_sine_fma.argtypes = [C.c_float]
+        L.dab_atan2f.restype = C.c_float
+        L.dab_atan2f.argtypes = [C.c_float, C.c_float]
+        L.dab_db20f.restype = C.c_float
+        L.dab_db20f.argtypes = [C.c_float]
+        L.dab_undb20f.restype = C.c_float
+        L.dab_undb20f.argtypes = [C.c_float]
+        L.dab_apply_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+        L.dab_apply_pll_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+        L.dab_demod_frame.restype = C.c_float
+        L.dab_demod_frame.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_update_fine_freq.restype = C.c_float
+        L.dab_update_fine_freq.argtypes = [C.c_float, C.c_float]
+        L.dab_fine_freq_add.restype = C.c_float
+        L.dab_fine_freq_add.argtypes = [C.c_float, C.c_float]
+        L.dab_crc16.restype = C.c_uint16
+        L.dab_crc16.argtypes = [C.c_void_p, C.c_size_t]
+        L.dab_puncture_code.restype = C.POINTER(C.c_uint8)
+        L.dab_puncture_code.argtypes = [C.c_int]
+        L.dab_puncture_code_tail.restype = C.POINTER(C.c_uint8)
+        L.dab_viterbi_create.restype = C.c_void_p
+        L.dab_viterbi_create.argtypes = [C.c_size_t, C.c_int]
+        L.dab_viterbi_destroy.argtypes = [C.c_void_p]
+        L.dab_viterbi_reset.argtypes = [C.c_void_p, C.c_size_t]
+        L.dab_viterbi_update.restype = C.c_size_t
+        L.dab_viterbi_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.dab_viterbi_chainback.restype = C.c_uint64
+        L.dab_viterbi_chainback.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.dab_viterbi_current_decoded_bit.restype = C.c_size_t
+        L.dab_viterbi_current_decoded_bit.argtypes = [C.c_void_p]
+        L.dab_viterbi_decisions.restype = C.POINTER(C.c_uint64)
+        L.dab_viterbi_decisions.argtypes = [C.c_void_p]
+        L.dab_viterbi_metrics.restype = C.POINTER(C.c_uint16)
+        L.dab_viterbi_metrics.argtypes = [C.c_void_p]
+        L.dab_fic_decode_group.restype = C.c_uint64
+        L.dab_fic_decode_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.dab_subchannel_plan.restype = C.c_int
+        L.dab_subchannel_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_msc_decode_logical.restype = C.c_uint64
+        L.dab_msc_decode_logical.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.dab_deinterleaver_create.restype = C.c_void_p
+        L.dab_deinterleaver_create.argtypes = [C.c_int]
+        L.dab_deinterleaver_destroy.argtypes = [C.c_void_p]
+        L.dab_deinterleaver_consume.argtypes = [C.c_void_p, C.c_void_p]
+        L.dab_deinterleaver_deinterleave.restype = C.c_int
+        L.dab_deinterleaver_deinterleave.argtypes = [C.c_void_p, C.c_void_p]
+        L.dab_puncture.restype = C.c_size_t
+        L.dab_puncture.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dab_fine_time_sync.restype = C.c_int
+        L.dab_fine_time_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+        L.dab_coarse_freq_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+# ------------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ------------------------------------------------------------------------------------------------
+def c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def mapper():
+    m = np.zeros(NB_CARRIERS, dtype=np.int32)
+    lib().dab_get_mapper(_p(m))
+    return m
+
+
+def prs_fft():
+    p = np.zeros(NB_FFT, dtype=np.complex64)
+    lib().dab_get_prs_fft(_p(p))
+    return p
+
+
+def twiddles():
+    t = np.zeros(NB_FFT, dtype=np.complex64)
+    lib().dab_get_twiddles(_p(t))
+    return t
+
+
+def apply_pll(x, f, dt0=0.0, scalar=False):
+    x = c64(x)
+    y = np.empty_like(x)
+    fn = lib().dab_apply_pll_scalar if scalar else lib().dab_apply_pll
+    fn(_p(x), _p(y), x.size, np.float32(f), np.float32(dt0))
+    return y
+
+
+def cp_correlation(sym):
+    sym = c64(sym)
+    assert sym.size == NB_SYMBOL_PERIOD
+
+    class CF(C.Structure):
+        _fields_ = [("re", C.c_float), ("im", C.c_float)]
+    L = lib()
+    L.dab_cp_correlation.restype = CF
+    L.dab_cp_correlation.argtypes = [C.c_void_p]
+    r = L.dab_cp_correlation(_p(sym))
+    return np.complex64(complex(r.re, r.im))
+
+
+def fft2048(x, inverse=False):
+    x = c64(x)
+    assert x.size == NB_FFT
+    y = np.empty_like(x)
+    (lib().dab_ifft2048 if inverse else lib().dab_fft2048)(_p(x), _p(y))
+    return y
+
+
+def dqpsk_demap(fft_i, fft_ip1, m=None):
+    m = mapper() if m is None else np.ascontiguousarray(m, dtype=np.int32)
+    out = np.empty(NB_SYM_BITS, dtype=np.int8)
+    lib().dab_dqpsk_demap(_p(c64(fft_i)), _p(c64(fft_ip1)), _p(m), _p(out))
+    return out
+
+
+def demod_frame(frame, freq_offset=0.0, want_fft=False, m=None):
+    """frame: 196608 c64 in frame-buffer layout (76 symbols then NULL). Returns dict."""
+    frame = c64(frame)
+    assert frame.size == NB_FRAME_SAMPLES
+    m = mapper() if m is None else np.ascontiguousarray(m, dtype=np.int32)
+    bits = np.empty(NB_FRAME_BITS, dtype=np.int8)
+    corr = np.empty(NB_FRAME_SYMBOLS, dtype=np.complex64)
+    phase = np.empty(NB_FRAME_SYMBOLS, dtype=np.float32)
+    fft = np.empty(77 * NB_FFT, dtype=np.complex64) if want_fft else None
+    total = lib().dab_demod_frame(_p(frame), np.float32(freq_offset), _p(m), _p(bits), _p(corr), _p(phase),
+                                  _p(fft) if want_fft else None)
+    return {"bits": bits, "cp_corr": corr, "cp_phase": phase, "total_phase": np.float32(total), "fft": fft}
+
+
+def update_fine_freq(fine, total_phase):
+    return np.float32(lib().dab_update_fine_freq(np.float32(fine), np.float32(total_phase)))
+
+
+def scrambler_bytes(n):
+    out = np.empty(n, dtype=np.uint8)
+    lib().dab_scrambler_bytes(_p(out), n)
+    return out
+
+
+def crc16(data):
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    return int(lib().dab_crc16(_p(d), d.size))
+
+
+def puncture_code(pi):
+    return np.array([lib().dab_puncture_code(pi)[i] for i in range(8)], dtype=np.uint8)
+
+
+def puncture_code_tail():
+    return np.array([lib().dab_puncture_code_tail()[i] for i in range(6)], dtype=np.uint8)
+
+
+def fic_decode_group(bits, tie_rule=0):
+    bits = np.ascontiguousarray(bits, dtype=np.int8)
+    assert bits.size == NB_FIB_GROUP_BITS
+    out = np.empty(96, dtype=np.uint8)
+    mask = C.c_uint32(0)
+    err = lib().dab_fic_decode_group(_p(bits), tie_rule, _p(out), C.byref(mask))
+    return out, mask.value, int(err)
+
+
+def subchannel(start, length, eep_level=2, eep_type=0, is_uep=False, uep_index=0):
+    return SubChannel(start, length, int(is_uep), uep_index, eep_level, eep_type)
+
+
+def subchannel_plan(sc):
+    pi = np.zeros(4, dtype=np.int32)
+    lx = np.zeros(4, dtype=np.int32)
+    nb = C.c_int(0)
+    n = lib().dab_subchannel_plan(C.byref(sc), _p(pi), _p(lx), C.byref(nb))
+    return pi[:n].copy(), lx[:n].copy(), nb.value
+
+
+def msc_decode_logical(sc, bits, tie_rule=0):
+    bits = np.ascontiguousarray(bits, dtype=np.int8)
+    assert bits.size == sc.length * 64
+    out = np.empty(sc.length * 8, dtype=np.uint8)
+    nb = C.c_int(0)
+    err = lib().dab_msc_decode_logical(C.byref(sc), _p(bits), tie_rule, _p(out), C.byref(nb))
+    return out[:nb.value].copy(), int(err)
+
+
+class Deinterleaver:
+    def __init__(self, nb_bytes):
+        self.n = nb_bytes * 8
+        self.h = lib().dab_deinterleaver_create(nb_bytes)
+
+    def consume(self, bits):
+        bits = np.ascontiguousarray(bits, dtype=np.int8)
+        assert bits.size == self.n
+        lib().dab_deinterleaver_consume(self.h, _p(bits))
+
+    def deinterleave(self):
+        out = np.empty(self.n, dtype=np.int8)
+        ok = lib().dab_deinterleaver_deinterleave(self.h, _p(out))
+        return out if ok else None
+
+    def __del__(self):
+        if self.h:
+            lib().dab_deinterleaver_destroy(self.h)
+            self.h = None
+
+
+class Viterbi:
+    def __init__(self, traceback_length, tie_rule=0):
+        self.h = lib().dab_viterbi_create(traceback_length, tie_rule)
+
+    def reset(self, state=0):
+        lib().dab_viterbi_reset(self.h, state)
+
+    def update(self, punctured, code, requested):
+        punctured = np.ascontiguousarray(punctured, dtype=np.int8)
+        code = np.ascontiguousarray(code, dtype=np.uint8)
+        return lib().dab_viterbi_update(self.h, _p(punctured), punctured.size, _p(code), code.size, requested)
+
+    def chainback(self, n_bytes, end_state=0):
+        out = np.empty(n_bytes, dtype=np.uint8)
+        err = lib().dab_viterbi_chainback(self.h, _p(out), n_bytes, end_state)
+        return out, int(err)
+
+    def decoded_bits(self):
+        return lib().dab_viterbi_current_decoded_bit(self.h)
+
+    def decisions(self, n):
+        p = lib().dab_viterbi_decisions(self.h)
+        return np.array([p[i] for i in range(n)], dtype=np.uint64)
+
+    def metrics(self):
+        p = lib().dab_viterbi_metrics(self.h)
+        return np.array([p[i] for i in range(64)], dtype=np.uint16)
+
+    def __del__(self):
+        if self.h:
+            lib().dab_viterbi_destroy(self.h)
+            self.h = None
+
+
+# ---- transmit side ----
+def conv_encode(data_bytes):
+    d = np.ascontiguousarray(data_bytes, dtype=np.uint8)
+    n_bits = d.size * 8
+    out = np.empty(4 * (n_bits + 6), dtype=np.uint8)
+    lib().dab_conv_encode(_p(d), n_bits, _p(out))
+    return out
+
+
+def fic_encode_group(fib_data90):
+    d = np.ascontiguousarray(fib_data90, dtype=np.uint8)
+    assert d.size == 90
+    out = np.empty(NB_FIB_GROUP_BITS, dtype=np.uint8)
+    lib().dab_fic_encode_group(_p(d), _p(out))
+    return out
+
+
+def msc_encode_logical(sc, data_bytes):
+    _, _, nb = subchannel_plan(sc)
+    d = np.ascontiguousarray(data_bytes, dtype=np.uint8)
+    assert d.size == nb
+    out = np.empty(sc.length * 64, dtype=np.uint8)
+    lib().dab_msc_encode_logical(C.byref(sc), _p(d), _p(out))
+    return out
+
+
+def modulate_frame(frame_bits, m=None):
+    """frame_bits: 230400 values 0/1 in RX frame-bit layout -> 196608 c64 in transmission order (NULL first)."""
+    b = np.ascontiguousarray(frame_bits, dtype=np.uint8)
+    assert b.size == NB_FRAME_BITS
+    m = mapper() if m is None else np.ascontiguousarray(m, dtype=np.int32)
+    out = np.empty(NB_FRAME_SAMPLES, dtype=np.complex64)
+    lib().dab_modulate_frame(_p(b), _p(m), _p(out))
+    return out
+
+
+def modulate_frame_reference_payload(payload):
+    p = np.ascontiguousarray(payload, dtype=np.uint8)
+    assert p.size == 75 * 384
+    out = np.empty(NB_FRAME_SAMPLES, dtype=np.complex64)
+    lib().dab_modulate_frame_reference_payload(_p(p), _p(out))
+    return out
+
+
+def tx_to_frame_buffer(tx_stream, k=0):
+    """Slice frame k of a NULL-first stream of back-to-back frames into the demodulator's frame-buffer
+    layout (PRS, 75 data symbols, then the NULL of the following frame; zeros if the stream ends)."""
+    s = c64(tx_stream)
+    start = NB_NULL_PERIOD + k * NB_FRAME_SAMPLES
+    out = np.zeros(NB_FRAME_SAMPLES, dtype=np.complex64)
+    seg = s[start:start + NB_FRAME_SAMPLES]
+    out[:seg.size] = seg
+    return out
+
+
+def soft_from_bits(bits01, amp=127):
+    """logical bit b -> soft value (2b-1)*amp (ofdm_demodulator.cpp:64-68)"""
+    return ((2 * np.asarray(bits01, dtype=np.int16) - 1) * amp).astype(np.int8)
+
+
+def time_interleave(logical_frames):
+    """ETSI EN 300 401 clause 12 transmit side: logical_frames [T][n] -> transmitted CIF content [T][n];
+    bit i of logical frame r is sent in CIF r + T[i % 16]. CIFs before enough history are zero-filled."""
+    lf = np.asarray(logical_frames)
+    T, n = lf.shape
+    offs = np.array([0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15])
+    out = np.zeros_like(lf)
+    idx = np.arange(n)
+    d = offs[idx % 16]
+    for t in range(T):
+        src = t - d
+        ok = src >= 0
+        out[t, ok] = lf[src[ok], idx[ok]]
+    return out
+
+
+# ---- sync ----
+def sync_refs():
+    p = prs_fft()
+    a = np.empty(NB_FFT, dtype=np.complex64)
+    b = np.empty(NB_FFT, dtype=np.complex64)
+    lib().dab_sync_refs(_p(p), _p(a), _p(b))
+    return a, b
+
+
+def sync_cfg_default():
+    c = SyncCfg()
+    lib().dab_sync_cfg_default(C.byref(c))
+    return c
+
+
+def fine_time_sync(prs_sym, freq_offset, cfg=None, prs_fft_conj=None):
+    cfg = cfg or sync_cfg_default()
+    if prs_fft_conj is None:
+        prs_fft_conj, _ = sync_refs()
+    x = c64(prs_sym)[:NB_FFT].copy()
+    ir = np.empty(NB_FFT, dtype=np.float32)
+    off = C.c_int(0)
+    ok = lib().dab_fine_time_sync(_p(x), _p(c64(prs_fft_conj)), C.byref(cfg), np.float32(freq_offset), C.byref(off), _p(ir))
+    return bool(ok), off.value, ir
+
+
+def coarse_freq_sync(prs_sym, state, cfg=None, prs_time_ref=None):
+    cfg = cfg or sync_cfg_default()
+    if prs_time_ref is None:
+        _, prs_time_ref = sync_refs()
+    x = c64(prs_sym)[:NB_FFT].copy()
+    fr = np.empty(NB_FFT, dtype=np.float32)
+    lib().dab_coarse_freq_sync(_p(x), _p(c64(prs_time_ref)), C.byref(cfg), C.byref(state), _p(fr))
+    return fr
+
+
+# ------------------------------------------------------------------------------------------------
+# reference objects (only present where /root/reference was available at build time)
+# ------------------------------------------------------------------------------------------------
+_ref = None
+
+
+def ref():
+    """Returns the ctypes handle of oracle/_ref/libdab_ref.so or None when it was never built."""
+    global _ref
+    if _ref is None:
+        build()
+        if not os.path.exists(_REF_SO):
+            return None
+        R = C.CDLL(_REF_SO)
+        R.ref_apply_pll.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+        R.ref_apply_pll_baseline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
+        R.ref_conj_mul_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        R.ref_conj_mul_sum_baseline.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        R.ref_chebyshev_sine.restype = C.c_float
+        R.ref_chebyshev_sine.argtypes = [C.c_float]
+        R.ref_get_mapper.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        R.ref_get_prs.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        R.ref_get_ofdm_params.argtypes = [C.c_int, C.c_void_p]
+        R.ref_get_dab_params.argtypes = [C.c_int, C.c_void_p]
+        R.ref_deint_create.restype = C.c_void_p
+        R.ref_deint_create.argtypes = [C.c_int]
+        R.ref_deint_destroy.argtypes = [C.c_void_p]
+        R.ref_deint_consume.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        R.ref_deint_deinterleave.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        R.ref_scrambler_bytes.argtypes = [C.c_void_p, C.c_size_t]
+        R.ref_crc16.restype = C.c_uint16
+        R.ref_crc16.argtypes = [C.c_void_p, C.c_size_t]
+        R.ref_puncture_tables.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_subchannel_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        R.ref_uep_row.argtypes = [C.c_int, C.c_void_p]
+        _ref = R
+    return _ref
