@@ -1,0 +1,252 @@
+// dabgpu_abi.hip -- the C ABI declared in include/dabgpu.h (host side: contexts, constant tables,
+// argument checking, launches).  No CPU compute path exists here: every compute entry point needs
+// a gfx950 device and fails with DABGPU_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+
+static thread_local std::string g_last_error;
+
+void dabgpu_set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_last_error = buf;
+}
+
+int dabgpu_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return DABGPU_OK;
+    dabgpu_set_error("%s: %s", what, hipGetErrorString(e));
+    return DABGPU_ERR_HIP;
+}
+
+extern "C" {
+
+const char* dabgpu_strerror(int status) {
+    switch (status) {
+    case DABGPU_OK: return "ok";
+    case DABGPU_ERR_NO_DEVICE: return "no usable gfx950 device (this library has no CPU fallback)";
+    case DABGPU_ERR_INVALID_ARG: return "invalid argument";
+    case DABGPU_ERR_HIP: return "HIP runtime error";
+    case DABGPU_ERR_NOT_READY: return "not ready";
+    case DABGPU_ERR_UNSUPPORTED: return "unsupported transmission mode";
+    default: return "unknown status";
+    }
+}
+const char* dabgpu_last_error(void) { return g_last_error.c_str(); }
+int dabgpu_abi_version(void) { return DABGPU_ABI_VERSION; }
+
+int dabgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int usable = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) usable++;
+    }
+    return usable;
+}
+
+// ---- built-in Mode I tables ----
+// ETSI EN 300 401 14.3.2 tables 23/24, Mode I (replaces get_DAB_PRS_reference, src/ofdm/dab_prs_ref.cpp:140-195)
+static const signed char PRS_ROW_I[48] = {
+    0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,
+    0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 };
+static const signed char PRS_ROW_N[48] = {
+    1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,
+    3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 };
+static const signed char PRS_H_TABLE[4][32] = {
+    {0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1,0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1},
+    {0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0,0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0},
+    {0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3,0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3},
+    {0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2,0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2},
+};
+
+int dabgpu_get_prs_fft_ref(int mode, float* out) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    if (mode != 1) { dabgpu_set_error("transmission mode %d: only Mode I tables are built in", mode); return DABGPU_ERR_UNSUPPORTED; }
+    memset(out, 0, sizeof(float) * 2 * DABGPU_NB_FFT);
+    for (int row = 0; row < 48; row++) {
+        const int k_min = (row < 24) ? (-768 + 32 * row) : (1 + 32 * (row - 24));
+        for (int j = 0; j < 32; j++) {
+            const int k = k_min + j;
+            const int h = PRS_H_TABLE[(int)PRS_ROW_I[row]][j];
+            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_ROW_N[row]);
+            const int bin = (k < 0) ? (DABGPU_NB_FFT + k) : k;
+            out[2 * bin] = cosf(phi);
+            out[2 * bin + 1] = sinf(phi);
+        }
+    }
+    return DABGPU_OK;
+}
+
+// ETSI EN 300 401 14.6.1 (replaces get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
+int dabgpu_get_carrier_mapper(int mode, int* out) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    if (mode != 1) { dabgpu_set_error("transmission mode %d: only Mode I tables are built in", mode); return DABGPU_ERR_UNSUPPORTED; }
+    const int N = DABGPU_NB_FFT, nb = DABGPU_NB_DATA_CARRIERS, dc = N / 2, lo = dc - nb / 2, hi = dc + nb / 2;
+    int v = 0, n = 0;
+    for (int i = 0; i < N; i++) {
+        if (i > 0) v = (13 * v + N / 4 - 1) % N;
+        if (v < lo || v > hi || v == dc) continue;
+        out[n++] = (v < dc) ? (v - lo) : (v - lo - 1);
+    }
+    return DABGPU_OK;
+}
+
+int dabgpu_get_fft_twiddles(float* out) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    for (int m = 0; m < DABGPU_NB_FFT; m++) {
+        const double a = 2.0 * M_PI * (double)m / (double)DABGPU_NB_FFT;
+        out[2 * m] = (float)cos(a);
+        out[2 * m + 1] = (float)(-sin(a));
+    }
+    return DABGPU_OK;
+}
+
+// ---- context ----
+int dabgpu_create(dabgpu_ctx** out, int device, const float* h_prs, const int* h_mapper) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        dabgpu_set_error("hipGetDeviceCount found no device");
+        return DABGPU_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { dabgpu_set_error("device %d out of range (%d devices)", device, n); return DABGPU_ERR_INVALID_ARG; }
+    hipDeviceProp_t prop;
+    int st = dabgpu_check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (st) return st;
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        dabgpu_set_error("device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+        return DABGPU_ERR_NO_DEVICE;
+    }
+    st = dabgpu_check_hip(hipSetDevice(device), "hipSetDevice");
+    if (st) return st;
+
+    dabgpu_ctx* c = new dabgpu_ctx();
+    c->device = device;
+    c->prs.resize(2 * DABGPU_NB_FFT);
+    c->mapper.resize(DABGPU_NB_DATA_CARRIERS);
+    if (h_prs) memcpy(c->prs.data(), h_prs, sizeof(float) * 2 * DABGPU_NB_FFT); else dabgpu_get_prs_fft_ref(1, c->prs.data());
+    if (h_mapper) memcpy(c->mapper.data(), h_mapper, sizeof(int) * DABGPU_NB_DATA_CARRIERS); else dabgpu_get_carrier_mapper(1, c->mapper.data());
+
+    // inverse of the frequency de-interleaver: output position n of carrier c (mapper[n] = c)
+    std::vector<uint16_t> inv(DABGPU_NB_DATA_CARRIERS, 0xFFFF);
+    for (int i = 0; i < DABGPU_NB_DATA_CARRIERS; i++) {
+        const int cidx = c->mapper[i];
+        if (cidx < 0 || cidx >= DABGPU_NB_DATA_CARRIERS || inv[cidx] != 0xFFFF) {
+            dabgpu_set_error("carrier_mapper is not a permutation of 0..1535 (entry %d = %d)", i, cidx);
+            delete c;
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        inv[cidx] = (uint16_t)i;
+    }
+    std::vector<float> tw(2 * DABGPU_NB_FFT);
+    dabgpu_get_fft_twiddles(tw.data());
+
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) { dabgpu_destroy(c); return st; } } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipMalloc(&c->d_tw, sizeof(float) * tw.size()));
+    CK(hipMalloc(&c->d_inv_map, sizeof(uint16_t) * inv.size()));
+    CK(hipMalloc(&c->d_prs, sizeof(float) * c->prs.size()));
+    CK(hipMemcpy(c->d_tw, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_inv_map, inv.data(), sizeof(uint16_t) * inv.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(c->d_prs, c->prs.data(), sizeof(float) * c->prs.size(), hipMemcpyHostToDevice));
+#undef CK
+    *out = c;
+    return DABGPU_OK;
+}
+
+void dabgpu_destroy(dabgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_tw) (void)hipFree(c->d_tw);
+    if (c->d_inv_map) (void)hipFree(c->d_inv_map);
+    if (c->d_prs) (void)hipFree(c->d_prs);
+    for (void* p : c->scratch) if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
+    if (!c) return DABGPU_ERR_INVALID_ARG;
+    return dabgpu_check_hip(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream), "hipStreamSynchronize");
+}
+
+// ---- OFDM ----
+int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                             float* d_cp_corr, float* d_fft, int symbols_per_block, void* stream) {
+    if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
+    if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_demod_frames: d_iq and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    float* corr = d_cp_corr;
+    if (!corr) {     // the kernel always produces the correlation; park it in context scratch when unwanted
+        int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
+        if (st) return st;
+    }
+    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, d_freq, d_bits, corr, d_fft, c->d_tw, c->d_inv_map,
+                                                     (int)n_frames, symbols_per_block, s), "ofdm_demod_kernel launch");
+}
+
+int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,
+                             float* d_fine_freq, void* stream) {
+    if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, s),
+                            "ofdm_phase_kernel launch");
+}
+
+int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t n_frames, const float* h_freq,
+                                       int8_t* h_bits, float* h_total_phase, float* h_fft) {
+    if (!c || !h_iq || !h_bits) { dabgpu_set_error("ofdm_demod_frames_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    int st;
+    (void)hipSetDevice(c->device);
+    const size_t iq_bytes = n_frames * DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
+    const size_t bits_bytes = n_frames * DABGPU_NB_FRAME_BITS;
+    const size_t fft_bytes = n_frames * 77 * DABGPU_NB_FFT * 2 * sizeof(float);
+    float *d_iq, *d_freq, *d_corr, *d_total, *d_fft = nullptr; int8_t* d_bits;
+    if ((st = dabgpu_scratch(c, 1, iq_bytes, (void**)&d_iq))) return st;
+    if ((st = dabgpu_scratch(c, 2, bits_bytes, (void**)&d_bits))) return st;
+    if ((st = dabgpu_scratch(c, 3, n_frames * sizeof(float), (void**)&d_freq))) return st;
+    if ((st = dabgpu_scratch(c, 4, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&d_corr))) return st;
+    if ((st = dabgpu_scratch(c, 5, n_frames * sizeof(float), (void**)&d_total))) return st;
+    if (h_fft && (st = dabgpu_scratch(c, 6, fft_bytes, (void**)&d_fft))) return st;
+    hipStream_t s = c->stream;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
+    if (h_freq) CK(hipMemcpyAsync(d_freq, h_freq, n_frames * sizeof(float), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, n_frames, h_freq ? d_freq : nullptr, d_bits, d_corr, d_fft, 0, s))) return st;
+    if ((st = dabgpu_ofdm_phase_update(c, d_corr, n_frames, 0.0f, d_total, nullptr, s))) return st;
+    CK(hipMemcpyAsync(h_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
+    if (h_total_phase) CK(hipMemcpyAsync(h_total_phase, d_total, n_frames * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h_fft) CK(hipMemcpyAsync(h_fft, d_fft, fft_bytes, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+#undef CK
+    return DABGPU_OK;
+}
+
+}  // extern "C"
+
+// grow-only scratch slots owned by the context (never shrinks; freed in dabgpu_destroy)
+int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out) {
+    if ((size_t)slot >= c->scratch.size()) { c->scratch.resize(slot + 1, nullptr); c->scratch_bytes.resize(slot + 1, 0); }
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
+        int st = dabgpu_check_hip(hipMalloc(&c->scratch[slot], bytes), "hipMalloc(scratch)");
+        if (st) return st;
+        c->scratch_bytes[slot] = bytes;
+    }
+    *out = c->scratch[slot];
+    return DABGPU_OK;
+}

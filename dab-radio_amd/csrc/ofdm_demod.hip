@@ -1,0 +1,371 @@
+// ofdm_demod.hip -- gfx950 kernels for the OFDM half of the hot path.
+//
+// ofdm_demod_kernel: one 256-thread workgroup walks a run of consecutive OFDM symbols of one frame.
+// Per symbol, entirely on-chip between one coalesced HBM read of the 2552 IQ samples and one
+// coalesced HBM write of the 3072 soft bits:
+//   PLL (ref: src/ofdm/dsp/apply_pll.cpp:81-117 AVX+FMA arithmetic)            -> registers
+//   cyclic-prefix correlation (ref: ofdm_demodulator.cpp:768-777)               -> wave shuffle tree
+//   2048-pt FFT, Stockham 4x8x8x8 (replaces FFTW, ofdm_demodulator.cpp:891-894) -> 3 LDS exchanges
+//   DQPSK against the previous symbol kept in registers (ref: :842-865)
+//   L-inf normalise, x(-127), truncate to int8 (ref: :57-72, :867-889)
+//   frequency de-interleave (ref: :874) as a byte scatter into LDS, then 16-byte row stores.
+// The arithmetic contract (operation order, explicit FMAs, reduction tree) is the one DESIGN.md
+// section 3 states; this file is compiled with -ffp-contract=off so only the FMAs written here exist.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dabgpu {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int NB_SYMBOL_PERIOD = 2552;
+constexpr int NB_FFT = 2048;
+constexpr int NB_CP = 504;
+constexpr int NB_FRAME_SAMPLES = 196608;
+constexpr int NB_SYM_BITS = 3072;
+constexpr int NB_FRAME_BITS = 230400;
+constexpr int NB_FRAME_SYMBOLS = 76;
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+
+// ---- PLL: chebyshev sine on a (cos-arg, sin-arg) pair, FMA Horner (chebyshev_sine.h:82-107, __FMA__) ----
+__device__ __forceinline__ f2 cheb2(f2 x) {
+    const f2 z = x * x;
+    f2 b = fma2(mk2(3.20396066f, 3.20396066f), z, mk2(-14.07150173f, -14.07150173f));
+    b = fma2(b, z, mk2(38.50016403f, 38.50016403f));
+    b = fma2(b, z, mk2(-67.07687378f, -67.07687378f));
+    b = fma2(b, z, mk2(64.83583069f, 64.83583069f));
+    b = fma2(b, z, mk2(-25.13274193f, -25.13274193f));
+    const f2 c0 = z - mk2(0.25f, 0.25f);
+    return (b * c0) * x;
+}
+
+// one sample: base = dt0 + float(i4)*f (group of 4), step = (k*f + .25, k*f); v * (cos + j sin)
+__device__ __forceinline__ f2 pll1(f2 v, float base, f2 step) {
+    f2 d = mk2(base, base) + step;
+    d = d - mk2(__builtin_rintf(d.x), __builtin_rintf(d.y));
+    const f2 cs = cheb2(d);                               // (cos, sin)
+    // c32_mul_avx with FMA (x86/c32_mul.h:9-38): b0 = s*(xi, xr); y = (fma(c,xr,-b0.x), fma(c,xi,+b0.y))
+    const f2 b0 = mk2(cs.y, cs.y) * mk2(v.y, v.x);
+    return fma2(mk2(cs.x, cs.x), v, mk2(-b0.x, b0.y));
+}
+
+// x0 * conj(x1), FMA form of x86/c32_conj_mul.h:12-44
+__device__ __forceinline__ f2 conj_mul(f2 x0, f2 x1) {
+    const float a = x0.x, b = x0.y, c = x1.x, d = x1.y;
+    return mk2(fma_(b, d, a * c), fma_(b, c, -(a * d)));
+}
+
+// ---- FFT butterflies (contract identical to oracle/dab_oracle_ofdm.c dft4/dft8/cmul) ----
+__device__ __forceinline__ f2 mul_mi(f2 a) { return mk2(a.y, -a.x); }
+__device__ __forceinline__ f2 cmul(f2 b, f2 w) {
+    const f2 t = mk2(b.y, b.y) * mk2(w.y, w.x);           // (b.im*w.im, b.im*w.re)
+    return fma2(mk2(b.x, b.x), w, mk2(-t.x, t.y));
+}
+constexpr float SQRT_HALF = 0.707106769084930420f;
+__device__ __forceinline__ f2 mul_w8_1(f2 a) { return mk2((a.x + a.y) * SQRT_HALF, (a.y - a.x) * SQRT_HALF); }
+__device__ __forceinline__ f2 mul_w8_3(f2 a) { return mk2((a.y - a.x) * SQRT_HALF, -((a.x + a.y) * SQRT_HALF)); }
+
+__device__ __forceinline__ void dft4(const f2 a0, const f2 a1, const f2 a2, const f2 a3, f2& b0, f2& b1, f2& b2, f2& b3) {
+    const f2 s02 = a0 + a2, d02 = a0 - a2;
+    const f2 s13 = a1 + a3, d13 = mul_mi(a1 - a3);
+    b0 = s02 + s13; b1 = d02 + d13; b2 = s02 - s13; b3 = d02 - d13;
+}
+
+__device__ __forceinline__ void dft8(f2 (&a)[8]) {
+    const f2 c0 = a[0] + a[4], c1 = a[0] - a[4];
+    const f2 c2 = a[2] + a[6], c3 = mul_mi(a[2] - a[6]);
+    const f2 c4 = a[1] + a[5], c5 = a[1] - a[5];
+    const f2 c6 = a[3] + a[7], c7 = mul_mi(a[3] - a[7]);
+    const f2 d0 = c0 + c2, d2 = c0 - c2;
+    const f2 d1 = c1 + c3, d3 = c1 - c3;
+    const f2 d4 = c4 + c6, d6 = mul_mi(c4 - c6);
+    const f2 d5 = mul_w8_1(c5 + c7), d7 = mul_w8_3(c5 - c7);
+    a[0] = d0 + d4; a[4] = d0 - d4;
+    a[1] = d1 + d5; a[5] = d1 - d5;
+    a[2] = d2 + d6; a[6] = d2 - d6;
+    a[3] = d3 + d7; a[7] = d3 - d7;
+}
+
+// LDS exchange-buffer swizzle on float2 element indices: conflict-free for the stride-1 reads and
+// all three scattered write patterns of the Stockham passes (derivation: DESIGN.md section 4.3)
+__device__ __forceinline__ int swz(int i) { return ((i >> 4) & 7) ^ (((i >> 5) & 1) << 3); }
+
+// convert_to_viterbi_bit (ofdm_demodulator.cpp:57-72): (int8)(-x*127), truncation, NaN -> 0
+__device__ __forceinline__ int to_vbit(float x) {
+    const float v = -x * 127.0f;
+    return (v != v) ? 0 : (int)v;
+}
+
+// blockIdx -> work unit so that consecutive units (chunks of one frame share a halo symbol) sit on one XCD
+__device__ __forceinline__ int xcd_remap(int b, int G) {
+    const int nx = 8, q = G / nx, r = G % nx, x = b % nx, s = b / nx;
+    return (x < r) ? (x * (q + 1) + s) : (r * (q + 1) + (x - r) * q + s);
+}
+
+__global__ __launch_bounds__(256)
+void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset,
+                       int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
+                       const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
+                       int n_frames, int sym_per_chunk, int chunks_per_frame)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f2* bufA = reinterpret_cast<f2*>(smem);                       // 2048 x 8 B
+    f2* bufB = bufA + NB_FFT;                                     // 2048 x 8 B
+    int8_t* obuf = reinterpret_cast<int8_t*>(bufB + NB_FFT);      // 3072 B
+    f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);          // 4 x 8 B
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int unit = xcd_remap(blockIdx.x, gridDim.x);
+    const int frame = unit / chunks_per_frame;
+    const int chunk = unit % chunks_per_frame;
+    if (frame >= n_frames) return;
+
+    // DQPSK outputs [out0, out1) need FFTs of symbols [out0, out1]; the last chunk also owns the
+    // correlation of symbol 75 and (only when fft_out != nullptr) the display-only NULL symbol 76.
+    const int out0 = chunk * sym_per_chunk;
+    const int out1 = min(out0 + sym_per_chunk, NB_FRAME_SYMBOLS - 1);
+    const bool last_chunk = (out1 == NB_FRAME_SYMBOLS - 1);
+    const int sym_end = (last_chunk && fft_out != nullptr) ? NB_FRAME_SYMBOLS : out1;   // inclusive
+
+    const float f = freq_offset ? freq_offset[frame] : 0.0f;
+    const f2* fbase = iq + (size_t)frame * NB_FRAME_SAMPLES;
+
+    // ---- per-thread constants ----
+    // PLL: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
+    const int k0 = 2 * (t & 1);
+    const float ss0 = (float)k0 * f, ss1 = (float)(k0 + 1) * f;          // apply_pll.cpp:95-99
+    const f2 step0 = mk2(ss0 + 0.25f, ss0), step1 = mk2(ss1 + 0.25f, ss1);
+    float gidx[5];                                                       // float(i4) of the five float4 slots
+#pragma unroll
+    for (int k = 0; k < 4; k++) gidx[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3);
+    gidx[4] = (float)((2 * (t - 4)) & ~3);
+
+    // twiddles (tw[m] = (cos, -sin)(2 pi m / 2048))
+    f2 w1a[3], w1b[3], w2[7], w3[7];
+#pragma unroll
+    for (int k = 1; k < 4; k++) { w1a[k - 1] = tw[(2 * t) * k]; w1b[k - 1] = tw[(2 * t + 1) * k]; }
+#pragma unroll
+    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * (t >> 2) * k]; w3[k - 1] = tw[32 * (t >> 5) * k]; }
+
+    // LDS exchange addresses (float2 element indices)
+    const int wr1 = (8 * t) ^ swz(8 * t);                                // ^ k'
+    const int rd  = t ^ swz(t);                                          // + 256 j
+    const int i02 = (t & 3) + 32 * (t >> 2);
+    const int wr2 = i02 ^ ((((t >> 2) & 1) << 1) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3));
+    const int i03 = (t & 31) + 256 * (t >> 5);
+    const int wr3 = i03 ^ ((t >> 4) & 1);
+
+    // de-interleave: this thread's six active bins (slot 0 of thread 0 carries bin 768 instead of DC)
+    int pos[6];
+    {
+        const int c0 = (t == 0) ? 1535 : (767 + t);
+        pos[0] = inv_map[c0];
+        pos[1] = inv_map[1023 + t];
+        pos[2] = inv_map[1279 + t];
+        pos[3] = inv_map[t];
+        pos[4] = inv_map[256 + t];
+        pos[5] = inv_map[512 + t];
+    }
+
+    f2 prev[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
+
+    for (int i = out0; i <= sym_end; i++) {
+        const f2* sym = fbase + (size_t)i * NB_SYMBOL_PERIOD;
+        const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
+
+        // ---- coalesced loads: 16 B per lane ----
+        f4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f4*>(sym + NB_CP + 2 * t + 512 * k);
+        const bool do_corr = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+        f4 h = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (do_corr && t >= 4) h = *reinterpret_cast<const f4*>(sym + 2 * (t - 4));
+
+        // ---- PLL ----
+        f2 a[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float base = dt0 + gidx[k] * f;                        // apply_pll.cpp:103
+            a[k]     = pll1(mk2(v[k].x, v[k].y), base, step0);
+            a[4 + k] = pll1(mk2(v[k].z, v[k].w), base, step1);
+        }
+
+        // ---- cyclic prefix correlation: tail (slot k=3) x conj(head) ----
+        if (do_corr) {                                                   // uniform per workgroup
+            f2 p = mk2(0.0f, 0.0f);
+            if (t >= 4) {
+                const float base = dt0 + gidx[4] * f;
+                const f2 h0 = pll1(mk2(h.x, h.y), base, step0);
+                const f2 h1 = pll1(mk2(h.z, h.w), base, step1);
+                p = conj_mul(a[3], h0) + conj_mul(a[7], h1);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                p.x += __shfl_xor(p.x, off);
+                p.y += __shfl_xor(p.y, off);
+            }
+            if (lane == 0) red[wave] = p;
+        }
+
+        // ---- pass 1: radix 4 (p = 2t and 2t+1), write y[8t + k'] ----
+        {
+            f2 b0, b1, b2, b3;
+            dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
+            bufA[wr1 ^ 0] = b0;
+            bufA[wr1 ^ 1] = cmul(b1, w1a[0]);
+            bufA[wr1 ^ 2] = cmul(b2, w1a[1]);
+            bufA[wr1 ^ 3] = cmul(b3, w1a[2]);
+            dft4(a[4], a[5], a[6], a[7], b0, b1, b2, b3);
+            bufA[wr1 ^ 4] = b0;
+            bufA[wr1 ^ 5] = cmul(b1, w1b[0]);
+            bufA[wr1 ^ 6] = cmul(b2, w1b[1]);
+            bufA[wr1 ^ 7] = cmul(b3, w1b[2]);
+        }
+        __syncthreads();
+        if (do_corr && t == 0) {
+            const f2 r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+            cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
+        }
+
+        // ---- pass 2: radix 8, n=512, s=4 ----
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = bufA[rd + 256 * j];
+        dft8(a);
+        bufB[wr2] = a[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) bufB[wr2 ^ ((4 * k) ^ (k >> 2))] = cmul(a[k], w2[k - 1]);
+        __syncthreads();
+
+        // ---- pass 3: radix 8, n=64, s=32 ----
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = bufB[rd + 256 * j];
+        dft8(a);
+        bufA[wr3] = a[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++)
+            bufA[wr3 ^ ((32 * k) ^ ((k & 1) * 10) ^ (((k >> 1) & 1) << 2))] = cmul(a[k], w3[k - 1]);
+        __syncthreads();
+
+        // ---- pass 4: radix 8, n=8, s=256 : thread t ends with bins t + 256 k ----
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = bufA[rd + 256 * j];
+        dft8(a);
+
+        if (fft_out != nullptr) {
+            f2* dst = fft_out + ((size_t)frame * (NB_FRAME_SYMBOLS + 1) + i) * NB_FFT + t;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[256 * k] = a[k];
+        }
+
+        f2 cur[6];
+        cur[0] = (t == 0) ? a[3] : a[0];
+        cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
+
+        if (i > out0 && i < NB_FRAME_SYMBOLS) {
+            // ---- DQPSK (X_{i-1} * conj(X_i)) + soft bits, scattered to their de-interleaved positions ----
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const f2 d = conj_mul(prev[k], cur[k]);
+                const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
+                const float A = (ar < ai) ? ai : ar;
+                const float nr = d.x / A, ni = d.y / A;
+                obuf[pos[k]] = (int8_t)to_vbit(nr);
+                obuf[pos[k] + 1536] = (int8_t)to_vbit(-ni);
+            }
+            __syncthreads();
+            if (t < NB_SYM_BITS / 16) {
+                const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
+                uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * NB_FRAME_BITS + (size_t)(i - 1) * NB_SYM_BITS);
+                dst[t] = o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = cur[k];
+    }
+}
+
+// ---- deterministic atan2 (same operation sequence as the oracle's dab_atan2f) ----
+__device__ __forceinline__ float atan2_det(float y, float x) {
+    const float PI_F = 3.14159274101257324f, PIO2_F = 1.57079637050628662f, PIO4_F = 0.785398185253143311f;
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = (ax > ay) ? ax : ay;
+    const float mn = (ax > ay) ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float base = 0.0f;
+    if (a > 0.4142135679721832f) { base = PIO4_F; a = (a - 1.0f) / (a + 1.0f); }
+    const float z = a * a;
+    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fma_(p, z, 1.99777106478e-1f);
+    p = fma_(p, z, -3.33329491539e-1f);
+    float r = fma_(p * z, a, a);
+    r = base + r;
+    if (ay > ax) r = PIO2_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// one thread per frame: sequential sum of the 76 per-symbol phase errors, then the fine-frequency IIR
+// (ofdm_demodulator.cpp:606-618, :779-824, :829-840)
+__global__ __launch_bounds__(64)
+void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
+                       float* __restrict__ total_phase, float* __restrict__ fine_freq)
+{
+    const int fr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fr >= n_frames) return;
+    const f2* c = cp_corr + (size_t)fr * NB_FRAME_SYMBOLS;
+    float total = 0.0f;
+    for (int i = 0; i < NB_FRAME_SYMBOLS; i++) {
+        const f2 v = c[i];
+        total += atan2_det(v.y, v.x);
+    }
+    if (total_phase) total_phase[fr] = total;
+    if (fine_freq) {
+        const float TWO_PI = 3.14159274101257324f * 2.0f;
+        const float avg = total / (float)NB_FRAME_SYMBOLS;
+        const float spacing = 1.0f / (float)NB_FFT;
+        const float err = spacing * avg / TWO_PI;
+        const float delta = -beta * err;
+        const float wrap = 0.5f * spacing * 1.01f;
+        float fine = fine_freq[fr] + delta;
+        fine = fmodf(fine, wrap);
+        fine_freq[fr] = fine;
+    }
+}
+
+}  // namespace dabgpu
+
+// ---- launchers (called from dabgpu_abi.hip) ----
+extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+                                               float* d_fft, const float* d_tw, const uint16_t* d_inv_map,
+                                               int n_frames, int sym_per_chunk, hipStream_t stream)
+{
+    using namespace dabgpu;
+    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
+    const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
+    const size_t lds = 2 * NB_FFT * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
+    const dim3 grid((unsigned)(n_frames * chunks));
+    hipLaunchKernelGGL(ofdm_demod_kernel, grid, dim3(256), lds, stream,
+                       reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr),
+                       reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(d_tw), d_inv_map,
+                       n_frames, sym_per_chunk, chunks);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
+                                               float* d_fine_freq, hipStream_t stream)
+{
+    using namespace dabgpu;
+    const dim3 grid((unsigned)((n_frames + 63) / 64));
+    hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
+                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq);
+    return hipGetLastError();
+}

@@ -1,0 +1,175 @@
+"""dabgpu -- thin ctypes binding over the C ABI in include/dabgpu.h (dab-radio_amd/libdabgpu.so).
+
+This is plumbing for tests and bench.py: device memory comes from torch tensors (or any object with
+`data_ptr()`), the compute is the hand-written HIP in dab-radio_amd/csrc.  There is NO CPU fallback:
+if the shared library is missing or no gfx950 device is present, calls raise DabGpuError.
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_ROOT, "libdabgpu.so")
+
+NB_FRAME_SYMBOLS = 76
+NB_SYMBOL_PERIOD = 2552
+NB_NULL_PERIOD = 2656
+NB_FFT = 2048
+NB_CP = 504
+NB_CARRIERS = 1536
+NB_FRAME_SAMPLES = 196608
+NB_SYM_BITS = 3072
+NB_FRAME_BITS = 230400
+NB_FIC_BITS = 9216
+NB_FIB_GROUP_BITS = 2304
+NB_CIF_BITS = 55296
+
+# every symbol include/dabgpu.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = [
+    "dabgpu_strerror", "dabgpu_last_error", "dabgpu_abi_version", "dabgpu_device_count",
+    "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize",
+    "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
+    "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync",
+]
+
+
+class DabGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libdabgpu.so; loud failure when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DabGpuError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dab-radio_amd/csrc` (no CPU fallback exists)")
+        # torch bundles its own libamdhip64.so.7; when torch is in the process it must be the one HIP runtime
+        # (same SONAME as /opt/rocm's): import it first so libdabgpu.so binds to the already-loaded copy and
+        # tensors, streams and our kernels share one runtime.  Stand-alone C/C++ users link /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        L.dabgpu_strerror.restype = C.c_char_p
+        L.dabgpu_strerror.argtypes = [C.c_int]
+        L.dabgpu_last_error.restype = C.c_char_p
+        L.dabgpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
+        L.dabgpu_destroy.argtypes = [C.c_void_p]
+        L.dabgpu_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+        L.dabgpu_get_prs_fft_ref.argtypes = [C.c_int, C.c_void_p]
+        L.dabgpu_get_carrier_mapper.argtypes = [C.c_int, C.c_void_p]
+        L.dabgpu_get_fft_twiddles.argtypes = [C.c_void_p]
+        L.dabgpu_ofdm_demod_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+        L.dabgpu_ofdm_demod_frames_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        L = lib()
+        raise DabGpuError(f"{what}: {L.dabgpu_strerror(status).decode()} -- {L.dabgpu_last_error().decode()}")
+
+
+def _ptr(x):
+    """device/host pointer of a torch tensor, numpy array, int or None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if hasattr(x, "ctypes"):
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError(f"cannot take a pointer of {type(x)}")
+
+
+def device_count():
+    return lib().dabgpu_device_count()
+
+
+def host_tables():
+    """(prs_fft_ref complex64[2048], carrier_mapper int32[1536], twiddles complex64[2048]) from the product's host code"""
+    import numpy as np
+    prs = np.zeros(NB_FFT, dtype=np.complex64)
+    mapper = np.zeros(NB_CARRIERS, dtype=np.int32)
+    tw = np.zeros(NB_FFT, dtype=np.complex64)
+    check(lib().dabgpu_get_prs_fft_ref(1, _ptr(prs)), "get_prs_fft_ref")
+    check(lib().dabgpu_get_carrier_mapper(1, _ptr(mapper)), "get_carrier_mapper")
+    check(lib().dabgpu_get_fft_twiddles(_ptr(tw)), "get_fft_twiddles")
+    return prs, mapper, tw
+
+
+class Context:
+    """One device + constant tables (dabgpu_create / dabgpu_destroy)."""
+
+    def __init__(self, device=0, prs_fft_ref=None, carrier_mapper=None):
+        import numpy as np
+        self._h = C.c_void_p()
+        prs = None if prs_fft_ref is None else np.ascontiguousarray(prs_fft_ref, dtype=np.complex64)
+        mp = None if carrier_mapper is None else np.ascontiguousarray(carrier_mapper, dtype=np.int32)
+        check(lib().dabgpu_create(C.byref(self._h), device, _ptr(prs), _ptr(mp)), "dabgpu_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            except Exception:
+                pass
+            return None
+        return C.c_void_p(int(stream))
+
+    def synchronize(self, stream=None):
+        check(lib().dabgpu_synchronize(self._h, self._stream(stream)), "dabgpu_synchronize")
+
+    def ofdm_demod_frames(self, iq, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0,
+                          n_frames=None, stream=None):
+        """Launch the fused PLL+CP-phase+FFT+DQPSK+demap kernel on device buffers (asynchronous)."""
+        if n_frames is None:
+            n_frames = iq.numel() // NB_FRAME_SAMPLES if hasattr(iq, "numel") else None
+        check(lib().dabgpu_ofdm_demod_frames(self._h, _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits),
+                                             _ptr(cp_corr), _ptr(fft), symbols_per_block, self._stream(stream)),
+              "dabgpu_ofdm_demod_frames")
+
+    def ofdm_phase_update(self, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):
+        check(lib().dabgpu_ofdm_phase_update(self._h, _ptr(cp_corr), n_frames, beta, _ptr(total_phase),
+                                             _ptr(fine_freq), self._stream(stream)), "dabgpu_ofdm_phase_update")
+
+    def ofdm_demod_frames_host(self, iq, freq_offset=None, want_fft=False):
+        """numpy in / numpy out convenience over dabgpu_ofdm_demod_frames_host_sync"""
+        import numpy as np
+        iq = np.ascontiguousarray(iq, dtype=np.complex64).reshape(-1)
+        n = iq.size // NB_FRAME_SAMPLES
+        assert n * NB_FRAME_SAMPLES == iq.size
+        f = None if freq_offset is None else np.ascontiguousarray(freq_offset, dtype=np.float32).reshape(-1)
+        bits = np.empty((n, NB_FRAME_BITS), dtype=np.int8)
+        total = np.empty(n, dtype=np.float32)
+        fft = np.empty((n, 77, NB_FFT), dtype=np.complex64) if want_fft else None
+        check(lib().dabgpu_ofdm_demod_frames_host_sync(self._h, _ptr(iq), n, _ptr(f), _ptr(bits), _ptr(total),
+                                                       _ptr(fft)), "dabgpu_ofdm_demod_frames_host_sync")
+        return bits, total, fft

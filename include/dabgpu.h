@@ -1,0 +1,118 @@
+/*
+ * dabgpu.h -- C ABI of the MI355X-native DAB OFDM-demodulation + channel-decode hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, `int` status
+ * returns (0 = ok, see dabgpu_strerror), no exceptions cross it.  Each entry point names the
+ * reference interface (williamyang98/DAB-Radio @ 2025-08-29, paths relative to the repo root)
+ * it replaces.  Host-side C++ classes with the reference's own names and signatures
+ * (OFDM_Demod, FIC_Decoder, MSC_Decoder, DAB_Viterbi_Decoder, CIF_Deinterleaver) are layered on
+ * top of this ABI in dab-radio_amd/host/ ; INTEGRATION.md shows how basic_radio links them.
+ *
+ * Pointers prefixed d_ are DEVICE pointers (hipMalloc / torch tensor data_ptr), h_ are host.
+ * `stream` is a hipStream_t passed as void* (NULL = the context's own stream).  All launches are
+ * asynchronous on that stream unless the function name ends in _sync.
+ *
+ * All functions fail with DABGPU_ERR_NO_DEVICE when no gfx950 device is usable: there is no CPU
+ * fallback behind this ABI.
+ */
+#ifndef DABGPU_H
+#define DABGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABGPU_ABI_VERSION 1
+
+/* Mode I geometry (src/ofdm/dab_ofdm_params_ref.cpp:13-21, src/dab/constants/dab_parameters.h:31-40) */
+#define DABGPU_NB_FRAME_SYMBOLS 76
+#define DABGPU_NB_SYMBOL_PERIOD 2552
+#define DABGPU_NB_NULL_PERIOD   2656
+#define DABGPU_NB_FFT           2048
+#define DABGPU_NB_CYCLIC_PREFIX 504
+#define DABGPU_NB_DATA_CARRIERS 1536
+#define DABGPU_NB_FRAME_SAMPLES 196608
+#define DABGPU_NB_SYM_BITS      3072
+#define DABGPU_NB_FRAME_BITS    230400
+#define DABGPU_NB_FIC_BITS      9216
+#define DABGPU_NB_FIB_GROUP_BITS 2304
+#define DABGPU_NB_CIF_BITS      55296
+#define DABGPU_NB_CIFS          4
+
+enum {
+    DABGPU_OK = 0,
+    DABGPU_ERR_NO_DEVICE = 1,      /* no HIP device / not gfx950 / runtime missing */
+    DABGPU_ERR_INVALID_ARG = 2,
+    DABGPU_ERR_HIP = 3,            /* a HIP call failed; text via dabgpu_last_error() */
+    DABGPU_ERR_NOT_READY = 4,      /* e.g. time de-interleaver has fewer than 16 CIFs */
+    DABGPU_ERR_UNSUPPORTED = 5     /* transmission mode other than I */
+};
+
+typedef struct dabgpu_ctx dabgpu_ctx;
+
+const char *dabgpu_strerror(int status);
+const char *dabgpu_last_error(void);          /* thread-local detail of the last failure */
+int dabgpu_abi_version(void);
+/* number of usable gfx950 devices (0 when none; never initialises a HIP context on failure) */
+int dabgpu_device_count(void);
+
+/*
+ * Context = one device + its constant tables (FFT twiddles, inverse carrier map, conj(PRS), coarse-sync
+ * time reference).  Replaces the constructor-time work of OFDM_Demod::OFDM_Demod
+ * (src/ofdm/ofdm_demodulator.cpp:80-146): h_prs_fft_ref is get_DAB_PRS_reference() output
+ * (2048 complex float, interleaved re/im), h_carrier_mapper is get_DAB_mapper_ref() output (1536 int).
+ * Passing NULL for either uses the built-in Mode I tables.
+ */
+int dabgpu_create(dabgpu_ctx **out, int device, const float *h_prs_fft_ref, const int *h_carrier_mapper);
+void dabgpu_destroy(dabgpu_ctx *ctx);
+int dabgpu_synchronize(dabgpu_ctx *ctx, void *stream);
+
+/* Built-in Mode I tables, host side (replace get_DAB_PRS_reference src/ofdm/dab_prs_ref.cpp:140,
+ * get_DAB_mapper_ref src/ofdm/dab_mapper_ref.cpp:10, and expose the FFT twiddle table of the arithmetic contract) */
+int dabgpu_get_prs_fft_ref(int transmission_mode, float *h_out /*[2*2048]*/);
+int dabgpu_get_carrier_mapper(int transmission_mode, int *h_out /*[1536]*/);
+int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
+
+/* ------------------------------------------------------------------------------------------------
+ * OFDM demodulation of frame-aligned frames: PLL + cyclic-prefix phase error + 2048-pt FFT + DQPSK +
+ * frequency de-interleave + soft-bit quantisation, batched over frames.
+ * Replaces OFDM_Demod::PipelineThread (src/ofdm/ofdm_demodulator.cpp:650-766) and its callees
+ * ApplyPLL, CalculateCyclicPhaseError, CalculateFFT, CalculateDQPSK, CalculateViterbiBits.
+ *
+ *   d_iq          [n_frames][196608] complex float; frame layout = OFDM_Frame_Buffer's logical layout
+ *                 (src/ofdm/ofdm_frame_buffer.h:87-99): 76 symbols x 2552 samples (PRS first) then the
+ *                 NULL symbol (2656).  16-byte aligned.
+ *   d_freq_offset [n_frames] net normalised frequency offset used by the PLL (coarse + fine), may be NULL (= 0)
+ *   d_bits        [n_frames][230400] int8 soft bits, layout of On_OFDM_Frame() (ofdm_demodulator.cpp:635)
+ *   d_cp_corr     [n_frames][76] complex float raw cyclic-prefix correlation per symbol, may be NULL
+ *   d_fft         [n_frames][77][2048] complex float = GetFrameFFT() content, may be NULL (skips the
+ *                 display-only NULL-symbol FFT, ofdm_demodulator.cpp:701-709)
+ *   symbols_per_block  data symbols handled by one workgroup (0 = default); any value gives identical results
+ */
+int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_frames, const float *d_freq_offset,
+                             int8_t *d_bits, float *d_cp_corr, float *d_fft, int symbols_per_block, void *stream);
+
+/*
+ * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]
+ * (sequential, i = 0..75), and optionally fine <- fmod(fine - beta*err, wrap).
+ * Replaces OFDM_Demod::CoordinatorThread's phase section (ofdm_demodulator.cpp:606-618) +
+ * CalculateFineFrequencyError (:779-824) + UpdateFineFrequencyOffset (:829-840).
+ *   d_cp_corr     [n_frames][76] complex float (from dabgpu_ofdm_demod_frames)
+ *   d_total_phase [n_frames] out, may be NULL
+ *   d_fine_freq   [n_frames] in/out, may be NULL (no update)
+ */
+int dabgpu_ofdm_phase_update(dabgpu_ctx *ctx, const float *d_cp_corr, size_t n_frames, float fine_freq_update_beta,
+                             float *d_total_phase, float *d_fine_freq, void *stream);
+
+/* Host-buffer convenience: H2D of the frames, demod, D2H of bits (+ totals); synchronous.
+ * h_total_phase may be NULL. This is what the single-stream OFDM_Demod mirror class calls per frame. */
+int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx *ctx, const float *h_iq, size_t n_frames, const float *h_freq_offset,
+                                       int8_t *h_bits, float *h_total_phase, float *h_fft);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DABGPU_H */

@@ -282,7 +282,7 @@ uint64_t dab_msc_decode_logical(const dab_subchannel *sc, const int8_t *bits, in
     dab_viterbi *v = dab_viterbi_create(n, tie_rule);                /* msc_decoder.cpp:37 */
     size_t pos = 0;
     for (int i = 0; i < nseg; i++) {
-        if (lx[i] == 0 && sc->is_uep) { /* update with 0 requested symbols consumes nothing */ continue; }
+        if (lx[i] == 0) continue;   /* update() with 0 requested symbols consumes nothing */
         pos += dab_viterbi_update(v, bits + pos, n - pos, dab_puncture_code(pi[i]), 8, (size_t)128 * lx[i]);
     }
     pos += dab_viterbi_update(v, bits + pos, n - pos, PI_X_CODE, 6, 24);
@@ -375,6 +375,7 @@ void dab_msc_encode_logical(const dab_subchannel *sc, const uint8_t *bytes_in, u
     dab_conv_encode(bytes, (size_t)nb * 8, mother);
     size_t o = 0, m = 0;
     for (int i = 0; i < nseg; i++) {
+        if (lx[i] == 0) continue;
         o += dab_puncture(mother + m, (size_t)128 * lx[i], dab_puncture_code(pi[i]), 8, out_bits + o);
         m += (size_t)128 * lx[i];
     }
