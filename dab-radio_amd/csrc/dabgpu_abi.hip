@@ -177,7 +177,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
 
 int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
     if (!c) return DABGPU_ERR_INVALID_ARG;
-    return dabgpu_check_hip(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream), "hipStreamSynchronize");
+    return dabgpu_check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
 }
 
 // ---- OFDM ----
@@ -187,7 +187,7 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, 
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
     if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_demod_frames: d_iq and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;      // NULL = the HIP default (null) stream
     float* corr = d_cp_corr;
     if (!corr) {     // the kernel always produces the correlation; park it in context scratch when unwanted
         int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
@@ -201,7 +201,7 @@ int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_fra
                              float* d_fine_freq, void* stream) {
     if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, s),
                             "ofdm_phase_kernel launch");
 }

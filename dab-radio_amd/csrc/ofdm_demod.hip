@@ -1,23 +1,33 @@
 // ofdm_demod.hip -- gfx950 kernels for the OFDM half of the hot path.
 //
 // ofdm_demod_kernel: one 256-thread workgroup walks a run of consecutive OFDM symbols of one frame.
-// Per symbol, entirely on-chip between one coalesced HBM read of the 2552 IQ samples and one
-// coalesced HBM write of the 3072 soft bits:
-//   PLL (ref: src/ofdm/dsp/apply_pll.cpp:81-117 AVX+FMA arithmetic)            -> registers
+// Per symbol, entirely on-chip between one coalesced HBM read of the 2552 IQ samples (16 B per lane)
+// and one coalesced HBM write of the 3072 soft bits (16 B per lane):
+//   PLL (ref: src/ofdm/dsp/apply_pll.cpp:81-117, AVX+FMA arithmetic)            -> registers
 //   cyclic-prefix correlation (ref: ofdm_demodulator.cpp:768-777)               -> wave shuffle tree
-//   2048-pt FFT, Stockham 4x8x8x8 (replaces FFTW, ofdm_demodulator.cpp:891-894) -> 3 LDS exchanges
+//   2048-pt FFT = 4x8x8x8 butterflies (replaces FFTW, ofdm_demodulator.cpp:891-894)
+//        exchange 1 crosses waves (LDS + one __syncthreads); exchanges 2 and 3 are 8x8 transposes
+//        between lane-index bits and the register index inside a wave (wave-private LDS patch)
 //   DQPSK against the previous symbol kept in registers (ref: :842-865)
 //   L-inf normalise, x(-127), truncate to int8 (ref: :57-72, :867-889)
 //   frequency de-interleave (ref: :874) as a byte scatter into LDS, then 16-byte row stores.
+//
 // The arithmetic contract (operation order, explicit FMAs, reduction tree) is the one DESIGN.md
-// section 3 states; this file is compiled with -ffp-contract=off so only the FMAs written here exist.
+// section 3 states; this file is compiled with -ffp-contract=off -fno-slp-vectorize so only the FMAs
+// written here exist and nothing is re-associated.  Complex values are kept as two scalar floats on
+// purpose: on gfx950 a packed fp32 op (v_pk_*) issues at half the rate of a scalar one (measured with
+// tools/ubench/valu_rate.hip), so packing buys no ALU throughput and costs operand-pairing moves and
+// hazard nops (A/B: 0.51 ms packed vs 0.46 ms scalar per 1024 frames, profiles/r01/README.md).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace dabgpu {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+struct alignas(8) f2 { float x, y; };
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
 
 constexpr int NB_SYMBOL_PERIOD = 2552;
 constexpr int NB_FFT = 2048;
@@ -26,10 +36,11 @@ constexpr int NB_FRAME_SAMPLES = 196608;
 constexpr int NB_SYM_BITS = 3072;
 constexpr int NB_FRAME_BITS = 230400;
 constexpr int NB_FRAME_SYMBOLS = 76;
+constexpr int WAVE_PATCH = 576;          // float2 elements per wave transpose patch (8 rows x 72, padded)
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{fma_(a.x, b.x, c.x), fma_(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f2 mk2(float a, float b) { return f2{a, b}; }
 
 // ---- PLL: chebyshev sine on a (cos-arg, sin-arg) pair, FMA Horner (chebyshev_sine.h:82-107, __FMA__) ----
 __device__ __forceinline__ f2 cheb2(f2 x) {
@@ -49,8 +60,8 @@ __device__ __forceinline__ f2 pll1(f2 v, float base, f2 step) {
     d = d - mk2(__builtin_rintf(d.x), __builtin_rintf(d.y));
     const f2 cs = cheb2(d);                               // (cos, sin)
     // c32_mul_avx with FMA (x86/c32_mul.h:9-38): b0 = s*(xi, xr); y = (fma(c,xr,-b0.x), fma(c,xi,+b0.y))
-    const f2 b0 = mk2(cs.y, cs.y) * mk2(v.y, v.x);
-    return fma2(mk2(cs.x, cs.x), v, mk2(-b0.x, b0.y));
+    const float b0x = cs.y * v.y, b0y = cs.y * v.x;
+    return mk2(fma_(cs.x, v.x, -b0x), fma_(cs.x, v.y, b0y));
 }
 
 // x0 * conj(x1), FMA form of x86/c32_conj_mul.h:12-44
@@ -62,8 +73,8 @@ __device__ __forceinline__ f2 conj_mul(f2 x0, f2 x1) {
 // ---- FFT butterflies (contract identical to oracle/dab_oracle_ofdm.c dft4/dft8/cmul) ----
 __device__ __forceinline__ f2 mul_mi(f2 a) { return mk2(a.y, -a.x); }
 __device__ __forceinline__ f2 cmul(f2 b, f2 w) {
-    const f2 t = mk2(b.y, b.y) * mk2(w.y, w.x);           // (b.im*w.im, b.im*w.re)
-    return fma2(mk2(b.x, b.x), w, mk2(-t.x, t.y));
+    const float t0 = b.y * w.y, t1 = b.y * w.x;          // (b.im*w.im, b.im*w.re)
+    return mk2(fma_(b.x, w.x, -t0), fma_(b.x, w.y, t1));
 }
 constexpr float SQRT_HALF = 0.707106769084930420f;
 __device__ __forceinline__ f2 mul_w8_1(f2 a) { return mk2((a.x + a.y) * SQRT_HALF, (a.y - a.x) * SQRT_HALF); }
@@ -90,33 +101,43 @@ __device__ __forceinline__ void dft8(f2 (&a)[8]) {
     a[3] = d3 + d7; a[7] = d3 - d7;
 }
 
-// LDS exchange-buffer swizzle on float2 element indices: conflict-free for the stride-1 reads and
-// all three scattered write patterns of the Stockham passes (derivation: DESIGN.md section 4.3)
-__device__ __forceinline__ int swz(int i) { return ((i >> 4) & 7) ^ (((i >> 5) & 1) << 3); }
-
-// convert_to_viterbi_bit (ofdm_demodulator.cpp:57-72): (int8)(-x*127), truncation, NaN -> 0
+// convert_to_viterbi_bit (ofdm_demodulator.cpp:57-72): (int8)(-x*127); v_cvt_i32_f32 truncates and maps NaN to 0
 __device__ __forceinline__ int to_vbit(float x) {
     const float v = -x * 127.0f;
-    return (v != v) ? 0 : (int)v;
+    return (int)v;
 }
 
 // blockIdx -> work unit so that consecutive units (chunks of one frame share a halo symbol) sit on one XCD
+// (blocks are dealt round-robin to the 8 XCDs, each with a private L2)
 __device__ __forceinline__ int xcd_remap(int b, int G) {
     const int nx = 8, q = G / nx, r = G % nx, x = b % nx, s = b / nx;
     return (x < r) ? (x * (q + 1) + s) : (r * (q + 1) + (x - r) * q + s);
 }
 
-__global__ __launch_bounds__(256)
+// wave-private LDS hand-off: order this wave's LDS writes before its later reads for the compiler; the LDS unit
+// itself executes one wave's instructions in order, so no s_barrier is involved
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// In-place decimation-in-frequency view of the 4x8x8x8 factorisation: after the radix-4 pass the transform splits
+// into four independent 512-point problems, one per wave.  Thread (w, l) ends holding bins
+//   Kb + 256*k,  Kb = w + 4*(l>>3) + 32*(l&7),  k = 0..7
+// of which k in {0,1,2,5,6,7} are data carriers (thread 0: DC is replaced by bin 768, its k = 3).
+template <bool PREFETCH>
+__global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
                        const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f2* bufA = reinterpret_cast<f2*>(smem);                       // 2048 x 8 B
-    f2* bufB = bufA + NB_FFT;                                     // 2048 x 8 B
-    int8_t* obuf = reinterpret_cast<int8_t*>(bufB + NB_FFT);      // 3072 B
-    f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);          // 4 x 8 B
+    f2* bufA = reinterpret_cast<f2*>(smem);                              // 2048 x 8 B, position-indexed
+    f2* patch0 = bufA + NB_FFT;                                          // 4 x WAVE_PATCH x 8 B
+    int8_t* obuf = reinterpret_cast<int8_t*>(patch0 + 4 * WAVE_PATCH);   // 3072 B
+    f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 4 x 8 B
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -135,58 +156,62 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
     const float f = freq_offset ? freq_offset[frame] : 0.0f;
     const f2* fbase = iq + (size_t)frame * NB_FRAME_SAMPLES;
 
-    // ---- per-thread constants ----
-    // PLL: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
+    // PLL constants: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
     const int k0 = 2 * (t & 1);
     const float ss0 = (float)k0 * f, ss1 = (float)(k0 + 1) * f;          // apply_pll.cpp:95-99
     const f2 step0 = mk2(ss0 + 0.25f, ss0), step1 = mk2(ss1 + 0.25f, ss1);
-    float gidx[5];                                                       // float(i4) of the five float4 slots
+    float gidx[5];                                                       // float(i4) of the five 16-byte slots
 #pragma unroll
     for (int k = 0; k < 4; k++) gidx[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3);
     gidx[4] = (float)((2 * (t - 4)) & ~3);
 
-    // twiddles (tw[m] = (cos, -sin)(2 pi m / 2048))
+    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1), pass 2 w_512^{lane k},
+    // pass 3 w_64^{(lane&7) k}; resident in registers for the whole run of symbols
     f2 w1a[3], w1b[3], w2[7], w3[7];
 #pragma unroll
     for (int k = 1; k < 4; k++) { w1a[k - 1] = tw[(2 * t) * k]; w1b[k - 1] = tw[(2 * t + 1) * k]; }
 #pragma unroll
-    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * (t >> 2) * k]; w3[k - 1] = tw[32 * (t >> 5) * k]; }
+    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
 
-    // LDS exchange addresses (float2 element indices)
-    const int wr1 = (8 * t) ^ swz(8 * t);                                // ^ k'
-    const int rd  = t ^ swz(t);                                          // + 256 j
-    const int i02 = (t & 3) + 32 * (t >> 2);
-    const int wr2 = i02 ^ ((((t >> 2) & 1) << 1) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3));
-    const int i03 = (t & 31) + 256 * (t >> 5);
-    const int wr3 = i03 ^ ((t >> 4) & 1);
+    // LDS addresses (float2 element indices); every per-k term below is an instruction immediate
+    f2* patch = patch0 + wave * WAVE_PATCH;
+    const int la = lane & 7, lb = lane >> 3;
+    const int rd2 = lane + 512 * wave;            // pass-2 inputs: + 64 j           (stride-1 across lanes)
+    const int ta_w = lane;                        // transpose A write: + 72 r       (element a + 8b + 72r)
+    const int ta_r = la + 72 * lb;                // transpose A read : + 8 r'       (element a + 8r' + 72b')
+    const int tb_w = la + 72 * lb;                // transpose B write: + 9 r        (element a + 9r + 72b)
+    const int tb_r = 9 * la + 72 * lb;            // transpose B read : + r'         (element r' + 9a' + 72b)
 
-    // de-interleave: this thread's six active bins (slot 0 of thread 0 carries bin 768 instead of DC)
+    // de-interleave positions of this thread's six active bins Kb + 256*{0,1,2,5,6,7}
+    const int Kb = wave + 4 * lb + 32 * la;
     int pos[6];
-    {
-        const int c0 = (t == 0) ? 1535 : (767 + t);
-        pos[0] = inv_map[c0];
-        pos[1] = inv_map[1023 + t];
-        pos[2] = inv_map[1279 + t];
-        pos[3] = inv_map[t];
-        pos[4] = inv_map[256 + t];
-        pos[5] = inv_map[512 + t];
-    }
+    pos[0] = inv_map[(Kb == 0) ? 1535 : (767 + Kb)];
+    pos[1] = inv_map[1023 + Kb];
+    pos[2] = inv_map[1279 + Kb];
+    pos[3] = inv_map[Kb];
+    pos[4] = inv_map[256 + Kb];
+    pos[5] = inv_map[512 + Kb];
 
     f2 prev[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
 
-    for (int i = out0; i <= sym_end; i++) {
+    // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head
+    auto load_symbol = [&](int i, f4 (&v)[4], f4& h) {
         const f2* sym = fbase + (size_t)i * NB_SYMBOL_PERIOD;
-        const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
-
-        // ---- coalesced loads: 16 B per lane ----
-        f4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f4*>(sym + NB_CP + 2 * t + 512 * k);
+        const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+        h = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (dc && t >= 4) h = *reinterpret_cast<const f4*>(sym + 2 * (t - 4));
+    };
+    f4 v[4], h;
+    if constexpr (PREFETCH) load_symbol(out0, v, h);
+
+    for (int i = out0; i <= sym_end; i++) {
+        const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
+        if constexpr (!PREFETCH) load_symbol(i, v, h);
         const bool do_corr = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
-        f4 h = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (do_corr && t >= 4) h = *reinterpret_cast<const f4*>(sym + 2 * (t - 4));
 
         // ---- PLL ----
         f2 a[8];
@@ -197,7 +222,7 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
             a[4 + k] = pll1(mk2(v[k].z, v[k].w), base, step1);
         }
 
-        // ---- cyclic prefix correlation: tail (slot k=3) x conj(head) ----
+        // ---- cyclic prefix correlation: tail (slot k=3) x conj(head), fixed 256-leaf tree ----
         if (do_corr) {                                                   // uniform per workgroup
             f2 p = mk2(0.0f, 0.0f);
             if (t >= 4) {
@@ -213,78 +238,79 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
             }
             if (lane == 0) red[wave] = p;
         }
+        if constexpr (PREFETCH) { if (i < sym_end) load_symbol(i + 1, v, h); }
 
-        // ---- pass 1: radix 4 (p = 2t and 2t+1), write y[8t + k'] ----
+        // ---- pass 1: radix 4 on positions p + 512 j (p = 2t, 2t+1); outputs stay in place ----
         {
-            f2 b0, b1, b2, b3;
+            f2 b0, b1, b2, b3, c0, c1, c2, c3;
             dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
-            bufA[wr1 ^ 0] = b0;
-            bufA[wr1 ^ 1] = cmul(b1, w1a[0]);
-            bufA[wr1 ^ 2] = cmul(b2, w1a[1]);
-            bufA[wr1 ^ 3] = cmul(b3, w1a[2]);
-            dft4(a[4], a[5], a[6], a[7], b0, b1, b2, b3);
-            bufA[wr1 ^ 4] = b0;
-            bufA[wr1 ^ 5] = cmul(b1, w1b[0]);
-            bufA[wr1 ^ 6] = cmul(b2, w1b[1]);
-            bufA[wr1 ^ 7] = cmul(b3, w1b[2]);
+            dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
+            b1 = cmul(b1, w1a[0]); b2 = cmul(b2, w1a[1]); b3 = cmul(b3, w1a[2]);
+            c1 = cmul(c1, w1b[0]); c2 = cmul(c2, w1b[1]); c3 = cmul(c3, w1b[2]);
+            f4* dst = reinterpret_cast<f4*>(bufA + 2 * t);
+            dst[0]   = f4{b0.x, b0.y, c0.x, c0.y};
+            dst[256] = f4{b1.x, b1.y, c1.x, c1.y};
+            dst[512] = f4{b2.x, b2.y, c2.x, c2.y};
+            dst[768] = f4{b3.x, b3.y, c3.x, c3.y};
         }
-        __syncthreads();
+        __syncthreads();                       // the only cross-wave exchange of the transform
         if (do_corr && t == 0) {
             const f2 r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
             cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
         }
 
-        // ---- pass 2: radix 8, n=512, s=4 ----
+        // ---- pass 2: radix 8 inside this wave's 512-point block ----
 #pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = bufA[rd + 256 * j];
+        for (int j = 0; j < 8; j++) a[j] = bufA[rd2 + 64 * j];
         dft8(a);
-        bufB[wr2] = a[0];
+        patch[ta_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) bufB[wr2 ^ ((4 * k) ^ (k >> 2))] = cmul(a[k], w2[k - 1]);
-        __syncthreads();
+        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
+        wave_lds_fence();
 
-        // ---- pass 3: radix 8, n=64, s=32 ----
-#pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = bufB[rd + 256 * j];
+        // ---- pass 3: radix 8 inside 64-point blocks ----
         dft8(a);
-        bufA[wr3] = a[0];
+        patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++)
-            bufA[wr3 ^ ((32 * k) ^ ((k & 1) * 10) ^ (((k >> 1) & 1) << 2))] = cmul(a[k], w3[k - 1]);
-        __syncthreads();
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3[k - 1]);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
+        wave_lds_fence();
 
-        // ---- pass 4: radix 8, n=8, s=256 : thread t ends with bins t + 256 k ----
-#pragma unroll
-        for (int j = 0; j < 8; j++) a[j] = bufA[rd + 256 * j];
+        // ---- pass 4: radix 8; thread ends with bins Kb + 256 k ----
         dft8(a);
 
         if (fft_out != nullptr) {
-            f2* dst = fft_out + ((size_t)frame * (NB_FRAME_SYMBOLS + 1) + i) * NB_FFT + t;
+            f2* dst = fft_out + ((size_t)frame * (NB_FRAME_SYMBOLS + 1) + i) * NB_FFT + Kb;
 #pragma unroll
             for (int k = 0; k < 8; k++) dst[256 * k] = a[k];
         }
 
         f2 cur[6];
-        cur[0] = (t == 0) ? a[3] : a[0];
+        cur[0] = (Kb == 0) ? a[3] : a[0];
         cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
 
-        if (i > out0 && i < NB_FRAME_SYMBOLS) {
+        const bool emit = (i > out0) && (i < NB_FRAME_SYMBOLS);
+        if (emit) {
             // ---- DQPSK (X_{i-1} * conj(X_i)) + soft bits, scattered to their de-interleaved positions ----
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const f2 d = conj_mul(prev[k], cur[k]);
                 const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
-                const float A = (ar < ai) ? ai : ar;
-                const float nr = d.x / A, ni = d.y / A;
-                obuf[pos[k]] = (int8_t)to_vbit(nr);
-                obuf[pos[k] + 1536] = (int8_t)to_vbit(-ni);
+                const float A = (ar < ai) ? ai : ar;                     // std::max, ofdm_demodulator.cpp:882
+                obuf[pos[k]] = (int8_t)to_vbit(d.x / A);
+                obuf[pos[k] + 1536] = (int8_t)to_vbit(-(d.y / A));
             }
-            __syncthreads();
-            if (t < NB_SYM_BITS / 16) {
-                const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
-                uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * NB_FRAME_BITS + (size_t)(i - 1) * NB_SYM_BITS);
-                dst[t] = o;
-            }
+        }
+        __syncthreads();       // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
+        if (emit && t < NB_SYM_BITS / 16) {
+            const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
+            uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * NB_FRAME_BITS + (size_t)(i - 1) * NB_SYM_BITS);
+            dst[t] = o;
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) prev[k] = cur[k];
@@ -344,6 +370,9 @@ void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
 }  // namespace dabgpu
 
 // ---- launchers (called from dabgpu_abi.hip) ----
+static int g_dabgpu_variant = 0;
+extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // development switch (tools/kbench.py)
+
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, hipStream_t stream)
@@ -351,12 +380,14 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d
     using namespace dabgpu;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
-    const size_t lds = 2 * NB_FFT * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
+    const size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
     const dim3 grid((unsigned)(n_frames * chunks));
-    hipLaunchKernelGGL(ofdm_demod_kernel, grid, dim3(256), lds, stream,
-                       reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr),
-                       reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(d_tw), d_inv_map,
-                       n_frames, sym_per_chunk, chunks);
+#define DABGPU_LAUNCH(PF) hipLaunchKernelGGL((ofdm_demod_kernel<PF>), grid, dim3(256), lds, stream, \
+                       reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
+                       reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
+                       n_frames, sym_per_chunk, chunks)
+    if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true); else DABGPU_LAUNCH(false);
+#undef DABGPU_LAUNCH
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_ROOT, "libdabgpu.so")
+LIB_PATH = os.environ.get("DABGPU_LIB") or os.path.join(_ROOT, "libdabgpu.so")   # DABGPU_LIB: development A/B builds
 
 NB_FRAME_SYMBOLS = 76
 NB_SYMBOL_PERIOD = 2552

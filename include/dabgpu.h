@@ -9,8 +9,9 @@
  * top of this ABI in dab-radio_amd/host/ ; INTEGRATION.md shows how basic_radio links them.
  *
  * Pointers prefixed d_ are DEVICE pointers (hipMalloc / torch tensor data_ptr), h_ are host.
- * `stream` is a hipStream_t passed as void* (NULL = the context's own stream).  All launches are
- * asynchronous on that stream unless the function name ends in _sync.
+ * `stream` is a hipStream_t passed as void* (NULL = the HIP default stream, as in HIP itself).  All launches
+ * are asynchronous on that stream unless the function name ends in _sync (those use a private stream of the
+ * context and return when the results are in host memory).
  *
  * All functions fail with DABGPU_ERR_NO_DEVICE when no gfx950 device is usable: there is no CPU
  * fallback behind this ABI.

@@ -100,6 +100,9 @@ void dab_dqpsk_demap(const dab_cf32 *fft_i, const dab_cf32 *fft_ip1, const int *
  */
 float dab_demod_frame(const dab_cf32 *frame, float freq_offset, const int *mapper,
                       int8_t *bits, dab_cf32 *cp_corr, float *cp_phase, dab_cf32 *fft_out);
+/* timing helper: n_total frame demods cycling over n_distinct frames (bits_scratch [230400]) */
+void dab_demod_frames(const dab_cf32 *frames, size_t n_distinct, size_t n_total, float freq_offset, const int *mapper,
+                      int8_t *bits_scratch, float *totals);
 /* src/ofdm/ofdm_demodulator.cpp:606-618,779-840 : fine frequency IIR update */
 float dab_update_fine_freq(float fine, float total_phase_error);
 /* fmod wrap only (UpdateFineFrequencyOffset :829-840) */

@@ -411,6 +411,15 @@ float dab_demod_frame(const dab_cf32 *frame, float f, const int *mapper,
     return total;
 }
 
+/* n back-to-back frames through dab_demod_frame (cpu_baseline timing loop: one GIL-free call per thread) */
+void dab_demod_frames(const dab_cf32 *frames, size_t n_distinct, size_t n_total, float f, const int *mapper,
+                      int8_t *bits_scratch, float *totals) {
+    for (size_t k = 0; k < n_total; k++) {
+        const float t = dab_demod_frame(frames + (k % n_distinct) * DAB_NB_FRAME_SAMPLES, f, mapper, bits_scratch, NULL, NULL, NULL);
+        if (totals) totals[k] = t;
+    }
+}
+
 /* ofdm_demodulator.cpp:829-840 */
 float dab_fine_freq_add(float fine, float delta) {
     const float spacing = 1.0f / (float)DAB_NB_FFT;

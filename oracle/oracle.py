@@ -81,6 +81,7 @@ def lib():
         L.dab_apply_pll_scalar.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float]
         L.dab_demod_frame.restype = C.c_float
         L.dab_demod_frame.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_demod_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dab_update_fine_freq.restype = C.c_float
         L.dab_update_fine_freq.argtypes = [C.c_float, C.c_float]
         L.dab_fine_freq_add.restype = C.c_float
@@ -198,6 +199,15 @@ def demod_frame(frame, freq_offset=0.0, want_fft=False, m=None):
     total = lib().dab_demod_frame(_p(frame), np.float32(freq_offset), _p(m), _p(bits), _p(corr), _p(phase),
                                   _p(fft) if want_fft else None)
     return {"bits": bits, "cp_corr": corr, "cp_phase": phase, "total_phase": np.float32(total), "fft": fft}
+
+
+def demod_frames_timing(frames, n_total, freq_offset, m=None):
+    """n_total frame demods cycling over `frames` [k,196608] in ONE C call (releases the GIL for its whole duration)"""
+    frames = c64(frames).reshape(-1, NB_FRAME_SAMPLES)
+    m = mapper() if m is None else np.ascontiguousarray(m, dtype=np.int32)
+    scratch = np.empty(NB_FRAME_BITS, dtype=np.int8)
+    lib().dab_demod_frames(_p(frames), frames.shape[0], n_total, np.float32(freq_offset), _p(m), _p(scratch), None)
+    return scratch
 
 
 def update_fine_freq(fine, total_phase):
