@@ -1,0 +1,188 @@
+// dabgpu_decode_abi.hip -- channel-decode entry points of the C ABI (include/dabgpu.h): protection-profile
+// tables, codeword descriptors, scratch sizing and launches.  Host side only; the arithmetic is in viterbi.hip.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+
+// ETSI EN 300 401 tables 8 + 15: {size CU, kbps, level, L1..L4, PI1..PI4, padding bits}; row order (and the two
+// exchanged size fields of rows 33/34) as the reference lists them, src/dab/constants/subchannel_protection_tables.h:21-86,
+// because FIG 0/1 short-form sub-channels index this table by position
+static const uint16_t UEP_ROWS[64][12] = {
+    {16,32,5,3,4,17,0,5,3,2,0,0},       {21,32,4,3,3,18,0,11,6,5,0,0},      {24,32,3,3,4,14,3,15,9,6,8,0},
+    {29,32,2,3,4,14,3,22,13,8,13,0},    {35,32,1,3,5,13,3,24,17,12,17,4},   {24,48,5,4,3,26,3,5,4,2,3,0},
+    {29,48,4,3,4,26,3,9,6,4,6,0},       {35,48,3,3,4,26,3,15,10,6,9,4},     {42,48,2,3,4,26,3,24,14,8,15,0},
+    {52,48,1,3,5,25,3,24,18,13,18,0},   {29,56,5,6,10,23,3,5,4,2,3,0},      {35,56,4,6,10,23,3,9,6,4,5,0},
+    {42,56,3,6,12,21,3,16,7,6,9,0},     {52,56,2,6,10,23,3,23,13,8,13,8},   {32,64,5,6,9,31,2,5,3,2,3,0},
+    {42,64,4,6,9,33,0,11,6,5,0,0},      {48,64,3,6,12,27,3,16,8,6,9,0},     {58,64,2,6,10,29,3,23,13,8,13,8},
+    {70,64,1,6,11,28,3,24,18,12,18,4},  {40,80,5,6,10,41,3,6,3,2,3,0},      {52,80,4,6,10,41,3,11,6,5,6,0},
+    {58,80,3,6,11,40,3,16,8,6,7,0},     {70,80,2,6,10,41,3,23,13,8,13,8},   {84,80,1,6,10,41,3,24,17,12,18,4},
+    {48,96,5,7,9,53,3,5,4,2,4,0},       {58,96,4,7,10,52,3,9,6,4,6,0},      {70,96,3,6,12,51,3,16,9,6,10,4},
+    {84,96,2,6,10,53,3,22,12,9,12,0},   {104,96,1,6,13,50,3,24,18,13,19,0}, {58,112,5,14,17,50,3,5,4,2,5,0},
+    {70,112,4,11,21,49,3,9,6,4,8,0},    {84,112,3,11,23,47,3,16,8,6,9,0},   {104,112,2,11,21,49,3,23,12,9,14,4},
+    {84,128,5,12,19,62,3,5,3,2,4,0},    {64,128,4,11,21,61,3,11,6,5,7,0},   {96,128,3,11,22,60,3,16,9,6,10,4},
+    {116,128,2,11,21,61,3,22,12,9,14,0},{140,128,1,11,20,62,3,24,17,13,19,8},{80,160,5,11,19,87,3,5,4,2,4,0},
+    {104,160,4,11,23,83,3,11,6,5,9,0},  {116,160,3,11,24,82,3,16,8,6,11,0}, {140,160,2,11,21,85,3,22,11,9,13,0},
+    {168,160,1,11,22,84,3,24,18,12,19,0},{96,192,5,11,20,110,3,6,4,2,5,0},  {116,192,4,11,22,108,3,10,6,4,9,0},
+    {140,192,3,11,24,106,3,16,10,6,11,0},{168,192,2,11,20,110,3,22,13,9,13,8},{208,192,1,11,21,109,3,24,20,13,24,0},
+    {116,224,5,12,22,131,3,8,6,2,6,4},  {140,224,4,12,26,127,3,12,8,4,11,0},{168,224,3,11,20,134,3,16,10,7,9,0},
+    {208,224,2,11,22,132,3,24,16,10,15,0},{232,224,1,11,24,130,3,24,20,12,20,4},{128,256,5,11,24,154,3,6,5,2,5,0},
+    {168,256,4,11,24,154,3,12,9,5,10,4},{192,256,3,11,27,151,3,16,10,7,10,0},{232,256,2,11,22,156,3,24,14,10,13,8},
+    {280,256,1,11,26,152,3,24,19,14,18,4},{160,320,5,11,26,200,3,8,5,2,6,4}, {208,320,4,11,25,201,3,13,9,5,10,8},
+    {280,320,2,11,26,200,3,24,17,9,17,0},{192,384,5,11,27,247,3,8,6,2,7,0}, {280,384,3,11,24,250,3,16,9,7,10,4},
+    {416,384,1,12,28,245,3,24,20,14,23,8},
+};
+// ETSI EN 300 401 tables 9/18 (EEP-A) and 10/20 (EEP-B): {CU multiple, m1, b1, m2, b2, PI1, PI2}, L = m*n + b;
+// same data as subchannel_protection_tables.h:121-139
+static const int EEP_A_ROWS[4][7] = { {12,6,-3,0,3,24,23}, {8,2,-3,4,3,14,13}, {6,6,-3,0,3,8,7}, {4,4,-3,2,3,3,2} };
+static const int EEP_2A_N1[7] = { 8,0,5,0,1,13,12 };
+static const int EEP_B_ROWS[4][7] = { {27,24,-3,0,3,10,9}, {21,24,-3,0,3,6,5}, {18,24,-3,0,3,4,3}, {15,24,-3,0,3,2,1} };
+
+extern "C" int dabgpu_subchannel_plan(const dabgpu_subchannel* sc, int* pi, int* lx, int* n_decoded_bytes) {
+    if (!sc || !pi || !lx) return -1;
+    int nseg, total = 0;
+    for (int i = 0; i < 4; i++) { pi[i] = 0; lx[i] = 0; }
+    if (!sc->is_uep) {
+        if (sc->eep_prot_level < 0 || sc->eep_prot_level > 3 || sc->length <= 0) return -1;
+        const int* d = (sc->eep_type == 0) ? ((sc->length == 8) ? EEP_2A_N1 : EEP_A_ROWS[sc->eep_prot_level])
+                                            : EEP_B_ROWS[sc->eep_prot_level];       // GetEEPDescriptor :145-154
+        const int n = sc->length / d[0];
+        pi[0] = d[5]; lx[0] = d[1] * n + d[2];
+        pi[1] = d[6]; lx[1] = d[3] * n + d[4];
+        if (lx[0] < 0 || lx[1] < 0) return -1;
+        nseg = 2;
+    } else {
+        if (sc->uep_prot_index < 0 || sc->uep_prot_index > 63) return -1;
+        const uint16_t* d = UEP_ROWS[sc->uep_prot_index];
+        for (int i = 0; i < 4; i++) { lx[i] = d[3 + i]; pi[i] = d[7 + i]; }
+        nseg = 4;
+    }
+    for (int i = 0; i < nseg; i++) total += lx[i];
+    if (n_decoded_bytes) *n_decoded_bytes = 4 * total;     // (32*sum(L) + 6 - 6) / 8, msc_decoder.cpp:99-103
+    return nseg;
+}
+
+static int device_waves(dabgpu_ctx* c) {
+    if (c->n_cu <= 0) {
+        hipDeviceProp_t p;
+        c->n_cu = (hipGetDeviceProperties(&p, c->device) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
+    return c->n_cu * 32;          // 8 waves per SIMD: the decoder is a serial recurrence per wave, throughput = waves in flight
+}
+
+static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t max_steps, uint32_t max_out_bytes,
+                       int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s) {
+    const int n_waves = (int)std::min<size_t>(n, (size_t)device_waves(c));
+    const size_t words = ((size_t)max_steps + 63) & ~(size_t)63;
+    uint64_t* d_scratch = nullptr;
+    int st = dabgpu_scratch(c, 11, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch);
+    if (st) return st;
+    return dabgpu_check_hip(dabgpu_launch_viterbi(d_descs, (int)n, d_scratch, words, n_waves, (int)max_out_bytes, d_results,
+                                                  tie_rule ? 1 : 0, s), "viterbi_kernel launch");
+}
+
+static int validate_codeword(const dabgpu_codeword& d, size_t i) {
+    uint64_t steps = 0;
+    for (int k = 0; k < 4; k++) {
+        if (d.seg_steps[k] == 0) continue;
+        if (d.seg_pi[k] < 1 || d.seg_pi[k] > 24 || (d.seg_steps[k] & 7)) {
+            dabgpu_set_error("codeword %zu: segment %d has PI=%u steps=%u (PI must be 1..24, steps a multiple of 8)", i, k,
+                             d.seg_pi[k], d.seg_steps[k]);
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        steps += d.seg_steps[k];
+    }
+    if (steps + 6 != d.n_steps || ((d.n_steps - 6) & 7) || !d.d_src || !d.d_out) {
+        dabgpu_set_error("codeword %zu: n_steps=%u does not equal sum(seg_steps)+6 with whole output bytes, or null address", i, d.n_steps);
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    if (d.n_slots != 0 && (d.n_slots < 16 || d.cifs_per_frame == 0 || d.newest_slot >= d.n_slots)) {
+        dabgpu_set_error("codeword %zu: bad CIF ring geometry (n_slots=%u newest=%u cifs_per_frame=%u)", i, d.n_slots, d.newest_slot, d.cifs_per_frame);
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword* h_cw, size_t n, int tie_rule,
+                                           dabgpu_codeword_result* d_results, void* stream) {
+    if (!c || (!h_cw && n) || (!d_results && n)) { dabgpu_set_error("viterbi_decode_batch: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n == 0) return DABGPU_OK;
+    uint32_t max_steps = 0;
+    for (size_t i = 0; i < n; i++) {
+        int st = validate_codeword(h_cw[i], i);
+        if (st) return st;
+        max_steps = std::max(max_steps, h_cw[i].n_steps);
+    }
+    (void)hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    dabgpu_cw_desc* d_descs = nullptr;
+    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    if (st) return st;
+    st = dabgpu_check_hip(hipMemcpyAsync(d_descs, h_cw, n * sizeof(dabgpu_cw_desc), hipMemcpyHostToDevice, s), "hipMemcpyAsync(descs)");
+    if (st) return st;
+    // pageable host memory: the copy above has consumed h_cw when it returns, the caller may reuse it
+    return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
+}
+
+extern "C" int dabgpu_fic_decode_frames(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride,
+                                        uint8_t* d_fib_bytes, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    if (!c || !d_bits || !d_fib_bytes || !d_results) { dabgpu_set_error("fic_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    if (frame_stride < DABGPU_NB_FIC_BITS) { dabgpu_set_error("fic_decode_frames: frame_stride %zu < 9216", frame_stride); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = n_frames * 4;
+    dabgpu_cw_desc* d_descs = nullptr;
+    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    if (st) return st;
+    st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, s), "fic_build_descs launch");
+    if (st) return st;
+    return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s);
+}
+
+extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                        int newest_frame_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                                        size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    if (!c || !d_hist || !h_sub || !d_out || !d_results) { dabgpu_set_error("msc_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_ens == 0 || n_sub == 0) return DABGPU_OK;
+    if (hist_frames < 5 || newest_frame_slot < 0 || newest_frame_slot >= hist_frames || n_sub < 0) {
+        dabgpu_set_error("msc_decode_frames: history_frames must be >= 5 (16 CIFs of delay + the 4 new ones) and 0 <= newest < history_frames");
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    std::vector<dabgpu_msc_plan> plans((size_t)n_sub);
+    uint32_t off = 0, max_steps = 0, max_out = 0;
+    for (int s = 0; s < n_sub; s++) {
+        int pi[4], lx[4], nb = 0;
+        if (dabgpu_subchannel_plan(&h_sub[s], pi, lx, &nb) < 0 || h_sub[s].start_address < 0 ||
+            h_sub[s].start_address + h_sub[s].length > 864) {
+            dabgpu_set_error("msc_decode_frames: sub-channel %d has an invalid protection profile or exceeds 864 CU", s);
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        dabgpu_msc_plan& P = plans[(size_t)s];
+        P.start_address = (uint32_t)h_sub[s].start_address;
+        uint32_t steps = 0;
+        for (int k = 0; k < 4; k++) { P.seg_pi[k] = lx[k] ? (uint32_t)pi[k] : 0u; P.seg_steps[k] = 32u * (uint32_t)lx[k]; steps += P.seg_steps[k]; }
+        P.n_steps = steps + 6;
+        P.out_offset = off;
+        P.n_out_bytes = (uint32_t)nb;
+        off += (uint32_t)nb;
+        max_steps = std::max(max_steps, P.n_steps);
+        max_out = std::max(max_out, (uint32_t)nb);
+    }
+    if (out_ens_stride < (size_t)4 * off) { dabgpu_set_error("msc_decode_frames: out_ensemble_stride %zu < 4 x %u", out_ens_stride, off); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = n_ens * 4 * (size_t)n_sub;
+    dabgpu_cw_desc* d_descs = nullptr;
+    dabgpu_msc_plan* d_plans = nullptr;
+    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    if (st) return st;
+    if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
+    if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
+    if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
+                                                       d_out, out_ens_stride, (int)off, s), "msc_build_descs launch"))) return st;
+    return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
+}

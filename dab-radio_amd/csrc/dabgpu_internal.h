@@ -5,8 +5,11 @@
 #include <stdint.h>
 #include <vector>
 
+#include "dabgpu.h"
+
 struct dabgpu_ctx {
     int device = 0;
+    int n_cu = 0;
     hipStream_t stream = nullptr;
     std::vector<float> prs;          // host copy, 2*2048
     std::vector<int> mapper;         // host copy, 1536
@@ -26,3 +29,23 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d
                                                int n_frames, int sym_per_chunk, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
                                                float* d_fine_freq, hipStream_t stream);
+
+// ---- channel decode ----
+typedef dabgpu_codeword dabgpu_cw_desc;
+typedef dabgpu_codeword_result dabgpu_cw_result;
+struct dabgpu_msc_plan {            // device-side sub-channel plan (one per sub-channel of the multiplex)
+    uint32_t start_address;         // CUs
+    uint32_t n_steps;               // trellis steps incl. tail
+    uint32_t seg_pi[4];
+    uint32_t seg_steps[4];
+    uint32_t out_offset;            // byte offset of this sub-channel inside one CIF's output record
+    uint32_t n_out_bytes;
+};
+extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
+                                            size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
+                                            dabgpu_cw_result* d_results, int tie_rule, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
+                                              size_t frame_stride, uint8_t* d_out, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
+                                              int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
+                                              uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, hipStream_t stream);

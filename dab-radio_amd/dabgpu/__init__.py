@@ -30,7 +30,31 @@ ABI_SYMBOLS = [
     "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize",
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync",
+    "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
 ]
+
+
+class Codeword(C.Structure):
+    """dabgpu_codeword (include/dabgpu.h)"""
+    _fields_ = [("d_src", C.c_uint64), ("d_out", C.c_uint64), ("n_steps", C.c_uint32),
+                ("seg_pi", C.c_uint32 * 4), ("seg_steps", C.c_uint32 * 4), ("start_state", C.c_uint32),
+                ("n_crc_blocks", C.c_uint32), ("n_slots", C.c_uint32), ("newest_slot", C.c_uint32),
+                ("cifs_per_frame", C.c_uint32), ("frame_stride", C.c_uint32), ("cif_stride", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class CodewordResult(C.Structure):
+    """dabgpu_codeword_result"""
+    _fields_ = [("path_error", C.c_uint64), ("crc_ok_mask", C.c_uint32), ("n_out_bytes", C.c_uint32)]
+
+
+class SubChannel(C.Structure):
+    """dabgpu_subchannel"""
+    _fields_ = [("start_address", C.c_int), ("length", C.c_int), ("is_uep", C.c_int),
+                ("uep_prot_index", C.c_int), ("eep_prot_level", C.c_int), ("eep_type", C.c_int)]
+
+
+RESULT_DTYPE = [("path_error", "<u8"), ("crc_ok_mask", "<u4"), ("n_out_bytes", "<u4")]
 
 
 class DabGpuError(RuntimeError):
@@ -71,6 +95,12 @@ def lib():
                                                C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_viterbi_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.dabgpu_fic_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p]
+        L.dabgpu_subchannel_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_msc_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -173,3 +203,34 @@ class Context:
         check(lib().dabgpu_ofdm_demod_frames_host_sync(self._h, _ptr(iq), n, _ptr(f), _ptr(bits), _ptr(total),
                                                        _ptr(fft)), "dabgpu_ofdm_demod_frames_host_sync")
         return bits, total, fft
+
+    # ---- channel decode ----
+    def viterbi_decode_batch(self, codewords, results, tie_rule=0, stream=None):
+        """codewords: list/ctypes array of Codeword (host); results: device buffer of n CodewordResult"""
+        n = len(codewords)
+        arr = (Codeword * n)(*codewords) if not isinstance(codewords, C.Array) else codewords
+        check(lib().dabgpu_viterbi_decode_batch(self._h, arr, n, tie_rule, _ptr(results), self._stream(stream)),
+              "dabgpu_viterbi_decode_batch")
+
+    def fic_decode_frames(self, bits, n_frames, fib_bytes, results, frame_stride=NB_FRAME_BITS, tie_rule=0, stream=None):
+        check(lib().dabgpu_fic_decode_frames(self._h, _ptr(bits), n_frames, frame_stride, _ptr(fib_bytes), _ptr(results),
+                                             tie_rule, self._stream(stream)), "dabgpu_fic_decode_frames")
+
+    def msc_decode_frames(self, history, n_ensembles, ensemble_stride, history_frames, newest_frame_slot, subchannels,
+                          out, out_ensemble_stride, results, tie_rule=0, stream=None):
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels)
+        check(lib().dabgpu_msc_decode_frames(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames,
+                                             newest_frame_slot, arr, n, _ptr(out), out_ensemble_stride, _ptr(results),
+                                             tie_rule, self._stream(stream)), "dabgpu_msc_decode_frames")
+
+
+def subchannel_plan(sc):
+    """(pi[], l[], n_decoded_bytes) of a SubChannel via the product's host tables"""
+    pi = (C.c_int * 4)()
+    lx = (C.c_int * 4)()
+    nb = C.c_int(0)
+    n = lib().dabgpu_subchannel_plan(C.byref(sc), pi, lx, C.byref(nb))
+    if n < 0:
+        raise DabGpuError("invalid sub-channel protection profile")
+    return list(pi)[:n], list(lx)[:n], nb.value

@@ -113,6 +113,89 @@ int dabgpu_ofdm_phase_update(dabgpu_ctx *ctx, const float *d_cp_corr, size_t n_f
 int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx *ctx, const float *h_iq, size_t n_frames, const float *h_freq_offset,
                                        int8_t *h_bits, float *h_total_phase, float *h_fft);
 
+/* ------------------------------------------------------------------------------------------------
+ * Channel decoding: punctured K=7 rate-1/4 Viterbi (+ time de-interleave, energy dispersal, FIB CRC16),
+ * one wavefront per codeword, batched.
+ * Replaces DAB_Viterbi_Decoder::update/chainback (src/dab/algorithms/dab_viterbi_decoder.cpp:114-181) and the
+ * vendor/viterbi_decoder core behind it, AdditiveScrambler (src/dab/algorithms/additive_scrambler.h:16-35),
+ * CRC_Calculator<uint16_t> as used by the FIC (src/dab/fic/fic_decoder.cpp:19-31,103-116) and
+ * CIF_Deinterleaver::Deinterleave (src/dab/msc/cif_deinterleaver.cpp:36-71).
+ *
+ * tie_rule: 0 = upstream scalar core (upper predecessor only when strictly smaller), 1 = upstream SIMD cores
+ * (min + compare-equal: upper predecessor on ties).  Decoded bytes differ only on exact metric ties.
+ * Soft bits are int8 in [-127,+127], 0 = punctured/erased (src/viterbi_config.h:11-14); -128 is read as -127.
+ */
+typedef struct {
+    uint64_t d_src;            /* device address. direct (n_slots == 0): first soft bit of the codeword;
+                                  ring: first soft bit of this sub-channel inside CIF slot 0 */
+    uint64_t d_out;            /* device address of the decoded, descrambled bytes ((n_steps-6)/8 of them) */
+    uint32_t n_steps;          /* trellis steps = information bits + 6 tail bits */
+    uint32_t seg_pi[4];        /* puncturing vector index PI (1..24) of up to 4 segments, 0 = unused
+                                  (src/dab/constants/puncture_codes.h:42-72); the 24-symbol tail PI_X is implicit */
+    uint32_t seg_steps[4];     /* trellis steps of each segment = 32 * L (L = number of 128-bit blocks) */
+    uint32_t start_state;      /* DAB_Viterbi_Decoder::reset(starting_state) */
+    uint32_t n_crc_blocks;     /* > 0: output is that many equal blocks each ending in a CRC16 (FIBs) */
+    uint32_t n_slots;          /* 0 = direct; else length of the CIF ring in slots (>= 16) */
+    uint32_t newest_slot;      /* ring slot holding the most recent CIF of this codeword */
+    uint32_t cifs_per_frame;   /* ring geometry: slot s lives at d_src + (s / cifs_per_frame) * frame_stride */
+    uint32_t frame_stride;     /*                                      + (s % cifs_per_frame) * cif_stride   (bytes) */
+    uint32_t cif_stride;
+    uint32_t reserved;
+} dabgpu_codeword;
+
+typedef struct {
+    uint64_t path_error;       /* DAB_Viterbi_Decoder::chainback() return value (dab_viterbi_decoder.cpp:124-129) */
+    uint32_t crc_ok_mask;      /* bit i = CRC16 of block i matches (only when n_crc_blocks > 0) */
+    uint32_t n_out_bytes;
+} dabgpu_codeword_result;
+
+/* generic batch: h_codewords is a HOST array (copied to the device on `stream`); d_results a DEVICE array [n] */
+int dabgpu_viterbi_decode_batch(dabgpu_ctx *ctx, const dabgpu_codeword *h_codewords, size_t n, int tie_rule,
+                                dabgpu_codeword_result *d_results, void *stream);
+
+/*
+ * FIC of whole frames: for every frame the 4 FIB groups of 2304 soft bits (first 9216 bits of the frame) are
+ * decoded with PI_16 x21, PI_15 x3, PI_X, descrambled and CRC-checked.
+ * Replaces BasicFICRunner::Process + FIC_Decoder::DecodeFIBGroup (src/basic_radio/basic_fic_runner.cpp:34-49,
+ * src/dab/fic/fic_decoder.cpp:53-117) for a batch.
+ *   d_bits       frame f starts at d_bits + f * frame_stride (bytes); pass DABGPU_NB_FRAME_BITS for packed frames
+ *   d_fib_bytes  [n_frames][4][96]: 3 x (30 data bytes + 2 CRC bytes) per group
+ *   d_results    [n_frames][4]
+ */
+int dabgpu_fic_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits, size_t n_frames, size_t frame_stride,
+                             uint8_t *d_fib_bytes, dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
+/* Sub-channel description: the fields of `Subchannel` the decoder reads (src/dab/database/dab_database_entities.h:179-190) */
+typedef struct {
+    int start_address;   /* capacity units */
+    int length;          /* capacity units */
+    int is_uep;
+    int uep_prot_index;  /* 0..63, row of the UEP table */
+    int eep_prot_level;  /* 0..3 = level 1..4 */
+    int eep_type;        /* 0 = EEP-A, 1 = EEP-B */
+} dabgpu_subchannel;
+
+/* (PI, L) plan of a sub-channel as MSC_Decoder::DecodeEEP/DecodeUEP derive it (src/dab/msc/msc_decoder.cpp:77-131,
+ * src/dab/constants/subchannel_protection_tables.h); returns the number of segments (<= 4) or -1 */
+int dabgpu_subchannel_plan(const dabgpu_subchannel *sc, int *pi4, int *l4, int *n_decoded_bytes);
+
+/*
+ * MSC of whole frames for many ensembles that share one multiplex configuration.  The time de-interleaver reads
+ * straight from the history of demodulated frames: d_bits_history holds, per ensemble, `history_frames` (>= 5)
+ * frame slots of 230400 soft bits used as a ring; the frame most recently written is slot `newest_frame_slot`.
+ * Every call decodes the 4 CIFs of that newest frame for every listed sub-channel (the first 3 frames after a
+ * (re)start yield garbage until 16 CIFs are in the ring -- the caller tracks that, as CIF_Deinterleaver's
+ * m_total_frames_stored does, cif_deinterleaver.cpp:28-42).
+ * Replaces MSC_Decoder::DecodeCIF (src/dab/msc/msc_decoder.cpp:46-115) x 4 CIFs x sub-channels x ensembles.
+ *   ensemble e's history starts at d_bits_history + e * ensemble_stride (bytes)
+ *   output of (ensemble e, cif c, sub-channel s) is written at d_out + e * out_ensemble_stride + c * B + off_s where
+ *   B = sum of decoded bytes of all listed sub-channels and off_s the running sum; d_results is [n_ensembles][4][n_sub]
+ */
+int dabgpu_msc_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits_history, size_t n_ensembles, size_t ensemble_stride,
+                             int history_frames, int newest_frame_slot, const dabgpu_subchannel *h_subchannels,
+                             int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
+                             dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
