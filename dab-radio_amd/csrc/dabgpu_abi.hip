@@ -159,6 +159,9 @@ int dabgpu_create(dabgpu_ctx** out, int device, const float* h_prs, const int* h
     CK(hipMemcpy(c->d_tw, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_inv_map, inv.data(), sizeof(uint16_t) * inv.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_prs, c->prs.data(), sizeof(float) * c->prs.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&c->d_prs_time_ref, sizeof(float) * 2 * DABGPU_NB_FFT));
+    CK(dabgpu_launch_sync_init(c->d_prs, c->d_tw, c->d_prs_time_ref, c->stream));     // ofdm_demodulator.cpp:134-140
+    CK(hipStreamSynchronize(c->stream));
 #undef CK
     *out = c;
     return DABGPU_OK;
@@ -170,6 +173,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     if (c->d_tw) (void)hipFree(c->d_tw);
     if (c->d_inv_map) (void)hipFree(c->d_inv_map);
     if (c->d_prs) (void)hipFree(c->d_prs);
+    if (c->d_prs_time_ref) (void)hipFree(c->d_prs_time_ref);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -231,6 +235,49 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t 
     CK(hipMemcpyAsync(h_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
     if (h_total_phase) CK(hipMemcpyAsync(h_total_phase, d_total, n_frames * sizeof(float), hipMemcpyDeviceToHost, s));
     if (h_fft) CK(hipMemcpyAsync(h_fft, d_fft, fft_bytes, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+#undef CK
+    return DABGPU_OK;
+}
+
+// ---- sync ----
+void dabgpu_sync_cfg_default(dabgpu_sync_cfg* cfg) {          // ofdm_demodulator.h:34-44
+    if (!cfg) return;
+    cfg->fine_freq_update_beta = 0.9f;
+    cfg->is_coarse_freq_correction = 1;
+    cfg->max_coarse_freq_correction_norm = 0.5f;
+    cfg->coarse_freq_slow_beta = 0.1f;
+    cfg->impulse_peak_threshold_db = 20.0f;
+    cfg->impulse_peak_distance_probability = 0.15f;
+}
+
+int dabgpu_ofdm_sync(dabgpu_ctx* c, const float* d_prs_syms, size_t n_streams, size_t stride_samples, const dabgpu_sync_cfg* cfg,
+                     dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, void* stream) {
+    if (!c || !d_prs_syms || !cfg || !d_states) { dabgpu_set_error("ofdm_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_streams == 0) return DABGPU_OK;
+    if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
+    return dabgpu_check_hip(dabgpu_launch_sync(d_prs_syms, stride_samples, (int)n_streams, cfg, d_states, d_impulse, d_freq,
+                                               c->d_tw, c->d_prs, c->d_prs_time_ref, (hipStream_t)stream), "ofdm_sync_kernel launch");
+}
+
+int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* h_state,
+                               float* h_impulse, float* h_freq) {
+    if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    int st;
+    float *d_sym, *d_imp, *d_frq; dabgpu_sync_state* d_st;
+    if ((st = dabgpu_scratch(c, 7, sizeof(float) * 2 * DABGPU_NB_FFT, (void**)&d_sym))) return st;
+    if ((st = dabgpu_scratch(c, 8, sizeof(dabgpu_sync_state), (void**)&d_st))) return st;
+    if ((st = dabgpu_scratch(c, 9, sizeof(float) * 2 * DABGPU_NB_FFT, (void**)&d_imp))) return st;
+    d_frq = d_imp + DABGPU_NB_FFT;
+    hipStream_t s = c->stream;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    CK(hipMemcpyAsync(d_sym, h_prs_sym, sizeof(float) * 2 * DABGPU_NB_FFT, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_st, h_state, sizeof(dabgpu_sync_state), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_ofdm_sync(c, d_sym, 1, DABGPU_NB_FFT, cfg, d_st, d_imp, d_frq, s))) return st;
+    CK(hipMemcpyAsync(h_state, d_st, sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, s));
+    if (h_impulse) CK(hipMemcpyAsync(h_impulse, d_imp, sizeof(float) * DABGPU_NB_FFT, hipMemcpyDeviceToHost, s));
+    if (h_freq) CK(hipMemcpyAsync(h_freq, d_frq, sizeof(float) * DABGPU_NB_FFT, hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
 #undef CK
     return DABGPU_OK;

@@ -16,6 +16,7 @@ struct dabgpu_ctx {
     float* d_tw = nullptr;           // 2048 x (cos, -sin)
     uint16_t* d_inv_map = nullptr;   // carrier -> de-interleaved position
     float* d_prs = nullptr;          // PRS spectrum
+    float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
 };
@@ -49,3 +50,9 @@ extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, hipStream_t stream);
+
+// ---- sync ----
+extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
+                                         dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
+                                         const float* d_prs, const float* d_prs_time_ref, hipStream_t stream);

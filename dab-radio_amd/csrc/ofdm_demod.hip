@@ -21,105 +21,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ofdm_device.h"
+
 namespace dabgpu {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-struct alignas(8) f2 { float x, y; };
-__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
-
-constexpr int NB_SYMBOL_PERIOD = 2552;
-constexpr int NB_FFT = 2048;
-constexpr int NB_CP = 504;
-constexpr int NB_FRAME_SAMPLES = 196608;
-constexpr int NB_SYM_BITS = 3072;
-constexpr int NB_FRAME_BITS = 230400;
-constexpr int NB_FRAME_SYMBOLS = 76;
-constexpr int WAVE_PATCH = 576;          // float2 elements per wave transpose patch (8 rows x 72, padded)
-
-__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{fma_(a.x, b.x, c.x), fma_(a.y, b.y, c.y)}; }
-__device__ __forceinline__ f2 mk2(float a, float b) { return f2{a, b}; }
-
-// ---- PLL: chebyshev sine on a (cos-arg, sin-arg) pair, FMA Horner (chebyshev_sine.h:82-107, __FMA__) ----
-__device__ __forceinline__ f2 cheb2(f2 x) {
-    const f2 z = x * x;
-    f2 b = fma2(mk2(3.20396066f, 3.20396066f), z, mk2(-14.07150173f, -14.07150173f));
-    b = fma2(b, z, mk2(38.50016403f, 38.50016403f));
-    b = fma2(b, z, mk2(-67.07687378f, -67.07687378f));
-    b = fma2(b, z, mk2(64.83583069f, 64.83583069f));
-    b = fma2(b, z, mk2(-25.13274193f, -25.13274193f));
-    const f2 c0 = z - mk2(0.25f, 0.25f);
-    return (b * c0) * x;
-}
-
-// one sample: base = dt0 + float(i4)*f (group of 4), step = (k*f + .25, k*f); v * (cos + j sin)
-__device__ __forceinline__ f2 pll1(f2 v, float base, f2 step) {
-    f2 d = mk2(base, base) + step;
-    d = d - mk2(__builtin_rintf(d.x), __builtin_rintf(d.y));
-    const f2 cs = cheb2(d);                               // (cos, sin)
-    // c32_mul_avx with FMA (x86/c32_mul.h:9-38): b0 = s*(xi, xr); y = (fma(c,xr,-b0.x), fma(c,xi,+b0.y))
-    const float b0x = cs.y * v.y, b0y = cs.y * v.x;
-    return mk2(fma_(cs.x, v.x, -b0x), fma_(cs.x, v.y, b0y));
-}
-
-// x0 * conj(x1), FMA form of x86/c32_conj_mul.h:12-44
-__device__ __forceinline__ f2 conj_mul(f2 x0, f2 x1) {
-    const float a = x0.x, b = x0.y, c = x1.x, d = x1.y;
-    return mk2(fma_(b, d, a * c), fma_(b, c, -(a * d)));
-}
-
-// ---- FFT butterflies (contract identical to oracle/dab_oracle_ofdm.c dft4/dft8/cmul) ----
-__device__ __forceinline__ f2 mul_mi(f2 a) { return mk2(a.y, -a.x); }
-__device__ __forceinline__ f2 cmul(f2 b, f2 w) {
-    const float t0 = b.y * w.y, t1 = b.y * w.x;          // (b.im*w.im, b.im*w.re)
-    return mk2(fma_(b.x, w.x, -t0), fma_(b.x, w.y, t1));
-}
-constexpr float SQRT_HALF = 0.707106769084930420f;
-__device__ __forceinline__ f2 mul_w8_1(f2 a) { return mk2((a.x + a.y) * SQRT_HALF, (a.y - a.x) * SQRT_HALF); }
-__device__ __forceinline__ f2 mul_w8_3(f2 a) { return mk2((a.y - a.x) * SQRT_HALF, -((a.x + a.y) * SQRT_HALF)); }
-
-__device__ __forceinline__ void dft4(const f2 a0, const f2 a1, const f2 a2, const f2 a3, f2& b0, f2& b1, f2& b2, f2& b3) {
-    const f2 s02 = a0 + a2, d02 = a0 - a2;
-    const f2 s13 = a1 + a3, d13 = mul_mi(a1 - a3);
-    b0 = s02 + s13; b1 = d02 + d13; b2 = s02 - s13; b3 = d02 - d13;
-}
-
-__device__ __forceinline__ void dft8(f2 (&a)[8]) {
-    const f2 c0 = a[0] + a[4], c1 = a[0] - a[4];
-    const f2 c2 = a[2] + a[6], c3 = mul_mi(a[2] - a[6]);
-    const f2 c4 = a[1] + a[5], c5 = a[1] - a[5];
-    const f2 c6 = a[3] + a[7], c7 = mul_mi(a[3] - a[7]);
-    const f2 d0 = c0 + c2, d2 = c0 - c2;
-    const f2 d1 = c1 + c3, d3 = c1 - c3;
-    const f2 d4 = c4 + c6, d6 = mul_mi(c4 - c6);
-    const f2 d5 = mul_w8_1(c5 + c7), d7 = mul_w8_3(c5 - c7);
-    a[0] = d0 + d4; a[4] = d0 - d4;
-    a[1] = d1 + d5; a[5] = d1 - d5;
-    a[2] = d2 + d6; a[6] = d2 - d6;
-    a[3] = d3 + d7; a[7] = d3 - d7;
-}
-
-// convert_to_viterbi_bit (ofdm_demodulator.cpp:57-72): (int8)(-x*127); v_cvt_i32_f32 truncates and maps NaN to 0
-__device__ __forceinline__ int to_vbit(float x) {
-    const float v = -x * 127.0f;
-    return (int)v;
-}
 
 // blockIdx -> work unit so that consecutive units (chunks of one frame share a halo symbol) sit on one XCD
 // (blocks are dealt round-robin to the 8 XCDs, each with a private L2)
 __device__ __forceinline__ int xcd_remap(int b, int G) {
     const int nx = 8, q = G / nx, r = G % nx, x = b % nx, s = b / nx;
     return (x < r) ? (x * (q + 1) + s) : (r * (q + 1) + (x - r) * q + s);
-}
-
-// wave-private LDS hand-off: order this wave's LDS writes before its later reads for the compiler; the LDS unit
-// itself executes one wave's instructions in order, so no s_barrier is involved
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // In-place decimation-in-frequency view of the 4x8x8x8 factorisation: after the radix-4 pass the transform splits

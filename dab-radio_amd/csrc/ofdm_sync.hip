@@ -1,0 +1,313 @@
+// ofdm_sync.hip -- PRS-based synchronisation on the device, one 256-thread workgroup per stream:
+//   coarse frequency sync  (ref: OFDM_Demod::RunCoarseFreqSync, src/ofdm/ofdm_demodulator.cpp:360-471)
+//   fine time sync          (ref: OFDM_Demod::RunFineTimeSync,   src/ofdm/ofdm_demodulator.cpp:473-548)
+// Five 2048-point transforms per frame, all through the same butterflies as the symbol kernel (ofdm_device.h), the
+// dB / argmax / lerp tails with the deterministic log/exp of the arithmetic contract.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dabgpu_internal.h"
+#include "ofdm_device.h"
+
+namespace dabgpu {
+
+// ---- deterministic scalar functions (operation-for-operation the oracle's dab_cabsf / dab_db20f / dab_undb20f) ----
+__device__ __forceinline__ float cabs_det(f2 v) { return __builtin_sqrtf(fma_(v.x, v.x, v.y * v.y)); }
+
+__device__ __forceinline__ float db20_det(float m) {
+    if (!(m > 0.0f)) return -__builtin_inff();
+    float e_adj = 0.0f;
+    if (m < 1.17549435e-38f) { m = m * 16777216.0f; e_adj = -24.0f; }
+    uint32_t u = __float_as_uint(m);
+    int e = (int)((u >> 23) & 0xFFu) - 126;
+    u = (u & 0x007FFFFFu) | 0x3F000000u;
+    float f = __uint_as_float(u);
+    if (f < 0.707106769084930420f) { e -= 1; f = f + f; }
+    const float x = f - 1.0f;
+    const float z = x * x;
+    float p = fma_(7.0376836292e-2f, x, -1.1514610310e-1f);
+    p = fma_(p, x, 1.1676998740e-1f);
+    p = fma_(p, x, -1.2420140846e-1f);
+    p = fma_(p, x, 1.4249322787e-1f);
+    p = fma_(p, x, -1.6668057665e-1f);
+    p = fma_(p, x, 2.0000714765e-1f);
+    p = fma_(p, x, -2.4999993993e-1f);
+    p = fma_(p, x, 3.3333331174e-1f);
+    float y = (p * x) * z;
+    y = fma_(-0.5f, z, y);
+    const float fe = (float)e + e_adj;
+    const float ln = fma_(fe, 0.693147182464599609f, x + y);
+    return ln * 8.68588924407958984f;
+}
+
+__device__ __forceinline__ float undb20_det(float db) {
+    float x = db * 0.166096404194831848f;
+    if (x > 127.0f) return __builtin_inff();
+    if (!(x > -149.0f)) return 0.0f;
+    float n = __builtin_floorf(x);
+    x = x - n;
+    if (x > 0.5f) { n += 1.0f; x -= 1.0f; }
+    float p = fma_(1.535336188319500e-4f, x, 1.339887440266574e-3f);
+    p = fma_(p, x, 9.618437357674640e-3f);
+    p = fma_(p, x, 5.550332471162809e-2f);
+    p = fma_(p, x, 2.402264791363012e-1f);
+    p = fma_(p, x, 6.931472028550421e-1f);
+    p = fma_(p, x, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+// UpdateFineFrequencyOffset (ofdm_demodulator.cpp:829-840)
+__device__ __forceinline__ float fine_freq_add(float fine, float delta) {
+    const float spacing = 1.0f / (float)NB_FFT;
+    const float wrap = 0.5f * spacing * 1.01f;
+    fine += delta;
+    return fmodf(fine, wrap);
+}
+
+// ---- 2048-point transform between natural-order LDS arrays (x -> y), same pass structure as ofdm_demod_kernel ----
+// conj_io: inverse transform as conj(FFT(conj(x))), unnormalised like FFTW_BACKWARD
+__device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* __restrict__ tw, bool conj_io) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int la = lane & 7, lb = lane >> 3;
+    f2* patch = patch0 + wave * WAVE_PATCH;
+    f2 a[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { a[j] = x[2 * t + 512 * j]; a[4 + j] = x[2 * t + 1 + 512 * j]; }
+    if (conj_io) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j].y = -a[j].y;
+    }
+    {
+        f2 b0, b1, b2, b3, c0, c1, c2, c3;
+        dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
+        dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
+        b1 = cmul(b1, tw[(2 * t) * 1]); b2 = cmul(b2, tw[(2 * t) * 2]); b3 = cmul(b3, tw[(2 * t) * 3]);
+        c1 = cmul(c1, tw[(2 * t + 1) * 1]); c2 = cmul(c2, tw[(2 * t + 1) * 2]); c3 = cmul(c3, tw[(2 * t + 1) * 3]);
+        bufA[2 * t] = b0;        bufA[2 * t + 1] = c0;
+        bufA[2 * t + 512] = b1;  bufA[2 * t + 513] = c1;
+        bufA[2 * t + 1024] = b2; bufA[2 * t + 1025] = c2;
+        bufA[2 * t + 1536] = b3; bufA[2 * t + 1537] = c3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = bufA[lane + 512 * wave + 64 * j];
+    dft8(a);
+    patch[lane] = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) patch[lane + 72 * k] = cmul(a[k], tw[4 * lane * k]);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[la + 72 * lb + 8 * j];
+    wave_lds_fence();
+    dft8(a);
+    patch[la + 72 * lb] = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) patch[la + 72 * lb + 9 * k] = cmul(a[k], tw[32 * la * k]);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[9 * la + 72 * lb + j];
+    wave_lds_fence();
+    dft8(a);
+    const int Kb = wave + 4 * lb + 32 * la;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        f2 v = a[k];
+        if (conj_io) v.y = -v.y;
+        y[Kb + 256 * k] = v;
+    }
+    __syncthreads();
+}
+
+struct SyncLds {
+    f2 X[NB_FFT];
+    f2 Y[NB_FFT];
+    f2 bufA[NB_FFT];
+    f2 patch[4 * WAVE_PATCH];
+    float R[NB_FFT];
+    float redv[4];
+    int redi[4];
+    float reds[4];
+};
+
+// (value, index) reduction with "largest value, ties -> lowest index" == first maximum of a sequential strict-> scan
+__device__ __forceinline__ void argmax_reduce(float& v, int& i, SyncLds* S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float v2 = __shfl_xor(v, off);
+        const int i2 = __shfl_xor(i, off);
+        if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+    }
+    if (lane == 0) { S->redv[wave] = v; S->redi[wave] = i; }
+    __syncthreads();
+    v = S->redv[0]; i = S->redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        const float v2 = S->redv[w]; const int i2 = S->redi[w];
+        if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+    }
+    __syncthreads();
+}
+
+// constructor-time reference of the coarse sync (ofdm_demodulator.cpp:134-140): conj(IFFT(relative_phase(PRS)))
+__global__ __launch_bounds__(256)
+void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2* __restrict__ prs_time_ref) {
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
+    const int t = threadIdx.x;
+    for (int i = t; i < NB_FFT; i += 256)
+        S->X[i] = (i < NB_FFT - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);      // CalculateRelativePhase :901-909
+    __syncthreads();
+    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);
+    for (int i = t; i < NB_FFT; i += 256) prs_time_ref[i] = mk2(S->Y[i].x, -S->Y[i].y);
+}
+
+__global__ __launch_bounds__(256)
+void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, int n_streams, dabgpu_sync_cfg cfg,
+                      dabgpu_sync_state* __restrict__ states, float* __restrict__ impulse_out, float* __restrict__ freq_out,
+                      const f2* __restrict__ tw, const f2* __restrict__ prs_fft, const f2* __restrict__ prs_time_ref)
+{
+    extern __shared__ __attribute__((aligned(16))) char ssm[];
+    SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int sidx = blockIdx.x;
+    if (sidx >= n_streams) return;
+    const f2* prs_sym = prs_syms + (size_t)sidx * stride_samples;
+    dabgpu_sync_state st = states[sidx];
+    const int N = NB_FFT, M = N / 2;
+
+    // ================= coarse frequency sync (:360-471) =================
+    if (cfg.is_coarse_freq_correction) {
+        for (int i = t; i < N; i += 256) S->X[i] = prs_sym[i];
+        __syncthreads();
+        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                              // :377
+        for (int i = t; i < N; i += 256)
+            S->X[i] = (i < N - 1) ? conj_mul(S->Y[i + 1], S->Y[i]) : mk2(0.0f, 0.0f);       // :380
+        __syncthreads();
+        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);                               // :383
+        for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], prs_time_ref[i]);          // :387-389
+        __syncthreads();
+        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                              // :392
+        for (int i = t; i < N; i += 256) {                                                  // :911-920
+            const float r = db20_det(cabs_det(S->Y[(i + M) % N]));
+            S->R[i] = r;
+            if (freq_out) freq_out[(size_t)sidx * N + i] = r;
+        }
+        __syncthreads();
+        int max_off = (int)(cfg.max_coarse_freq_correction_norm * (float)N);                // :399-402
+        if (max_off < 0) max_off = 0;
+        if (max_off > M) max_off = M;
+        float bv = -__builtin_inff(); int bi = 0x7FFFFFFF;
+        for (int idx = t; idx < N; idx += 256) {                                            // :405-413, idx == N never occurs
+            const int i = idx - M;
+            if (i < -max_off || i > max_off) continue;
+            const float v = S->R[idx];
+            if (v > bv || (v == bv && idx < bi)) { bv = v; bi = idx; }
+        }
+        argmax_reduce(bv, bi, S);
+        if (t == 0) {
+            const int max_index = (bi == 0x7FFFFFFF) ? -max_off : (bi - M);
+            int pidx[3]; float pmag[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {                                                   // :423-434
+                int index = max_index - 1 + j;
+                if (index < -max_off) index = -max_off;
+                if (index > max_off) index = max_off;
+                int fi = index + M;
+                if (fi >= N) fi = N - 1;
+                pidx[j] = fi - M;
+                pmag[j] = undb20_det(S->R[fi]);
+            }
+            float peak_sum = 0.0f, lerp = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) peak_sum += pmag[j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) lerp += (float)pidx[j] * pmag[j] / peak_sum;        // :438
+            const float predicted = -lerp / (float)N;
+            const float error = predicted - st.freq_coarse;
+            const float large_thresh = 1.5f / (float)N;
+            const bool is_large = __builtin_fabsf(error) > large_thresh;
+            const bool is_fast = is_large || !st.is_found_coarse;
+            const float beta = is_fast ? 1.0f : cfg.coarse_freq_slow_beta;
+            const float delta = beta * error;
+            st.freq_coarse += delta;                                                        // :461
+            st.is_found_coarse = 1;
+            st.freq_fine = fine_freq_add(st.freq_fine, -delta);                             // :467
+            S->reds[0] = st.freq_coarse; S->reds[1] = st.freq_fine;
+        }
+        __syncthreads();
+        st.freq_coarse = S->reds[0]; st.freq_fine = S->reds[1]; st.is_found_coarse = 1;
+        __syncthreads();
+    } else {
+        st.freq_coarse = 0.0f;                                                              // :363-367
+    }
+
+    // ================= fine time sync (:473-548) =================
+    const float f = st.freq_coarse + st.freq_fine;                                          // :480
+    for (int i = t; i < N; i += 256) {                                                      // :481-482, apply_pll.cpp:81-117
+        const int k = i & 3;
+        const float ss = (float)k * f;
+        const float base = 0.0f + (float)(i & ~3) * f;
+        S->X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
+    }
+    __syncthreads();
+    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                                  // :487
+    for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], mk2(prs_fft[i].x, -prs_fft[i].y));   // :488-490
+    __syncthreads();
+    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);                                   // :493
+    for (int i = t; i < N; i += 256) {                                                      // :494-498
+        const float r = db20_det(cabs_det(S->Y[i]));
+        S->R[i] = r;
+        if (impulse_out) impulse_out[(size_t)sidx * N + i] = r;
+    }
+    __syncthreads();
+    // weighted arg-max (:505-524) and mean of the dB response with the contract's 256-leaf tree
+    const float decay = 1.0f - cfg.impulse_peak_distance_probability;
+    float bv = -__builtin_inff(); int bi = 0x7FFFFFFF;
+    float leaf = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int i = t + 256 * j;
+        const float r = S->R[i];
+        leaf = (j == 0) ? r : (leaf + r);
+        const int dist = abs(NB_CP - i);
+        const float norm_dist = (float)dist / (float)NB_SYMBOL_PERIOD;
+        const float prob = 1.0f - decay * norm_dist;
+        const float w = prob * r;
+        if (w > bv || (w == bv && i < bi)) { bv = w; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) leaf += __shfl_xor(leaf, off);
+    if (lane == 0) S->reds[wave] = leaf;
+    argmax_reduce(bv, bi, S);                                                               // (contains the barriers)
+    if (t == 0) {
+        const float total = (S->reds[0] + S->reds[1]) + (S->reds[2] + S->reds[3]);
+        const float avg = total / (float)N;
+        const float r0 = S->R[0];                                                           // scan starts from the unweighted [0] (:503)
+        float max_value = r0; int max_index = 0;
+        if (bv > r0) { max_value = bv; max_index = bi; }
+        const bool valid = !((max_value - avg) < cfg.impulse_peak_threshold_db);            // :529
+        st.sync_valid = valid ? 1 : 0;
+        if (valid) st.fine_time_offset = max_index - NB_CP;                                 // :536
+        states[sidx] = st;
+    }
+}
+
+}  // namespace dabgpu
+
+extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, hipStream_t stream) {
+    using namespace dabgpu;
+    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(256), sizeof(SyncLds), stream,
+                       reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_tw), reinterpret_cast<f2*>(d_prs_time_ref));
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
+                                         dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
+                                         const float* d_prs, const float* d_prs_time_ref, hipStream_t stream) {
+    using namespace dabgpu;
+    hipLaunchKernelGGL(ofdm_sync_kernel, dim3((unsigned)n_streams), dim3(256), sizeof(SyncLds), stream,
+                       reinterpret_cast<const f2*>(d_prs_syms), stride_samples, n_streams, *cfg, d_states, d_impulse, d_freq,
+                       reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref));
+    return hipGetLastError();
+}

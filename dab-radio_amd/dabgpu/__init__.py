@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize",
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync",
+    "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",
     "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
 ]
 
@@ -54,6 +55,21 @@ class SubChannel(C.Structure):
                 ("uep_prot_index", C.c_int), ("eep_prot_level", C.c_int), ("eep_type", C.c_int)]
 
 
+class SyncCfg(C.Structure):
+    """dabgpu_sync_cfg"""
+    _fields_ = [("fine_freq_update_beta", C.c_float), ("is_coarse_freq_correction", C.c_int),
+                ("max_coarse_freq_correction_norm", C.c_float), ("coarse_freq_slow_beta", C.c_float),
+                ("impulse_peak_threshold_db", C.c_float), ("impulse_peak_distance_probability", C.c_float)]
+
+
+class SyncState(C.Structure):
+    """dabgpu_sync_state"""
+    _fields_ = [("freq_coarse", C.c_float), ("freq_fine", C.c_float), ("is_found_coarse", C.c_int),
+                ("fine_time_offset", C.c_int), ("sync_valid", C.c_int), ("reserved", C.c_int)]
+
+
+SYNC_STATE_DTYPE = [("freq_coarse", "<f4"), ("freq_fine", "<f4"), ("is_found_coarse", "<i4"),
+                    ("fine_time_offset", "<i4"), ("sync_valid", "<i4"), ("reserved", "<i4")]
 RESULT_DTYPE = [("path_error", "<u8"), ("crc_ok_mask", "<u4"), ("n_out_bytes", "<u4")]
 
 
@@ -95,6 +111,10 @@ def lib():
                                                C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_sync_cfg_default.argtypes = [C.c_void_p]
+        L.dabgpu_ofdm_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+        L.dabgpu_ofdm_sync_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_viterbi_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_fic_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p]
@@ -204,6 +224,23 @@ class Context:
                                                        _ptr(fft)), "dabgpu_ofdm_demod_frames_host_sync")
         return bits, total, fft
 
+    # ---- sync ----
+    def ofdm_sync(self, prs_syms, n_streams, stride_samples, states, cfg=None, impulse=None, freq_response=None, stream=None):
+        cfg = cfg or sync_cfg_default()
+        check(lib().dabgpu_ofdm_sync(self._h, _ptr(prs_syms), n_streams, stride_samples, C.byref(cfg), _ptr(states),
+                                     _ptr(impulse), _ptr(freq_response), self._stream(stream)), "dabgpu_ofdm_sync")
+
+    def ofdm_sync_host(self, prs_sym, state, cfg=None):
+        """numpy convenience: returns (state, impulse_response, freq_response)"""
+        import numpy as np
+        cfg = cfg or sync_cfg_default()
+        x = np.ascontiguousarray(prs_sym, dtype=np.complex64)[:NB_FFT].copy()
+        imp = np.empty(NB_FFT, dtype=np.float32)
+        frq = np.empty(NB_FFT, dtype=np.float32)
+        check(lib().dabgpu_ofdm_sync_host_sync(self._h, _ptr(x), C.byref(cfg), C.byref(state), _ptr(imp), _ptr(frq)),
+              "dabgpu_ofdm_sync_host_sync")
+        return state, imp, frq
+
     # ---- channel decode ----
     def viterbi_decode_batch(self, codewords, results, tie_rule=0, stream=None):
         """codewords: list/ctypes array of Codeword (host); results: device buffer of n CodewordResult"""
@@ -223,6 +260,12 @@ class Context:
         check(lib().dabgpu_msc_decode_frames(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames,
                                              newest_frame_slot, arr, n, _ptr(out), out_ensemble_stride, _ptr(results),
                                              tie_rule, self._stream(stream)), "dabgpu_msc_decode_frames")
+
+
+def sync_cfg_default():
+    c = SyncCfg()
+    lib().dabgpu_sync_cfg_default(C.byref(c))
+    return c
 
 
 def subchannel_plan(sc):

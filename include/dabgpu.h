@@ -114,6 +114,44 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx *ctx, const float *h_iq, size_
                                        int8_t *h_bits, float *h_total_phase, float *h_fft);
 
 /* ------------------------------------------------------------------------------------------------
+ * PRS synchronisation: integer-bin frequency offset (coarse) then symbol timing from the impulse response (fine).
+ * Replaces OFDM_Demod::RunCoarseFreqSync and ::RunFineTimeSync (src/ofdm/ofdm_demodulator.cpp:360-471, :473-548),
+ * one workgroup per stream.  `dabgpu_sync_cfg` mirrors OFDM_Demod_Config::sync (src/ofdm/ofdm_demodulator.h:34-44).
+ */
+typedef struct {
+    float fine_freq_update_beta;              /* 0.9  */
+    int   is_coarse_freq_correction;          /* 1    */
+    float max_coarse_freq_correction_norm;    /* 0.5  */
+    float coarse_freq_slow_beta;              /* 0.1  */
+    float impulse_peak_threshold_db;          /* 20   */
+    float impulse_peak_distance_probability;  /* 0.15 */
+} dabgpu_sync_cfg;
+
+typedef struct {
+    float freq_coarse;        /* in/out: m_freq_coarse_offset */
+    float freq_fine;          /* in/out: m_freq_fine_offset */
+    int   is_found_coarse;    /* in/out: m_is_found_coarse_freq_offset */
+    int   fine_time_offset;   /* out: m_fine_time_offset (PRS start relative to the expected position), when sync_valid */
+    int   sync_valid;         /* out: 0 = impulse peak below threshold -> the caller must Reset() (:529-532) */
+    int   reserved;
+} dabgpu_sync_state;
+
+void dabgpu_sync_cfg_default(dabgpu_sync_cfg *cfg);
+/*
+ *   d_prs_syms   stream s: 2048 complex float starting at d_prs_syms + s * stride_samples (complex samples) =
+ *                m_correlation_time_buffer[nb_null_period ...], i.e. the first 2048 samples of the expected PRS slot
+ *   d_states     [n_streams] in/out
+ *   d_impulse_response / d_freq_response  [n_streams][2048] float dB, may be NULL
+ *                (GetImpulseResponse() / GetCoarseFrequencyResponse())
+ */
+int dabgpu_ofdm_sync(dabgpu_ctx *ctx, const float *d_prs_syms, size_t n_streams, size_t stride_samples,
+                     const dabgpu_sync_cfg *cfg, dabgpu_sync_state *d_states, float *d_impulse_response,
+                     float *d_freq_response, void *stream);
+/* single stream from host memory, synchronous; used by the OFDM_Demod mirror class once per frame */
+int dabgpu_ofdm_sync_host_sync(dabgpu_ctx *ctx, const float *h_prs_sym, const dabgpu_sync_cfg *cfg,
+                               dabgpu_sync_state *h_state, float *h_impulse_response, float *h_freq_response);
+
+/* ------------------------------------------------------------------------------------------------
  * Channel decoding: punctured K=7 rate-1/4 Viterbi (+ time de-interleave, energy dispersal, FIB CRC16),
  * one wavefront per codeword, batched.
  * Replaces DAB_Viterbi_Decoder::update/chainback (src/dab/algorithms/dab_viterbi_decoder.cpp:114-181) and the
