@@ -186,7 +186,7 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 
 // ---- OFDM ----
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
-                             float* d_cp_corr, float* d_fft, int symbols_per_block, void* stream) {
+                             float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, void* stream) {
     if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
@@ -197,7 +197,7 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, 
         int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
         if (st) return st;
     }
-    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, d_freq, d_bits, corr, d_fft, c->d_tw, c->d_inv_map,
+    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
                                                      (int)n_frames, symbols_per_block, s), "ofdm_demod_kernel launch");
 }
 
@@ -230,13 +230,47 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
     CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
     if (h_freq) CK(hipMemcpyAsync(d_freq, h_freq, n_frames * sizeof(float), hipMemcpyHostToDevice, s));
-    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, n_frames, h_freq ? d_freq : nullptr, d_bits, d_corr, d_fft, 0, s))) return st;
+    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, n_frames, h_freq ? d_freq : nullptr, d_bits, d_corr, d_fft, nullptr, 0, s))) return st;
     if ((st = dabgpu_ofdm_phase_update(c, d_corr, n_frames, 0.0f, d_total, nullptr, s))) return st;
     CK(hipMemcpyAsync(h_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
     if (h_total_phase) CK(hipMemcpyAsync(h_total_phase, d_total, n_frames * sizeof(float), hipMemcpyDeviceToHost, s));
     if (h_fft) CK(hipMemcpyAsync(h_fft, d_fft, fft_bytes, hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
 #undef CK
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float freq_coarse, float* h_freq_fine, float beta,
+                                        int8_t* h_bits, float* h_total_phase, float* h_fft, float* h_dqpsk) {
+    if (!c || !h_iq || !h_bits || !h_freq_fine) { dabgpu_set_error("ofdm_demod_stream_frame_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    int st;
+    (void)hipSetDevice(c->device);
+    const size_t iq_bytes = (size_t)DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
+    const size_t fft_bytes = (size_t)77 * DABGPU_NB_FFT * 2 * sizeof(float);
+    const size_t dq_bytes = (size_t)75 * DABGPU_NB_DATA_CARRIERS * 2 * sizeof(float);
+    float *d_iq, *d_small, *d_corr, *d_fft = nullptr, *d_dq = nullptr; int8_t* d_bits;
+    if ((st = dabgpu_scratch(c, 1, iq_bytes, (void**)&d_iq))) return st;
+    if ((st = dabgpu_scratch(c, 2, DABGPU_NB_FRAME_BITS, (void**)&d_bits))) return st;
+    if ((st = dabgpu_scratch(c, 3, 4 * sizeof(float), (void**)&d_small))) return st;       // [0] net freq, [1] fine, [2] total phase
+    if ((st = dabgpu_scratch(c, 4, DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&d_corr))) return st;
+    if (h_fft && (st = dabgpu_scratch(c, 6, fft_bytes, (void**)&d_fft))) return st;
+    if (h_dqpsk && (st = dabgpu_scratch(c, 13, dq_bytes, (void**)&d_dq))) return st;
+    hipStream_t s = c->stream;
+    const float h_small[2] = { freq_coarse + *h_freq_fine, *h_freq_fine };               // :672 net offset of this frame
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_small, h_small, sizeof(h_small), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, 1, d_small, d_bits, d_corr, d_fft, d_dq, 0, s))) return st;
+    if ((st = dabgpu_ofdm_phase_update(c, d_corr, 1, beta, d_small + 2, d_small + 1, s))) return st;
+    CK(hipMemcpyAsync(h_bits, d_bits, DABGPU_NB_FRAME_BITS, hipMemcpyDeviceToHost, s));
+    float back[2];
+    CK(hipMemcpyAsync(back, d_small + 1, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h_fft) CK(hipMemcpyAsync(h_fft, d_fft, fft_bytes, hipMemcpyDeviceToHost, s));
+    if (h_dqpsk) CK(hipMemcpyAsync(h_dqpsk, d_dq, dq_bytes, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+#undef CK
+    *h_freq_fine = back[0];
+    if (h_total_phase) *h_total_phase = back[1];
     return DABGPU_OK;
 }
 

@@ -186,3 +186,152 @@ extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, siz
                                                        d_out, out_ens_stride, (int)off, s), "msc_build_descs launch"))) return st;
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// single-stream host-buffer forms (C++ mirror classes)
+// ------------------------------------------------------------------------------------------------
+static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src, size_t n_src, uint8_t* h_out, size_t n_out,
+                           dabgpu_codeword_result* h_res, int tie_rule) {
+    (void)hipSetDevice(c->device);
+    int st;
+    int8_t* d_src = nullptr; uint8_t* d_out; dabgpu_codeword_result* d_res; dabgpu_cw_desc* d_desc;
+    if (h_src && (st = dabgpu_scratch(c, 14, n_src, (void**)&d_src))) return st;
+    if ((st = dabgpu_scratch(c, 15, std::max<size_t>(n_out, 16), (void**)&d_out))) return st;
+    if ((st = dabgpu_scratch(c, 16, sizeof(dabgpu_codeword_result), (void**)&d_res))) return st;
+    if ((st = dabgpu_scratch(c, 10, sizeof(dabgpu_cw_desc), (void**)&d_desc))) return st;
+    hipStream_t s = c->stream;
+    if (h_src) D.d_src = (uint64_t)(uintptr_t)d_src;
+    D.d_out = (uint64_t)(uintptr_t)d_out;
+    if ((st = validate_codeword(D, 0))) return st;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    if (h_src) CK(hipMemcpyAsync(d_src, h_src, n_src, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, s));
+    if ((st = run_viterbi(c, d_desc, 1, D.n_steps, (D.n_steps - 6) / 8, tie_rule, d_res, s))) return st;
+    CK(hipMemcpyAsync(h_out, d_out, n_out, hipMemcpyDeviceToHost, s));
+    CK(hipMemcpyAsync(h_res, d_res, sizeof(*h_res), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+#undef CK
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_fic_decode_group_host_sync(dabgpu_ctx* c, const int8_t* h_bits, uint8_t* h_bytes, uint32_t* crc_ok_mask,
+                                                 uint64_t* path_error, int tie_rule) {
+    if (!c || !h_bits || !h_bytes) { dabgpu_set_error("fic_decode_group_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_cw_desc D = {};
+    D.n_steps = 774;
+    D.seg_pi[0] = 16; D.seg_steps[0] = 32 * 21;
+    D.seg_pi[1] = 15; D.seg_steps[1] = 32 * 3;
+    D.n_crc_blocks = 3;
+    D.d_src = 1;    // placeholder, replaced by the staging buffer
+    dabgpu_codeword_result R;
+    const int st = decode_one_sync(c, D, h_bits, DABGPU_NB_FIB_GROUP_BITS, h_bytes, 96, &R, tie_rule);
+    if (st) return st;
+    if (crc_ok_mask) *crc_ok_mask = R.crc_ok_mask;
+    if (path_error) *path_error = R.path_error;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_viterbi_decode_host_sync(dabgpu_ctx* c, const int8_t* h_src, size_t n_src, const uint32_t* seg_pi,
+                                               const uint32_t* seg_steps, uint32_t start_state, uint32_t end_state, uint32_t flags,
+                                               uint8_t* h_out, size_t n_out_bytes, uint64_t* path_error, int tie_rule) {
+    if (!c || !h_src || !seg_pi || !seg_steps || !h_out) { dabgpu_set_error("viterbi_decode_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_cw_desc D = {};
+    uint32_t steps = 0; size_t need = 12;
+    for (int k = 0; k < 4; k++) {
+        D.seg_pi[k] = seg_steps[k] ? seg_pi[k] : 0; D.seg_steps[k] = seg_steps[k]; steps += seg_steps[k];
+        need += (size_t)(seg_steps[k] / 8) * (8 + seg_pi[k]);
+    }
+    D.n_steps = steps + 6;
+    D.start_state = start_state; D.end_state = end_state; D.flags = flags;
+    D.d_src = 1;
+    if (n_src < need || n_out_bytes * 8 != steps) {
+        dabgpu_set_error("viterbi_decode_host_sync: %zu soft bits given, %zu needed; %zu output bytes for %u information bits", n_src, need, n_out_bytes, steps);
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    dabgpu_codeword_result R;
+    const int st = decode_one_sync(c, D, h_src, need, h_out, n_out_bytes, &R, tie_rule);
+    if (st) return st;
+    if (path_error) *path_error = R.path_error;
+    return DABGPU_OK;
+}
+
+struct dabgpu_msc_stream {
+    dabgpu_ctx* ctx;
+    dabgpu_subchannel sc;
+    dabgpu_cw_desc proto;       // plan with ring geometry, d_src = ring base
+    int8_t* d_ring;
+    int8_t* d_logical;
+    int n_bits;
+    int n_out_bytes;
+    int next_slot;
+    int stored;
+};
+
+extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* sc, dabgpu_msc_stream** out) {
+    if (!c || !sc || !out) return DABGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int pi[4], lx[4], nb = 0;
+    if (dabgpu_subchannel_plan(sc, pi, lx, &nb) < 0) { dabgpu_set_error("msc_stream_create: invalid protection profile"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    dabgpu_msc_stream* s = new dabgpu_msc_stream();
+    s->ctx = c; s->sc = *sc; s->n_bits = sc->length * 64; s->n_out_bytes = nb; s->next_slot = 0; s->stored = 0;
+    s->d_ring = nullptr; s->d_logical = nullptr;
+    int st = dabgpu_check_hip(hipMalloc((void**)&s->d_ring, (size_t)16 * s->n_bits), "hipMalloc(ring)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_logical, (size_t)s->n_bits), "hipMalloc(logical)");
+    if (!st) st = dabgpu_check_hip(hipMemset(s->d_ring, 0, (size_t)16 * s->n_bits), "hipMemset(ring)");
+    if (st) { dabgpu_msc_stream_destroy(s); return st; }
+    dabgpu_cw_desc& D = s->proto;
+    D = dabgpu_cw_desc{};
+    uint32_t steps = 0;
+    for (int k = 0; k < 4; k++) { D.seg_pi[k] = lx[k] ? (uint32_t)pi[k] : 0u; D.seg_steps[k] = 32u * (uint32_t)lx[k]; steps += D.seg_steps[k]; }
+    D.n_steps = steps + 6;
+    D.d_src = (uint64_t)(uintptr_t)s->d_ring;
+    D.n_slots = 16; D.cifs_per_frame = 1; D.frame_stride = (uint32_t)s->n_bits; D.cif_stride = 0;
+    *out = s;
+    return DABGPU_OK;
+}
+
+extern "C" void dabgpu_msc_stream_destroy(dabgpu_msc_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    if (s->d_ring) (void)hipFree(s->d_ring);
+    if (s->d_logical) (void)hipFree(s->d_logical);
+    delete s;
+}
+
+extern "C" int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_bits) {
+    if (!s || !h_bits) return DABGPU_ERR_INVALID_ARG;
+    (void)hipSetDevice(s->ctx->device);
+    int st = dabgpu_check_hip(hipMemcpyAsync(s->d_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits,
+                                             hipMemcpyHostToDevice, s->ctx->stream), "hipMemcpyAsync(cif)");
+    if (st) return st;
+    s->next_slot = (s->next_slot + 1) % 16;                    // cif_deinterleaver.cpp:28-33
+    if (s->stored < 16) s->stored++;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t* h_out) {
+    if (!s || !h_out) return DABGPU_ERR_INVALID_ARG;
+    if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // cif_deinterleaver.cpp:40-42
+    (void)hipSetDevice(s->ctx->device);
+    hipStream_t q = s->ctx->stream;
+    int st = dabgpu_check_hip(dabgpu_launch_cif_deinterleave(s->d_ring, s->n_bits, 16, (s->next_slot + 15) % 16, s->d_logical, q),
+                              "cif_deinterleave launch");
+    if (!st) st = dabgpu_check_hip(hipMemcpyAsync(h_out, s->d_logical, (size_t)s->n_bits, hipMemcpyDeviceToHost, q), "hipMemcpyAsync");
+    if (!st) st = dabgpu_check_hip(hipStreamSynchronize(q), "hipStreamSynchronize");
+    return st;
+}
+
+extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_out, size_t* n_out, uint64_t* path_error, int tie_rule) {
+    if (!s || !h_out || !n_out) return DABGPU_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // msc_decoder.cpp:60-63
+    dabgpu_cw_desc D = s->proto;
+    D.newest_slot = (uint32_t)((s->next_slot + 15) % 16);
+    dabgpu_codeword_result R;
+    const int st = decode_one_sync(s->ctx, D, nullptr, 0, h_out, (size_t)s->n_out_bytes, &R, tie_rule);
+    if (st) return st;
+    *n_out = (size_t)s->n_out_bytes;
+    if (path_error) *path_error = R.path_error;
+    return DABGPU_OK;
+}

@@ -26,7 +26,7 @@ int dabgpu_check_hip(hipError_t e, const char* what);
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
-                                               float* d_fft, const float* d_tw, const uint16_t* d_inv_map,
+                                               float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
                                                float* d_fine_freq, hipStream_t stream);
@@ -56,3 +56,5 @@ extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
                                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
                                          const float* d_prs, const float* d_prs_time_ref, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_cif_deinterleave(const int8_t* d_ring, int n_bits, int n_slots, int newest_slot,
+                                                     int8_t* d_out, hipStream_t stream);

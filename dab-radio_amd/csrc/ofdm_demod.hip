@@ -40,7 +40,7 @@ template <bool PREFETCH>
 __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
-                       const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
+                       f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -210,6 +210,11 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const f2 d = conj_mul(prev[k], cur[k]);
+                if (dqpsk_out != nullptr) {                              // GetFrameDataVec() view, natural carrier order
+                    const int cbase[6] = {767, 1023, 1279, 0, 256, 512};
+                    const int c = (k == 0 && Kb == 0) ? 1535 : (cbase[k] + Kb);
+                    dqpsk_out[((size_t)frame * (NB_FRAME_SYMBOLS - 1) + (i - 1)) * 1536 + c] = d;
+                }
                 const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
                 const float A = (ar < ai) ? ai : ar;                     // std::max, ofdm_demodulator.cpp:882
                 obuf[pos[k]] = (int8_t)to_vbit(d.x / A);
@@ -284,7 +289,7 @@ static int g_dabgpu_variant = 0;
 extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // development switch (tools/kbench.py)
 
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
-                                               float* d_fft, const float* d_tw, const uint16_t* d_inv_map,
+                                               float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, hipStream_t stream)
 {
     using namespace dabgpu;
@@ -294,7 +299,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d
     const dim3 grid((unsigned)(n_frames * chunks));
 #define DABGPU_LAUNCH(PF) hipLaunchKernelGGL((ofdm_demod_kernel<PF>), grid, dim3(256), lds, stream, \
                        reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
-                       reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
+                       reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks)
     if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true); else DABGPU_LAUNCH(false);
 #undef DABGPU_LAUNCH

@@ -20,7 +20,6 @@
 
 namespace dabgpu {
 
-constexpr uint32_t V_MAX_ERROR = 1016u;
 constexpr uint32_t V_NONSTART = 5080u;
 constexpr uint32_t V_RENORM = 60455u;
 constexpr int PRBS_PERIOD = 511;
@@ -178,13 +177,14 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 if (base + lane < n_steps) my_dec[base + lane] = ((uint64_t)vhi << 32) | vlo;
             }
         }
-        const uint32_t end_metric = (uint32_t)__builtin_amdgcn_readlane((int)metric, 0);   // end_state 0
+        const int end_state = (int)(D.end_state & 63u);
+        const uint32_t end_metric = (uint32_t)__shfl((int)metric, end_state);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);       // decision words are re-read by this same wave: drain its stores first
 
         // ---- chain-back (Karn layout): 8-bit window, state in bits 7..2 ----
         const int n_bits = n_steps - 6;
-        unsigned reg = 0;
+        unsigned reg = (unsigned)end_state << 2;
         int cur_chunk = -1;
         uint32_t clo = 0, chi = 0;
         for (int bit = n_bits - 1; bit >= 0; bit--) {
@@ -203,7 +203,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
             reg = (reg >> 1) | (in << 7);
             if ((bit & 7) == 0 && lane == 0) {
                 const int k = bit >> 3;
-                obytes[k] = (unsigned char)(reg ^ prbs[k % PRBS_PERIOD]);          // descramble in the same pass
+                obytes[k] = (unsigned char)(reg ^ ((D.flags & DABGPU_CW_RAW) ? 0u : prbs[k % PRBS_PERIOD]));   // descramble in the same pass
             }
         }
         __syncthreads();
@@ -298,7 +298,28 @@ __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist
     descs[i] = D;
 }
 
+// CIF_Deinterleaver::Deinterleave as a stand-alone gather (cif_deinterleaver.cpp:36-71); the decoder itself never
+// materialises this buffer, this exists for callers of the CIF_Deinterleaver class
+__global__ void cif_deinterleave_kernel(const int8_t* __restrict__ ring, int n_bits, int n_slots, int newest_slot,
+                                        int8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bits) return;
+    const int age = 15 - (int)(__brev((unsigned)i & 15u) >> 28);
+    int slot = newest_slot - age;
+    if (slot < 0) slot += n_slots;
+    out[i] = ring[(size_t)slot * n_bits + i];
+}
+
 }  // namespace dabgpu
+
+extern "C" hipError_t dabgpu_launch_cif_deinterleave(const int8_t* d_ring, int n_bits, int n_slots, int newest_slot,
+                                                     int8_t* d_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dabgpu::cif_deinterleave_kernel, dim3((unsigned)((n_bits + 255) / 256)), dim3(256), 0, stream,
+                       d_ring, n_bits, n_slots, newest_slot, d_out);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
                                               size_t frame_stride, uint8_t* d_out, hipStream_t stream)

@@ -29,9 +29,12 @@ ABI_SYMBOLS = [
     "dabgpu_strerror", "dabgpu_last_error", "dabgpu_abi_version", "dabgpu_device_count",
     "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize",
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
-    "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync",
+    "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync", "dabgpu_ofdm_demod_stream_frame_sync",
     "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",
     "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
+    "dabgpu_fic_decode_group_host_sync", "dabgpu_viterbi_decode_host_sync", "dabgpu_msc_stream_create",
+    "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
+    "dabgpu_msc_stream_decode_sync",
 ]
 
 
@@ -41,7 +44,7 @@ class Codeword(C.Structure):
                 ("seg_pi", C.c_uint32 * 4), ("seg_steps", C.c_uint32 * 4), ("start_state", C.c_uint32),
                 ("n_crc_blocks", C.c_uint32), ("n_slots", C.c_uint32), ("newest_slot", C.c_uint32),
                 ("cifs_per_frame", C.c_uint32), ("frame_stride", C.c_uint32), ("cif_stride", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("end_state", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class CodewordResult(C.Structure):
@@ -106,7 +109,9 @@ def lib():
         L.dabgpu_get_carrier_mapper.argtypes = [C.c_int, C.c_void_p]
         L.dabgpu_get_fft_twiddles.argtypes = [C.c_void_p]
         L.dabgpu_ofdm_demod_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
                                                C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
@@ -198,12 +203,12 @@ class Context:
         check(lib().dabgpu_synchronize(self._h, self._stream(stream)), "dabgpu_synchronize")
 
     def ofdm_demod_frames(self, iq, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0,
-                          n_frames=None, stream=None):
+                          n_frames=None, stream=None, dqpsk=None):
         """Launch the fused PLL+CP-phase+FFT+DQPSK+demap kernel on device buffers (asynchronous)."""
         if n_frames is None:
             n_frames = iq.numel() // NB_FRAME_SAMPLES if hasattr(iq, "numel") else None
         check(lib().dabgpu_ofdm_demod_frames(self._h, _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits),
-                                             _ptr(cp_corr), _ptr(fft), symbols_per_block, self._stream(stream)),
+                                             _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, self._stream(stream)),
               "dabgpu_ofdm_demod_frames")
 
     def ofdm_phase_update(self, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):

@@ -1,0 +1,36 @@
+// dab/msc/msc_decoder.cpp -- reference: src/dab/msc/msc_decoder.cpp:26-154
+#include "./msc_decoder.h"
+
+#include <stdexcept>
+#include <string>
+
+#include "dabgpu.h"
+#include "../dabgpu_shared_context.h"
+
+MSC_Decoder::MSC_Decoder(const Subchannel subchannel) : m_subchannel(subchannel), m_stream(nullptr) {
+    dabgpu_subchannel sc;
+    sc.start_address = subchannel.start_address;
+    sc.length = subchannel.length;
+    sc.is_uep = subchannel.is_uep ? 1 : 0;
+    sc.uep_prot_index = subchannel.uep_prot_index;
+    sc.eep_prot_level = subchannel.eep_prot_level;
+    sc.eep_type = (subchannel.eep_type == EEP_Type::TYPE_B) ? 1 : 0;
+    const int st = dabgpu_msc_stream_create(dabgpu_shared_context(), &sc, &m_stream);
+    if (st != DABGPU_OK)
+        throw std::runtime_error(std::string("MSC_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
+    m_decoded_bytes.resize((size_t)subchannel.length * 8);                              // :30
+}
+
+MSC_Decoder::~MSC_Decoder() { dabgpu_msc_stream_destroy(m_stream); }
+
+tcb::span<uint8_t> MSC_Decoder::DecodeCIF(tcb::span<const viterbi_bit_t> buf) {
+    const size_t start_bit = (size_t)m_subchannel.start_address * 64, n_bits = (size_t)m_subchannel.length * 64;
+    if (start_bit + n_bits > buf.size()) return {};                                     // :50-54
+    if (dabgpu_msc_stream_push_cif(m_stream, buf.data() + start_bit) != DABGPU_OK) return {};
+    size_t n_out = 0;
+    const int st = dabgpu_msc_stream_decode_sync(m_stream, m_decoded_bytes.data(), &n_out, &m_last_error, dabgpu_tie_rule_from_env());
+    if (st == DABGPU_ERR_NOT_READY) return {};                                          // :60-63
+    if (st != DABGPU_OK)
+        throw std::runtime_error(std::string("MSC_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
+    return tcb::span<uint8_t>(m_decoded_bytes.data(), n_out);
+}

@@ -91,10 +91,13 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *   d_cp_corr     [n_frames][76] complex float raw cyclic-prefix correlation per symbol, may be NULL
  *   d_fft         [n_frames][77][2048] complex float = GetFrameFFT() content, may be NULL (skips the
  *                 display-only NULL-symbol FFT, ofdm_demodulator.cpp:701-709)
+ *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
+ *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
  *   symbols_per_block  data symbols handled by one workgroup (0 = default); any value gives identical results
  */
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_frames, const float *d_freq_offset,
-                             int8_t *d_bits, float *d_cp_corr, float *d_fft, int symbols_per_block, void *stream);
+                             int8_t *d_bits, float *d_cp_corr, float *d_fft, float *d_dqpsk, int symbols_per_block,
+                             void *stream);
 
 /*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]
@@ -112,6 +115,16 @@ int dabgpu_ofdm_phase_update(dabgpu_ctx *ctx, const float *d_cp_corr, size_t n_f
  * h_total_phase may be NULL. This is what the single-stream OFDM_Demod mirror class calls per frame. */
 int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx *ctx, const float *h_iq, size_t n_frames, const float *h_freq_offset,
                                        int8_t *h_bits, float *h_total_phase, float *h_fft);
+
+/*
+ * One frame of one stream, host buffers, synchronous, including the fine-frequency loop update: the PLL runs with
+ * freq_coarse + *h_freq_fine, then *h_freq_fine <- fmod(*h_freq_fine - beta * err, wrap) on the device
+ * (src/ofdm/ofdm_demodulator.cpp:606-618, :829-840).  h_fft [77][2048] and h_dqpsk [75][1536] complex float may be NULL.
+ * This is the per-frame call of the OFDM_Demod mirror class (replaces CoordinatorThread + PipelineThread for one frame).
+ */
+int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx *ctx, const float *h_iq, float freq_coarse, float *h_freq_fine,
+                                        float fine_freq_update_beta, int8_t *h_bits, float *h_total_phase, float *h_fft,
+                                        float *h_dqpsk);
 
 /* ------------------------------------------------------------------------------------------------
  * PRS synchronisation: integer-bin frequency offset (coarse) then symbol timing from the impulse response (fine).
@@ -178,8 +191,10 @@ typedef struct {
     uint32_t cifs_per_frame;   /* ring geometry: slot s lives at d_src + (s / cifs_per_frame) * frame_stride */
     uint32_t frame_stride;     /*                                      + (s % cifs_per_frame) * cif_stride   (bytes) */
     uint32_t cif_stride;
-    uint32_t reserved;
+    uint32_t end_state;        /* DAB_Viterbi_Decoder::chainback(bytes_out, end_state), normally 0 */
+    uint32_t flags;            /* DABGPU_CW_RAW: emit the decoder output without the energy-dispersal XOR */
 } dabgpu_codeword;
+#define DABGPU_CW_RAW 1u
 
 typedef struct {
     uint64_t path_error;       /* DAB_Viterbi_Decoder::chainback() return value (dab_viterbi_decoder.cpp:124-129) */
@@ -233,6 +248,31 @@ int dabgpu_msc_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits_history, size
                              int history_frames, int newest_frame_slot, const dabgpu_subchannel *h_subchannels,
                              int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
                              dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-stream, host-buffer, synchronous forms used by the C++ mirror classes (one codeword per call).
+ */
+/* one FIB group: FIC_Decoder::DecodeFIBGroup (src/dab/fic/fic_decoder.cpp:53-117) */
+int dabgpu_fic_decode_group_host_sync(dabgpu_ctx *ctx, const int8_t *h_bits /*[2304]*/, uint8_t *h_bytes /*[96]*/,
+                                      uint32_t *crc_ok_mask, uint64_t *path_error, int tie_rule);
+/* DAB_Viterbi_Decoder reset/update.../chainback collapsed into one call: h_src holds the punctured soft bits of all
+ * segments back to back (src/dab/algorithms/dab_viterbi_decoder.cpp:109-129) */
+int dabgpu_viterbi_decode_host_sync(dabgpu_ctx *ctx, const int8_t *h_src, size_t n_src, const uint32_t *seg_pi4,
+                                    const uint32_t *seg_steps4, uint32_t start_state, uint32_t end_state, uint32_t flags,
+                                    uint8_t *h_out, size_t n_out_bytes, uint64_t *path_error, int tie_rule);
+
+/* per-sub-channel stream: a 16-slot device ring of the sub-channel's slice of every CIF + its protection plan.
+ * Replaces MSC_Decoder + CIF_Deinterleaver state (src/dab/msc/msc_decoder.cpp:26-75, cif_deinterleaver.cpp:13-34). */
+typedef struct dabgpu_msc_stream dabgpu_msc_stream;
+int dabgpu_msc_stream_create(dabgpu_ctx *ctx, const dabgpu_subchannel *sc, dabgpu_msc_stream **out);
+void dabgpu_msc_stream_destroy(dabgpu_msc_stream *s);
+/* CIF_Deinterleaver::Consume: h_bits = length*64 soft bits of this sub-channel from one CIF */
+int dabgpu_msc_stream_push_cif(dabgpu_msc_stream *s, const int8_t *h_bits);
+/* CIF_Deinterleaver::Deinterleave: DABGPU_ERR_NOT_READY until 16 CIFs were pushed */
+int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream *s, int8_t *h_out);
+/* Deinterleave + DecodeEEP/DecodeUEP of the logical frame completed by the last push; *n_out = decoded bytes.
+ * DABGPU_ERR_NOT_READY (and *n_out = 0) until 16 CIFs were pushed (msc_decoder.cpp:60-63) */
+int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *n_out, uint64_t *path_error, int tie_rule);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+// mirror_harness.cpp -- drives the C++ mirror classes the way basic_radio_app does (examples/basic_radio_app.cpp:404-419,
+// src/basic_radio/basic_radio.cpp:41-65, basic_fic_runner.cpp:34-49, basic_dab_plus_channel.cpp:47-51): raw IQ file ->
+// OFDM_Demod::Process in blocks -> frame bits -> FIC_Decoder x4 + MSC_Decoder x4 per sub-channel.  Everything it
+// produces is written to files that tests/test_gpu_cpp_mirror.py compares byte for byte with the CPU oracle.
+//
+//   mirror_harness <iq.c32> <out_dir> <block_size> [<start_cu> <length_cu> <eep_level> <eep_type_b>]...
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "dab/algorithms/dab_viterbi_decoder.h"
+#include "dab/constants/dab_parameters.h"
+#include "dab/constants/puncture_codes.h"
+#include "dab/fic/fic_decoder.h"
+#include "dab/msc/cif_deinterleaver.h"
+#include "dab/msc/msc_decoder.h"
+#include "ofdm/ofdm_helpers.h"
+
+static void append(const std::string& path, const void* p, size_t n) {
+    std::ofstream f(path, std::ios::binary | std::ios::app);
+    f.write(reinterpret_cast<const char*>(p), (std::streamsize)n);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: %s iq.c32 out_dir block_size [start len level type_b]...\n", argv[0]); return 2; }
+    const std::string out = argv[2];
+    const size_t block = (size_t)std::atol(argv[3]);
+    std::ifstream in(argv[1], std::ios::binary);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
+
+    const DAB_Parameters dab = get_dab_parameters(1);
+    auto demod = Create_OFDM_Demodulator(1);
+    demod->EnableDebugBuffers(true);
+    FIC_Decoder fic((size_t)dab.nb_fib_cif_bits, (size_t)dab.nb_fibs_per_cif);
+    fic.OnFIB().Attach([&](tcb::span<const uint8_t> fib) { append(out + "/fibs.bin", fib.data(), fib.size()); });
+
+    std::vector<std::unique_ptr<MSC_Decoder>> msc;
+    std::vector<Subchannel> subs;
+    for (int a = 4; a + 3 < argc; a += 4) {
+        Subchannel sc((subchannel_id_t)subs.size());
+        sc.start_address = (subchannel_addr_t)std::atoi(argv[a]);
+        sc.length = (subchannel_size_t)std::atoi(argv[a + 1]);
+        sc.eep_prot_level = (eep_protection_level_t)std::atoi(argv[a + 2]);
+        sc.eep_type = std::atoi(argv[a + 3]) ? EEP_Type::TYPE_B : EEP_Type::TYPE_A;
+        sc.is_complete = true;
+        subs.push_back(sc);
+        msc.push_back(std::make_unique<MSC_Decoder>(sc));
+    }
+    std::unique_ptr<CIF_Deinterleaver> deint;
+    if (!subs.empty()) deint = std::make_unique<CIF_Deinterleaver>(subs[0].length * 8);
+    DAB_Viterbi_Decoder vit;
+    vit.set_traceback_length(768);
+
+    int n_frames = 0;
+    demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) {
+        n_frames++;
+        append(out + "/frame_bits.bin", bits.data(), bits.size());
+        const float st[4] = {demod->GetCoarseFrequencyOffset(), demod->GetFineFrequencyOffset(), (float)demod->GetFineTimeOffset(),
+                             (float)demod->GetTotalFramesDesync()};
+        append(out + "/states.bin", st, sizeof(st));
+        auto fft = demod->GetFrameFFT();
+        append(out + "/fft_sym1.bin", fft.data() + 2048, 2048 * sizeof(std::complex<float>));
+        auto dq = demod->GetFrameDataVec();
+        append(out + "/dqpsk_sym0.bin", dq.data(), 1536 * sizeof(std::complex<float>));
+        auto fic_bits = bits.subspan(0, (size_t)dab.nb_fic_bits);
+        auto msc_bits = bits.subspan((size_t)dab.nb_fic_bits, (size_t)dab.nb_msc_bits);
+        for (int c = 0; c < dab.nb_cifs; c++) {                                         // basic_fic_runner.cpp:44-48
+            auto grp = fic_bits.subspan((size_t)c * dab.nb_fib_cif_bits, (size_t)dab.nb_fib_cif_bits);
+            fic.DecodeFIBGroup(grp, (size_t)c);
+            const uint32_t m = fic.GetLastCrcMask();
+            const uint64_t e = fic.GetLastPathError();
+            append(out + "/fic_status.bin", &m, 4);
+            append(out + "/fic_status.bin", &e, 8);
+            if (c == 0) {                                                               // DAB_Viterbi_Decoder used directly, fic_decoder.cpp:74-87
+                uint8_t raw[96];
+                vit.reset();
+                size_t used = vit.update(grp, GetPunctureCode(16), 128 * 21);
+                used += vit.update(grp.subspan(used), GetPunctureCode(15), 128 * 3);
+                used += vit.update(grp.subspan(used), PI_X, 24);
+                const uint64_t err = vit.chainback(raw);
+                append(out + "/viterbi_raw.bin", raw, 96);
+                const uint64_t meta[3] = {used, vit.get_current_decoded_bit(), err};
+                append(out + "/viterbi_meta.bin", meta, sizeof(meta));
+            }
+        }
+        for (int c = 0; c < dab.nb_cifs; c++) {                                         // basic_dab_plus_channel.cpp:47-51
+            auto cif = msc_bits.subspan((size_t)c * dab.nb_cif_bits, (size_t)dab.nb_cif_bits);
+            for (size_t s = 0; s < msc.size(); s++) {
+                auto bytes = msc[s]->DecodeCIF(cif);
+                const uint32_t nb = (uint32_t)bytes.size();
+                append(out + "/msc_" + std::to_string(s) + ".bin", &nb, 4);
+                append(out + "/msc_" + std::to_string(s) + ".bin", bytes.data(), bytes.size());
+            }
+            if (deint) {
+                const size_t nbits = (size_t)subs[0].length * 64;
+                std::vector<viterbi_bit_t> lf(nbits);
+                deint->Consume(cif.subspan((size_t)subs[0].start_address * 64, nbits));
+                const uint8_t ok = deint->Deinterleave(lf) ? 1 : 0;
+                append(out + "/deint.bin", &ok, 1);
+                if (ok) append(out + "/deint.bin", lf.data(), nbits);
+            }
+        }
+    });
+
+    std::vector<std::complex<float>> buf(block);
+    while (in) {
+        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(block * sizeof(std::complex<float>)));
+        const size_t got = (size_t)in.gcount() / sizeof(std::complex<float>);
+        if (got == 0) break;
+        demod->Process(tcb::span<const std::complex<float>>(buf.data(), got));
+    }
+    std::printf("frames=%d read=%d desync=%d state=%d signal_avg=%.9g\n", n_frames, demod->GetTotalFramesRead(),
+                demod->GetTotalFramesDesync(), (int)demod->GetState(), demod->GetSignalAverage());
+    return 0;
+}
