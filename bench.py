@@ -30,6 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import dabgpu  # noqa: E402
+from dabgpu import shard  # noqa: E402
 
 ALGO_BYTES_PER_FRAME = 196608 * 8 + 230400          # c32 IQ read + int8 soft bits written
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8 TB/s spec
@@ -144,7 +145,10 @@ def main():
     ctx = dabgpu.Context(local_rank)
     prs, mapper, _ = dabgpu.host_tables()
     F = args.frames
-    iq, tx_bits, freq = synth_frames(F, seed=1000 + rank, device=device, mapper=mapper, prs=prs)
+    # weak scaling: the ensemble set grows with the number of GPUs; rank r owns the contiguous block shard_range gives
+    first_unit, n_units = shard.shard_range(F * world, rank, world)
+    assert n_units == F
+    iq, tx_bits, freq = synth_frames(F, seed=1000 + first_unit, device=device, mapper=mapper, prs=prs)
     # the receiver corrects with the negative of the applied shift... the PLL multiplies by e^{+j2pi f n}
     d_freq = freq.clone()
     d_bits = torch.empty((F, 230400), dtype=torch.int8, device=device)
@@ -170,10 +174,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, device)
 
     # ---- correctness of what was just timed (untimed) ----
     check = {}

@@ -186,10 +186,13 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 
 // ---- OFDM ----
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
-                             float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, void* stream) {
+                             float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
     if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_frame_stride != 0 && (bits_frame_stride < DABGPU_NB_FRAME_BITS || (bits_frame_stride & 15))) {
+        dabgpu_set_error("ofdm_demod_frames: bits_frame_stride must be 0 or a multiple of 16 >= 230400"); return DABGPU_ERR_INVALID_ARG;
+    }
     if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_demod_frames: d_iq and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)stream;      // NULL = the HIP default (null) stream
     float* corr = d_cp_corr;
@@ -198,7 +201,7 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, 
         if (st) return st;
     }
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
-                                                     (int)n_frames, symbols_per_block, s), "ofdm_demod_kernel launch");
+                                                     (int)n_frames, symbols_per_block, bits_frame_stride, s), "ofdm_demod_kernel launch");
 }
 
 int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,
@@ -230,7 +233,7 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
     CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
     if (h_freq) CK(hipMemcpyAsync(d_freq, h_freq, n_frames * sizeof(float), hipMemcpyHostToDevice, s));
-    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, n_frames, h_freq ? d_freq : nullptr, d_bits, d_corr, d_fft, nullptr, 0, s))) return st;
+    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, n_frames, h_freq ? d_freq : nullptr, d_bits, d_corr, d_fft, nullptr, 0, 0, s))) return st;
     if ((st = dabgpu_ofdm_phase_update(c, d_corr, n_frames, 0.0f, d_total, nullptr, s))) return st;
     CK(hipMemcpyAsync(h_bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, s));
     if (h_total_phase) CK(hipMemcpyAsync(h_total_phase, d_total, n_frames * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -260,7 +263,7 @@ int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
     CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(d_small, h_small, sizeof(h_small), hipMemcpyHostToDevice, s));
-    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, 1, d_small, d_bits, d_corr, d_fft, d_dq, 0, s))) return st;
+    if ((st = dabgpu_ofdm_demod_frames(c, d_iq, 1, d_small, d_bits, d_corr, d_fft, d_dq, 0, 0, s))) return st;
     if ((st = dabgpu_ofdm_phase_update(c, d_corr, 1, beta, d_small + 2, d_small + 1, s))) return st;
     CK(hipMemcpyAsync(h_bits, d_bits, DABGPU_NB_FRAME_BITS, hipMemcpyDeviceToHost, s));
     float back[2];

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
                        f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
-                       int n_frames, int sym_per_chunk, int chunks_per_frame)
+                       int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f2* bufA = reinterpret_cast<f2*>(smem);                              // 2048 x 8 B, position-indexed
@@ -224,7 +224,7 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
         __syncthreads();       // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
         if (emit && t < NB_SYM_BITS / 16) {
             const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
-            uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * NB_FRAME_BITS + (size_t)(i - 1) * NB_SYM_BITS);
+            uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
             dst[t] = o;
         }
 #pragma unroll
@@ -290,9 +290,10 @@ extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // d
 
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
-                                               int n_frames, int sym_per_chunk, hipStream_t stream)
+                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, hipStream_t stream)
 {
     using namespace dabgpu;
+    if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
@@ -300,7 +301,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d
 #define DABGPU_LAUNCH(PF) hipLaunchKernelGGL((ofdm_demod_kernel<PF>), grid, dim3(256), lds, stream, \
                        reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride)
     if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true); else DABGPU_LAUNCH(false);
 #undef DABGPU_LAUNCH
     return hipGetLastError();

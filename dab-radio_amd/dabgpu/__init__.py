@@ -109,7 +109,7 @@ def lib():
         L.dabgpu_get_carrier_mapper.argtypes = [C.c_int, C.c_void_p]
         L.dabgpu_get_fft_twiddles.argtypes = [C.c_void_p]
         L.dabgpu_ofdm_demod_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
@@ -203,12 +203,12 @@ class Context:
         check(lib().dabgpu_synchronize(self._h, self._stream(stream)), "dabgpu_synchronize")
 
     def ofdm_demod_frames(self, iq, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0,
-                          n_frames=None, stream=None, dqpsk=None):
+                          n_frames=None, stream=None, dqpsk=None, bits_frame_stride=0):
         """Launch the fused PLL+CP-phase+FFT+DQPSK+demap kernel on device buffers (asynchronous)."""
         if n_frames is None:
             n_frames = iq.numel() // NB_FRAME_SAMPLES if hasattr(iq, "numel") else None
         check(lib().dabgpu_ofdm_demod_frames(self._h, _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits),
-                                             _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, self._stream(stream)),
+                                             _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, bits_frame_stride, self._stream(stream)),
               "dabgpu_ofdm_demod_frames")
 
     def ofdm_phase_update(self, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):

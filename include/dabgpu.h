@@ -94,10 +94,12 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
  *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
  *   symbols_per_block  data symbols handled by one workgroup (0 = default); any value gives identical results
+ *   bits_frame_stride  bytes between the soft bits of consecutive frames (0 = 230400, packed); lets the kernel write
+ *                 straight into slot k of a per-ensemble frame-history ring (see dabgpu_msc_decode_frames)
  */
 int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_frames, const float *d_freq_offset,
                              int8_t *d_bits, float *d_cp_corr, float *d_fft, float *d_dqpsk, int symbols_per_block,
-                             void *stream);
+                             size_t bits_frame_stride, void *stream);
 
 /*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]

@@ -47,7 +47,7 @@ def test_unsupported_mode_and_null_args(dabgpu):
     buf = np.zeros(4096, np.float32)
     assert L.dabgpu_get_prs_fft_ref(2, buf.ctypes.data) == 5          # DABGPU_ERR_UNSUPPORTED
     assert L.dabgpu_get_prs_fft_ref(1, None) == 2                      # DABGPU_ERR_INVALID_ARG
-    assert L.dabgpu_ofdm_demod_frames(None, None, 1, None, None, None, None, None, 0, None) == 2
+    assert L.dabgpu_ofdm_demod_frames(None, None, 1, None, None, None, None, None, 0, 0, None) == 2
 
 
 def test_no_cpu_fallback(dabgpu):
