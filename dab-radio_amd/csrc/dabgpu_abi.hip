@@ -174,6 +174,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     if (c->d_inv_map) (void)hipFree(c->d_inv_map);
     if (c->d_prs) (void)hipFree(c->d_prs);
     if (c->d_prs_time_ref) (void)hipFree(c->d_prs_time_ref);
+    if (c->d_vit_tables) (void)hipFree(c->d_vit_tables);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

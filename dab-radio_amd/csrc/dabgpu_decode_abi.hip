@@ -73,15 +73,46 @@ static int device_waves(dabgpu_ctx* c) {
     return c->n_cu * 32;          // 8 waves per SIMD: the decoder is a serial recurrence per wave, throughput = waves in flight
 }
 
+// kept-count vectors PI_1..PI_24 (ETSI EN 300 401 table 13: PI_n keeps 8+n of every 32 mother bits, the e-th extra bit in
+// 4-bit group bitrev3(e mod 8)) as count | prefix << 8, and the energy-dispersal PRBS x^9+x^5+1 seeded with all ones
+static int ensure_vit_tables(dabgpu_ctx* c) {
+    if (c->d_vit_tables) return DABGPU_OK;
+    dabgpu_vit_tables T;
+    memset(&T, 0, sizeof(T));
+    static const int order[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    for (int pi = 1; pi <= 24; pi++) {
+        int cnt[8];
+        for (int g = 0; g < 8; g++) cnt[g] = 1;
+        for (int e = 0; e < pi; e++) cnt[order[e % 8]]++;
+        int pre = 0;
+        for (int g = 0; g < 8; g++) { T.pi_tab[pi * 8 + g] = (uint16_t)(cnt[g] | (pre << 8)); pre += cnt[g]; }
+    }
+    unsigned reg = 0xFFFFu;
+    for (int k = 0; k < 511; k++) {
+        unsigned b = 0;
+        for (int i = 0; i < 8; i++) {
+            const unsigned v = ((reg >> 8) ^ (reg >> 4)) & 1u;
+            b |= v << (7 - i);
+            reg = ((reg << 1) | v) & 0xFFFFu;
+        }
+        T.prbs[k] = (unsigned char)b;
+    }
+    int st = dabgpu_check_hip(hipMalloc((void**)&c->d_vit_tables, sizeof(T)), "hipMalloc(vit tables)");
+    if (st) return st;
+    return dabgpu_check_hip(hipMemcpy(c->d_vit_tables, &T, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(vit tables)");
+}
+
 static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t max_steps, uint32_t max_out_bytes,
                        int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s) {
+    int st0 = ensure_vit_tables(c);
+    if (st0) return st0;
     const int n_waves = (int)std::min<size_t>(n, (size_t)device_waves(c));
     const size_t words = ((size_t)max_steps + 63) & ~(size_t)63;
     uint64_t* d_scratch = nullptr;
     int st = dabgpu_scratch(c, 11, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch);
     if (st) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi(d_descs, (int)n, d_scratch, words, n_waves, (int)max_out_bytes, d_results,
-                                                  tie_rule ? 1 : 0, s), "viterbi_kernel launch");
+                                                  tie_rule ? 1 : 0, c->d_vit_tables, s), "viterbi_kernel launch");
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {

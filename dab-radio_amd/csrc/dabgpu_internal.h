@@ -17,6 +17,7 @@ struct dabgpu_ctx {
     uint16_t* d_inv_map = nullptr;   // carrier -> de-interleaved position
     float* d_prs = nullptr;          // PRS spectrum
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
+    struct dabgpu_vit_tables* d_vit_tables = nullptr;
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
 };
@@ -42,9 +43,14 @@ struct dabgpu_msc_plan {            // device-side sub-channel plan (one per sub
     uint32_t out_offset;            // byte offset of this sub-channel inside one CIF's output record
     uint32_t n_out_bytes;
 };
+struct dabgpu_vit_tables {          // constant tables of the Viterbi kernel, built on the host at context creation
+    uint16_t pi_tab[25 * 8];        // [PI][group]: kept count | running prefix << 8 (puncture_codes.h:42-67)
+    unsigned char prbs[512];        // energy-dispersal bytes, period 511 (additive_scrambler.h:16-35)
+};
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
-                                            dabgpu_cw_result* d_results, int tie_rule, hipStream_t stream);
+                                            dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
+                                            hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
                                               size_t frame_stride, uint8_t* d_out, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,

@@ -1,15 +1,23 @@
 // viterbi.hip -- gfx950 kernel for the channel-decode half of the hot path.
 //
 // One wavefront decodes one punctured K=7 rate-1/4 codeword (FIB group or sub-channel logical frame):
-//   lane j            = trellis state j (64 states = 64 lanes)
-//   branch metric     = 508 - v_dot4_i32_i8(sign pattern of the lane, 4 packed soft symbols)
-//   add-compare-select: predecessors j>>1 and (j>>1)+32 fetched with two ds_bpermute; u16 metrics with the
-//                       reference's renormalisation rule (dab_viterbi_decoder.cpp:31-41)
-//   decision word     = the 64-bit compare mask (v_cmp writes it straight into an SGPR pair), bit j = state j
+//   lanes             = the 64 trellis states, in a ROTATING layout: at step t (phase p = t mod 6) lane L holds state
+//                       rotl6(L, p).  The two states of a butterfly (s, s+32) then sit in lanes L and L ^ (32 >> p), so the
+//                       add-compare-select needs ONE cross-lane exchange per step and no LDS at all:
+//                       v_permlane32_swap / v_permlane16_swap (gfx950) for p = 0,1, DPP row_ror:8 / bank-masked row_shl:4
+//                       + row_shr:4 / quad_perm for p = 2..5.  Each lane keeps its own predecessor at branch cost e and
+//                       takes the partner's at 1016 - e; the survivor becomes state rotl6(s,1) = the layout of phase p+1.
+//   branch metric     = v_dot4_i32_i8 of the lane's sign pattern for this phase with 4 packed soft symbols,
+//                       accumulated straight onto metric + 508
+//   metrics           = u16 semantics (wrap) with the reference's renormalisation rule (dab_viterbi_decoder.cpp:31-41)
+//   decisions         = kept TRANSPOSED: every lane shifts its own decision bit into a history register with one
+//                       v_alignbit per step (sign bit of the candidate difference), 128 B (64 x u16) parked per 16 steps
 //   de-puncturing     = index arithmetic on the kept-count tables (dab_viterbi_decoder.cpp:131-181), never materialised
 //   time de-interleave= index arithmetic on a ring of past CIFs (cif_deinterleaver.cpp:36-71), never materialised
-//   chain-back        = scalar pointer chase over decision words parked in a per-wave HBM/L2 scratch ring,
-//                       MSB-first bytes, XOR with the energy-dispersal PRBS (additive_scrambler.h:16-35),
+//   chain-back        = done in lane-index space (the survivor's lane changes one bit per step), all 64 lanes
+//                       redundantly on the VALU -- the scalar unit is shared by the 32 waves of a CU and was the
+//                       bottleneck of a scalar chain-back; one ds_bpermute per bit fetches the survivor lane's history
+//                       word; MSB-first bytes, XOR with the energy-dispersal PRBS (additive_scrambler.h:16-35),
 //                       CRC16 of each FIB (fic_decoder.cpp:103-116) by three lanes
 // Restates williamyang98/ViterbiDecoderCpp's scalar core (vendor/viterbi_decoder, empty submodule in the reference
 // snapshot) behind DAB_Viterbi_Decoder's call sites; tie_rule 0 = scalar core, 1 = SIMD cores.
@@ -23,20 +31,134 @@ namespace dabgpu {
 constexpr uint32_t V_NONSTART = 5080u;
 constexpr uint32_t V_RENORM = 60455u;
 constexpr int PRBS_PERIOD = 511;
+constexpr int VBLOCK = 48;                 // steps per block: multiple of 6 (layout phases), 8 (bytes), 16 (history words)
 
 __device__ __forceinline__ int parity7(unsigned v) { return __builtin_popcount(v & 0x7Fu) & 1; }
+__device__ __forceinline__ unsigned rotl6(unsigned v, int p) { return ((v << p) | (v >> (6 - p))) & 63u; }   // 0 <= p < 6
+__device__ __forceinline__ unsigned rotr6(unsigned v, int p) { return ((v >> p) | (v << (6 - p))) & 63u; }
 
-// kept-count (low nibble) and running prefix (high bits) of puncture vector PI_pi, 4-bit group g (0..7):
-// the n-th extra kept bit of a 32-bit period goes to group bitrev3(n mod 8) (ETSI EN 300 401 table 13;
-// same data as src/dab/constants/puncture_codes.h:42-67).  PI_X (tail) == PI_8 restricted to 6 groups.
+// kept-count of puncture vector PI_pi, 4-bit group g (0..7): the n-th extra kept bit of a 32-bit period goes to group
+// bitrev3(n mod 8) (ETSI EN 300 401 table 13; same data as src/dab/constants/puncture_codes.h:42-67).
+// PI_X (tail) == PI_8 restricted to 6 groups.
 __device__ __forceinline__ int pi_count(int pi, int g) {
     const int ord = ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);
     return 1 + ((pi > ord) ? (((pi - 1 - ord) >> 3) + 1) : 0);
 }
 
+// value of `m` held by lane (lane ^ (32 >> P))
+template <int P>
+__device__ __forceinline__ uint32_t xchg(uint32_t m, int lane) {
+    if constexpr (P == 0) {
+        const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    } else if constexpr (P == 1) {
+        const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (P == 2) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0x128, 0xF, 0xF, true);                 // row_ror:8
+    } else if constexpr (P == 3) {
+        const int a = __builtin_amdgcn_update_dpp((int)m, (int)m, 0x104, 0xF, 0x5, false);        // row_shl:4 -> banks 0,2
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)m, 0x114, 0xF, 0xA, false);          // row_shr:4 -> banks 1,3
+    } else if constexpr (P == 4) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
+    } else {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xF, 0xF, true);                  // quad_perm [1,0,3,2]
+    }
+}
+
+struct LaneConst {
+    int sig[6];       // +sigma pattern of the lane's butterfly at phase p (4 x int8)
+    int nsig[6];      // -sigma
+    int um[6];        // -1 when the lane holds the upper predecessor (state bit 5 = lane bit 5-p) at phase p, else 0
+    int up1[6];       // -um (0 or 1)
+};
+
+// one trellis step at phase P: survivors, and the lane's decision bit (1 = upper predecessor s+32) shifted into `hist`
+template <int P, int TIE>
+__device__ __forceinline__ void acs_step(uint32_t& metric, uint32_t& hist, const LaneConst& K, int ysym, int lane) {
+    const uint32_t m508 = metric + 508u;
+    const uint32_t p508 = xchg<P>(m508, lane);
+    // own predecessor at branch cost e = 508 - dot, partner at 1016 - e = 508 + dot
+    const uint32_t c_self = (uint32_t)__builtin_amdgcn_sdot4(K.nsig[P], ysym, (int)m508, false);
+    const uint32_t c_part = (uint32_t)__builtin_amdgcn_sdot4(K.sig[P], ysym, (int)p508, false);
+    const uint16_t cs = (uint16_t)c_self, cp = (uint16_t)c_part;          // u16 wrap like the reference core
+    // lower lanes: upper predecessor = partner, chosen iff cp < cs (TIE 0) / <= (TIE 1);
+    // upper lanes: upper predecessor = self,    chosen iff cs < cp (TIE 0) / <= (TIE 1)
+    int d = (int)cp - (int)cs;
+    d = (d ^ K.um[P]) + K.up1[P];
+    if constexpr (TIE != 0) d -= 1;
+    hist = __builtin_amdgcn_alignbit(hist, (uint32_t)d, 31);          // hist = hist << 1 | sign(d)
+    metric = (uint32_t)((cs < cp) ? cs : cp);
+}
+
+// up to 48 trellis steps; ypk[q] lane 4j = packed symbols of step t0 + 16 q + j
+template <int TIE>
+__device__ __forceinline__ void forward_block(uint32_t& metric, uint32_t& hist, uint64_t& renorm_total, const LaneConst& K,
+                                              const int (&ypk)[3], int t0, int n_steps, int lane, uint16_t* my_dec16) {
+#pragma unroll
+    for (int j = 0; j < VBLOCK; j++) {
+        const int t = t0 + j;
+        if (t < n_steps) {                                                       // wave-uniform
+            const int ysym = __builtin_amdgcn_readlane(ypk[j >> 4], 4 * (j & 15));
+            switch (j % 6) {                                                     // constant after unrolling
+            case 0: acs_step<0, TIE>(metric, hist, K, ysym, lane); break;
+            case 1: acs_step<1, TIE>(metric, hist, K, ysym, lane); break;
+            case 2: acs_step<2, TIE>(metric, hist, K, ysym, lane); break;
+            case 3: acs_step<3, TIE>(metric, hist, K, ysym, lane); break;
+            case 4: acs_step<4, TIE>(metric, hist, K, ysym, lane); break;
+            default: acs_step<5, TIE>(metric, hist, K, ysym, lane); break;
+            }
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)metric);   // state 0 is lane 0 in every phase
+            if (m0 >= V_RENORM) {                                                // rare, wave-uniform
+                uint32_t mn = metric;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+                metric -= mn;
+                renorm_total += mn;
+            }
+            if ((j & 15) == 15) my_dec16[(size_t)(t >> 4) * 64 + lane] = (uint16_t)hist;   // 16 steps x 64 lanes = 128 B, coalesced
+        }
+    }
+}
+
+// up to 48 chain-back steps t = tb+47 .. tb (those with 6 <= t < n_steps).
+// l4 = 4 * (lane holding the survivor after step t); acc collects the bits of the byte in flight
+__device__ __forceinline__ void chainback_block(int& l4, uint32_t& acc, uint32_t& outreg, int tb, int n_steps, int lane,
+                                                const uint16_t* my_dec16, unsigned char* obytes, const unsigned char* prbs, bool raw) {
+    const int kb = tb >> 3;                       // bits tb-6 .. tb-1 belong to byte kb - 1, finished by the next (lower) block
+    const int rel = (lane - (kb - 1)) & 63;       // the lane that parks byte (kb - 1 + c) is the one with rel == c
+    uint32_t W = 0;
+#pragma unroll
+    for (int u = VBLOCK - 1; u >= 0; u--) {
+        const int t = tb + u;
+        if (t < n_steps && t >= 6) {                                             // wave-uniform
+            if ((u & 15) == 15 || t == n_steps - 1)                              // entering history word t >> 4
+                W = __builtin_nontemporal_load(&my_dec16[(size_t)(t >> 4) * 64 + lane]);
+            const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)W);
+            const uint32_t d = __builtin_amdgcn_ubfe(w, 15 - (u & 15), 1);
+            const int q = 5 - (u % 6);                                           // the survivor's lane changes bit q (see header)
+            l4 = (int)(((uint32_t)l4 & ~(4u << q)) | (d << (q + 2)));
+            acc |= d << (7 - ((u + 2) & 7));                                     // bit (t-6) & 7, MSB first
+            if (((u + 2) & 7) == 0) {                                            // byte (t - 6) >> 3 complete
+                const int c = ((u - 6) >> 3) + 1;                                // byte index - (kb - 1): 1..6
+                outreg = (rel == c) ? acc : outreg;
+                acc = 0;
+                const int k = kb - 1 + c;
+                if ((k & 63) == 0) {                                             // bytes k .. k+63 parked (k = 0 ends the codeword): to LDS
+                    const int kk = k + lane;
+                    const unsigned char pb = raw ? (unsigned char)0 : prbs[kk % PRBS_PERIOD];
+                    obytes[kk] = (unsigned char)(outreg ^ pb);
+                }
+            }
+        }
+    }
+}
+
+template <int TIE>
 __global__ __launch_bounds__(64)
 void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t* __restrict__ dec_scratch,
-                    size_t scratch_words_per_wave, dabgpu_cw_result* __restrict__ results, int tie_rule)
+                    size_t scratch_words_per_wave, dabgpu_cw_result* __restrict__ results,
+                    const dabgpu_vit_tables* __restrict__ tables)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     uint16_t* pi_tab = reinterpret_cast<uint16_t*>(vsm);            // [25][8]: count | prefix << 8
@@ -44,43 +166,31 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
     unsigned char* obytes = prbs + 512;                             // decoded bytes of the current codeword
 
     const int lane = threadIdx.x;
-    // ---- tables ----
-    for (int e = lane; e < 25 * 8; e += 64) {
-        const int pi = e >> 3, g = e & 7;
-        int pre = 0;
-        for (int q = 0; q < g; q++) pre += pi_count(pi, q);
-        pi_tab[e] = (uint16_t)(pi_count(pi, g) | (pre << 8));
-    }
-    if (lane == 0) {                                                // additive_scrambler.h:16-35, syncword 0xFFFF
-        unsigned reg = 0xFFFFu;
-        for (int k = 0; k < PRBS_PERIOD; k++) {
-            unsigned b = 0;
-            for (int i = 0; i < 8; i++) {
-                const unsigned v = ((reg >> 8) ^ (reg >> 4)) & 1u;
-                b |= v << (7 - i);
-                reg = ((reg << 1) | v) & 0xFFFFu;
-            }
-            prbs[k] = (unsigned char)b;
-        }
-    }
+    // ---- tables (host-computed constants of the context) ----
+    for (int e = lane; e < 25 * 8; e += 64) pi_tab[e] = tables->pi_tab[e];
+    for (int e = lane; e < 512; e += 64) prbs[e] = tables->prbs[e];
     __syncthreads();
 
-    // ---- per-lane trellis constants ----
-    // new state j = lane: butterfly s = j>>1, input bit b = j&1.  Branch table sign for symbol r of butterfly s is
-    // +127 if parity((2s) & G_r) (ViterbiBranchTable), error = sum_r |branch_r - y_r| = 508 - sum_r sigma_r y_r,
-    // and the other transition of the butterfly costs 1016 - error: fold that into the sign for odd lanes.
-    const int s_idx = lane >> 1, b_in = lane & 1;
+    // ---- per-lane, per-phase constants: butterfly s' = rotl6(lane,p) & 31, symbol r expects +127 when
+    // parity((2s') & G_r) (ViterbiBranchTable), error e = sum_r |branch_r - y_r| = 508 - sum_r sigma_r y_r ----
     const unsigned G[4] = {109u, 79u, 83u, 109u};                   // dab_viterbi_decoder.cpp:25
-    int sig = 0;
+    LaneConst K;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int sg = parity7((unsigned)(2 * s_idx) & G[r]) ? 1 : -1;
-        if (b_in) sg = -sg;
-        sig |= (sg & 0xFF) << (8 * r);
+    for (int p = 0; p < 6; p++) {
+        const unsigned sp = rotl6((unsigned)lane, p) & 31u;
+        int v = 0, nv = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int sg = parity7((2u * sp) & G[r]) ? 1 : -1;
+            v |= (sg & 0xFF) << (8 * r);
+            nv |= ((-sg) & 0xFF) << (8 * r);
+        }
+        K.sig[p] = v; K.nsig[p] = nv;
+        K.um[p] = ((lane >> (5 - p)) & 1) ? -1 : 0;
+        K.up1[p] = -K.um[p];
     }
-    const int bp_lo = 4 * s_idx, bp_hi = 4 * (s_idx + 32);
 
-    uint64_t* my_dec = dec_scratch + (size_t)blockIdx.x * scratch_words_per_wave;
+    uint16_t* my_dec16 = reinterpret_cast<uint16_t*>(dec_scratch + (size_t)blockIdx.x * scratch_words_per_wave);
 
     for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
         const dabgpu_cw_desc D = descs[cw];
@@ -100,22 +210,23 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
             seg_pi[4] = 8; seg_in0[4] = in0; seg_end[4] = st + 6;
         }
 
-        uint32_t metric = (lane == (int)(D.start_state & 63u)) ? 0u : V_NONSTART;
+        uint32_t metric = (lane == (int)(D.start_state & 63u)) ? 0u : V_NONSTART;   // phase 0: lane = state
         uint64_t renorm_total = 0;
-        uint32_t vlo = 0, vhi = 0;
+        uint32_t hist = 0;
 
-        for (int t0 = 0; t0 < n_steps; t0 += 16) {
-            // ---- fetch + de-puncture + time de-interleave: lane L owns mother symbol 4*t0 + L ----
-            int ypk;
-            {
-                const int M = 4 * t0 + lane;
+        for (int t0 = 0; t0 < n_steps; t0 += VBLOCK) {
+            // ---- fetch + de-puncture + time de-interleave: lane L owns mother symbols 4*t0 + 64*q + L ----
+            int ypk[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int M = 4 * t0 + 64 * q + lane;
                 const int step = M >> 2, r = M & 3;
                 int k = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) k += (step >= seg_end[q]) ? 1 : 0;
+                for (int u = 0; u < 4; u++) k += (step >= seg_end[u]) ? 1 : 0;
                 int sstart = 0, pi = seg_pi[0], in0 = seg_in0[0];
 #pragma unroll
-                for (int q = 1; q < 5; q++) if (k == q) { sstart = seg_end[q - 1]; pi = seg_pi[q]; in0 = seg_in0[q]; }
+                for (int u = 1; u < 5; u++) if (k == u) { sstart = seg_end[u - 1]; pi = seg_pi[u]; in0 = seg_in0[u]; }
                 const int sis = step - sstart;
                 const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
                 const int cnt = e & 0xFF, pre = e >> 8;
@@ -141,75 +252,31 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 const int y1 = __builtin_amdgcn_mov_dpp(y, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
                 const int y2 = __builtin_amdgcn_mov_dpp(y, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
                 const int y3 = __builtin_amdgcn_mov_dpp(y, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
-                ypk = (y0 & 0xFF) | ((y1 & 0xFF) << 8) | ((y2 & 0xFF) << 16) | (y3 << 24);
+                ypk[q] = (y0 & 0xFF) | ((y1 & 0xFF) << 8) | ((y2 & 0xFF) << 16) | (y3 << 24);
             }
-
-            // ---- 16 trellis steps ----
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int t = t0 + j;
-                if (t < n_steps) {                                                   // wave-uniform
-                    const int ysym = __builtin_amdgcn_readlane(ypk, 4 * j);
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_lo, (int)metric);
-                    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(bp_hi, (int)metric);
-                    const int dot = __builtin_amdgcn_sdot4(sig, ysym, 0, false);
-                    const uint32_t c0 = (lo + (uint32_t)(508 - dot)) & 0xFFFFu;      // u16 wrap like the reference core
-                    const uint32_t c1 = (hi + (uint32_t)(508 + dot)) & 0xFFFFu;
-                    const bool d = tie_rule ? (c1 <= c0) : (c0 > c1);
-                    metric = d ? c1 : c0;
-                    const uint64_t dec = __ballot(d);
-                    const bool mine = (lane == (t & 63));                           // lane t mod 64 parks step t's word
-                    vlo = mine ? (uint32_t)dec : vlo;
-                    vhi = mine ? (uint32_t)(dec >> 32) : vhi;
-                    const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)metric);
-                    if (m0 >= V_RENORM) {                                            // rare, wave-uniform
-                        uint32_t mn = metric;
-#pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-                        metric -= mn;
-                        renorm_total += mn;
-                    }
-                }
-            }
-            // park 64 decision words (512 B, one coalesced store) every 64 steps and at the end
-            if (((t0 + 16) & 63) == 0 || t0 + 16 >= n_steps) {
-                const int base = (t0 + 15) & ~63;
-                if (base + lane < n_steps) my_dec[base + lane] = ((uint64_t)vhi << 32) | vlo;
-            }
+            forward_block<TIE>(metric, hist, renorm_total, K, ypk, t0, n_steps, lane, my_dec16);
         }
+        if (n_steps & 15) {                                           // last, partial history word: left-align it
+            hist <<= (16 - (n_steps & 15));
+            my_dec16[(size_t)(n_steps >> 4) * 64 + lane] = (uint16_t)hist;
+        }
+        // layout after the last step (n_steps - 1) is phase n_steps % 6
         const int end_state = (int)(D.end_state & 63u);
-        const uint32_t end_metric = (uint32_t)__shfl((int)metric, end_state);
+        int l4 = (int)(rotr6((unsigned)end_state, n_steps % 6) << 2);
+        const uint32_t end_metric = (uint32_t)__builtin_amdgcn_ds_bpermute(l4, (int)metric);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);       // decision words are re-read by this same wave: drain its stores first
+        __builtin_amdgcn_s_waitcnt(0);       // history words are re-read by this same wave: drain its stores first
 
-        // ---- chain-back (Karn layout): 8-bit window, state in bits 7..2 ----
-        const int n_bits = n_steps - 6;
-        unsigned reg = (unsigned)end_state << 2;
-        int cur_chunk = -1;
-        uint32_t clo = 0, chi = 0;
-        for (int bit = n_bits - 1; bit >= 0; bit--) {
-            const int di = bit + 6;
-            if ((di >> 6) != cur_chunk) {
-                cur_chunk = di >> 6;
-                const int w = cur_chunk * 64 + lane;
-                uint64_t word = 0;
-                if (w < n_steps) word = __builtin_nontemporal_load(&my_dec[w]);
-                clo = (uint32_t)word; chi = (uint32_t)(word >> 32);
-            }
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)clo, di & 63);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)chi, di & 63);
-            const unsigned st = reg >> 2;
-            const unsigned in = (unsigned)((((uint64_t)hi << 32) | lo) >> st) & 1u;
-            reg = (reg >> 1) | (in << 7);
-            if ((bit & 7) == 0 && lane == 0) {
-                const int k = bit >> 3;
-                obytes[k] = (unsigned char)(reg ^ ((D.flags & DABGPU_CW_RAW) ? 0u : prbs[k % PRBS_PERIOD]));   // descramble in the same pass
-            }
+        // ---- chain-back over steps n_steps-1 .. 6 in aligned blocks of 48 ----
+        const bool raw = (D.flags & DABGPU_CW_RAW) != 0;
+        uint32_t acc = 0, outreg = 0;
+        for (int tb = ((n_steps - 1) / VBLOCK) * VBLOCK; tb >= 0; tb -= VBLOCK) {
+            chainback_block(l4, acc, outreg, tb, n_steps, lane, my_dec16, obytes, prbs, raw);
         }
         __syncthreads();
 
         // ---- write-out + optional FIB CRC16 ----
-        const int n_out = n_bits >> 3;
+        const int n_out = (n_steps - 6) >> 3;
         unsigned char* out = reinterpret_cast<unsigned char*>(D.d_out);
         for (int k = lane; k < n_out; k += 64) out[k] = obytes[k];
         uint32_t crc_mask = 0;
@@ -244,12 +311,17 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
 
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
-                                            dabgpu_cw_result* d_results, int tie_rule, hipStream_t stream)
+                                            dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
+                                            hipStream_t stream)
 {
     using namespace dabgpu;
-    const size_t lds = 25 * 8 * 2 + 512 + (size_t)((max_out_bytes + 15) & ~15);
-    hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)n_waves), dim3(64), lds, stream,
-                       d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, tie_rule);
+    const size_t lds = 25 * 8 * 2 + 512 + (size_t)((max_out_bytes + 63 + 15) & ~15);
+    if (tie_rule)
+        hipLaunchKernelGGL(viterbi_kernel<1>, dim3((unsigned)n_waves), dim3(64), lds, stream,
+                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables);
+    else
+        hipLaunchKernelGGL(viterbi_kernel<0>, dim3((unsigned)n_waves), dim3(64), lds, stream,
+                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables);
     return hipGetLastError();
 }
 
