@@ -141,11 +141,8 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
                 const f2 h1 = pll1(mk2(h.z, h.w), base, step1);
                 p = conj_mul(a[3], h0) + conj_mul(a[7], h1);
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                p.x += __shfl_xor(p.x, off);
-                p.y += __shfl_xor(p.y, off);
-            }
+            p.x = wave_tree_sum(p.x, lane);
+            p.y = wave_tree_sum(p.y, lane);
             if (lane == 0) red[wave] = p;
         }
         if constexpr (PREFETCH) { if (i < sym_end) load_symbol(i + 1, v, h); }

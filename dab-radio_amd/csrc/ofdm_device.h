@@ -91,6 +91,42 @@ __device__ __forceinline__ int to_vbit(float x) {
     return (int)v;
 }
 
+// value of `v` held by lane (lane ^ XORMASK), XORMASK in {32,16,8,4,2,1}, without touching the LDS crossbar:
+// v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row_ror:8 / bank-masked row shifts / quad_perm
+template <int XORMASK>
+__device__ __forceinline__ float lane_xor(float v, int lane) {
+    const int i = __float_as_int(v);
+    int r;
+    if constexpr (XORMASK == 32) {
+        const auto t = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
+        r = (int)((lane & 32) ? t[0] : t[1]);
+    } else if constexpr (XORMASK == 16) {
+        const auto t = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+        r = (int)((lane & 16) ? t[0] : t[1]);
+    } else if constexpr (XORMASK == 8) {
+        r = __builtin_amdgcn_mov_dpp(i, 0x128, 0xF, 0xF, true);                      // row_ror:8
+    } else if constexpr (XORMASK == 4) {
+        const int a = __builtin_amdgcn_update_dpp(i, i, 0x104, 0xF, 0x5, false);      // row_shl:4 -> banks 0,2
+        r = __builtin_amdgcn_update_dpp(a, i, 0x114, 0xF, 0xA, false);                // row_shr:4 -> banks 1,3
+    } else if constexpr (XORMASK == 2) {
+        r = __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true);                        // quad_perm [2,3,0,1]
+    } else {
+        r = __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true);                        // quad_perm [1,0,3,2]
+    }
+    return __int_as_float(r);
+}
+
+// the contract's 64-leaf reduction: a[i] += a[i ^ h] for h = 32, 16, ..., 1 (every lane ends with the same sum)
+__device__ __forceinline__ float wave_tree_sum(float v, int lane) {
+    v += lane_xor<32>(v, lane);
+    v += lane_xor<16>(v, lane);
+    v += lane_xor<8>(v, lane);
+    v += lane_xor<4>(v, lane);
+    v += lane_xor<2>(v, lane);
+    v += lane_xor<1>(v, lane);
+    return v;
+}
+
 // wave-private LDS hand-off: order this wave's LDS writes before its later reads for the compiler; the LDS unit
 // itself executes one wave's instructions in order, so no s_barrier is involved
 __device__ __forceinline__ void wave_lds_fence() {

@@ -13,11 +13,24 @@ ap.add_argument("--variants", type=str, default="0")
 ap.add_argument("--spb", type=str, default="19")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--data", type=str, default="randn", help="randn | ofdm (bench.py synthetic frames) | zeros")
 a = ap.parse_args()
 ctx = dabgpu.Context(0)
 F = a.frames
-iq = torch.randn((F, 196608, 2), dtype=torch.float32, device="cuda")
-freq = ((torch.rand(F, device="cuda") * 2 - 1) * 2.4e-3).float()
+if a.data == "ofdm":
+    sys.path.insert(0, ROOT)
+    src = open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0]
+    ns = {"__file__": os.path.join(ROOT, "bench.py")}
+    exec(compile(src, "bench_head", "exec"), ns)
+    prs, mapper, _ = dabgpu.host_tables()
+    iqc, _, freq = ns["synth_frames"](F, 1000, torch.device("cuda", 0), mapper, prs)
+    iq = torch.view_as_real(iqc).contiguous()
+elif a.data == "zeros":
+    iq = torch.zeros((F, 196608, 2), dtype=torch.float32, device="cuda")
+    freq = ((torch.rand(F, device="cuda") * 2 - 1) * 2.4e-3).float()
+else:
+    iq = torch.randn((F, 196608, 2), dtype=torch.float32, device="cuda")
+    freq = ((torch.rand(F, device="cuda") * 2 - 1) * 2.4e-3).float()
 bits = torch.empty((F, 230400), dtype=torch.int8, device="cuda")
 corr = torch.empty((F, 76, 2), dtype=torch.float32, device="cuda")
 L = dabgpu.lib()
