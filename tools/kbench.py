@@ -58,4 +58,5 @@ for r in range(a.rounds):
 for (v, s), t in sorted(res.items()):
     t = np.array(t)
     gbs = (196608 * 8 + 230400) * F / (np.median(t) * 1e-3) / 1e9
+    print("   rounds:", " ".join(f"{x:.4f}" for x in t))
     print(f"variant {v:2d} spb {s:2d}: median {np.median(t):.4f} ms  min {t.min():.4f}  -> {gbs:7.1f} GB/s  {F/np.median(t)*1e3/1e6:.3f} Mframes/s")
