@@ -35,7 +35,23 @@ ABI_SYMBOLS = [
     "dabgpu_fic_decode_group_host_sync", "dabgpu_viterbi_decode_host_sync", "dabgpu_msc_stream_create",
     "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
     "dabgpu_msc_stream_decode_sync",
+    "dabgpu_iq_format_from_mode", "dabgpu_iq_format_sample_bytes", "dabgpu_wav_parse_header",
+    "dabgpu_iq_convert", "dabgpu_iq_convert_host_sync",
+    "dabgpu_soft_bits_to_hard_bytes", "dabgpu_hard_bytes_to_soft_bits",
+    "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
 ]
+
+IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
+              "raw_f32l", "raw_f32b", "raw_f64l", "raw_f64b",
+              "wav_pcm8", "wav_pcm16", "wav_pcm24", "wav_pcm32", "wav_f32", "wav_f64", "wav_alaw", "wav_mulaw"]
+
+
+class WavHeader(C.Structure):
+    """dabgpu_wav_header"""
+    _fields_ = [("iq_format", C.c_int32), ("audio_format", C.c_uint16), ("total_channels", C.c_uint16),
+                ("samples_per_second", C.c_uint32), ("average_bytes_per_second", C.c_uint32),
+                ("data_block_align_bytes", C.c_uint16), ("bits_per_sample", C.c_uint16),
+                ("data_chunk_size", C.c_uint32), ("data_chunk_offset", C.c_uint64)]
 
 
 class Codeword(C.Structure):
@@ -126,6 +142,16 @@ def lib():
         L.dabgpu_subchannel_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_msc_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
                                                C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_iq_format_from_mode.argtypes = [C.c_char_p]
+        L.dabgpu_iq_format_sample_bytes.restype = C.c_size_t
+        L.dabgpu_iq_format_sample_bytes.argtypes = [C.c_int]
+        L.dabgpu_wav_parse_header.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dabgpu_iq_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.dabgpu_iq_convert_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        L.dabgpu_soft_bits_to_hard_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.dabgpu_hard_bytes_to_soft_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.dabgpu_soft_bits_to_hard_bytes_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dabgpu_hard_bytes_to_soft_bits_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -265,6 +291,61 @@ class Context:
         check(lib().dabgpu_msc_decode_frames(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames,
                                              newest_frame_slot, arr, n, _ptr(out), out_ensemble_stride, _ptr(results),
                                              tie_rule, self._stream(stream)), "dabgpu_msc_decode_frames")
+
+
+    def iq_convert(self, raw, fmt, n_samples, iq, stream=None):
+        """device raw samples in format number `fmt` -> device interleaved float IQ (asynchronous)"""
+        check(lib().dabgpu_iq_convert(self._h, _ptr(raw), int(fmt), n_samples, _ptr(iq), self._stream(stream)), "dabgpu_iq_convert")
+
+    def iq_convert_host(self, raw, fmt):
+        import numpy as np
+        raw = np.ascontiguousarray(raw, dtype=np.uint8)
+        sb = iq_format_sample_bytes(fmt)
+        if sb == 0:
+            raise DabGpuError(f"unknown IQ format number {fmt}")
+        n = raw.size // sb
+        out = np.empty(2 * n, np.float32)
+        check(lib().dabgpu_iq_convert_host_sync(self._h, _ptr(raw), int(fmt), n, _ptr(out)), "dabgpu_iq_convert_host_sync")
+        return out
+
+    def soft_bits_to_hard_bytes(self, bits, n_bytes, out, stream=None):
+        check(lib().dabgpu_soft_bits_to_hard_bytes(self._h, _ptr(bits), n_bytes, _ptr(out), self._stream(stream)),
+              "dabgpu_soft_bits_to_hard_bytes")
+
+    def hard_bytes_to_soft_bits(self, data, n_bytes, out, stream=None):
+        check(lib().dabgpu_hard_bytes_to_soft_bits(self._h, _ptr(data), n_bytes, _ptr(out), self._stream(stream)),
+              "dabgpu_hard_bytes_to_soft_bits")
+
+    def soft_bits_to_hard_bytes_host(self, bits):
+        import numpy as np
+        bits = np.ascontiguousarray(bits, dtype=np.int8)
+        out = np.empty(bits.size // 8, np.uint8)
+        check(lib().dabgpu_soft_bits_to_hard_bytes_host_sync(self._h, _ptr(bits), out.size, _ptr(out)), "soft_bits_to_hard_bytes_host_sync")
+        return out
+
+    def hard_bytes_to_soft_bits_host(self, data):
+        import numpy as np
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        out = np.empty(data.size * 8, np.int8)
+        check(lib().dabgpu_hard_bytes_to_soft_bits_host_sync(self._h, _ptr(data), data.size, _ptr(out)), "hard_bytes_to_soft_bits_host_sync")
+        return out
+
+
+def iq_format_from_mode(mode):
+    return lib().dabgpu_iq_format_from_mode(mode.encode())
+
+
+def iq_format_sample_bytes(fmt):
+    return int(lib().dabgpu_iq_format_sample_bytes(int(fmt)))
+
+
+def wav_parse_header(image):
+    """host-only: WavHeader of a file image (numpy uint8 / bytes); raises DabGpuError where the reference's reader throws"""
+    import numpy as np
+    image = np.frombuffer(bytes(image), np.uint8) if isinstance(image, (bytes, bytearray)) else np.ascontiguousarray(image, np.uint8)
+    h = WavHeader()
+    check(lib().dabgpu_wav_parse_header(_ptr(image), image.size, C.byref(h)), "dabgpu_wav_parse_header")
+    return h
 
 
 def sync_cfg_default():

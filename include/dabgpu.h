@@ -276,6 +276,65 @@ int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream *s, int8_t *h_out);
  * DABGPU_ERR_NOT_READY (and *n_out = 0) until 16 CIFs were pushed (msc_decoder.cpp:60-63) */
 int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *n_out, uint64_t *path_error, int tie_rule);
 
+/* ==================================================================================================
+ * Data formats either side of the path.
+ *
+ * IQ input: the reference's readers (examples/app_helpers/app_iq_readers.h:17-159, app_wav_reader.h:257-470)
+ * turn a byte stream into std::complex<float>; here the raw bytes go to the device as they are and one
+ * kernel applies the same arithmetic:
+ *   quantised integers (app_iq_readers.h:19-44,79-84): (float(v) - BIAS) * (1.0f/MAX_AMPLITUDE), BIAS = 0 and
+ *     MAX_AMPLITUDE = float(max) for signed T; BIAS = MAX_AMPLITUDE = float(max/2) + 0.5f for unsigned T;
+ *   raw_f32*: bit copy (after the byte swap); raw_f64*: (float)double;
+ *   wav: PCM8 (v-127.5f)*(1/127.5f), PCM16 v*(1/32767.f), PCM24 v*(1/8388607.f), PCM32 v*(1/float(INT32_MAX)),
+ *     IEEE float 32/64, G.711 A-law / mu-law (app_wav_reader.h:271-456).
+ * Soft/hard bit files: examples/app_helpers/app_viterbi_convert_block.h:12-44 (bit i of a byte, LSB first,
+ * <-> soft bit +127 / -127; hard = soft >= 0).
+ */
+typedef enum {
+    DABGPU_IQ_RAW_U8 = 0, DABGPU_IQ_RAW_S8,
+    DABGPU_IQ_RAW_S16L, DABGPU_IQ_RAW_S16B, DABGPU_IQ_RAW_U16L, DABGPU_IQ_RAW_U16B,
+    DABGPU_IQ_RAW_S32L, DABGPU_IQ_RAW_S32B, DABGPU_IQ_RAW_U32L, DABGPU_IQ_RAW_U32B,
+    DABGPU_IQ_RAW_F32L, DABGPU_IQ_RAW_F32B, DABGPU_IQ_RAW_F64L, DABGPU_IQ_RAW_F64B,
+    DABGPU_IQ_WAV_PCM8, DABGPU_IQ_WAV_PCM16, DABGPU_IQ_WAV_PCM24, DABGPU_IQ_WAV_PCM32,
+    DABGPU_IQ_WAV_F32, DABGPU_IQ_WAV_F64, DABGPU_IQ_WAV_ALAW, DABGPU_IQ_WAV_MULAW,
+    DABGPU_IQ_NB_FORMATS
+} dabgpu_iq_format;
+
+/* mode strings of app_iq_readers.h:107-113 ("raw_u8" ... "raw_f64b") -> dabgpu_iq_format; "wav" and unknown
+ * strings return -1 (a wav file's format comes from dabgpu_wav_parse_header). Host only, needs no device. */
+int dabgpu_iq_format_from_mode(const char *mode);
+/* bytes of one IQ sample (two components) in the given format, 0 for an invalid format. Host only. */
+size_t dabgpu_iq_format_sample_bytes(int format);
+
+typedef struct {
+    int32_t  iq_format;             /* dabgpu_iq_format of the sample data (DABGPU_IQ_WAV_*) */
+    uint16_t audio_format;          /* 1 PCM, 3 IEEE float, 6 A-law, 7 mu-law (after resolving WAVE_FORMAT_EXTENSIBLE) */
+    uint16_t total_channels;
+    uint32_t samples_per_second;
+    uint32_t average_bytes_per_second;
+    uint16_t data_block_align_bytes;
+    uint16_t bits_per_sample;
+    uint32_t data_chunk_size;       /* bytes */
+    uint64_t data_chunk_offset;     /* byte offset of the sample data from the start of the file */
+} dabgpu_wav_header;
+/* wav_read_header (app_wav_reader.h:107-255) over the first n_bytes of a file held in memory; accepts what it
+ * accepts (fmt chunk of 16/18/40 bytes, 1 or 2 channels, fact chunk required for non-PCM, non-data chunks skipped)
+ * and rejects what it or WavFileReader's constructor rejects (DABGPU_ERR_INVALID_ARG + dabgpu_last_error()).
+ * get_iq_file_reader_from_mode_string additionally requires total_channels == 2 (app_iq_readers.h:122-126): callers
+ * feeding dabgpu_iq_convert check that. Host only, needs no device. */
+int dabgpu_wav_parse_header(const uint8_t *bytes, size_t n_bytes, dabgpu_wav_header *out);
+
+/* d_raw: n_samples IQ pairs in `format` on the device (16-byte aligned); d_iq: n_samples interleaved (re, im) floats */
+int dabgpu_iq_convert(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_samples, float *d_iq, void *stream);
+int dabgpu_iq_convert_host_sync(dabgpu_ctx *ctx, const void *h_raw, int format, size_t n_samples, float *h_iq);
+
+/* convert_viterbi_bits_to_bytes (app_viterbi_convert_block.h:28-44): n_bytes output bytes from 8*n_bytes soft bits */
+int dabgpu_soft_bits_to_hard_bytes(dabgpu_ctx *ctx, const int8_t *d_bits, size_t n_bytes, uint8_t *d_bytes, void *stream);
+/* convert_viterbi_bytes_to_bits (app_viterbi_convert_block.h:12-26) */
+int dabgpu_hard_bytes_to_soft_bits(dabgpu_ctx *ctx, const uint8_t *d_bytes, size_t n_bytes, int8_t *d_bits, void *stream);
+int dabgpu_soft_bits_to_hard_bytes_host_sync(dabgpu_ctx *ctx, const int8_t *h_bits, size_t n_bytes, uint8_t *h_bytes);
+int dabgpu_hard_bytes_to_soft_bits_host_sync(dabgpu_ctx *ctx, const uint8_t *h_bytes, size_t n_bytes, int8_t *h_bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,6 +208,25 @@ void dab_modulate_frame(const uint8_t *frame_bits /*[230400]*/, const int *mappe
  * the receiver's de-interleave */
 void dab_modulate_frame_reference_payload(const uint8_t *payload /*[28800]*/, dab_cf32 *out /*[196608]*/);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data formats either side of the path.
+ * IQ readers: examples/app_helpers/app_iq_readers.h:17-159 + app_wav_reader.h:257-456; format numbers follow
+ * the order of iq_read_modes (app_iq_readers.h:107-113) after "wav", then the wav encodings:
+ *  0 raw_u8 1 raw_s8 2 raw_s16l 3 raw_s16b 4 raw_u16l 5 raw_u16b 6 raw_s32l 7 raw_s32b 8 raw_u32l 9 raw_u32b
+ *  10 raw_f32l 11 raw_f32b 12 raw_f64l 13 raw_f64b 14 wav pcm8 15 pcm16 16 pcm24 17 pcm32 18 f32 19 f64 20 A-law 21 mu-law
+ */
+#define DAB_IQ_NB_FORMATS 22
+size_t dab_iq_component_bytes(int format);
+/* n_comp components (2 per IQ sample) -> floats; returns 0, or -1 for an unknown format */
+int dab_iq_convert(const uint8_t *raw, int format, size_t n_comp, float *out);
+/* app_viterbi_convert_block.h:12-44 */
+void dab_hard_bytes_to_soft_bits(const uint8_t *bytes, size_t n_bytes, int8_t *bits);
+void dab_soft_bits_to_hard_bytes(const int8_t *bits, size_t n_bytes, uint8_t *bytes);
+/* wav_read_header (app_wav_reader.h:107-255) + the WavFileReader constructor's format checks (:268-466) over a
+ * file image; out7 = {format number above, audio format code, channels, samples_per_second, bits_per_sample,
+ * data_chunk_size, data_chunk_offset}; returns 0, or -1 where the reference throws */
+int dab_wav_parse_header(const uint8_t *bytes, size_t n_bytes, uint64_t *out7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,10 +32,12 @@ def build(force=False):
     """Compile the oracle (and _ref when /root/reference exists). Building the checker is not using it."""
     if force or not os.path.exists(_ORACLE_SO) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_ORACLE_SO)
-        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle.h")
+        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "libdab_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO)):
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_REF_SO) for f in ("ref_harness.cpp", "ref_harness_io.cpp")
+    )):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -122,6 +124,12 @@ def lib():
         L.dab_fine_time_sync.restype = C.c_int
         L.dab_fine_time_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
         L.dab_coarse_freq_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_iq_component_bytes.restype = C.c_size_t
+        L.dab_iq_component_bytes.argtypes = [C.c_int]
+        L.dab_iq_convert.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        L.dab_hard_bytes_to_soft_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dab_soft_bits_to_hard_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dab_wav_parse_header.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -129,6 +137,47 @@ def lib():
 # ------------------------------------------------------------------------------------------------
 # numpy-level helpers
 # ------------------------------------------------------------------------------------------------
+IQ_MODES = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
+            "raw_f32l", "raw_f32b", "raw_f64l", "raw_f64b",
+            "wav_pcm8", "wav_pcm16", "wav_pcm24", "wav_pcm32", "wav_f32", "wav_f64", "wav_alaw", "wav_mulaw"]
+
+
+def iq_component_bytes(fmt):
+    return int(lib().dab_iq_component_bytes(int(fmt)))
+
+
+def iq_convert(raw, fmt):
+    """raw: uint8 array holding whole components of format number `fmt` -> float32 per component"""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    n = raw.size // iq_component_bytes(fmt)
+    out = np.empty(n, np.float32)
+    assert lib().dab_iq_convert(_p(raw), int(fmt), n, _p(out)) == 0
+    return out
+
+
+def hard_bytes_to_soft_bits(b):
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.empty(b.size * 8, np.int8)
+    lib().dab_hard_bytes_to_soft_bits(_p(b), b.size, _p(out))
+    return out
+
+
+def soft_bits_to_hard_bytes(bits):
+    bits = np.ascontiguousarray(bits, dtype=np.int8)
+    out = np.empty(bits.size // 8, np.uint8)
+    lib().dab_soft_bits_to_hard_bytes(_p(bits), out.size, _p(out))
+    return out
+
+
+def wav_parse_header(image):
+    """-> None where the reference throws, else dict(format, code, channels, rate, bits, data_size, data_offset)"""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    o = np.zeros(7, np.uint64)
+    if lib().dab_wav_parse_header(_p(image), image.size, _p(o)) != 0:
+        return None
+    return dict(zip(("format", "code", "channels", "rate", "bits", "data_size", "data_offset"), (int(v) for v in o)))
+
+
 def c64(a):
     return np.ascontiguousarray(a, dtype=np.complex64)
 
@@ -465,5 +514,10 @@ def ref():
         R.ref_puncture_tables.argtypes = [C.c_void_p, C.c_void_p]
         R.ref_subchannel_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_uep_row.argtypes = [C.c_int, C.c_void_p]
+        R.ref_iq_read_file.restype = C.c_long
+        R.ref_iq_read_file.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        R.ref_wav_header.argtypes = [C.c_char_p, C.c_void_p]
+        R.ref_bytes_to_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        R.ref_bits_to_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         _ref = R
     return _ref
