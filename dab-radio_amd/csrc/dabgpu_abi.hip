@@ -186,8 +186,8 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 }
 
 // ---- OFDM ----
-int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
-                             float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
+static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                         float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
     if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
@@ -201,8 +201,35 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, 
         int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
         if (st) return st;
     }
-    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
+    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
                                                      (int)n_frames, symbols_per_block, bits_frame_stride, s), "ofdm_demod_kernel launch");
+}
+
+int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                             float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
+    return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
+}
+
+int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                                 float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
+    int src = -1;
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: src = 0; break;
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: src = 1; break;
+    case DABGPU_IQ_RAW_S8: src = 2; break;
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: src = 3; break;
+    default: break;
+    }
+    if (src >= 0) return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
+    // formats without a fused loader: convert into context scratch on the same stream, then demodulate
+    if (!c) { dabgpu_set_error("ofdm_demod_frames_raw: null context"); return DABGPU_ERR_INVALID_ARG; }
+    if (dabgpu_iq_format_sample_bytes(format) == 0) { dabgpu_set_error("ofdm_demod_frames_raw: unknown format %d", format); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    float* d_iq;
+    int st = dabgpu_scratch(c, 22, n_frames * DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float), (void**)&d_iq);
+    if (st) return st;
+    if ((st = dabgpu_iq_convert(c, d_raw, format, n_frames * DABGPU_NB_FRAME_SAMPLES, d_iq, stream))) return st;
+    return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
 }
 
 int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,

@@ -26,7 +26,7 @@ void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 
-extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,

@@ -21,9 +21,35 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "iq_decode.h"
 #include "ofdm_device.h"
 
 namespace dabgpu {
+
+// Input sample formats the loader can read straight from HBM (anything else goes through iq_convert_kernel first).
+// The decode is iq_decode.h's, i.e. the same operations as the stand-alone converter: results are bit-identical to
+// convert-then-demodulate while the kernel reads 2 or 4 bytes per sample instead of 8.
+enum { SRC_C32 = 0, SRC_U8 = 1, SRC_S8 = 2, SRC_S16 = 3 };
+template <int SRC> struct src_bytes { static constexpr int value = (SRC == SRC_C32) ? 8 : (SRC == SRC_S16) ? 4 : 2; };
+
+// two consecutive IQ samples starting at sample index n (n even) of a frame -> (re0, im0, re1, im1)
+template <int SRC>
+__device__ __forceinline__ f4 load_pair(const uint8_t* __restrict__ frame_base, size_t n) {
+    const uint8_t* p = frame_base + n * src_bytes<SRC>::value;
+    if constexpr (SRC == SRC_C32) {
+        return *reinterpret_cast<const f4*>(p);
+    } else if constexpr (SRC == SRC_S16) {
+        raw_words<2> r;
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        r.w[0] = q.x; r.w[1] = q.y;
+        return f4{decode<K_S16, 2, false>(r, 0), decode<K_S16, 2, false>(r, 1), decode<K_S16, 2, false>(r, 2), decode<K_S16, 2, false>(r, 3)};
+    } else {
+        constexpr comp_kind K = (SRC == SRC_U8) ? K_U8 : K_S8;
+        raw_words<1> r;
+        r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+        return f4{decode<K, 1, false>(r, 0), decode<K, 1, false>(r, 1), decode<K, 1, false>(r, 2), decode<K, 1, false>(r, 3)};
+    }
+}
 
 // blockIdx -> work unit so that consecutive units (chunks of one frame share a halo symbol) sit on one XCD
 // (blocks are dealt round-robin to the 8 XCDs, each with a private L2)
@@ -36,9 +62,9 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
 // into four independent 512-point problems, one per wave.  Thread (w, l) ends holding bins
 //   Kb + 256*k,  Kb = w + 4*(l>>3) + 32*(l&7),  k = 0..7
 // of which k in {0,1,2,5,6,7} are data carriers (thread 0: DC is replaced by bin 768, its k = 3).
-template <bool PREFETCH>
+template <bool PREFETCH, int SRC>
 __global__ __launch_bounds__(256, 4)
-void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset,
+void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
                        f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride)
@@ -64,7 +90,7 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
     const int sym_end = (last_chunk && fft_out != nullptr) ? NB_FRAME_SYMBOLS : out1;   // inclusive
 
     const float f = freq_offset ? freq_offset[frame] : 0.0f;
-    const f2* fbase = iq + (size_t)frame * NB_FRAME_SAMPLES;
+    const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * NB_FRAME_SAMPLES * src_bytes<SRC>::value;
 
     // PLL constants: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
     const int k0 = 2 * (t & 1);
@@ -108,12 +134,12 @@ void ofdm_demod_kernel(const f2* __restrict__ iq, const float* __restrict__ freq
 
     // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head
     auto load_symbol = [&](int i, f4 (&v)[4], f4& h) {
-        const f2* sym = fbase + (size_t)i * NB_SYMBOL_PERIOD;
+        const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f4*>(sym + NB_CP + 2 * t + 512 * k);
+        for (int k = 0; k < 4; k++) v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
         h = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (dc && t >= 4) h = *reinterpret_cast<const f4*>(sym + 2 * (t - 4));
+        if (dc && t >= 4) h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
     };
     f4 v[4], h;
     if constexpr (PREFETCH) load_symbol(out0, v, h);
@@ -285,7 +311,8 @@ void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
 static int g_dabgpu_variant = 0;
 extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // development switch (tools/kbench.py)
 
-extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+// src: 0 interleaved complex float, 1 raw_u8 / wav pcm8, 2 raw_s8, 3 raw_s16l / wav pcm16
+extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride, hipStream_t stream)
 {
@@ -295,11 +322,17 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const float* d_iq, const float* d
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
     const dim3 grid((unsigned)(n_frames * chunks));
-#define DABGPU_LAUNCH(PF) hipLaunchKernelGGL((ofdm_demod_kernel<PF>), grid, dim3(256), lds, stream, \
-                       reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
+#define DABGPU_LAUNCH(PF, SRC) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC>), grid, dim3(256), lds, stream, \
+                       d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks, bits_frame_stride)
-    if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true); else DABGPU_LAUNCH(false);
+    switch (src) {
+    case SRC_C32: if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32); else DABGPU_LAUNCH(false, SRC_C32); break;
+    case SRC_U8: DABGPU_LAUNCH(false, SRC_U8); break;
+    case SRC_S8: DABGPU_LAUNCH(false, SRC_S8); break;
+    case SRC_S16: DABGPU_LAUNCH(false, SRC_S16); break;
+    default: return hipErrorInvalidValue;
+    }
 #undef DABGPU_LAUNCH
     return hipGetLastError();
 }

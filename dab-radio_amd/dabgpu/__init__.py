@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
     "dabgpu_msc_stream_decode_sync",
     "dabgpu_iq_format_from_mode", "dabgpu_iq_format_sample_bytes", "dabgpu_wav_parse_header",
-    "dabgpu_iq_convert", "dabgpu_iq_convert_host_sync",
+    "dabgpu_iq_convert", "dabgpu_iq_convert_host_sync", "dabgpu_ofdm_demod_frames_raw",
     "dabgpu_soft_bits_to_hard_bytes", "dabgpu_hard_bytes_to_soft_bits",
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
 ]
@@ -126,6 +126,8 @@ def lib():
         L.dabgpu_get_fft_twiddles.argtypes = [C.c_void_p]
         L.dabgpu_ofdm_demod_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        L.dabgpu_ofdm_demod_frames_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
@@ -236,6 +238,13 @@ class Context:
         check(lib().dabgpu_ofdm_demod_frames(self._h, _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits),
                                              _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, bits_frame_stride, self._stream(stream)),
               "dabgpu_ofdm_demod_frames")
+
+    def ofdm_demod_frames_raw(self, raw, fmt, n_frames, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0,
+                              stream=None, dqpsk=None, bits_frame_stride=0):
+        """The same from frames still in capture format number `fmt` (u8 / s8 / s16l are read by the kernel itself)."""
+        check(lib().dabgpu_ofdm_demod_frames_raw(self._h, _ptr(raw), int(fmt), n_frames, _ptr(freq_offset), _ptr(bits),
+                                                 _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, bits_frame_stride,
+                                                 self._stream(stream)), "dabgpu_ofdm_demod_frames_raw")
 
     def ofdm_phase_update(self, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):
         check(lib().dabgpu_ofdm_phase_update(self._h, _ptr(cp_corr), n_frames, beta, _ptr(total_phase),

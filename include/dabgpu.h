@@ -102,6 +102,18 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_frames
                              size_t bits_frame_stride, void *stream);
 
 /*
+ * The same with the frames still in their capture format (dabgpu_iq_format below; n_frames x 196608 IQ samples, 16-byte
+ * aligned).  For raw_u8 / raw_s8 / raw_s16l (and wav PCM8 / PCM16 / float32 payloads) the kernel's loader reads the raw
+ * samples straight from HBM and dequantises them in registers with the reader arithmetic of
+ * examples/app_helpers/app_iq_readers.h:19-44,79-84 -- 2 or 4 bytes per sample instead of 8 and no conversion pass;
+ * every other format is converted into context scratch on `stream` first.  Results are bit-identical to
+ * dabgpu_iq_convert followed by dabgpu_ofdm_demod_frames.
+ */
+int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, const float *d_freq_offset,
+                                 int8_t *d_bits, float *d_cp_corr, float *d_fft, float *d_dqpsk, int symbols_per_block,
+                                 size_t bits_frame_stride, void *stream);
+
+/*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]
  * (sequential, i = 0..75), and optionally fine <- fmod(fine - beta*err, wrap).
  * Replaces OFDM_Demod::CoordinatorThread's phase section (ofdm_demodulator.cpp:606-618) +

@@ -108,3 +108,64 @@ def test_invalid_arguments_are_rejected(ctx):
     o = torch.zeros(64, dtype=torch.float32, device="cuda")
     with pytest.raises(dabgpu.DabGpuError):
         ctx.iq_convert(d[1:], 0, 4, o)            # misaligned raw pointer
+
+
+def quantise(frames, name):
+    """complex64 frames -> capture bytes of format `name` the way an SDR front end would deliver them"""
+    x = np.stack([frames.real, frames.imag], axis=-1).reshape(-1)
+    x = x / np.abs(x).max()
+    if name == "raw_u8":
+        return np.clip(np.rint(x * 127.0 + 127.5), 0, 255).astype(np.uint8)
+    if name == "raw_s8":
+        return np.clip(np.rint(x * 127.0), -128, 127).astype(np.int8).view(np.uint8)
+    if name in ("raw_s16l", "raw_s16b", "raw_u16l"):
+        v = np.clip(np.rint(x * 30000.0), -32768, 32767).astype(np.int16)
+        if name == "raw_u16l":
+            return (v.astype(np.int32) + 32768).astype("<u2").view(np.uint8)
+        return v.astype("<i2" if name.endswith("l") else ">i2").view(np.uint8)
+    if name == "raw_f32l":
+        return x.astype("<f4").view(np.uint8)
+    if name == "raw_f64b":
+        return x.astype(">f8").view(np.uint8)
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("name", ["raw_u8", "raw_s8", "raw_s16l", "raw_f32l", "raw_s16b", "raw_u16l", "raw_f64b"])
+def test_demod_from_capture_format_matches_oracle(ctx, oracle, name):
+    """fused raw-input loader (u8/s8/s16l/f32l) and convert-then-demod (the rest): soft bits, CP correlation and FFT
+    bit-identical to oracle.iq_convert -> oracle.demod_frame, and to the product's own two-step path"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(17)
+    n_frames = 3
+    frames = []
+    for k in range(n_frames):
+        bits = rng.integers(0, 2, oracle.NB_FRAME_BITS, dtype=np.uint8)
+        tx = oracle.tx_to_frame_buffer(np.concatenate([oracle.modulate_frame(bits)] * 2))
+        tx = oracle.apply_pll(tx, 2.1e-4 * (k + 1), 0.2)
+        frames.append((tx + 2.0 * (rng.standard_normal(tx.size) + 1j * rng.standard_normal(tx.size))).astype(np.complex64))
+    frames = np.stack(frames)
+    fmt = dabgpu.IQ_FORMATS.index(name)
+    raw = quantise(frames, name)
+    freq = np.array([-2.1e-4 * (k + 1) for k in range(n_frames)], dtype=np.float32)
+    d_raw = torch.from_numpy(raw.copy()).cuda()
+    d_freq = torch.from_numpy(freq).cuda()
+    d_bits = torch.zeros((n_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")
+    d_corr = torch.zeros((n_frames, 76, 2), dtype=torch.float32, device="cuda")
+    d_fft = torch.zeros((n_frames, 77, 2048, 2), dtype=torch.float32, device="cuda")
+    ctx.ofdm_demod_frames_raw(d_raw, fmt, n_frames, d_bits, freq_offset=d_freq, cp_corr=d_corr, fft=d_fft)
+    torch.cuda.synchronize()
+    # the product's two-step path
+    d_iq = torch.empty(n_frames * dabgpu.NB_FRAME_SAMPLES * 2, dtype=torch.float32, device="cuda")
+    d_bits2 = torch.zeros_like(d_bits)
+    ctx.iq_convert(d_raw, fmt, n_frames * dabgpu.NB_FRAME_SAMPLES, d_iq)
+    ctx.ofdm_demod_frames(d_iq, d_bits2, freq_offset=d_freq, n_frames=n_frames)
+    torch.cuda.synchronize()
+    assert torch.equal(d_bits, d_bits2)
+    iq = oracle.iq_convert(raw, fmt).view(np.complex64).reshape(n_frames, -1)
+    m = oracle.mapper()
+    for k in range(n_frames):
+        r = oracle.demod_frame(iq[k], float(freq[k]), want_fft=True, m=m)
+        assert np.array_equal(d_bits[k].cpu().numpy(), r["bits"]), (name, k)
+        assert np.array_equal(d_corr[k].cpu().numpy().view(np.uint32).reshape(-1), r["cp_corr"].view(np.uint32).reshape(-1)), (name, k)
+        assert np.array_equal(d_fft[k].cpu().numpy().view(np.uint32).reshape(-1), r["fft"].view(np.uint32).reshape(-1)), (name, k)

@@ -46,6 +46,19 @@ def main():
         ms = timed(lambda: ctx.iq_convert(raw, fmt, n, out), args.reps)
         res["iq_convert"][name] = {"ms": ms, "GB_per_s": n * (sb + 8) / ms / 1e6, "Msamples_per_s": n / ms / 1e3}
         del raw
+    # demodulating straight from a capture format (fused loader) vs convert + demodulate
+    bits = torch.empty((args.frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")
+    corr = torch.empty((args.frames, 76, 2), dtype=torch.float32, device="cuda")
+    res["demod"] = {}
+    out.normal_()
+    res["demod"]["c32"] = {"ms": timed(lambda: ctx.ofdm_demod_frames(out, bits, cp_corr=corr, n_frames=args.frames), args.reps)}
+    for name in ("raw_u8", "raw_s16l", "raw_s16b"):
+        fmt = dabgpu.IQ_FORMATS.index(name)
+        sb = dabgpu.iq_format_sample_bytes(fmt)
+        raw = torch.randint(0, 256, (n * sb,), dtype=torch.uint8, device="cuda")
+        ms = timed(lambda: ctx.ofdm_demod_frames_raw(raw, fmt, args.frames, bits, cp_corr=corr), args.reps)
+        res["demod"][name] = {"ms": ms, "frames_per_s": args.frames / ms * 1e3}
+        del raw
     nb = args.frames * dabgpu.NB_FRAME_BITS // 8
     soft = torch.randint(-128, 128, (8 * nb,), dtype=torch.int8, device="cuda")
     hard = torch.empty(nb, dtype=torch.uint8, device="cuda")
