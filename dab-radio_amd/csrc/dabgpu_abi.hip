@@ -202,7 +202,7 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
-                                                     (int)n_frames, symbols_per_block, bits_frame_stride, s), "ofdm_demod_kernel launch");
+                                                     (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, s), "ofdm_demod_kernel launch");
 }
 
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
@@ -237,7 +237,7 @@ int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_fra
     if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = (hipStream_t)stream;
-    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, s),
+    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, s),
                             "ofdm_phase_kernel launch");
 }
 
@@ -322,7 +322,7 @@ int dabgpu_ofdm_sync(dabgpu_ctx* c, const float* d_prs_syms, size_t n_streams, s
     if (n_streams == 0) return DABGPU_OK;
     if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
     return dabgpu_check_hip(dabgpu_launch_sync(d_prs_syms, stride_samples, (int)n_streams, cfg, d_states, d_impulse, d_freq,
-                                               c->d_tw, c->d_prs, c->d_prs_time_ref, (hipStream_t)stream), "ofdm_sync_kernel launch");
+                                               c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, (hipStream_t)stream), "ofdm_sync_kernel launch");
 }
 
 int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* h_state,

@@ -28,9 +28,10 @@ int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
-                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, hipStream_t stream);
+                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, const int* d_frame_slot,
+                                               hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, hipStream_t stream);
+                                               float* d_fine_freq, int fine_freq_stride, const int* d_frame_slot, hipStream_t stream);
 
 // ---- channel decode ----
 typedef dabgpu_codeword dabgpu_cw_desc;
@@ -61,6 +62,6 @@ extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int
 extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
                                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
-                                         const float* d_prs, const float* d_prs_time_ref, hipStream_t stream);
+                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_cif_deinterleave(const int8_t* d_ring, int n_bits, int n_slots, int newest_slot,
                                                      int8_t* d_out, hipStream_t stream);

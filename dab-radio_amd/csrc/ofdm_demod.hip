@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
                        f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
-                       int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride)
+                       int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
+                       const int* __restrict__ frame_slot)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f2* bufA = reinterpret_cast<f2*>(smem);                              // 2048 x 8 B, position-indexed
@@ -81,6 +82,14 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int frame = unit / chunks_per_frame;
     const int chunk = unit % chunks_per_frame;
     if (frame >= n_frames) return;
+    // stream banks (ofdm_stream.hip): frame = stream index, frame_slot[stream] = output slot of its completed frame
+    // or < 0 when the stream has no frame to demodulate in this round
+    size_t out_frame = (size_t)frame;
+    if (frame_slot != nullptr) {
+        const int slot = frame_slot[frame];
+        if (slot < 0) return;
+        out_frame = (size_t)slot;
+    }
 
     // DQPSK outputs [out0, out1) need FFTs of symbols [out0, out1]; the last chunk also owns the
     // correlation of symbol 75 and (only when fft_out != nullptr) the display-only NULL symbol 76.
@@ -247,7 +256,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         __syncthreads();       // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
         if (emit && t < NB_SYM_BITS / 16) {
             const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
-            uint4* dst = reinterpret_cast<uint4*>(bits + (size_t)frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
+            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
             dst[t] = o;
         }
 #pragma unroll
@@ -281,10 +290,12 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
 // (ofdm_demodulator.cpp:606-618, :779-824, :829-840)
 __global__ __launch_bounds__(64)
 void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
-                       float* __restrict__ total_phase, float* __restrict__ fine_freq)
+                       float* __restrict__ total_phase, float* __restrict__ fine_freq, int fine_freq_stride,
+                       const int* __restrict__ frame_slot)
 {
     const int fr = blockIdx.x * blockDim.x + threadIdx.x;
     if (fr >= n_frames) return;
+    if (frame_slot != nullptr && frame_slot[fr] < 0) return;
     const f2* c = cp_corr + (size_t)fr * NB_FRAME_SYMBOLS;
     float total = 0.0f;
     for (int i = 0; i < NB_FRAME_SYMBOLS; i++) {
@@ -299,9 +310,9 @@ void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
         const float err = spacing * avg / TWO_PI;
         const float delta = -beta * err;
         const float wrap = 0.5f * spacing * 1.01f;
-        float fine = fine_freq[fr] + delta;
+        float fine = fine_freq[(size_t)fr * fine_freq_stride] + delta;
         fine = fmodf(fine, wrap);
-        fine_freq[fr] = fine;
+        fine_freq[(size_t)fr * fine_freq_stride] = fine;
     }
 }
 
@@ -314,7 +325,8 @@ extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // d
 // src: 0 interleaved complex float, 1 raw_u8 / wav pcm8, 2 raw_s8, 3 raw_s16l / wav pcm16
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
-                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, hipStream_t stream)
+                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, const int* d_frame_slot,
+                                               hipStream_t stream)
 {
     using namespace dabgpu;
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
@@ -325,7 +337,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 #define DABGPU_LAUNCH(PF, SRC) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks, bits_frame_stride)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_frame_slot)
     switch (src) {
     case SRC_C32: if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32); else DABGPU_LAUNCH(false, SRC_C32); break;
     case SRC_U8: DABGPU_LAUNCH(false, SRC_U8); break;
@@ -338,11 +350,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 }
 
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, hipStream_t stream)
+                                               float* d_fine_freq, int fine_freq_stride, const int* d_frame_slot, hipStream_t stream)
 {
     using namespace dabgpu;
     const dim3 grid((unsigned)((n_frames + 63) / 64));
     hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
-                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq);
+                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_frame_slot);
     return hipGetLastError();
 }

@@ -1,0 +1,400 @@
+// ofdm_stream.hip -- device-side unsynchronised front end: a BANK of independent OFDM receivers,
+// each with the state OFDM_Demod keeps between Process() calls (src/ofdm/ofdm_demodulator.h:131-176) resident in
+// HBM, advanced by device kernels.  One dabgpu_stream_bank_process() = one OFDM_Demod::Process(block) for every
+// stream of the bank (src/ofdm/ofdm_demodulator.cpp:235-275):
+//
+//   stream_advance_kernel   one workgroup per stream: UpdateSignalAverage (:934-950), FindNullPowerDip (:291-347),
+//                           ReadNullPRS (:349-358), ReadSymbols' buffering (:550-562), Reset (:277-289) and the
+//                           bookkeeping after a sync / a demodulated frame.  Runs until the stream needs the PRS
+//                           synchroniser or the frame demodulator, or has consumed its block.
+//   ofdm_sync_kernel        (ofdm_sync.hip) for the streams whose correlation window just filled
+//   ofdm_demod_kernel + ofdm_phase_kernel  (ofdm_demod.hip) for the streams whose frame buffer just filled
+//
+// repeated ("rounds") until every stream has consumed its block; the host only reads one counter back per round
+// after the rounds every stream needs in steady state.  Every float is produced by the same operations in the same
+// order as the host mirror class (host/ofdm/ofdm_demodulator.cpp) and the oracle composition tests/stream_model.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+#include "ofdm_device.h"
+
+namespace dabgpu {
+
+constexpr int NB_NULL_PERIOD = 2656;
+constexpr int NB_CORR = NB_NULL_PERIOD + NB_SYMBOL_PERIOD;      // 5208
+enum { ST_FINDING_NULL = 0, ST_READING_NULL_PRS = 1, ST_RUNNING_COARSE = 2, ST_RUNNING_FINE = 3, ST_READING_SYMBOLS = 4 };
+enum { PEND_NONE = 0, PEND_SYNC = 1, PEND_DEMOD = 2 };
+
+struct StreamState {
+    int state;
+    float signal_avg;
+    int null_start, null_end;
+    int ring_index, ring_length;
+    int corr_length, frame_length;
+    int pending;
+    int n_out;                       // frames completed in the current process() call
+    int fine_time_offset;
+    int total_frames_read, total_frames_desync;
+    int avg_done;                    // UpdateSignalAverage already applied to the current block
+    long long pos;                   // samples of the current block consumed
+};
+
+struct BankView {
+    StreamState* st;
+    dabgpu_sync_state* sync;
+    f2* ring;                        // [n][2656]
+    f2* corr;                        // [n][5208]
+    f2* frame;                       // [n][196608]
+    float* freq;                     // [n] coarse + fine handed to the PLL
+    int* sync_active;                // [n]
+    int* frame_slot;                 // [n]
+    int* not_done;                   // [1]
+};
+
+__device__ __forceinline__ float l1_window(const f2* p, int k) {           // CalculateL1Average :922-932
+    float acc = 0.0f;
+    for (int i = 0; i < k; i++) { const f2 v = p[i]; acc += __builtin_fabsf(v.x) + __builtin_fabsf(v.y); }
+    return acc / (float)k;
+}
+
+__device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __restrict__ src, long long n, int t) {
+    for (long long i = t; i < n; i += 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256)
+void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq, size_t stream_stride, long long n_samples,
+                           dabgpu_stream_cfg cfg, int max_frames, int first_round)
+{
+    __shared__ StreamState S;
+    __shared__ float win[256];
+    __shared__ int sh_i[2];
+    __shared__ long long sh_w;
+    const int s = blockIdx.x, t = threadIdx.x;
+    if (s >= n_streams) return;
+    if (t == 0) S = B.st[s];
+    __syncthreads();
+    const f2* block = iq + (size_t)s * stream_stride;
+    f2* ring = B.ring + (size_t)s * NB_NULL_PERIOD;
+    f2* corr = B.corr + (size_t)s * NB_CORR;
+    f2* frame = B.frame + (size_t)s * NB_FRAME_SAMPLES;
+    const int k = cfg.signal_l1_nb_samples;
+
+    if (first_round) {
+        if (t == 0) { S.pos = 0; S.n_out = 0; S.avg_done = 0; }
+        __syncthreads();
+    }
+
+    // ---- what the previous round's sync / demod kernels produced ----
+    if (S.pending == PEND_SYNC) {
+        const dabgpu_sync_state y = B.sync[s];
+        if (!y.sync_valid) {                                               // Reset() :277-289, :529-532
+            __syncthreads();
+            if (t == 0) {
+                S.state = ST_FINDING_NULL; S.corr_length = 0; S.total_frames_desync++; S.fine_time_offset = 0;
+                dabgpu_sync_state z = y; z.is_found_coarse = 0; z.freq_coarse = 0.0f; z.freq_fine = 0.0f; z.fine_time_offset = 0;
+                B.sync[s] = z;
+            }
+        } else {                                                           // :536-546
+            const int start = NB_NULL_PERIOD + y.fine_time_offset;
+            const int count = NB_CORR - start;
+            copy_samples(frame, corr + start, count, t);
+            __syncthreads();
+            if (t == 0) { S.frame_length = count; S.corr_length = 0; S.fine_time_offset = y.fine_time_offset; S.state = ST_READING_SYMBOLS; }
+        }
+        if (t == 0) { S.pending = PEND_NONE; B.sync_active[s] = 0; }
+        __syncthreads();
+    } else if (S.pending == PEND_DEMOD) {
+        __syncthreads();
+        if (t == 0) {                                                      // :563-576
+            S.total_frames_read++; S.n_out++; S.frame_length = 0; S.state = ST_READING_NULL_PRS;
+            S.pending = PEND_NONE; B.frame_slot[s] = -1;
+        }
+        __syncthreads();
+    }
+
+    // ---- UpdateSignalAverage over the whole block, once per process() (:934-950) ----
+    if (!S.avg_done) {
+        if (n_samples >= k) {
+            const long long stride = (long long)k * cfg.signal_l1_nb_decimate;
+            const long long n_win = (n_samples - k + stride - 1) / stride;         // i = 0, stride, ... < n - k
+            for (long long w0 = 0; w0 < n_win; w0 += 256) {
+                const long long w = w0 + t;
+                if (w < n_win) win[t] = l1_window(block + w * stride, k);
+                __syncthreads();
+                if (t == 0) {
+                    const int m = (int)((n_win - w0 < 256) ? (n_win - w0) : 256);
+                    float a = S.signal_avg;
+                    const float beta = cfg.signal_l1_update_beta;
+                    for (int j = 0; j < m; j++) a = beta * a + (1.0f - beta) * win[j];
+                    S.signal_avg = a;
+                }
+                __syncthreads();
+            }
+        }
+        if (t == 0) S.avg_done = 1;
+        __syncthreads();
+    }
+
+    // ---- the Process() loop (:241-274) up to the next device-kernel request ----
+    while (S.pos < n_samples && S.pending == PEND_NONE) {
+        const f2* buf = block + S.pos;
+        const long long rest = n_samples - S.pos;
+        if (S.state == ST_FINDING_NULL) {
+            // FindNullPowerDip :291-347
+            const float start_thresh = S.signal_avg * cfg.thresh_null_start;
+            const float end_thresh = S.signal_avg * cfg.thresh_null_end;
+            const long long n_win = (rest > k) ? (rest - 1) / k : 0;                // i = 0, k, ... while i < rest - k
+            if (t == 0) { sh_i[0] = S.null_start; sh_i[1] = 0; }                    // [1] = null end found
+            long long nb_read = rest;
+            __syncthreads();
+            for (long long w0 = 0; w0 < n_win; w0 += 256) {
+                const long long w = w0 + t;
+                if (w < n_win) win[t] = l1_window(buf + w * k, k);
+                __syncthreads();
+                if (t == 0) {
+                    const int m = (int)((n_win - w0 < 256) ? (n_win - w0) : 256);
+                    int started = sh_i[0];
+                    for (int j = 0; j < m; j++) {
+                        const float l1 = win[j];
+                        if (started) {
+                            if (l1 > end_thresh) { sh_i[1] = 1; sh_w = w0 + j; break; }
+                        } else if (l1 < start_thresh) {
+                            started = 1;
+                        }
+                    }
+                    sh_i[0] = started;
+                }
+                __syncthreads();
+                if (sh_i[1]) break;
+            }
+            const int null_end = sh_i[1];
+            if (null_end) nb_read = sh_w * k + k;
+            // circular buffer of the last nb_null_period samples (:325, circular_buffer.h:18-37)
+            const int cap = NB_NULL_PERIOD;
+            const long long keep = (nb_read < cap) ? nb_read : cap;
+            const long long first = nb_read - keep;
+            const int ring_index = S.ring_index;
+            for (long long j = t; j < keep; j += 256) ring[(int)((ring_index + first + j) % cap)] = buf[first + j];
+            __syncthreads();
+            const int new_index = (int)((ring_index + nb_read) % cap);
+            const int new_length = (int)(((long long)S.ring_length + nb_read < cap) ? (S.ring_length + nb_read) : cap);
+            if (null_end) {                                                         // :333-338
+                for (int j = t; j < new_length; j += 256) corr[j] = ring[(j + new_index) % cap];
+            }
+            __syncthreads();
+            if (t == 0) {
+                S.ring_index = new_index; S.ring_length = new_length; S.null_start = sh_i[0];
+                if (null_end) { S.corr_length = new_length; S.null_start = 0; S.null_end = 0; S.ring_length = 0; S.state = ST_READING_NULL_PRS; }
+                S.pos += nb_read;
+            }
+            __syncthreads();
+        } else if (S.state == ST_READING_NULL_PRS) {
+            // ReadNullPRS :349-358
+            const long long want = NB_CORR - S.corr_length;
+            const long long take = (want < rest) ? want : rest;
+            copy_samples(corr + S.corr_length, buf, take, t);
+            __syncthreads();
+            if (t == 0) {
+                S.corr_length += (int)take; S.pos += take;
+                // like the reference, a window that fills with the last sample of a block is synchronised by the NEXT Process()
+                if (S.corr_length == NB_CORR) {
+                    S.state = ST_RUNNING_COARSE;
+                    if (S.pos < n_samples) { S.pending = PEND_SYNC; B.sync_active[s] = 1; }
+                }
+            }
+            __syncthreads();
+        } else if (S.state == ST_READING_SYMBOLS) {
+            // ReadSymbols :550-577
+            const long long want = NB_FRAME_SAMPLES - S.frame_length;
+            const long long take = (want < rest) ? want : rest;
+            copy_samples(frame + S.frame_length, buf, take, t);
+            __syncthreads();
+            const bool full = (S.frame_length + take == NB_FRAME_SAMPLES);
+            if (full) copy_samples(corr, frame + NB_FRAME_SYMBOLS * NB_SYMBOL_PERIOD, NB_NULL_PERIOD, t);   // :558-562
+            __syncthreads();
+            if (t == 0) {
+                S.frame_length += (int)take; S.pos += take;
+                if (full) {
+                    S.corr_length = NB_NULL_PERIOD;
+                    const dabgpu_sync_state y = B.sync[s];
+                    B.freq[s] = y.freq_coarse + y.freq_fine;
+                    // a frame beyond the caller's capacity is demodulated into the last slot (and reported through n_frames)
+                    const int slot = (S.n_out < max_frames) ? S.n_out : (max_frames - 1);
+                    B.frame_slot[s] = s * max_frames + slot;
+                    S.pending = PEND_DEMOD;
+                }
+            }
+            __syncthreads();
+        } else {
+            // RUNNING_*: the correlation window filled at the very end of the previous block (:247-262)
+            __syncthreads();
+            if (t == 0) { S.pending = PEND_SYNC; B.sync_active[s] = 1; }
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        B.st[s] = S;
+        if (S.pos < n_samples || S.pending != PEND_NONE) atomicAdd(B.not_done, 1);
+    }
+}
+
+__global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const StreamState S = B.st[s];
+    if (n_frames) n_frames[s] = S.n_out;
+    if (status) {
+        const dabgpu_sync_state y = B.sync[s];
+        dabgpu_stream_status o;
+        o.state = S.state; o.signal_l1_average = S.signal_avg; o.freq_coarse = y.freq_coarse; o.freq_fine = y.freq_fine;
+        o.is_found_coarse = y.is_found_coarse; o.fine_time_offset = S.fine_time_offset;
+        o.total_frames_read = S.total_frames_read; o.total_frames_desync = S.total_frames_desync;
+        status[s] = o;
+    }
+}
+
+}  // namespace dabgpu
+
+using namespace dabgpu;
+
+struct dabgpu_stream_bank {
+    dabgpu_ctx* ctx = nullptr;
+    size_t n = 0;
+    dabgpu_stream_cfg cfg{};
+    BankView view{};
+    float* d_corr_out = nullptr;       // [n][76][2] cyclic-prefix correlations of the last demodulated frames
+    dabgpu_stream_status* d_status = nullptr;
+    std::vector<void*> allocs;
+};
+
+extern "C" {
+
+void dabgpu_stream_cfg_default(dabgpu_stream_cfg* c) {
+    if (!c) return;
+    c->signal_l1_update_beta = 0.95f; c->signal_l1_nb_samples = 100; c->signal_l1_nb_decimate = 5;      // ofdm_demodulator.h:25-29
+    c->thresh_null_start = 0.35f; c->thresh_null_end = 0.75f;                                            // :30-33
+    dabgpu_sync_cfg_default(&c->sync);
+}
+
+void dabgpu_stream_bank_destroy(dabgpu_stream_bank* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : b->allocs) (void)hipFree(p);
+    delete b;
+}
+
+int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
+    if (!b) { dabgpu_set_error("stream_bank_reset: null bank"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(b->ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    CK(hipMemsetAsync(b->view.st, 0, b->n * sizeof(StreamState), s));
+    CK(hipMemsetAsync(b->view.sync, 0, b->n * sizeof(dabgpu_sync_state), s));
+    CK(hipMemsetAsync(b->view.sync_active, 0, b->n * sizeof(int), s));
+    CK(hipMemsetAsync(b->view.frame_slot, 0xFF, b->n * sizeof(int), s));
+    CK(hipMemsetAsync(b->view.ring, 0, b->n * NB_NULL_PERIOD * sizeof(f2), s));
+    CK(hipMemsetAsync(b->view.corr, 0, b->n * NB_CORR * sizeof(f2), s));
+    CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
+#undef CK
+    return DABGPU_OK;
+}
+
+int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stream_cfg* cfg, dabgpu_stream_bank** out) {
+    if (!c || !out || n_streams == 0 || n_streams > (size_t)(1 << 20)) { dabgpu_set_error("stream_bank_create: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_stream_cfg k;
+    if (cfg) k = *cfg; else dabgpu_stream_cfg_default(&k);
+    if (k.signal_l1_nb_samples <= 0 || k.signal_l1_nb_decimate <= 0) { dabgpu_set_error("stream_bank_create: invalid L1 window"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    dabgpu_stream_bank* b = new (std::nothrow) dabgpu_stream_bank();
+    if (!b) return DABGPU_ERR_HIP;
+    b->ctx = c; b->n = n_streams; b->cfg = k;
+    int st = DABGPU_OK;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (st) return;
+        st = dabgpu_check_hip(hipMalloc(p, bytes), "hipMalloc(stream bank)");
+        if (!st) b->allocs.push_back(*p);
+    };
+    alloc((void**)&b->view.st, n_streams * sizeof(StreamState));
+    alloc((void**)&b->view.sync, n_streams * sizeof(dabgpu_sync_state));
+    alloc((void**)&b->view.ring, n_streams * NB_NULL_PERIOD * sizeof(f2));
+    alloc((void**)&b->view.corr, n_streams * NB_CORR * sizeof(f2));
+    alloc((void**)&b->view.frame, n_streams * (size_t)NB_FRAME_SAMPLES * sizeof(f2));
+    alloc((void**)&b->view.freq, n_streams * sizeof(float));
+    alloc((void**)&b->view.sync_active, n_streams * sizeof(int));
+    alloc((void**)&b->view.frame_slot, n_streams * sizeof(int));
+    alloc((void**)&b->view.not_done, sizeof(int));
+    alloc((void**)&b->d_corr_out, n_streams * NB_FRAME_SYMBOLS * 2 * sizeof(float));
+    alloc((void**)&b->d_status, n_streams * sizeof(dabgpu_stream_status));
+    if (!st) st = dabgpu_stream_bank_reset(b, c->stream);
+    if (!st) st = dabgpu_check_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    if (st) { dabgpu_stream_bank_destroy(b); return st; }
+    *out = b;
+    return DABGPU_OK;
+}
+
+int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t stream_stride_samples, size_t n_samples,
+                               int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+    if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_samples == 0) return DABGPU_OK;
+    // a frame needs at least 76 symbols + a NULL minus the sync's pull-back of new samples
+    const size_t need = n_samples / (size_t)(NB_FRAME_SAMPLES - NB_CORR) + 2;
+    if (max_frames_per_stream < need || max_frames_per_stream > (size_t)(1 << 20) || b->n * max_frames_per_stream > (size_t)0x7FFFFFFF) {
+        dabgpu_set_error("stream_bank_process: max_frames_per_stream must be at least %zu for %zu samples", need, n_samples);
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    if (((uintptr_t)d_iq & 7) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("stream_bank_process: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = (int)b->n;
+    int st;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    // rounds every locked stream needs: (sync, demod) per frame that can complete inside this block, plus one to drain
+    const int blind_rounds = 2 * (int)(n_samples / NB_FRAME_SAMPLES + 1) + 1;
+    int h_not_done = 1;
+    for (int round = 0; h_not_done != 0; round++) {
+        CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
+        hipLaunchKernelGGL(stream_advance_kernel, dim3((unsigned)n), dim3(256), 0, s, b->view, n, reinterpret_cast<const f2*>(d_iq),
+                           stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0);
+        CK(hipGetLastError());
+        CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
+                              nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, s));
+        CK(dabgpu_launch_ofdm_demod(b->view.frame, 0, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
+                                    n, 0, 0, b->view.frame_slot, s));
+        CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
+                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.frame_slot, s));
+        if (round + 1 >= blind_rounds) {
+            CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
+            CK(hipStreamSynchronize(s));
+        }
+        if (round > (1 << 22)) { dabgpu_set_error("stream_bank_process: no progress"); return DABGPU_ERR_HIP; }
+    }
+    if (d_n_frames) {
+        hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, d_n_frames,
+                           (dabgpu_stream_status*)nullptr);
+        CK(hipGetLastError());
+    }
+#undef CK
+    return DABGPU_OK;
+}
+
+int dabgpu_stream_bank_status(dabgpu_stream_bank* b, dabgpu_stream_status* h_status, void* stream) {
+    if (!b || !h_status) { dabgpu_set_error("stream_bank_status: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(b->ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = (int)b->n;
+    int st;
+    hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, (int*)nullptr, b->d_status);
+    if ((st = dabgpu_check_hip(hipGetLastError(), "stream_report_kernel launch"))) return st;
+    if ((st = dabgpu_check_hip(hipMemcpyAsync(h_status, b->d_status, b->n * sizeof(dabgpu_stream_status), hipMemcpyDeviceToHost, s), "hipMemcpyAsync"))) return st;
+    return dabgpu_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+
+}  // extern "C"

@@ -165,13 +165,15 @@ void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2*
 __global__ __launch_bounds__(256)
 void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, int n_streams, dabgpu_sync_cfg cfg,
                       dabgpu_sync_state* __restrict__ states, float* __restrict__ impulse_out, float* __restrict__ freq_out,
-                      const f2* __restrict__ tw, const f2* __restrict__ prs_fft, const f2* __restrict__ prs_time_ref)
+                      const f2* __restrict__ tw, const f2* __restrict__ prs_fft, const f2* __restrict__ prs_time_ref,
+                      const int* __restrict__ active)
 {
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int sidx = blockIdx.x;
     if (sidx >= n_streams) return;
+    if (active != nullptr && active[sidx] == 0) return;        // stream banks: only streams whose PRS window just filled
     const f2* prs_sym = prs_syms + (size_t)sidx * stride_samples;
     dabgpu_sync_state st = states[sidx];
     const int N = NB_FFT, M = N / 2;
@@ -304,10 +306,10 @@ extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d
 
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
                                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
-                                         const float* d_prs, const float* d_prs_time_ref, hipStream_t stream) {
+                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, hipStream_t stream) {
     using namespace dabgpu;
     hipLaunchKernelGGL(ofdm_sync_kernel, dim3((unsigned)n_streams), dim3(256), sizeof(SyncLds), stream,
                        reinterpret_cast<const f2*>(d_prs_syms), stride_samples, n_streams, *cfg, d_states, d_impulse, d_freq,
-                       reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref));
+                       reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref), d_active);
     return hipGetLastError();
 }

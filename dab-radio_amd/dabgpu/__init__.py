@@ -39,6 +39,8 @@ ABI_SYMBOLS = [
     "dabgpu_iq_convert", "dabgpu_iq_convert_host_sync", "dabgpu_ofdm_demod_frames_raw",
     "dabgpu_soft_bits_to_hard_bytes", "dabgpu_hard_bytes_to_soft_bits",
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
+    "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
+    "dabgpu_stream_bank_process", "dabgpu_stream_bank_status",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -87,6 +89,15 @@ class SyncState(C.Structure):
                 ("fine_time_offset", C.c_int), ("sync_valid", C.c_int), ("reserved", C.c_int)]
 
 
+class StreamCfg(C.Structure):
+    """dabgpu_stream_cfg"""
+    _fields_ = [("signal_l1_update_beta", C.c_float), ("signal_l1_nb_samples", C.c_int), ("signal_l1_nb_decimate", C.c_int),
+                ("thresh_null_start", C.c_float), ("thresh_null_end", C.c_float), ("sync", SyncCfg)]
+
+
+STREAM_STATUS_DTYPE = [("state", "<i4"), ("signal_l1_average", "<f4"), ("freq_coarse", "<f4"), ("freq_fine", "<f4"),
+                       ("is_found_coarse", "<i4"), ("fine_time_offset", "<i4"), ("total_frames_read", "<i4"),
+                       ("total_frames_desync", "<i4")]
 SYNC_STATE_DTYPE = [("freq_coarse", "<f4"), ("freq_fine", "<f4"), ("is_found_coarse", "<i4"),
                     ("fine_time_offset", "<i4"), ("sync_valid", "<i4"), ("reserved", "<i4")]
 RESULT_DTYPE = [("path_error", "<u8"), ("crc_ok_mask", "<u4"), ("n_out_bytes", "<u4")]
@@ -154,6 +165,13 @@ def lib():
         L.dabgpu_hard_bytes_to_soft_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.dabgpu_soft_bits_to_hard_bytes_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dabgpu_hard_bytes_to_soft_bits_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dabgpu_stream_cfg_default.argtypes = [C.c_void_p]
+        L.dabgpu_stream_bank_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dabgpu_stream_bank_destroy.argtypes = [C.c_void_p]
+        L.dabgpu_stream_bank_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -338,6 +356,47 @@ class Context:
         out = np.empty(data.size * 8, np.int8)
         check(lib().dabgpu_hard_bytes_to_soft_bits_host_sync(self._h, _ptr(data), data.size, _ptr(out)), "hard_bytes_to_soft_bits_host_sync")
         return out
+
+
+class StreamBank:
+    """dabgpu_stream_bank: n unsynchronised receivers resident on the device (one OFDM_Demod each)"""
+
+    def __init__(self, ctx, n_streams, cfg=None):
+        self._ctx = ctx
+        self.n = n_streams
+        self._h = C.c_void_p()
+        check(lib().dabgpu_stream_bank_create(ctx._h, n_streams, C.byref(cfg) if cfg is not None else None, C.byref(self._h)),
+              "dabgpu_stream_bank_create")
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_stream_bank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=None):
+        check(lib().dabgpu_stream_bank_reset(self._h, Context._stream(stream)), "dabgpu_stream_bank_reset")
+
+    def process(self, iq, stream_stride_samples, n_samples, bits, max_frames, n_frames=None, stream=None):
+        check(lib().dabgpu_stream_bank_process(self._h, _ptr(iq), stream_stride_samples, n_samples, _ptr(bits), max_frames,
+                                               _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process")
+
+    def status(self, stream=None):
+        import numpy as np
+        out = np.zeros(self.n, dtype=np.dtype(STREAM_STATUS_DTYPE))
+        check(lib().dabgpu_stream_bank_status(self._h, _ptr(out), Context._stream(stream)), "dabgpu_stream_bank_status")
+        return out
+
+
+def stream_cfg_default():
+    c = StreamCfg()
+    lib().dabgpu_stream_cfg_default(C.byref(c))
+    return c
 
 
 def iq_format_from_mode(mode):

@@ -289,6 +289,51 @@ int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream *s, int8_t *h_out);
 int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *n_out, uint64_t *path_error, int tie_rule);
 
 /* ==================================================================================================
+ * Unsynchronised front end on the device: a bank of n independent receivers whose state between
+ * calls -- signal level, NULL-search flags, circular NULL buffer, correlation window, frame buffer, frequency
+ * offsets, counters (src/ofdm/ofdm_demodulator.h:131-176) -- lives in HBM.  One dabgpu_stream_bank_process() is one
+ * OFDM_Demod::Process(block) for every stream (src/ofdm/ofdm_demodulator.cpp:235-275): L1 signal average (:934-950),
+ * NULL power-dip search (:291-347), NULL+PRS read (:349-358), coarse/fine sync (:360-548), symbol read (:550-577),
+ * frame demodulation and the fine-frequency loop (:581-639), Reset on a failed impulse-peak test (:277-289,:529-532).
+ * Results equal the OFDM_Demod mirror class fed the same blocks, stream by stream, byte for byte.
+ */
+typedef struct {                      /* OFDM_Demod_Config, src/ofdm/ofdm_demodulator.h:24-45 */
+    float signal_l1_update_beta;      /* 0.95 */
+    int   signal_l1_nb_samples;       /* 100  */
+    int   signal_l1_nb_decimate;      /* 5    */
+    float thresh_null_start;          /* 0.35 */
+    float thresh_null_end;            /* 0.75 */
+    dabgpu_sync_cfg sync;
+} dabgpu_stream_cfg;
+void dabgpu_stream_cfg_default(dabgpu_stream_cfg *cfg);
+
+typedef struct {
+    int32_t state;                    /* OFDM_Demod::State, ofdm_demodulator.h:50-56 */
+    float   signal_l1_average;
+    float   freq_coarse, freq_fine;
+    int32_t is_found_coarse;
+    int32_t fine_time_offset;
+    int32_t total_frames_read, total_frames_desync;
+} dabgpu_stream_status;
+
+typedef struct dabgpu_stream_bank dabgpu_stream_bank;
+/* cfg NULL = the reference's defaults. Device memory: 1.64 MB per stream. */
+int dabgpu_stream_bank_create(dabgpu_ctx *ctx, size_t n_streams, const dabgpu_stream_cfg *cfg, dabgpu_stream_bank **out);
+void dabgpu_stream_bank_destroy(dabgpu_stream_bank *bank);
+int dabgpu_stream_bank_reset(dabgpu_stream_bank *bank, void *stream);     /* every stream back to its constructed state */
+/*
+ *   d_iq        stream s's block = n_samples complex float at d_iq + 2*s*stream_stride_samples (device, 8-byte aligned)
+ *   d_bits      [n_streams][max_frames_per_stream][230400] int8: frame j completed by stream s during this call
+ *   d_n_frames  [n_streams] out: frames completed during this call (may be NULL)
+ *   max_frames_per_stream >= n_samples / 191400 + 2
+ * Launches on `stream`; synchronises with it (the number of rounds depends on the data).
+ */
+int dabgpu_stream_bank_process(dabgpu_stream_bank *bank, const float *d_iq, size_t stream_stride_samples, size_t n_samples,
+                               int8_t *d_bits, size_t max_frames_per_stream, int32_t *d_n_frames, void *stream);
+/* snapshot of every stream's getters (GetState, GetSignalAverage, Get*FrequencyOffset, ...) into host memory; synchronous */
+int dabgpu_stream_bank_status(dabgpu_stream_bank *bank, dabgpu_stream_status *h_status, void *stream);
+
+/* ==================================================================================================
  * Data formats either side of the path.
  *
  * IQ input: the reference's readers (examples/app_helpers/app_iq_readers.h:17-159, app_wav_reader.h:257-470)

@@ -1,0 +1,101 @@
+"""-m gpu parity test of the device-side unsynchronised front end (dabgpu_stream_bank_*): several
+receivers with different carrier offsets, timing, noise and signal drop-outs advance in one bank; every completed frame's
+soft bits and every status field after every call must equal tests/stream_model.py (the oracle-composed OFDM_Demod state
+machine) fed the same blocks -- floats as uint32 bit patterns."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_stream(oracle, seed, n_frames, cfo, pad, noise, dropout=None, amplitude=1.0 / 39.2):
+    rng = np.random.default_rng(seed)
+    frames = [oracle.modulate_frame(rng.integers(0, 2, oracle.NB_FRAME_BITS, dtype=np.uint8)) for _ in range(n_frames)]
+    tx = oracle.apply_pll(np.concatenate(frames), cfo, 0.11)
+    stream = np.concatenate([tx[oracle.NB_NULL_PERIOD:oracle.NB_NULL_PERIOD + 20000 + pad], tx])
+    if dropout is not None:                    # the signal vanishes for a while: desync, NULL search, re-acquisition
+        a, b = dropout
+        stream[a:b] = 0
+    stream = stream + noise * (rng.standard_normal(stream.size) + 1j * rng.standard_normal(stream.size))
+    return (stream * amplitude).astype(np.complex64)
+
+
+def noise_with_dips(seed, streams_len):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(streams_len) + 1j * rng.standard_normal(streams_len)) * 0.1
+    for a in range(40000, streams_len - 4000, 53000):
+        x[a:a + 2600] *= 0.05
+    return x.astype(np.complex64)
+
+
+@pytest.mark.parametrize("block", [65536, 10007, 500000])
+def test_stream_bank_matches_stream_model(oracle, block):
+    import dabgpu
+    import stream_model as SM
+    import torch
+    ctx = dabgpu.Context(0)
+    streams = [
+        make_stream(oracle, 1, 4, 1.8e-3, 1234, 3.0),
+        make_stream(oracle, 2, 4, -7.3e-3, 77, 6.0),
+        make_stream(oracle, 3, 4, 2.0e-4, 2551, 1.0, dropout=(215000, 235000)),        # wipes the PRS of the 2nd frame
+        noise_with_dips(4, streams_len=850000),                                    # no DAB signal: false NULLs, failed syncs
+    ]
+    n = min(s.size for s in streams)
+    n -= n % 7                                                                     # a ragged last block
+    streams = [s[:n] for s in streams]
+    E = len(streams)
+    models = [SM.StreamModel(oracle) for _ in range(E)]
+    bank = dabgpu.StreamBank(ctx, E)
+    max_frames = block // 191400 + 2
+    d_bits = torch.zeros((E, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")
+    d_nf = torch.zeros(E, dtype=torch.int32, device="cuda")
+    total = [0] * E
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        blk = np.stack([s[k:k + m] for s in streams])
+        d_iq = torch.view_as_real(torch.from_numpy(blk).cuda())
+        d_bits.zero_()
+        bank.process(d_iq, m, m, d_bits, max_frames, d_nf)
+        torch.cuda.synchronize()
+        nf = d_nf.cpu().numpy()
+        st = bank.status()
+        for e in range(E):
+            before = len(models[e].out_frames)
+            models[e].process(blk[e])
+            new = models[e].out_frames[before:]
+            assert nf[e] == len(new), (block, k, e, nf[e], len(new))
+            for j, fr in enumerate(new):
+                assert np.array_equal(d_bits[e, j].cpu().numpy(), fr["bits"]), (block, k, e, j)
+            total[e] += len(new)
+            mo = models[e]
+            assert int(st["state"][e]) == mo.state, (block, k, e)
+            assert st["signal_l1_average"][e].view(np.uint32) == np.float32(mo.signal_avg).view(np.uint32), (block, k, e)
+            assert st["freq_coarse"][e].view(np.uint32) == np.float32(mo.sync.freq_coarse).view(np.uint32), (block, k, e)
+            assert st["freq_fine"][e].view(np.uint32) == np.float32(mo.sync.freq_fine).view(np.uint32), (block, k, e)
+            assert int(st["fine_time_offset"][e]) == mo.fine_time_offset
+            assert int(st["total_frames_read"][e]) == mo.frames_read and int(st["total_frames_desync"][e]) == mo.frames_desync
+    assert total[0] >= 3 and total[1] >= 3 and total[2] >= 1, total
+    assert models[2].frames_desync >= 1, "the drop-out must force a re-acquisition"
+    assert models[3].frames_desync >= 3 and total[3] == 0, "every false NULL must end in a failed impulse-peak test"
+    bank.close()
+
+
+def test_stream_bank_reset_and_argument_checks(oracle):
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    bank = dabgpu.StreamBank(ctx, 2)
+    s = make_stream(oracle, 9, 2, 1e-3, 10, 2.0)[:300000]
+    d_iq = torch.view_as_real(torch.from_numpy(np.stack([s, s])).cuda())
+    d_bits = torch.zeros((2, 3, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")
+    d_nf = torch.zeros(2, dtype=torch.int32, device="cuda")
+    bank.process(d_iq, s.size, s.size, d_bits, 3, d_nf)
+    first = (d_bits.cpu().numpy().copy(), d_nf.cpu().numpy().copy(), bank.status().copy())
+    assert first[1][0] == 1 and first[1][1] == 1 and np.array_equal(first[0][0], first[0][1])
+    bank.reset()
+    d_bits.zero_()
+    bank.process(d_iq, s.size, s.size, d_bits, 3, d_nf)
+    assert np.array_equal(d_bits.cpu().numpy(), first[0]) and np.array_equal(bank.status(), first[2])
+    with pytest.raises(dabgpu.DabGpuError):
+        bank.process(d_iq, s.size, s.size, d_bits, 1, d_nf)          # too few output slots for this block length
+    bank.close()
