@@ -202,7 +202,7 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
-                                                     (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, s), "ofdm_demod_kernel launch");
+                                                     (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0, s), "ofdm_demod_kernel launch");
 }
 
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,

@@ -26,12 +26,20 @@ void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 
+// per-stream work item of a stream bank round (ofdm_stream.hip -> ofdm_demod.hip)
+struct dabgpu_frame_desc {
+    int slot;               // output slot of the completed frame, < 0: nothing to demodulate
+    int split;              // samples [0, split) come from the stream's frame buffer (even)
+    long long tail_off;     // sample offset inside the stream's current block of frame sample `split`
+};
+
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
-                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, const int* d_frame_slot,
+                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride,
+                                               const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, int fine_freq_stride, const int* d_frame_slot, hipStream_t stream);
+                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, hipStream_t stream);
 
 // ---- channel decode ----
 typedef dabgpu_codeword dabgpu_cw_desc;

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dabgpu_internal.h"
 #include "iq_decode.h"
 #include "ofdm_device.h"
 
@@ -62,13 +63,22 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
 // into four independent 512-point problems, one per wave.  Thread (w, l) ends holding bins
 //   Kb + 256*k,  Kb = w + 4*(l>>3) + 32*(l&7),  k = 0..7
 // of which k in {0,1,2,5,6,7} are data carriers (thread 0: DC is replaced by bin 768, its k = 3).
-template <bool PREFETCH, int SRC>
+// stream banks (ofdm_stream.hip): samples [0, split) of a frame come from the stream's frame buffer, the rest straight
+// from the caller's block (no assembly copy); split is even, the block side is only 8-byte aligned
+typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_base, const uint8_t* __restrict__ tail_base, int split, size_t n) {
+    const uint8_t* p = (((int)n < split) ? frame_base : tail_base) + n * 8;
+    const f4u v = *reinterpret_cast<const f4u*>(p);
+    return f4{v.x, v.y, v.z, v.w};
+}
+
+template <bool PREFETCH, int SRC, bool BANK>
 __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
                        f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
-                       const int* __restrict__ frame_slot)
+                       const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f2* bufA = reinterpret_cast<f2*>(smem);                              // 2048 x 8 B, position-indexed
@@ -82,13 +92,16 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int frame = unit / chunks_per_frame;
     const int chunk = unit % chunks_per_frame;
     if (frame >= n_frames) return;
-    // stream banks (ofdm_stream.hip): frame = stream index, frame_slot[stream] = output slot of its completed frame
-    // or < 0 when the stream has no frame to demodulate in this round
+    // stream banks: frame = stream index; desc[stream].slot = output slot of its completed frame, < 0 = nothing to do
     size_t out_frame = (size_t)frame;
-    if (frame_slot != nullptr) {
-        const int slot = frame_slot[frame];
-        if (slot < 0) return;
-        out_frame = (size_t)slot;
+    int split = 0;
+    const uint8_t* tbase = nullptr;
+    if constexpr (BANK) {
+        const dabgpu_frame_desc d = desc[frame];
+        if (d.slot < 0) return;
+        out_frame = (size_t)d.slot;
+        split = d.split;
+        tbase = static_cast<const uint8_t*>(tail) + ((long long)frame * (long long)tail_stride + d.tail_off - (long long)d.split) * 8;
     }
 
     // DQPSK outputs [out0, out1) need FFTs of symbols [out0, out1]; the last chunk also owns the
@@ -145,10 +158,16 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     auto load_symbol = [&](int i, f4 (&v)[4], f4& h) {
         const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
+        for (int k = 0; k < 4; k++) {
+            if constexpr (BANK) v[k] = load_pair_bank(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
+            else v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
+        }
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
         h = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (dc && t >= 4) h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
+        if (dc && t >= 4) {
+            if constexpr (BANK) h = load_pair_bank(fbase, tbase, split, sym + 2 * (t - 4));
+            else h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
+        }
     };
     f4 v[4], h;
     if constexpr (PREFETCH) load_symbol(out0, v, h);
@@ -291,11 +310,11 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
 __global__ __launch_bounds__(64)
 void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
                        float* __restrict__ total_phase, float* __restrict__ fine_freq, int fine_freq_stride,
-                       const int* __restrict__ frame_slot)
+                       const dabgpu_frame_desc* __restrict__ desc)
 {
     const int fr = blockIdx.x * blockDim.x + threadIdx.x;
     if (fr >= n_frames) return;
-    if (frame_slot != nullptr && frame_slot[fr] < 0) return;
+    if (desc != nullptr && desc[fr].slot < 0) return;
     const f2* c = cp_corr + (size_t)fr * NB_FRAME_SYMBOLS;
     float total = 0.0f;
     for (int i = 0; i < NB_FRAME_SYMBOLS; i++) {
@@ -325,7 +344,8 @@ extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // d
 // src: 0 interleaved complex float, 1 raw_u8 / wav pcm8, 2 raw_s8, 3 raw_s16l / wav pcm16
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
-                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride, const int* d_frame_slot,
+                                               int n_frames, int sym_per_chunk, size_t bits_frame_stride,
+                                               const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                hipStream_t stream)
 {
     using namespace dabgpu;
@@ -334,15 +354,19 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
     const dim3 grid((unsigned)(n_frames * chunks));
-#define DABGPU_LAUNCH(PF, SRC) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC>), grid, dim3(256), lds, stream, \
+#define DABGPU_LAUNCH(PF, SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC, BANK>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_frame_slot)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
     switch (src) {
-    case SRC_C32: if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32); else DABGPU_LAUNCH(false, SRC_C32); break;
-    case SRC_U8: DABGPU_LAUNCH(false, SRC_U8); break;
-    case SRC_S8: DABGPU_LAUNCH(false, SRC_S8); break;
-    case SRC_S16: DABGPU_LAUNCH(false, SRC_S16); break;
+    case SRC_C32:
+        if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_C32, true);
+        else if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32, false);
+        else DABGPU_LAUNCH(false, SRC_C32, false);
+        break;
+    case SRC_U8: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_U8, false); break;
+    case SRC_S8: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_S8, false); break;
+    case SRC_S16: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_S16, false); break;
     default: return hipErrorInvalidValue;
     }
 #undef DABGPU_LAUNCH
@@ -350,11 +374,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 }
 
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, int fine_freq_stride, const int* d_frame_slot, hipStream_t stream)
+                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, hipStream_t stream)
 {
     using namespace dabgpu;
     const dim3 grid((unsigned)((n_frames + 63) / 64));
     hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
-                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_frame_slot);
+                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc);
     return hipGetLastError();
 }

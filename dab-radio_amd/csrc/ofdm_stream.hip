@@ -3,10 +3,15 @@
 // HBM, advanced by device kernels.  One dabgpu_stream_bank_process() = one OFDM_Demod::Process(block) for every
 // stream of the bank (src/ofdm/ofdm_demodulator.cpp:235-275):
 //
-//   stream_advance_kernel   one workgroup per stream: UpdateSignalAverage (:934-950), FindNullPowerDip (:291-347),
-//                           ReadNullPRS (:349-358), ReadSymbols' buffering (:550-562), Reset (:277-289) and the
-//                           bookkeeping after a sync / a demodulated frame.  Runs until the stream needs the PRS
-//                           synchroniser or the frame demodulator, or has consumed its block.
+//   stream_l1_kernel        the L1 windows of UpdateSignalAverage (:934-950) for the whole block, one thread per window
+//   stream_advance_kernel   one workgroup per stream: the level IIR, FindNullPowerDip (:291-347), ReadNullPRS (:349-358),
+//                           ReadSymbols' bookkeeping (:550-562), Reset (:277-289) and the bookkeeping after a sync / a
+//                           demodulated frame.  Runs until the stream needs the PRS synchroniser or the frame
+//                           demodulator, or has consumed its block.  A frame that completes inside the block is NOT
+//                           assembled: the demodulator reads its head from the stream's frame buffer and the rest
+//                           straight from the caller's block (dabgpu_frame_desc); only the unfinished frame at the end
+//                           of a block is carried over, by
+//   stream_copy_kernel      many workgroups per stream (the one bulk copy a stream can request per round)
 //   ofdm_sync_kernel        (ofdm_sync.hip) for the streams whose correlation window just filled
 //   ofdm_demod_kernel + ofdm_phase_kernel  (ofdm_demod.hip) for the streams whose frame buffer just filled
 //
@@ -16,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -52,9 +58,16 @@ struct BankView {
     f2* frame;                       // [n][196608]
     float* freq;                     // [n] coarse + fine handed to the PLL
     int* sync_active;                // [n]
-    int* frame_slot;                 // [n]
+    dabgpu_frame_desc* desc;         // [n] demodulation request of the round
+    long long* copy_src;             // [n] bulk copy of the round: block sample offset ...
+    int* copy_dst;                   // [n] ... frame buffer offset ...
+    int* copy_cnt;                   // [n] ... samples (0 = none)
+    float* win;                      // [n][win_cap] L1 windows of the current block
+    long long win_cap;
     int* not_done;                   // [1]
 };
+
+constexpr int COPY_WGS = 16;         // workgroups per stream of the bulk copy
 
 __device__ __forceinline__ float l1_window(const f2* p, int k) {           // CalculateL1Average :922-932
     float acc = 0.0f;
@@ -63,7 +76,12 @@ __device__ __forceinline__ float l1_window(const f2* p, int k) {           // Ca
 }
 
 __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __restrict__ src, long long n, int t) {
-    for (long long i = t; i < n; i += 256) dst[i] = src[i];
+    long long i = t;
+    for (; i + 768 < n; i += 1024) {                     // four independent loads in flight
+        const f2 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d;
+    }
+    for (; i < n; i += 256) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256)
@@ -112,19 +130,19 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
         __syncthreads();
         if (t == 0) {                                                      // :563-576
             S.total_frames_read++; S.n_out++; S.frame_length = 0; S.state = ST_READING_NULL_PRS;
-            S.pending = PEND_NONE; B.frame_slot[s] = -1;
+            S.pending = PEND_NONE; B.desc[s].slot = -1;
         }
         __syncthreads();
     }
 
-    // ---- UpdateSignalAverage over the whole block, once per process() (:934-950) ----
+    // ---- UpdateSignalAverage over the whole block, once per process() (:934-950); windows from stream_l1_kernel ----
     if (!S.avg_done) {
         if (n_samples >= k) {
             const long long stride = (long long)k * cfg.signal_l1_nb_decimate;
             const long long n_win = (n_samples - k + stride - 1) / stride;         // i = 0, stride, ... < n - k
+            const float* wsrc = B.win + (size_t)s * B.win_cap;
             for (long long w0 = 0; w0 < n_win; w0 += 256) {
-                const long long w = w0 + t;
-                if (w < n_win) win[t] = l1_window(block + w * stride, k);
+                if (w0 + t < n_win) win[t] = wsrc[w0 + t];
                 __syncthreads();
                 if (t == 0) {
                     const int m = (int)((n_win - w0 < 256) ? (n_win - w0) : 256);
@@ -139,6 +157,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
         if (t == 0) S.avg_done = 1;
         __syncthreads();
     }
+    if (t == 0) B.copy_cnt[s] = 0;
 
     // ---- the Process() loop (:241-274) up to the next device-kernel request ----
     while (S.pos < n_samples && S.pending == PEND_NONE) {
@@ -210,14 +229,26 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
             __syncthreads();
         } else if (S.state == ST_READING_SYMBOLS) {
             // ReadSymbols :550-577
-            const long long want = NB_FRAME_SAMPLES - S.frame_length;
-            const long long take = (want < rest) ? want : rest;
-            copy_samples(frame + S.frame_length, buf, take, t);
-            __syncthreads();
-            const bool full = (S.frame_length + take == NB_FRAME_SAMPLES);
-            if (full) copy_samples(corr, frame + NB_FRAME_SYMBOLS * NB_SYMBOL_PERIOD, NB_NULL_PERIOD, t);   // :558-562
+            const int have = S.frame_length;
+            const long long want = NB_FRAME_SAMPLES - have;
+            const bool full = (want <= rest);
+            const long long take = full ? want : rest;
+            if (full) {
+                // the frame completes inside this block: no assembly, the demodulator reads [0, split) from the frame
+                // buffer and the rest from the block; one sample is moved over when the boundary would split a pair
+                if ((have & 1) && t == 0) frame[have] = buf[0];
+                // the NULL symbol at the end of this frame heads the next correlation window (:558-562)
+                const int null_at = NB_FRAME_SYMBOLS * NB_SYMBOL_PERIOD;
+                for (int j = t; j < NB_NULL_PERIOD; j += 256) {
+                    const int idx = null_at + j;
+                    corr[j] = (idx < have) ? frame[idx] : buf[idx - have];
+                }
+            } else if (t == 0) {
+                B.copy_src[s] = S.pos; B.copy_dst[s] = have; B.copy_cnt[s] = (int)take;      // carried over by stream_copy_kernel
+            }
             __syncthreads();
             if (t == 0) {
+                const long long pos0 = S.pos;
                 S.frame_length += (int)take; S.pos += take;
                 if (full) {
                     S.corr_length = NB_NULL_PERIOD;
@@ -225,7 +256,11 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
                     B.freq[s] = y.freq_coarse + y.freq_fine;
                     // a frame beyond the caller's capacity is demodulated into the last slot (and reported through n_frames)
                     const int slot = (S.n_out < max_frames) ? S.n_out : (max_frames - 1);
-                    B.frame_slot[s] = s * max_frames + slot;
+                    dabgpu_frame_desc d;
+                    d.slot = s * max_frames + slot;
+                    d.split = have + (have & 1);
+                    d.tail_off = pos0 + (have & 1);
+                    B.desc[s] = d;
                     S.pending = PEND_DEMOD;
                 }
             }
@@ -241,6 +276,49 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
         B.st[s] = S;
         if (S.pos < n_samples || S.pending != PEND_NONE) atomicAdd(B.not_done, 1);
     }
+}
+
+// L1 windows of UpdateSignalAverage for every stream's block: window w covers samples [w*stride, w*stride + k).
+// 64 windows per workgroup: the samples are fetched coalesced (consecutive lanes = consecutive samples of a window) and
+// reduced to |re| + |im| into LDS; one lane per window then adds its k terms in the reference's sequential order.
+constexpr int L1_WINDOWS = 64;
+constexpr int L1_MAX_K = 128;
+__global__ __launch_bounds__(256)
+void stream_l1_kernel(BankView B, const f2* __restrict__ iq, size_t stream_stride, long long n_win, int k, long long stride) {
+    __shared__ float term[L1_WINDOWS * (L1_MAX_K + 1)];
+    const long long w0 = (long long)blockIdx.x * L1_WINDOWS;
+    const int s = blockIdx.y, t = threadIdx.x;
+    const f2* base = iq + (size_t)s * stream_stride;
+    const int m = (int)((n_win - w0 < L1_WINDOWS) ? (n_win - w0) : L1_WINDOWS);
+    if (k <= L1_MAX_K) {
+        for (int e = t; e < m * k; e += 256) {
+            const int w = e / k, i = e - w * k;
+            const f2 v = base[(w0 + w) * stride + i];
+            term[w * (k + 1) + i] = __builtin_fabsf(v.x) + __builtin_fabsf(v.y);
+        }
+        __syncthreads();
+        if (t < m) {
+            float acc = 0.0f;
+            for (int i = 0; i < k; i++) acc += term[t * (k + 1) + i];
+            B.win[(size_t)s * B.win_cap + w0 + t] = acc / (float)k;
+        }
+    } else if (t < m) {
+        B.win[(size_t)s * B.win_cap + w0 + t] = l1_window(base + (w0 + t) * stride, k);
+    }
+}
+
+// the round's bulk copy block -> frame buffer (the unfinished frame at the end of a block), COPY_WGS workgroups per stream
+__global__ __launch_bounds__(256)
+void stream_copy_kernel(BankView B, const f2* __restrict__ iq, size_t stream_stride) {
+    const int s = blockIdx.y;
+    const int cnt = B.copy_cnt[s];
+    if (cnt == 0) return;
+    const f2* src = iq + (size_t)s * stream_stride + B.copy_src[s];
+    f2* dst = B.frame + (size_t)s * NB_FRAME_SAMPLES + B.copy_dst[s];
+    const int per = (((cnt + COPY_WGS - 1) / COPY_WGS) + 255) & ~255;
+    const int a = blockIdx.x * per;
+    const int b = (a + per < cnt) ? (a + per) : cnt;
+    for (int i = a + threadIdx.x; i < b; i += 256) dst[i] = src[i];
 }
 
 __global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status) {
@@ -298,7 +376,8 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     CK(hipMemsetAsync(b->view.st, 0, b->n * sizeof(StreamState), s));
     CK(hipMemsetAsync(b->view.sync, 0, b->n * sizeof(dabgpu_sync_state), s));
     CK(hipMemsetAsync(b->view.sync_active, 0, b->n * sizeof(int), s));
-    CK(hipMemsetAsync(b->view.frame_slot, 0xFF, b->n * sizeof(int), s));
+    CK(hipMemsetAsync(b->view.desc, 0xFF, b->n * sizeof(dabgpu_frame_desc), s));
+    CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.ring, 0, b->n * NB_NULL_PERIOD * sizeof(f2), s));
     CK(hipMemsetAsync(b->view.corr, 0, b->n * NB_CORR * sizeof(f2), s));
     CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
@@ -328,7 +407,10 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
     alloc((void**)&b->view.frame, n_streams * (size_t)NB_FRAME_SAMPLES * sizeof(f2));
     alloc((void**)&b->view.freq, n_streams * sizeof(float));
     alloc((void**)&b->view.sync_active, n_streams * sizeof(int));
-    alloc((void**)&b->view.frame_slot, n_streams * sizeof(int));
+    alloc((void**)&b->view.desc, n_streams * sizeof(dabgpu_frame_desc));
+    alloc((void**)&b->view.copy_src, n_streams * sizeof(long long));
+    alloc((void**)&b->view.copy_dst, n_streams * sizeof(int));
+    alloc((void**)&b->view.copy_cnt, n_streams * sizeof(int));
     alloc((void**)&b->view.not_done, sizeof(int));
     alloc((void**)&b->d_corr_out, n_streams * NB_FRAME_SYMBOLS * 2 * sizeof(float));
     alloc((void**)&b->d_status, n_streams * sizeof(dabgpu_stream_status));
@@ -356,20 +438,42 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
     const int n = (int)b->n;
     int st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    // L1 windows of the signal-level IIR for every stream (grow-only scratch)
+    const int k = b->cfg.signal_l1_nb_samples;
+    if (n_samples >= (size_t)k) {
+        const long long stride = (long long)k * b->cfg.signal_l1_nb_decimate;
+        const long long n_win = ((long long)n_samples - k + stride - 1) / stride;
+        if (n_win > b->view.win_cap) {
+            CK(hipStreamSynchronize(s));
+            if (b->view.win) { (void)hipFree(b->view.win); b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)b->view.win)); }
+            b->view.win = nullptr; b->view.win_cap = 0;
+            CK(hipMalloc((void**)&b->view.win, (size_t)n * (size_t)n_win * sizeof(float)));
+            b->allocs.push_back(b->view.win);
+            b->view.win_cap = n_win;
+        }
+        if (n_win > 0) {
+            hipLaunchKernelGGL(stream_l1_kernel, dim3((unsigned)((n_win + L1_WINDOWS - 1) / L1_WINDOWS), (unsigned)n), dim3(256), 0, s,
+                               b->view, reinterpret_cast<const f2*>(d_iq), stream_stride_samples, n_win, k, stride);
+            CK(hipGetLastError());
+        }
+    }
     // rounds every locked stream needs: (sync, demod) per frame that can complete inside this block, plus one to drain
-    const int blind_rounds = 2 * (int)(n_samples / NB_FRAME_SAMPLES + 1) + 1;
+    const int blind_rounds = 2 * (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
     int h_not_done = 1;
     for (int round = 0; h_not_done != 0; round++) {
         CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
         hipLaunchKernelGGL(stream_advance_kernel, dim3((unsigned)n), dim3(256), 0, s, b->view, n, reinterpret_cast<const f2*>(d_iq),
                            stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0);
         CK(hipGetLastError());
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, reinterpret_cast<const f2*>(d_iq),
+                           stream_stride_samples);
+        CK(hipGetLastError());
         CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
                               nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, s));
         CK(dabgpu_launch_ofdm_demod(b->view.frame, 0, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
-                                    n, 0, 0, b->view.frame_slot, s));
+                                    n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
-                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.frame_slot, s));
+                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, s));
         if (round + 1 >= blind_rounds) {
             CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
             CK(hipStreamSynchronize(s));

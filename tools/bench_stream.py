@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Throughput of the device-side unsynchronised front end (dabgpu_stream_bank_*): E receivers, each fed a continuous
+synthetic Mode-I stream (own carrier offset and timing) in blocks, on one MI355X.
+
+    python tools/bench_stream.py [--streams 256] [--block-frames 2] [--calls 6]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dab-radio_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import dabgpu  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--block-frames", type=int, default=2)
+    ap.add_argument("--calls", type=int, default=6)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    ctx = dabgpu.Context(0)
+    prs, mapper, _ = dabgpu.host_tables()
+    E = args.streams
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    # one transmission frame per stream (NULL + PRS + 75 random QPSK symbols), repeated back to back: a legal signal
+    mp = torch.from_numpy(mapper.astype(np.int64)).to(dev)
+    bins = torch.where(mp < 768, mp + (2048 - 768), mp - 768 + 1)
+    prs_t = torch.from_numpy(prs).to(dev)
+    L = 196608
+    frame = torch.zeros((E, L), dtype=torch.complex64, device=dev)
+    a = 0.70710678
+    for e0 in range(0, E, 32):
+        m = min(32, E - e0)
+        b = torch.randint(0, 2, (m, 75, 3072), generator=g, device=dev, dtype=torch.uint8)
+        z = torch.complex((1.0 - 2.0 * b[:, :, :1536].float()) * a, (1.0 - 2.0 * b[:, :, 1536:].float()) * a)
+        spec = torch.zeros((m, 76, 2048), dtype=torch.complex64, device=dev)
+        spec[:, 0] = prs_t
+        cur = prs_t[bins].expand(m, -1).clone()
+        for s_ in range(75):
+            cur = cur * z[:, s_]
+            spec[:, s_ + 1, bins] = cur
+        t = torch.fft.ifft(spec, dim=2) * (2048.0 / 39.2)
+        body = frame[e0:e0 + m, 2656:].view(m, 76, 2552)
+        body[:, :, 504:] = t
+        body[:, :, :504] = t[:, :, 2048 - 504:]
+    n_block = args.block_frames * L
+    total = n_block * args.calls + L
+    reps = total // L + 2
+    shift = torch.randint(0, L, (E,), generator=g, device=dev)
+    cfo = (torch.rand(E, generator=g, device=dev) - 0.5) * 0.004
+    stream = torch.empty((E, total), dtype=torch.complex64, device=dev)
+    idx = torch.arange(total, device=dev)
+    for e in range(E):
+        x = frame[e].repeat(reps)[int(shift[e]):int(shift[e]) + total]
+        stream[e] = x * torch.polar(torch.ones(total, device=dev), 2 * np.pi * float(cfo[e]) * idx.float())
+    stream += 0.02 * torch.randn(stream.shape, dtype=torch.complex64, device=dev)
+    del frame
+    bank = dabgpu.StreamBank(ctx, E)
+    max_frames = n_block // 191400 + 2
+    bits = torch.zeros((E, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
+    nf = torch.zeros(E, dtype=torch.int32, device=dev)
+    sv = torch.view_as_real(stream)
+    frames_total, times = 0, []
+    for k in range(args.calls):
+        blk = sv[:, k * n_block:(k + 1) * n_block]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bank.process(blk, total, n_block, bits, max_frames, nf)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        got = int(nf.sum().item())
+        times.append((dt, got))
+        frames_total += got
+    st = bank.status()
+    steady = times[2:] if len(times) > 3 else times
+    fps = sum(g_ for _, g_ in steady) / sum(t for t, _ in steady)
+    print(json.dumps({"streams": E, "block_samples": n_block, "calls": args.calls, "frames_total": frames_total,
+                      "frames_desync_total": int(st["total_frames_desync"].sum()), "steady_frames_per_s": fps,
+                      "steady_x_realtime_per_stream": fps / E / (2.048e6 / 196608),
+                      "per_call_ms": [round(t * 1e3, 3) for t, _ in times], "per_call_frames": [g_ for _, g_ in times]}))
+
+
+if __name__ == "__main__":
+    main()
