@@ -1,0 +1,425 @@
+// dabplus.hip -- the DAB+ outer code on the device: what AAC_Frame_Processor does between the channel
+// decoder's bytes and the AAC access units (src/dab/audio/aac_frame_processor.cpp:127-361):
+//   super-frame acquisition on the fire code (:162-166, :178-189), accumulation of 5 logical frames (:191-197),
+//   RS(120,110) decoding of the byte-interleaved columns (:323-361; decoder: src/dab/algorithms/reed_solomon_decoder.cpp,
+//   Berlekamp-Massey / Chien / Forney over GF(2^8), p(x) = x^8+x^4+x^3+x^2+1, roots alpha^0..alpha^9, shortened by 135),
+//   fire code of the corrected super frame (:206-209), header walk (:215-283) and access-unit CRCs (:286-317),
+//   re-acquisition after 10 failed super frames (:151-154).
+// One wavefront per stream (an (ensemble, sub-channel) pair); its acquisition state and the super frame being collected
+// live in HBM between calls.  Syndromes are computed 64 (codeword, root) pairs at a time from an LDS copy of the super
+// frame; a codeword with a non-zero syndrome is decoded by one lane (all codewords of a super frame in parallel).
+// Integer / byte work, bit-exact by construction; checked against the oracle and the reference-generated vectors.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+
+namespace dabgpu {
+
+constexpr int RS_N = 120, RS_ROOTS = 10, RS_PAD = 135;
+constexpr int DP_MAX_FRAME_BYTES = 1536;                 // 5 n / 120 <= 64 codewords = one per lane
+constexpr int DP_MAX_SF = 5 * DP_MAX_FRAME_BYTES;
+
+struct GfTables { uint8_t exp[512]; uint8_t log[256]; };
+constexpr GfTables make_gf() {
+    GfTables t{};
+    unsigned x = 1;
+    for (int i = 0; i < 255; i++) {
+        t.exp[i] = (uint8_t)x; t.exp[i + 255] = (uint8_t)x; t.log[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 0x100u) x ^= 0x11Du;
+    }
+    t.exp[510] = t.exp[0]; t.exp[511] = t.exp[1];
+    t.log[0] = 0;
+    return t;
+}
+__constant__ GfTables GF_TABLES = make_gf();
+
+struct DpLds {
+    uint8_t exp[512];
+    uint8_t log[256];
+    uint16_t crc_tab[256];           // CRC-16 x^16+x^12+x^5+1, MSB first (access units)
+    uint8_t sf[DP_MAX_SF];
+    uint8_t syn[64 * RS_ROOTS];
+    int flags[4];
+};
+
+struct DpState {                     // per stream, persistent
+    int wait_frame_start, curr_dab_frame, prev_n, synced, desync_count;
+};
+
+__device__ __forceinline__ uint8_t gmul(const DpLds& L, uint8_t a, uint8_t b) { return (a && b) ? L.exp[L.log[a] + L.log[b]] : (uint8_t)0; }
+__device__ __forceinline__ uint8_t gdiv(const DpLds& L, uint8_t a, uint8_t b) { return a ? L.exp[L.log[a] + 255 - L.log[b]] : (uint8_t)0; }
+__device__ __forceinline__ uint8_t gpow(const DpLds& L, int e) { e %= 255; if (e < 0) e += 255; return L.exp[e]; }
+
+// one lane decodes codeword `i` of the super frame held in L.sf (columns interleaved with stride n_rs) from its syndromes;
+// returns the number of located errors or -1 (restates dab_rs120_decode of the oracle)
+__device__ int rs_decode_lane(DpLds& L, int i, int n_rs) {
+    uint8_t S[RS_ROOTS];
+#pragma unroll
+    for (int r = 0; r < RS_ROOTS; r++) S[r] = L.syn[i * RS_ROOTS + r];
+    uint8_t C[RS_ROOTS + 1], B[RS_ROOTS + 1], T[RS_ROOTS + 1];
+#pragma unroll
+    for (int k = 0; k <= RS_ROOTS; k++) { C[k] = (k == 0); B[k] = (k == 0); }
+    int len = 0;
+    for (int r = 1; r <= RS_ROOTS; r++) {
+        uint8_t d = 0;
+#pragma unroll
+        for (int k = 0; k < RS_ROOTS; k++) if (k < r) d ^= gmul(L, C[k], S[(r - 1 - k) < 0 ? 0 : (r - 1 - k)]);
+        if (d == 0) {
+#pragma unroll
+            for (int k = RS_ROOTS; k > 0; k--) B[k] = B[k - 1];
+            B[0] = 0;
+        } else {
+            T[0] = C[0];
+#pragma unroll
+            for (int k = 0; k < RS_ROOTS; k++) T[k + 1] = (uint8_t)(C[k + 1] ^ gmul(L, d, B[k]));
+            if (2 * len <= r - 1) {
+                len = r - len;
+#pragma unroll
+                for (int k = 0; k <= RS_ROOTS; k++) B[k] = gdiv(L, C[k], d);
+            } else {
+#pragma unroll
+                for (int k = RS_ROOTS; k > 0; k--) B[k] = B[k - 1];
+                B[0] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k <= RS_ROOTS; k++) C[k] = T[k];
+        }
+    }
+    int deg = 0;
+#pragma unroll
+    for (int k = 0; k <= RS_ROOTS; k++) if (C[k]) deg = k;
+    int root[RS_ROOTS], count = 0;
+    int reg[RS_ROOTS + 1];                                   // log C_k + x k (mod 255), advanced incrementally
+#pragma unroll
+    for (int k = 1; k <= RS_ROOTS; k++) reg[k] = L.log[C[k]];
+    for (int x = 1; x <= 255 && count < deg; x++) {
+        uint8_t q = 1;
+#pragma unroll
+        for (int k = 1; k <= RS_ROOTS; k++) {
+            if (k <= deg && C[k]) {
+                reg[k] += k;
+                if (reg[k] >= 255) reg[k] -= 255;
+                q ^= L.exp[reg[k]];
+            }
+        }
+        if (q) continue;
+#pragma unroll
+        for (int k = 0; k < RS_ROOTS; k++) if (k == count) root[k] = x;
+        count++;
+    }
+    if (count != deg) return -1;
+    uint8_t omega[RS_ROOTS];
+#pragma unroll
+    for (int a = 0; a < RS_ROOTS; a++) {
+        uint8_t t = 0;
+#pragma unroll
+        for (int b = 0; b < RS_ROOTS; b++) if (b <= a) t ^= gmul(L, S[a - b < 0 ? 0 : a - b], C[b]);
+        omega[a] = t;
+    }
+    for (int k = count - 1; k >= 0; k--) {
+        int rk = 0;
+#pragma unroll
+        for (int a = 0; a < RS_ROOTS; a++) if (a == k) rk = root[a];
+        uint8_t num1 = 0, den = 0;
+#pragma unroll
+        for (int a = RS_ROOTS - 1; a >= 0; a--) if (a < deg) num1 ^= gmul(L, omega[a], gpow(L, a * rk));
+        const uint8_t num2 = gpow(L, -rk);
+        const int top = ((deg < RS_ROOTS - 1) ? deg : (RS_ROOTS - 1)) & ~1;
+#pragma unroll
+        for (int a = 8; a >= 0; a -= 2) if (a <= top) den ^= gmul(L, C[a + 1], gpow(L, a * rk));
+        const int loc = rk - 1;
+        if (num1 != 0 && loc >= RS_PAD) L.sf[i + (loc - RS_PAD) * n_rs] ^= gdiv(L, gmul(L, num1, num2), den);
+    }
+    return count;
+}
+
+__device__ __forceinline__ uint16_t crc16_bits(const uint8_t* x, int n, uint16_t poly, uint16_t init) {
+    uint16_t crc = init;
+    for (int i = 0; i < n; i++) {
+        crc ^= (uint16_t)((uint16_t)x[i] << 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) crc = (crc & 0x8000u) ? (uint16_t)((crc << 1) ^ poly) : (uint16_t)(crc << 1);
+    }
+    return crc;
+}
+
+__global__ __launch_bounds__(64)
+void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ frames, const unsigned long long* __restrict__ stream_offsets,
+                    size_t frame_stride, const uint32_t* __restrict__ frame_bytes, int n_frames, uint8_t* __restrict__ sf_acc,
+                    uint8_t* __restrict__ sf_out, size_t sf_out_stride, dabgpu_superframe_result* __restrict__ results, int max_sf,
+                    int32_t* __restrict__ counts, int n_streams)
+{
+    __shared__ DpLds L;
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= n_streams) return;
+    for (int k = lane; k < 512; k += 64) L.exp[k] = GF_TABLES.exp[k];
+    for (int k = lane; k < 256; k += 64) {
+        L.log[k] = GF_TABLES.log[k];
+        uint16_t c = (uint16_t)(k << 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) c = (c & 0x8000u) ? (uint16_t)((c << 1) ^ 0x1021u) : (uint16_t)(c << 1);
+        L.crc_tab[k] = c;
+    }
+    DpState st = states[s];
+    const int n = (int)frame_bytes[s];
+    uint8_t* acc = sf_acc + (size_t)s * DP_MAX_SF;
+    const uint8_t* base = frames + stream_offsets[s];
+    int n_sf = 0, n_wait_failed = 0;
+    __syncthreads();
+
+    for (int f = 0; f < n_frames; f++) {
+        const uint8_t* frame = base + (size_t)f * frame_stride;
+        if (n < 11 || n > DP_MAX_FRAME_BYTES) continue;                    // :129-137 (and this kernel's buffer size)
+        if (st.prev_n != n) { st.prev_n = n; st.curr_dab_frame = 0; st.wait_frame_start = 1; }       // :140-147
+        if (st.desync_count >= 10) { st.desync_count = 0; st.synced = 0; }                           // :151-154
+        if (st.synced) st.wait_frame_start = 0;                                                       // :158-160
+        if (st.wait_frame_start) {                                                                    // :162-166
+            if (lane == 0) {
+                const uint16_t rx = (uint16_t)((frame[0] << 8) | frame[1]);
+                L.flags[0] = (rx == crc16_bits(frame + 2, 9, 0x782Fu, 0)) ? 1 : 0;
+            }
+            __syncthreads();
+            const int ok = L.flags[0];
+            __syncthreads();
+            if (!ok) { n_wait_failed++; continue; }
+            st.wait_frame_start = 0;
+        }
+        for (int k = lane; k < n; k += 64) acc[(size_t)st.curr_dab_frame * n + k] = frame[k];         // :191-197
+        st.curr_dab_frame++;
+        if (st.curr_dab_frame < 5) continue;
+
+        // ---- ProcessSuperFrame (:199-321) ----
+        st.wait_frame_start = 1;
+        st.curr_dab_frame = 0;
+        const int sf_bytes = 5 * n;
+        const int n_rs = sf_bytes / RS_N;
+        __syncthreads();                                                   // this wave's global writes of acc[] are visible to it
+        for (int k = lane; k < sf_bytes; k += 64) L.sf[k] = acc[k];
+        if (lane == 0) { L.flags[1] = -1; L.flags[2] = 0; }
+        __syncthreads();
+        // syndromes: work item = (codeword i, root r)
+        for (int w = lane; w < n_rs * RS_ROOTS; w += 64) {
+            const int i = w / RS_ROOTS, r = w - i * RS_ROOTS;
+            uint8_t sy = 0;
+            for (int j = 0; j < RS_N; j++) {
+                const uint8_t m = sy ? L.exp[L.log[sy] + r] : (uint8_t)0;
+                sy = (uint8_t)(m ^ L.sf[i + j * n_rs]);
+            }
+            L.syn[w] = sy;
+        }
+        __syncthreads();
+        int my_cnt = 0;
+        if (lane < n_rs) {
+            int any = 0;
+#pragma unroll
+            for (int r = 0; r < RS_ROOTS; r++) any |= L.syn[lane * RS_ROOTS + r];
+            if (any) my_cnt = rs_decode_lane(L, lane, n_rs);
+        }
+        __syncthreads();
+        if (lane == 0) L.flags[3] = 0x7FFFFFFF;
+        __syncthreads();
+        if (my_cnt < 0) atomicMin(&L.flags[3], lane);
+        if (my_cnt > 0) atomicAdd(&L.flags[2], my_cnt);
+        __syncthreads();
+        const int first_fail = L.flags[3];
+        dabgpu_superframe_result res;
+        memset(&res, 0, sizeof(res));
+        res.rs_failed_index = (first_fail == 0x7FFFFFFF) ? -1 : first_fail;
+        res.au_walk_stopped_at = -1;
+        res.frame_index = f;
+        bool good = (res.rs_failed_index < 0);
+        if (!good) {
+            // the reference stops at the first uncorrectable codeword (:336-341): later codewords keep their received
+            // symbols and the corrected-symbol count only covers the codewords before it
+            for (int k = lane; k < sf_bytes; k += 64) if ((k % n_rs) > first_fail) L.sf[k] = acc[k];
+            if (lane == 0) L.flags[2] = 0;
+            __syncthreads();
+            if (my_cnt > 0 && lane < first_fail) atomicAdd(&L.flags[2], my_cnt);
+            __syncthreads();
+        }
+        res.rs_corrected = L.flags[2];
+        if (good) {
+            if (lane == 0) {
+                const uint16_t rx = (uint16_t)((L.sf[0] << 8) | L.sf[1]);
+                L.flags[0] = (rx == crc16_bits(L.sf + 2, 9, 0x782Fu, 0)) ? 1 : 0;
+            }
+            __syncthreads();
+            good = L.flags[0] != 0;
+            res.firecode_ok = good ? 1 : 0;
+        }
+        if (!good) {
+            st.desync_count++;
+        } else {
+            st.desync_count = 0;
+            st.synced = 1;
+            const int descriptor = L.sf[2];
+            const int dac_rate = (descriptor >> 6) & 1, sbr = (descriptor >> 5) & 1;
+            res.header_valid = 1;
+            res.descriptor = descriptor;
+            const int num_aus = dac_rate ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
+            res.num_aus = num_aus;
+            int bit = 0;
+            for (int a = 1; a < num_aus; a++) {
+                int v = 0;
+                for (int b = 0; b < 12; b++, bit++) v = (v << 1) | ((L.sf[3 + (bit >> 3)] >> (7 - (bit & 7))) & 1);
+                res.au_start[a] = v;
+            }
+            res.au_start[0] = 3 + ((bit + 7) >> 3);
+            res.au_start[num_aus] = 110 * n_rs;
+            // the walk stops at the first access unit that fails the bounds test (:291-297)
+            int stop = -1;
+            for (int a = 0; a < num_aus; a++) {
+                const int nb_data = res.au_start[a + 1] - res.au_start[a] - 2;
+                if (nb_data < 0 || res.au_start[a + 1] >= sf_bytes) { stop = a; break; }
+            }
+            res.au_walk_stopped_at = stop;
+            const int walked = (stop < 0) ? num_aus : stop;
+            if (lane == 0) L.flags[0] = 0;
+            __syncthreads();
+            if (lane < walked) {
+                const int a0 = res.au_start[lane], nb_data = res.au_start[lane + 1] - a0 - 2;
+                uint16_t crc = 0xFFFF;
+                for (int k = 0; k < nb_data; k++) crc = (uint16_t)((crc << 8) ^ L.crc_tab[((crc >> 8) ^ L.sf[a0 + k]) & 0xFF]);
+                crc ^= 0xFFFF;
+                const uint16_t rx = (uint16_t)((L.sf[a0 + nb_data] << 8) | L.sf[a0 + nb_data + 1]);
+                if (rx == crc) atomicOr(&L.flags[0], 1 << lane);
+            }
+            __syncthreads();
+            res.au_crc_ok_mask = (uint32_t)L.flags[0];
+        }
+        // hand the (corrected) super frame and its record to the caller
+        if (n_sf < max_sf) {
+            uint8_t* out = sf_out + ((size_t)s * max_sf + n_sf) * sf_out_stride;
+            for (int k = lane; k < sf_bytes; k += 64) out[k] = L.sf[k];
+            if (lane == 0) results[(size_t)s * max_sf + n_sf] = res;
+        }
+        n_sf++;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        states[s] = st;
+        counts[2 * s] = n_sf;
+        counts[2 * s + 1] = n_wait_failed;
+    }
+}
+
+}  // namespace dabgpu
+
+using namespace dabgpu;
+
+struct dabgpu_dabplus_bank {
+    dabgpu_ctx* ctx = nullptr;
+    size_t n = 0;
+    DpState* d_states = nullptr;
+    uint8_t* d_acc = nullptr;
+    // single-stream host-buffer path
+    uint8_t* d_frame = nullptr; unsigned long long* d_off = nullptr; uint32_t* d_n = nullptr;
+    uint8_t* d_sf = nullptr; dabgpu_superframe_result* d_res = nullptr; int32_t* d_counts = nullptr;
+    std::vector<void*> allocs;
+};
+
+extern "C" {
+
+void dabgpu_dabplus_bank_destroy(dabgpu_dabplus_bank* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : b->allocs) (void)hipFree(p);
+    delete b;
+}
+
+int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank* b, void* stream) {
+    if (!b) { dabgpu_set_error("dabplus_bank_reset: null bank"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(b->ctx->device);
+    // AAC_Frame_Processor's constructor state (:121-125): WAIT_FRAME_START, nothing collected, unsynchronised
+    std::vector<DpState> init(b->n, DpState{1, 0, 0, 0, 0});
+    int st = dabgpu_check_hip(hipMemcpyAsync(b->d_states, init.data(), b->n * sizeof(DpState), hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync");
+    if (st) return st;
+    return dabgpu_check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+}
+
+int dabgpu_dabplus_bank_create(dabgpu_ctx* c, size_t n_streams, dabgpu_dabplus_bank** out) {
+    if (!c || !out || n_streams == 0 || n_streams > (size_t)(1 << 22)) { dabgpu_set_error("dabplus_bank_create: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    dabgpu_dabplus_bank* b = new (std::nothrow) dabgpu_dabplus_bank();
+    if (!b) return DABGPU_ERR_HIP;
+    b->ctx = c; b->n = n_streams;
+    int st = DABGPU_OK;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (st) return;
+        st = dabgpu_check_hip(hipMalloc(p, bytes), "hipMalloc(dabplus bank)");
+        if (!st) b->allocs.push_back(*p);
+    };
+    alloc((void**)&b->d_states, n_streams * sizeof(DpState));
+    alloc((void**)&b->d_acc, n_streams * (size_t)DP_MAX_SF);
+    alloc((void**)&b->d_frame, DP_MAX_FRAME_BYTES);
+    alloc((void**)&b->d_off, sizeof(unsigned long long));
+    alloc((void**)&b->d_n, sizeof(uint32_t));
+    alloc((void**)&b->d_sf, DP_MAX_SF);
+    alloc((void**)&b->d_res, sizeof(dabgpu_superframe_result));
+    alloc((void**)&b->d_counts, 2 * sizeof(int32_t));
+    if (!st) st = dabgpu_check_hip(hipMemsetAsync(b->d_off, 0, sizeof(unsigned long long), c->stream), "hipMemsetAsync");
+    if (!st) st = dabgpu_dabplus_bank_reset(b, c->stream);
+    if (st) { dabgpu_dabplus_bank_destroy(b); return st; }
+    *out = b;
+    return DABGPU_OK;
+}
+
+int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank* b, const uint8_t* d_frames, const uint64_t* d_stream_offsets, size_t frame_stride_bytes,
+                                const uint32_t* d_frame_bytes, int n_frames, uint8_t* d_superframes, size_t superframe_stride_bytes,
+                                dabgpu_superframe_result* d_results, int max_superframes, int32_t* d_counts, void* stream) {
+    if (!b || !d_frames || !d_stream_offsets || !d_frame_bytes || !d_superframes || !d_results || !d_counts) {
+        dabgpu_set_error("dabplus_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG;
+    }
+    if (n_frames <= 0) return DABGPU_OK;
+    if (max_superframes < (n_frames + 4) / 5 || superframe_stride_bytes == 0) {
+        dabgpu_set_error("dabplus_bank_process: max_superframes must be at least ceil(n_frames / 5)"); return DABGPU_ERR_INVALID_ARG;
+    }
+    (void)hipSetDevice(b->ctx->device);
+    hipLaunchKernelGGL(dabplus_kernel, dim3((unsigned)b->n), dim3(64), 0, (hipStream_t)stream, b->d_states, d_frames,
+                       reinterpret_cast<const unsigned long long*>(d_stream_offsets), frame_stride_bytes, d_frame_bytes, n_frames, b->d_acc,
+                       d_superframes, superframe_stride_bytes, d_results, max_superframes, d_counts, (int)b->n);
+    return dabgpu_check_hip(hipGetLastError(), "dabplus_kernel launch");
+}
+
+int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank* b, const uint8_t* h_frame, uint32_t n_bytes, int* superframe_done,
+                                           int* firecode_wait_failed, dabgpu_superframe_result* h_result, uint8_t* h_superframe) {
+    if (!b || !h_frame || !superframe_done || !firecode_wait_failed || !h_result || !h_superframe) {
+        dabgpu_set_error("dabplus_process_frame_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG;
+    }
+    if (b->n != 1) { dabgpu_set_error("dabplus_process_frame_host_sync: needs a bank of one stream"); return DABGPU_ERR_INVALID_ARG; }
+    *superframe_done = 0; *firecode_wait_failed = 0;
+    if (n_bytes > (uint32_t)DP_MAX_FRAME_BYTES) {
+        dabgpu_set_error("dabplus_process_frame_host_sync: logical frames of %u bytes are not supported (<= %d)", n_bytes, DP_MAX_FRAME_BYTES);
+        return DABGPU_ERR_UNSUPPORTED;
+    }
+    dabgpu_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    int st;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    CK(hipMemcpyAsync(b->d_frame, h_frame, n_bytes, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(b->d_n, &n_bytes, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_dabplus_bank_process(b, b->d_frame, reinterpret_cast<const uint64_t*>(b->d_off), 0, b->d_n, 1, b->d_sf, DP_MAX_SF, b->d_res, 1,
+                                          b->d_counts, s))) return st;
+    int32_t counts[2];
+    CK(hipMemcpyAsync(counts, b->d_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    *superframe_done = counts[0];
+    *firecode_wait_failed = counts[1];
+    if (counts[0]) {
+        CK(hipMemcpyAsync(h_result, b->d_res, sizeof(dabgpu_superframe_result), hipMemcpyDeviceToHost, s));
+        CK(hipMemcpyAsync(h_superframe, b->d_sf, 5 * (size_t)n_bytes, hipMemcpyDeviceToHost, s));
+        CK(hipStreamSynchronize(s));
+    }
+#undef CK
+    return DABGPU_OK;
+}
+
+}  // extern "C"

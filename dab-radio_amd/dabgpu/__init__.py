@@ -41,6 +41,8 @@ ABI_SYMBOLS = [
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
     "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
     "dabgpu_stream_bank_process", "dabgpu_stream_bank_status",
+    "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
+    "dabgpu_dabplus_process_frame_host_sync",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -98,6 +100,9 @@ class StreamCfg(C.Structure):
 STREAM_STATUS_DTYPE = [("state", "<i4"), ("signal_l1_average", "<f4"), ("freq_coarse", "<f4"), ("freq_fine", "<f4"),
                        ("is_found_coarse", "<i4"), ("fine_time_offset", "<i4"), ("total_frames_read", "<i4"),
                        ("total_frames_desync", "<i4")]
+SUPERFRAME_RESULT_DTYPE = [("rs_failed_index", "<i4"), ("rs_corrected", "<i4"), ("firecode_ok", "<i4"), ("header_valid", "<i4"),
+                           ("descriptor", "<i4"), ("num_aus", "<i4"), ("au_start", "<i4", (8,)), ("au_walk_stopped_at", "<i4"),
+                           ("au_crc_ok_mask", "<u4"), ("frame_index", "<i4"), ("reserved", "<i4")]
 SYNC_STATE_DTYPE = [("freq_coarse", "<f4"), ("freq_fine", "<f4"), ("is_found_coarse", "<i4"),
                     ("fine_time_offset", "<i4"), ("sync_valid", "<i4"), ("reserved", "<i4")]
 RESULT_DTYPE = [("path_error", "<u8"), ("crc_ok_mask", "<u4"), ("n_out_bytes", "<u4")]
@@ -172,6 +177,13 @@ def lib():
         L.dabgpu_stream_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_dabplus_bank_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.dabgpu_dabplus_bank_destroy.argtypes = [C.c_void_p]
+        L.dabgpu_dabplus_bank_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.dabgpu_dabplus_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.dabgpu_dabplus_process_frame_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                             C.c_void_p]
         _lib = L
     return _lib
 
@@ -391,6 +403,49 @@ class StreamBank:
         out = np.zeros(self.n, dtype=np.dtype(STREAM_STATUS_DTYPE))
         check(lib().dabgpu_stream_bank_status(self._h, _ptr(out), Context._stream(stream)), "dabgpu_stream_bank_status")
         return out
+
+
+class DabPlusBank:
+    """dabgpu_dabplus_bank: n AAC_Frame_Processor states resident on the device"""
+
+    def __init__(self, ctx, n_streams):
+        self._ctx = ctx
+        self.n = n_streams
+        self._h = C.c_void_p()
+        check(lib().dabgpu_dabplus_bank_create(ctx._h, n_streams, C.byref(self._h)), "dabgpu_dabplus_bank_create")
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_dabplus_bank_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=None):
+        check(lib().dabgpu_dabplus_bank_reset(self._h, Context._stream(stream)), "dabgpu_dabplus_bank_reset")
+
+    def process(self, frames, stream_offsets, frame_stride, frame_bytes, n_frames, superframes, superframe_stride, results,
+                max_superframes, counts, stream=None):
+        check(lib().dabgpu_dabplus_bank_process(self._h, _ptr(frames), _ptr(stream_offsets), frame_stride, _ptr(frame_bytes),
+                                                n_frames, _ptr(superframes), superframe_stride, _ptr(results), max_superframes,
+                                                _ptr(counts), Context._stream(stream)), "dabgpu_dabplus_bank_process")
+
+    def process_frame_host(self, frame):
+        """one-stream bank: -> (superframe_done, firecode_wait_failed, result record, super frame bytes or None)"""
+        import numpy as np
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        done, wait = C.c_int(0), C.c_int(0)
+        res = np.zeros(1, dtype=np.dtype(SUPERFRAME_RESULT_DTYPE))
+        res["rs_failed_index"] = -1                      # the record is only written when a super frame was attempted
+        res["au_walk_stopped_at"] = -1
+        sf = np.zeros(5 * frame.size, np.uint8)
+        check(lib().dabgpu_dabplus_process_frame_host_sync(self._h, _ptr(frame), frame.size, C.byref(done), C.byref(wait), _ptr(res),
+                                                           _ptr(sf)), "dabgpu_dabplus_process_frame_host_sync")
+        return done.value, wait.value, res[0], (sf if done.value else None)
 
 
 def stream_cfg_default():

@@ -334,6 +334,49 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank *bank, const float *d_iq, size
 int dabgpu_stream_bank_status(dabgpu_stream_bank *bank, dabgpu_stream_status *h_status, void *stream);
 
 /* ==================================================================================================
+ * DAB+ outer code on the device: AAC_Frame_Processor between the channel decoder's bytes and the AAC
+ * access units (src/dab/audio/aac_frame_processor.cpp:127-361): super-frame acquisition on the fire code, collection of 5
+ * logical frames, RS(120,110) decoding of the interleaved columns (src/dab/algorithms/reed_solomon_decoder.cpp), fire code
+ * of the corrected super frame, header walk and access-unit CRCs, re-acquisition after 10 failed super frames.  One
+ * wavefront per stream (an (ensemble, sub-channel) pair); acquisition state and the super frame under collection stay in
+ * HBM between calls.  Logical frames of 11..1536 bytes (every DAB+ sub-channel up to 512 kbit/s).
+ */
+typedef struct {
+    int32_t rs_failed_index;        /* -1, or the first uncorrectable RS codeword (OnRSError, :336-341): super frame dropped */
+    int32_t rs_corrected;           /* symbols reported corrected by the codewords decoded */
+    int32_t firecode_ok;            /* fire code of the corrected super frame (:206-209) */
+    int32_t header_valid;           /* OnSuperFrameHeader fired; the fields below are meaningful */
+    int32_t descriptor;             /* byte 2: rfa | dac_rate | sbr_flag | aac_channel_mode | ps_flag | mpeg_surround_config(3) */
+    int32_t num_aus;
+    int32_t au_start[8];            /* byte offsets au_start[0..num_aus] inside the super frame (:266-283) */
+    int32_t au_walk_stopped_at;     /* -1, or the access unit whose bounds test ended the walk (:291-297) */
+    uint32_t au_crc_ok_mask;        /* bit i: OnAccessUnit(i) fired (CRC passed); other walked units: OnAccessUnitCRCError */
+    int32_t frame_index;            /* index inside this call of the logical frame that completed the super frame */
+    int32_t reserved;
+} dabgpu_superframe_result;
+
+typedef struct dabgpu_dabplus_bank dabgpu_dabplus_bank;
+int dabgpu_dabplus_bank_create(dabgpu_ctx *ctx, size_t n_streams, dabgpu_dabplus_bank **out);
+void dabgpu_dabplus_bank_destroy(dabgpu_dabplus_bank *bank);
+int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank *bank, void *stream);
+/*
+ * n_frames x AAC_Frame_Processor::Process per stream.  Logical frame f of stream s = d_frame_bytes[s] bytes at
+ * d_frames + d_stream_offsets[s] + f*frame_stride_bytes (the layout dabgpu_msc_decode_frames writes: offset of the
+ * sub-channel inside one CIF record, stride of a CIF record).
+ *   d_superframes [n_streams][max_superframes][superframe_stride_bytes]: every super frame ATTEMPTED in this call (5 frames
+ *                 collected), corrected where RS succeeded;  d_results the matching records
+ *   d_counts      [n_streams][2]: super frames attempted, logical frames dropped while waiting for a valid fire code
+ *   max_superframes >= ceil(n_frames / 5), superframe_stride_bytes >= 5 * frame bytes
+ */
+int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank *bank, const uint8_t *d_frames, const uint64_t *d_stream_offsets,
+                                size_t frame_stride_bytes, const uint32_t *d_frame_bytes, int n_frames, uint8_t *d_superframes,
+                                size_t superframe_stride_bytes, dabgpu_superframe_result *d_results, int max_superframes,
+                                int32_t *d_counts, void *stream);
+/* one Process(buf) of a one-stream bank with host buffers (the AAC_Frame_Processor mirror class); h_superframe [5*n_bytes] */
+int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank *bank, const uint8_t *h_frame, uint32_t n_bytes, int *superframe_done,
+                                           int *firecode_wait_failed, dabgpu_superframe_result *h_result, uint8_t *h_superframe);
+
+/* ==================================================================================================
  * Data formats either side of the path.
  *
  * IQ input: the reference's readers (examples/app_helpers/app_iq_readers.h:17-159, app_wav_reader.h:257-470)

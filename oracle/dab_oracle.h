@@ -227,6 +227,39 @@ void dab_soft_bits_to_hard_bytes(const int8_t *bits, size_t n_bytes, uint8_t *by
  * data_chunk_size, data_chunk_offset}; returns 0, or -1 where the reference throws */
 int dab_wav_parse_header(const uint8_t *bytes, size_t n_bytes, uint64_t *out7);
 
+/* ---------------------------------------------------------------------------------------------
+ * DAB+ outer code: audio super-frame assembly, fire code, RS(120,110), access-unit CRCs
+ * (src/dab/audio/aac_frame_processor.cpp, src/dab/algorithms/reed_solomon_decoder.cpp; ETSI TS 102 563 clauses 5, 6)
+ */
+/* RS(255,245) over GF(2^8), p(x) = x^8+x^4+x^3+x^2+1, roots alpha^0..alpha^9, shortened by 135 leading zero symbols.
+ * Corrects cw[120] in place; returns the number of located errors (0..5) or -1; positions[] (may be NULL) receives the
+ * located symbol indices in the 255-symbol padded block (index - 135 = byte of cw), in Chien-search order. An error
+ * located inside the padding is counted but not applied (reed_solomon_decoder.cpp:474-478). */
+int dab_rs120_decode(uint8_t *cw, int *positions);
+void dab_rs120_encode(const uint8_t *data110, uint8_t *parity10);          /* test helper */
+uint16_t dab_firecode_crc(const uint8_t *data9);                           /* aac_frame_processor.cpp:75-86 */
+
+typedef struct {
+    int32_t superframe_done;        /* this call completed a super frame attempt (5th logical frame) */
+    int32_t firecode_wait_failed;   /* WAIT_FRAME_START: the frame's fire code did not match, frame dropped (:162-166) */
+    int32_t rs_failed_index;        /* -1, or the index of the RS codeword that was uncorrectable (:336-341) */
+    int32_t rs_corrected;           /* total symbols reported corrected (sum of Decode() returns) */
+    int32_t firecode_ok;            /* fire code of the corrected super frame (:206-209); 0 when RS failed */
+    int32_t header_valid;           /* header parsed, access units walked */
+    int32_t descriptor;             /* byte 2 of the super frame */
+    int32_t num_aus;
+    int32_t au_start[8];            /* au_start[0..num_aus] */
+    int32_t au_walk_stopped_at;     /* -1, or the AU index at which the bounds check aborted the walk (:291-297) */
+    uint32_t au_crc_ok_mask;        /* bit i: access unit i passed its CRC (:304-314) */
+} dab_superframe_result;
+
+typedef struct dab_aac_frame_processor dab_aac_frame_processor;
+dab_aac_frame_processor *dab_aac_create(void);
+void dab_aac_destroy(dab_aac_frame_processor *p);
+/* AAC_Frame_Processor::Process (:127-176); sf_out receives the (corrected) super frame bytes [5*n] when
+ * superframe_done; returns 0, or -1 when the reference rejects the buffer (empty / shorter than 11 bytes) */
+int dab_aac_process(dab_aac_frame_processor *p, const uint8_t *frame, int n, dab_superframe_result *res, uint8_t *sf_out);
+
 #ifdef __cplusplus
 }
 #endif

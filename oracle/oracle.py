@@ -32,11 +32,11 @@ def build(force=False):
     """Compile the oracle (and _ref when /root/reference exists). Building the checker is not using it."""
     if force or not os.path.exists(_ORACLE_SO) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_ORACLE_SO)
-        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle.h")
+        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle_dabplus.c", "dab_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "libdab_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO) or any(
-        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_REF_SO) for f in ("ref_harness.cpp", "ref_harness_io.cpp")
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_REF_SO) for f in ("ref_harness.cpp", "ref_harness_io.cpp", "ref_harness_dabplus.cpp")
     )):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -130,6 +130,13 @@ def lib():
         L.dab_hard_bytes_to_soft_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.dab_soft_bits_to_hard_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.dab_wav_parse_header.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.dab_rs120_decode.argtypes = [C.c_void_p, C.c_void_p]
+        L.dab_rs120_encode.argtypes = [C.c_void_p, C.c_void_p]
+        L.dab_firecode_crc.restype = C.c_uint16
+        L.dab_firecode_crc.argtypes = [C.c_void_p]
+        L.dab_aac_create.restype = C.c_void_p
+        L.dab_aac_destroy.argtypes = [C.c_void_p]
+        L.dab_aac_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -167,6 +174,52 @@ def soft_bits_to_hard_bytes(bits):
     out = np.empty(bits.size // 8, np.uint8)
     lib().dab_soft_bits_to_hard_bytes(_p(bits), out.size, _p(out))
     return out
+
+
+SUPERFRAME_RESULT_DTYPE = np.dtype([("superframe_done", "<i4"), ("firecode_wait_failed", "<i4"), ("rs_failed_index", "<i4"),
+                                    ("rs_corrected", "<i4"), ("firecode_ok", "<i4"), ("header_valid", "<i4"), ("descriptor", "<i4"),
+                                    ("num_aus", "<i4"), ("au_start", "<i4", (8,)), ("au_walk_stopped_at", "<i4"),
+                                    ("au_crc_ok_mask", "<u4")])
+
+
+def rs120_decode(cw):
+    """-> (count or -1, corrected copy, positions in the padded block)"""
+    cw = np.array(cw, dtype=np.uint8).copy()
+    pos = np.full(10, -1, np.int32)
+    n = lib().dab_rs120_decode(_p(cw), _p(pos))
+    return n, cw, pos[:max(n, 0)].copy()
+
+
+def rs120_encode(data110):
+    d = np.ascontiguousarray(data110, dtype=np.uint8)
+    par = np.zeros(10, np.uint8)
+    lib().dab_rs120_encode(_p(d), _p(par))
+    return par
+
+
+def firecode_crc(data9):
+    d = np.ascontiguousarray(data9, dtype=np.uint8)
+    return int(lib().dab_firecode_crc(_p(d)))
+
+
+class AacFrameProcessor:
+    """oracle restatement of AAC_Frame_Processor: process(frame) -> (result record, super frame bytes or None)"""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().dab_aac_create())
+
+    def process(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        res = np.zeros(1, SUPERFRAME_RESULT_DTYPE)
+        sf = np.zeros(5 * max(frame.size, 1), np.uint8)
+        rc = lib().dab_aac_process(self.h, _p(frame), frame.size, _p(res), _p(sf))
+        return rc, res[0], (sf if res[0]["superframe_done"] else None)
+
+    def __del__(self):
+        try:
+            lib().dab_aac_destroy(self.h)
+        except Exception:
+            pass
 
 
 def wav_parse_header(image):
@@ -519,5 +572,10 @@ def ref():
         R.ref_wav_header.argtypes = [C.c_char_p, C.c_void_p]
         R.ref_bytes_to_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         R.ref_bits_to_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        if hasattr(R, "ref_aac_create"):
+            R.ref_rs120_decode.argtypes = [C.c_void_p, C.c_void_p]
+            R.ref_aac_create.restype = C.c_void_p
+            R.ref_aac_destroy.argtypes = [C.c_void_p]
+            R.ref_aac_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _ref = R
     return _ref
