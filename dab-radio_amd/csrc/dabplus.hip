@@ -170,7 +170,7 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
     const int n = (int)frame_bytes[s];
     uint8_t* acc = sf_acc + (size_t)s * DP_MAX_SF;
     const uint8_t* base = frames + stream_offsets[s];
-    int n_sf = 0, n_wait_failed = 0;
+    int n_sf = 0, n_wait_failed = 0, last_wait_crc = 0;
     __syncthreads();
 
     for (int f = 0; f < n_frames; f++) {
@@ -182,10 +182,13 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         if (st.wait_frame_start) {                                                                    // :162-166
             if (lane == 0) {
                 const uint16_t rx = (uint16_t)((frame[0] << 8) | frame[1]);
-                L.flags[0] = (rx == crc16_bits(frame + 2, 9, 0x782Fu, 0)) ? 1 : 0;
+                const uint16_t calc = crc16_bits(frame + 2, 9, 0x782Fu, 0);
+                L.flags[0] = (rx == calc) ? 1 : 0;
+                L.flags[1] = (int)(((uint32_t)rx << 16) | calc);
             }
             __syncthreads();
             const int ok = L.flags[0];
+            if (!ok) last_wait_crc = L.flags[1];
             __syncthreads();
             if (!ok) { n_wait_failed++; continue; }
             st.wait_frame_start = 0;
@@ -247,11 +250,14 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         if (good) {
             if (lane == 0) {
                 const uint16_t rx = (uint16_t)((L.sf[0] << 8) | L.sf[1]);
-                L.flags[0] = (rx == crc16_bits(L.sf + 2, 9, 0x782Fu, 0)) ? 1 : 0;
+                const uint16_t calc = crc16_bits(L.sf + 2, 9, 0x782Fu, 0);
+                L.flags[0] = (rx == calc) ? 1 : 0;
+                L.flags[1] = (int)(((uint32_t)rx << 16) | calc);
             }
             __syncthreads();
             good = L.flags[0] != 0;
             res.firecode_ok = good ? 1 : 0;
+            res.firecode_rx_calc = (uint32_t)L.flags[1];
         }
         if (!good) {
             st.desync_count++;
@@ -289,9 +295,11 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
                 crc ^= 0xFFFF;
                 const uint16_t rx = (uint16_t)((L.sf[a0 + nb_data] << 8) | L.sf[a0 + nb_data + 1]);
                 if (rx == crc) atomicOr(&L.flags[0], 1 << lane);
+                L.syn[2 * lane] = (uint8_t)(crc >> 8); L.syn[2 * lane + 1] = (uint8_t)(crc & 0xFF);     // syndromes are done with
             }
             __syncthreads();
             res.au_crc_ok_mask = (uint32_t)L.flags[0];
+            for (int a = 0; a < walked; a++) res.au_crc_calc[a] = (uint16_t)((L.syn[2 * a] << 8) | L.syn[2 * a + 1]);
         }
         // hand the (corrected) super frame and its record to the caller
         if (n_sf < max_sf) {
@@ -304,8 +312,10 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
     }
     if (lane == 0) {
         states[s] = st;
-        counts[2 * s] = n_sf;
-        counts[2 * s + 1] = n_wait_failed;
+        counts[4 * s] = n_sf;
+        counts[4 * s + 1] = n_wait_failed;
+        counts[4 * s + 2] = last_wait_crc;
+        counts[4 * s + 3] = st.curr_dab_frame;
     }
 }
 
@@ -320,7 +330,7 @@ struct dabgpu_dabplus_bank {
     uint8_t* d_acc = nullptr;
     // single-stream host-buffer path
     uint8_t* d_frame = nullptr; unsigned long long* d_off = nullptr; uint32_t* d_n = nullptr;
-    uint8_t* d_sf = nullptr; dabgpu_superframe_result* d_res = nullptr; int32_t* d_counts = nullptr;
+    uint8_t* d_sf = nullptr; dabgpu_superframe_result* d_res = nullptr; int32_t* d_counts = nullptr;   // d_counts [4]
     std::vector<void*> allocs;
 };
 
@@ -363,7 +373,7 @@ int dabgpu_dabplus_bank_create(dabgpu_ctx* c, size_t n_streams, dabgpu_dabplus_b
     alloc((void**)&b->d_n, sizeof(uint32_t));
     alloc((void**)&b->d_sf, DP_MAX_SF);
     alloc((void**)&b->d_res, sizeof(dabgpu_superframe_result));
-    alloc((void**)&b->d_counts, 2 * sizeof(int32_t));
+    alloc((void**)&b->d_counts, 4 * sizeof(int32_t));
     if (!st) st = dabgpu_check_hip(hipMemsetAsync(b->d_off, 0, sizeof(unsigned long long), c->stream), "hipMemsetAsync");
     if (!st) st = dabgpu_dabplus_bank_reset(b, c->stream);
     if (st) { dabgpu_dabplus_bank_destroy(b); return st; }
@@ -389,7 +399,8 @@ int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank* b, const uint8_t* d_frames,
 }
 
 int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank* b, const uint8_t* h_frame, uint32_t n_bytes, int* superframe_done,
-                                           int* firecode_wait_failed, dabgpu_superframe_result* h_result, uint8_t* h_superframe) {
+                                           int* firecode_wait_failed, uint32_t* firecode_wait_rx_calc, dabgpu_superframe_result* h_result,
+                                           uint8_t* h_superframe) {
     if (!b || !h_frame || !superframe_done || !firecode_wait_failed || !h_result || !h_superframe) {
         dabgpu_set_error("dabplus_process_frame_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG;
     }
@@ -408,11 +419,12 @@ int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank* b, const uint8_t
     CK(hipMemcpyAsync(b->d_n, &n_bytes, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     if ((st = dabgpu_dabplus_bank_process(b, b->d_frame, reinterpret_cast<const uint64_t*>(b->d_off), 0, b->d_n, 1, b->d_sf, DP_MAX_SF, b->d_res, 1,
                                           b->d_counts, s))) return st;
-    int32_t counts[2];
+    int32_t counts[4];
     CK(hipMemcpyAsync(counts, b->d_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
     *superframe_done = counts[0];
     *firecode_wait_failed = counts[1];
+    if (firecode_wait_rx_calc) *firecode_wait_rx_calc = (uint32_t)counts[2];
     if (counts[0]) {
         CK(hipMemcpyAsync(h_result, b->d_res, sizeof(dabgpu_superframe_result), hipMemcpyDeviceToHost, s));
         CK(hipMemcpyAsync(h_superframe, b->d_sf, 5 * (size_t)n_bytes, hipMemcpyDeviceToHost, s));

@@ -102,7 +102,8 @@ STREAM_STATUS_DTYPE = [("state", "<i4"), ("signal_l1_average", "<f4"), ("freq_co
                        ("total_frames_desync", "<i4")]
 SUPERFRAME_RESULT_DTYPE = [("rs_failed_index", "<i4"), ("rs_corrected", "<i4"), ("firecode_ok", "<i4"), ("header_valid", "<i4"),
                            ("descriptor", "<i4"), ("num_aus", "<i4"), ("au_start", "<i4", (8,)), ("au_walk_stopped_at", "<i4"),
-                           ("au_crc_ok_mask", "<u4"), ("frame_index", "<i4"), ("reserved", "<i4")]
+                           ("au_crc_ok_mask", "<u4"), ("frame_index", "<i4"), ("firecode_rx_calc", "<u4"),
+                           ("au_crc_calc", "<u2", (6,)), ("reserved", "<u2", (2,))]
 SYNC_STATE_DTYPE = [("freq_coarse", "<f4"), ("freq_fine", "<f4"), ("is_found_coarse", "<i4"),
                     ("fine_time_offset", "<i4"), ("sync_valid", "<i4"), ("reserved", "<i4")]
 RESULT_DTYPE = [("path_error", "<u8"), ("crc_ok_mask", "<u4"), ("n_out_bytes", "<u4")]
@@ -183,7 +184,7 @@ def lib():
         L.dabgpu_dabplus_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
                                                   C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_dabplus_process_frame_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                             C.c_void_p]
+                                                             C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -443,7 +444,7 @@ class DabPlusBank:
         res["rs_failed_index"] = -1                      # the record is only written when a super frame was attempted
         res["au_walk_stopped_at"] = -1
         sf = np.zeros(5 * frame.size, np.uint8)
-        check(lib().dabgpu_dabplus_process_frame_host_sync(self._h, _ptr(frame), frame.size, C.byref(done), C.byref(wait), _ptr(res),
+        check(lib().dabgpu_dabplus_process_frame_host_sync(self._h, _ptr(frame), frame.size, C.byref(done), C.byref(wait), None, _ptr(res),
                                                            _ptr(sf)), "dabgpu_dabplus_process_frame_host_sync")
         return done.value, wait.value, res[0], (sf if done.value else None)
 

@@ -352,7 +352,9 @@ typedef struct {
     int32_t au_walk_stopped_at;     /* -1, or the access unit whose bounds test ended the walk (:291-297) */
     uint32_t au_crc_ok_mask;        /* bit i: OnAccessUnit(i) fired (CRC passed); other walked units: OnAccessUnitCRCError */
     int32_t frame_index;            /* index inside this call of the logical frame that completed the super frame */
-    int32_t reserved;
+    uint32_t firecode_rx_calc;      /* received << 16 | calculated fire code of the corrected super frame (OnFirecodeError arguments) */
+    uint16_t au_crc_calc[6];        /* calculated CRC of every walked access unit (OnAccessUnitCRCError arguments) */
+    uint16_t reserved[2];
 } dabgpu_superframe_result;
 
 typedef struct dabgpu_dabplus_bank dabgpu_dabplus_bank;
@@ -365,7 +367,8 @@ int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank *bank, void *stream);
  * sub-channel inside one CIF record, stride of a CIF record).
  *   d_superframes [n_streams][max_superframes][superframe_stride_bytes]: every super frame ATTEMPTED in this call (5 frames
  *                 collected), corrected where RS succeeded;  d_results the matching records
- *   d_counts      [n_streams][2]: super frames attempted, logical frames dropped while waiting for a valid fire code
+ *   d_counts      [n_streams][4]: super frames attempted, logical frames dropped while waiting for a valid fire code,
+ *                 received << 16 | calculated fire code of the last dropped frame, logical frames collected so far
  *   max_superframes >= ceil(n_frames / 5), superframe_stride_bytes >= 5 * frame bytes
  */
 int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank *bank, const uint8_t *d_frames, const uint64_t *d_stream_offsets,
@@ -374,7 +377,8 @@ int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank *bank, const uint8_t *d_fram
                                 int32_t *d_counts, void *stream);
 /* one Process(buf) of a one-stream bank with host buffers (the AAC_Frame_Processor mirror class); h_superframe [5*n_bytes] */
 int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank *bank, const uint8_t *h_frame, uint32_t n_bytes, int *superframe_done,
-                                           int *firecode_wait_failed, dabgpu_superframe_result *h_result, uint8_t *h_superframe);
+                                           int *firecode_wait_failed, uint32_t *firecode_wait_rx_calc /* may be NULL */,
+                                           dabgpu_superframe_result *h_result, uint8_t *h_superframe);
 
 /* ==================================================================================================
  * Data formats either side of the path.

@@ -577,5 +577,7 @@ def ref():
             R.ref_aac_create.restype = C.c_void_p
             R.ref_aac_destroy.argtypes = [C.c_void_p]
             R.ref_aac_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            R.ref_aac_log.restype = C.c_long
+            R.ref_aac_log.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         _ref = R
     return _ref

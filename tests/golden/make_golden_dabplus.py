@@ -54,6 +54,9 @@ def main():
             o = np.zeros(12, np.int32); al = np.zeros(6, np.int32); ab = np.zeros((6, 1024), np.uint8)
             R.ref_aac_process(h, fr.ctypes.data, n, o.ctypes.data, al.ctypes.data, ab.ctypes.data, 1024)
             ev.append(o); lens.append(al); byts.append(ab)
+        buf = C.create_string_buffer(1 << 20)
+        R.ref_aac_log(h, buf, 1 << 20)
+        out[f"{name}_log"] = np.frombuffer(buf.value, np.uint8).copy()
         R.ref_aac_destroy(h)
         names.append(name)
         out[f"{name}_frames"] = frames; out[f"{name}_n"] = np.int32(n); out[f"{name}_ref"] = np.stack(ev)

@@ -80,9 +80,9 @@ def test_batch_of_streams_matches_oracle(ctx, oracle):
     max_sf = (F + 4) // 5
     d_sf = torch.zeros((E, max_sf, 5 * max_n), dtype=torch.uint8, device="cuda")
     rec_bytes = np.dtype(dabgpu.SUPERFRAME_RESULT_DTYPE).itemsize
-    assert rec_bytes == 72
+    assert rec_bytes == 88
     d_res = torch.zeros((E, max_sf, rec_bytes), dtype=torch.uint8, device="cuda")
-    d_cnt = torch.zeros((E, 2), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros((E, 4), dtype=torch.int32, device="cuda")
     d_frames = torch.from_numpy(streams).cuda()
     procs = [oracle.AacFrameProcessor() for _ in range(E)]
     seen = {"ok": 0, "rs_fail": 0, "fire_fail": 0, "wait": 0}
@@ -145,7 +145,7 @@ def test_behind_the_msc_viterbi_kernel(ctx, oracle):
     d_n = torch.tensor(nbytes, dtype=torch.int32, device="cuda")
     d_sf = torch.zeros((len(subs), 1, 5 * max(nbytes)), dtype=torch.uint8, device="cuda")
     d_rec = torch.zeros((len(subs), 1, np.dtype(dabgpu.SUPERFRAME_RESULT_DTYPE).itemsize), dtype=torch.uint8, device="cuda")
-    d_cnt = torch.zeros((len(subs), 2), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros((len(subs), 4), dtype=torch.int32, device="cuda")
     got = [[] for _ in subs]
     for f in range(n_frames):
         frame = np.zeros((1, oracle.NB_FRAME_BITS), np.int8)
