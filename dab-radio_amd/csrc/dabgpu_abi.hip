@@ -88,8 +88,9 @@ int dabgpu_get_prs_fft_ref(int mode, float* out) {
 // ETSI EN 300 401 14.6.1 (replaces get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
 int dabgpu_get_carrier_mapper(int mode, int* out) {
     if (!out) return DABGPU_ERR_INVALID_ARG;
-    if (mode != 1) { dabgpu_set_error("transmission mode %d: only Mode I tables are built in", mode); return DABGPU_ERR_UNSUPPORTED; }
-    const int N = DABGPU_NB_FFT, nb = DABGPU_NB_DATA_CARRIERS, dc = N / 2, lo = dc - nb / 2, hi = dc + nb / 2;
+    int geom[9];
+    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
+    const int N = geom[3], nb = geom[5], dc = N / 2, lo = dc - nb / 2, hi = dc + nb / 2;
     int v = 0, n = 0;
     for (int i = 0; i < N; i++) {
         if (i > 0) v = (13 * v + N / 4 - 1) % N;
@@ -175,6 +176,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     if (c->d_prs) (void)hipFree(c->d_prs);
     if (c->d_prs_time_ref) (void)hipFree(c->d_prs_time_ref);
     if (c->d_vit_tables) (void)hipFree(c->d_vit_tables);
+    for (int* p : c->d_mode_mapper) if (p) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -232,12 +234,23 @@ int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, s
     return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
 }
 
+int dabgpu_ofdm_phase_update_mode(dabgpu_ctx* c, int mode, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,
+                                  float* d_fine_freq, void* stream) {
+    int geom[9];
+    if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update_mode: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
+    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
+    if (n_frames == 0) return DABGPU_OK;
+    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, geom[0], geom[3],
+                                                     (hipStream_t)stream), "ofdm_phase_kernel launch");
+}
+
 int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,
                              float* d_fine_freq, void* stream) {
     if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     hipStream_t s = (hipStream_t)stream;
-    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, s),
+    return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, DABGPU_NB_FRAME_SYMBOLS,
+                                                     DABGPU_NB_FFT, s),
                             "ofdm_phase_kernel launch");
 }
 

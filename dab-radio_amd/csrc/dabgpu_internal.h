@@ -18,6 +18,7 @@ struct dabgpu_ctx {
     float* d_prs = nullptr;          // PRS spectrum
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
+    int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
 };
@@ -39,7 +40,8 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, hipStream_t stream);
+                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
+                                               hipStream_t stream);
 
 // ---- channel decode ----
 typedef dabgpu_codeword dabgpu_cw_desc;

@@ -310,22 +310,22 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
 __global__ __launch_bounds__(64)
 void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
                        float* __restrict__ total_phase, float* __restrict__ fine_freq, int fine_freq_stride,
-                       const dabgpu_frame_desc* __restrict__ desc)
+                       const dabgpu_frame_desc* __restrict__ desc, int n_sym, int n_fft)
 {
     const int fr = blockIdx.x * blockDim.x + threadIdx.x;
     if (fr >= n_frames) return;
     if (desc != nullptr && desc[fr].slot < 0) return;
-    const f2* c = cp_corr + (size_t)fr * NB_FRAME_SYMBOLS;
+    const f2* c = cp_corr + (size_t)fr * n_sym;
     float total = 0.0f;
-    for (int i = 0; i < NB_FRAME_SYMBOLS; i++) {
+    for (int i = 0; i < n_sym; i++) {
         const f2 v = c[i];
         total += atan2_det(v.y, v.x);
     }
     if (total_phase) total_phase[fr] = total;
     if (fine_freq) {
         const float TWO_PI = 3.14159274101257324f * 2.0f;
-        const float avg = total / (float)NB_FRAME_SYMBOLS;
-        const float spacing = 1.0f / (float)NB_FFT;
+        const float avg = total / (float)n_sym;
+        const float spacing = 1.0f / (float)n_fft;
         const float err = spacing * avg / TWO_PI;
         const float delta = -beta * err;
         const float wrap = 0.5f * spacing * 1.01f;
@@ -374,11 +374,12 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 }
 
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
-                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, hipStream_t stream)
+                                               float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
+                                               hipStream_t stream)
 {
     using namespace dabgpu;
     const dim3 grid((unsigned)((n_frames + 63) / 64));
     hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
-                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc);
+                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc, n_sym, n_fft);
     return hipGetLastError();
 }

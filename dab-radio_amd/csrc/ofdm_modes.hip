@@ -1,0 +1,246 @@
+// ofdm_modes.hip -- OFDM demodulation of frame-aligned frames for transmission modes II, III and IV (SURVEY 8f row N4;
+// geometries of src/ofdm/dab_ofdm_params_ref.cpp:11-60): FFT 512 / 256 / 1024, 384 / 192 / 768 carriers, 76 / 153 / 76 symbols.
+// Same pipeline as ofdm_demod.hip -- PLL (apply_pll.cpp:81-117 incl. its scalar tail :115-116 for symbol periods that are
+// not a multiple of 4), cyclic-prefix correlation, FFT, DQPSK, frequency de-interleave, soft bits -- written size-generic:
+// the transform is a Stockham autosort through LDS with the butterflies and twiddle rule of the mode I contract
+// (r1 x 8 x 8 [x 8], r1 = 2 / none / 4), the correlation tree takes one leaf per sample.  Mode I itself runs through the
+// register-resident kernel of ofdm_demod.hip; this kernel also accepts mode I, which the tests use to cross-check the two.
+// The DAB layer above (FIC_Decoder) exists for mode I only in the reference (fic_decoder.cpp:61-72), so modes II-IV end at
+// the soft bits here as they do there.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+#include "ofdm_device.h"
+
+namespace dabgpu {
+
+struct ModeGeom { int n_sym, period, null_period, n_fft, n_cp, n_carriers, frame_samples, sym_bits, frame_bits; };
+
+__host__ __device__ inline bool mode_geometry(int mode, ModeGeom& g) {
+    switch (mode) {
+    case 1: g.n_sym = 76; g.period = 2552; g.null_period = 2656; g.n_fft = 2048; g.n_carriers = 1536; break;
+    case 2: g.n_sym = 76; g.period = 638; g.null_period = 664; g.n_fft = 512; g.n_carriers = 384; break;
+    case 3: g.n_sym = 153; g.period = 319; g.null_period = 345; g.n_fft = 256; g.n_carriers = 192; break;
+    case 4: g.n_sym = 76; g.period = 1276; g.null_period = 1328; g.n_fft = 1024; g.n_carriers = 768; break;
+    default: return false;
+    }
+    g.n_cp = g.period - g.n_fft;
+    g.frame_samples = g.n_sym * g.period + g.null_period;
+    g.sym_bits = 2 * g.n_carriers;
+    g.frame_bits = (g.n_sym - 1) * g.sym_bits;
+    return true;
+}
+
+// scalar Chebyshev of apply_pll_scalar (chebyshev_sine.h:22-41, no fused operations)
+__device__ __forceinline__ float cheb_scalar(float x) {
+    const float z = x * x;
+    const float b4 = 3.20396066f * z + -14.07150173f;
+    const float b3 = b4 * z + 38.50016403f;
+    const float b2 = b3 * z + -67.07687378f;
+    const float b1 = b2 * z + 64.83583069f;
+    const float b0 = b1 * z + -25.13274193f;
+    return b0 * (z - 0.25f) * x;
+}
+
+// sample n of a symbol of `period` samples: the vector body in groups of 4, then the scalar tail (apply_pll.cpp:12-30)
+__device__ __forceinline__ f2 pll_any(f2 v, int n, int period, float f, float dt0) {
+    const int nv = period & ~3;
+    if (n < nv) {
+        const int k = n & 3;
+        const float ss = (float)k * f;
+        return pll1(v, dt0 + (float)(n & ~3) * f, mk2(ss + 0.25f, ss));
+    }
+    const float dt_scalar = dt0 + (float)nv * f;
+    float dt_sin = dt_scalar + (float)(n - nv) * f;
+    float dt_cos = dt_sin + 0.25f;
+    dt_sin = dt_sin - __builtin_roundf(dt_sin);
+    dt_cos = dt_cos - __builtin_roundf(dt_cos);
+    const float c = cheb_scalar(dt_cos), s = cheb_scalar(dt_sin);
+    return mk2(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+
+template <int R>
+__device__ __forceinline__ void butterfly(f2 (&a)[8]) {
+    if constexpr (R == 8) {
+        dft8(a);
+    } else if constexpr (R == 4) {
+        f2 b0, b1, b2, b3;
+        dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
+        a[0] = b0; a[1] = b1; a[2] = b2; a[3] = b3;
+    } else {
+        const f2 s = a[0] + a[1], d = a[0] - a[1];
+        a[0] = s; a[1] = d;
+    }
+}
+
+// one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst`
+template <int R>
+__device__ __forceinline__ void stockham_pass(const f2* __restrict__ src, f2* __restrict__ dst, int n_total, int cur_n, int s, bool last,
+                                              const f2* __restrict__ tw, int t) {
+    const int m = cur_n / R, tw_step = NB_FFT / cur_n;
+    for (int u = t; u < n_total / R; u += 256) {
+        const int q = u % s, p = u / s;
+        f2 a[8];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = src[q + s * (p + m * j)];
+        butterfly<R>(a);
+#pragma unroll
+        for (int k = 0; k < R; k++) dst[q + s * (R * p + k)] = (k == 0 || last) ? a[k] : cmul(a[k], tw[tw_step * p * k]);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __restrict__ freq_offset, int8_t* __restrict__ bits,
+                            f2* __restrict__ cp_corr, f2* __restrict__ fft_out, const f2* __restrict__ tw,
+                            const int* __restrict__ mapper, int n_frames, int sym_per_chunk, int chunks_per_frame)
+{
+    extern __shared__ __attribute__((aligned(16))) char msm[];
+    ModeGeom g;
+    mode_geometry(mode, g);
+    const int N = g.n_fft;
+    f2* Y = reinterpret_cast<f2*>(msm);                 // one PLL-corrected symbol, `period` samples
+    f2* W0 = Y + g.period;                              // three transform buffers of N
+    float* red = reinterpret_cast<float*>(W0 + 3 * N);  // 2 x 256 reduction leaves
+    f2* W[3] = {W0, W0 + N, W0 + 2 * N};
+
+    const int t = threadIdx.x;
+    const int unit = blockIdx.x;
+    const int frame = unit / chunks_per_frame, chunk = unit % chunks_per_frame;
+    if (frame >= n_frames) return;
+    const int out0 = chunk * sym_per_chunk;
+    const int out1 = min(out0 + sym_per_chunk, g.n_sym - 1);
+    const bool last_chunk = (out1 == g.n_sym - 1);
+    const int sym_end = (last_chunk && fft_out != nullptr) ? g.n_sym : out1;     // inclusive
+    const float f = freq_offset ? freq_offset[frame] : 0.0f;
+    const f2* fbase = iq + (size_t)frame * g.frame_samples;
+    int L = 1;
+    while (L < g.n_cp) L <<= 1;
+    int prev = 0;                                       // index of the buffer holding the previous symbol's spectrum
+
+    for (int i = out0; i <= sym_end; i++) {
+        const float dt0 = (float)(i * g.period) * f;
+        const f2* sym = fbase + (size_t)i * g.period;
+        for (int n = t; n < g.period; n += 256) Y[n] = pll_any(sym[n], n, g.period, f, dt0);
+        __syncthreads();
+        const bool do_corr = (i < g.n_sym) && (i < out1 || i == g.n_sym - 1);
+        if (do_corr) {                                                           // uniform per workgroup
+            float pr = 0.0f, pi = 0.0f;
+            if (mode == 1) {
+                // the mode I contract: leaf t >= 4 = samples 2(t-4), 2(t-4)+1; 64-leaf groups halve with
+                // strides 32..1, then (g0+g1)+(g2+g3)
+                if (t >= 4) {
+                    const int n = 2 * (t - 4);
+                    const f2 p0 = conj_mul(Y[N + n], Y[n]), p1 = conj_mul(Y[N + n + 1], Y[n + 1]);
+                    pr = p0.x + p1.x; pi = p0.y + p1.y;
+                }
+                red[t] = pr; red[256 + t] = pi;
+                __syncthreads();
+                for (int h = 32; h >= 1; h >>= 1) {
+                    if ((t & 63) < h) { red[t] += red[t + h]; red[256 + t] += red[256 + t + h]; }
+                    __syncthreads();
+                }
+                if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2((red[0] + red[64]) + (red[128] + red[192]),
+                                                                       (red[256] + red[320]) + (red[384] + red[448]));
+            } else {
+                // modes II-IV: one leaf per sample, L = power of two >= n_cp (<= 256), strides L/2 .. 1
+                if (t < g.n_cp) { const f2 p = conj_mul(Y[N + t], Y[t]); pr = p.x; pi = p.y; }
+                red[t] = pr; red[256 + t] = pi;
+                __syncthreads();
+                for (int h = L / 2; h >= 1; h >>= 1) {
+                    if (t < h) { red[t] += red[t + h]; red[256 + t] += red[256 + t + h]; }
+                    __syncthreads();
+                }
+                if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2(red[0], red[256]);
+            }
+        }
+        // ---- FFT: Y[cp .. cp + N) -> W[cur]; the two buffers other than `prev` alternate as source and destination ----
+        const int wa = (prev + 1) % 3, wb = (prev + 2) % 3;
+        const f2* src = Y + g.n_cp;
+        int cur_n = N, s = 1, pass = 0, cur = wa;
+        const int r1 = (N == 2048 || N == 256) ? 4 : (N == 1024 ? 2 : 8);
+        int rem = N;
+        while (rem > 1) {
+            const int r = (pass == 0) ? r1 : 8;
+            const bool last = (rem == r);
+            f2* dst = W[(pass & 1) ? wb : wa];
+            if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t);
+            else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t);
+            else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t);
+            __syncthreads();
+            src = dst; cur = (pass & 1) ? wb : wa;
+            cur_n /= r; s *= r; rem /= r; pass++;
+        }
+        if (fft_out != nullptr) {
+            f2* dst = fft_out + ((size_t)frame * (g.n_sym + 1) + i) * N;
+            for (int k = t; k < N; k += 256) dst[k] = W[cur][k];
+        }
+        if (i > out0 && i < g.n_sym) {
+            // ---- DQPSK + frequency de-interleave + soft bits (ofdm_demodulator.cpp:842-889) ----
+            const int NC = g.n_carriers, M = NC / 2;
+            int8_t* o = bits + (size_t)frame * g.frame_bits + (size_t)(i - 1) * g.sym_bits;
+            for (int n = t; n < NC; n += 256) {
+                const int c = mapper[n];
+                const int k = (c < M) ? (c - M) : (c - M + 1);
+                const int bin = (N + k) % N;
+                const f2 d = conj_mul(W[prev][bin], W[cur][bin]);
+                const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
+                const float A = (ar < ai) ? ai : ar;
+                o[n] = (int8_t)to_vbit(d.x / A);
+                o[n + NC] = (int8_t)to_vbit(-(d.y / A));
+            }
+        }
+        __syncthreads();
+        prev = cur;
+    }
+}
+
+}  // namespace dabgpu
+
+using namespace dabgpu;
+
+extern "C" {
+
+int dabgpu_get_ofdm_params(int mode, int* out9) {
+    ModeGeom g;
+    if (!out9 || !mode_geometry(mode, g)) { dabgpu_set_error("get_ofdm_params: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    out9[0] = g.n_sym; out9[1] = g.period; out9[2] = g.null_period; out9[3] = g.n_fft; out9[4] = g.n_cp; out9[5] = g.n_carriers;
+    out9[6] = g.frame_samples; out9[7] = g.sym_bits; out9[8] = g.frame_bits;
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                                  float* d_cp_corr, float* d_fft, int symbols_per_block, void* stream) {
+    ModeGeom g;
+    if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames_mode: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
+    if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_frames_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0) return DABGPU_OK;
+    if (n_frames > (size_t)(1 << 22)) { dabgpu_set_error("ofdm_demod_frames_mode: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
+    if ((uintptr_t)d_iq & 7) { dabgpu_set_error("ofdm_demod_frames_mode: d_iq must be 8-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    // per-mode carrier mapper on the device, built on first use (get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
+    if (!c->d_mode_mapper[mode]) {
+        std::vector<int> m((size_t)g.n_carriers);
+        if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
+        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_mapper[mode], m.size() * sizeof(int)), "hipMalloc(mode mapper)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_mapper[mode], m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode mapper)"))) return st;
+    }
+    float* corr = d_cp_corr;
+    if (!corr && (st = dabgpu_scratch(c, 23, n_frames * (size_t)g.n_sym * 2 * sizeof(float), (void**)&corr))) return st;
+    if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
+    const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
+    const size_t lds = ((size_t)g.period + 3 * (size_t)g.n_fft) * sizeof(f2) + 512 * sizeof(float);
+    if (lds > 48 * 1024 && (st = dabgpu_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ofdm_demod_mode_kernel),
+                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                                                   "hipFuncSetAttribute(ofdm_demod_mode_kernel)"))) return st;
+    hipLaunchKernelGGL(ofdm_demod_mode_kernel, dim3((unsigned)(n_frames * chunks)), dim3(256), lds, s, mode, reinterpret_cast<const f2*>(d_iq),
+                       d_freq, d_bits, reinterpret_cast<f2*>(corr), reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(c->d_tw),
+                       c->d_mode_mapper[mode], (int)n_frames, symbols_per_block, chunks);
+    return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_mode_kernel launch");
+}
+
+}  // extern "C"

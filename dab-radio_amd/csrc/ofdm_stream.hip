@@ -473,7 +473,7 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
         CK(dabgpu_launch_ofdm_demod(b->view.frame, 0, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
                                     n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
-                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, s));
+                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, NB_FRAME_SYMBOLS, NB_FFT, s));
         if (round + 1 >= blind_rounds) {
             CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
             CK(hipStreamSynchronize(s));

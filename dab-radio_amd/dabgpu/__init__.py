@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "dabgpu_stream_bank_process", "dabgpu_stream_bank_status",
     "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
     "dabgpu_dabplus_process_frame_host_sync",
+    "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -185,6 +186,11 @@ def lib():
                                                   C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_dabplus_process_frame_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                              C.c_void_p, C.c_void_p]
+        L.dabgpu_get_ofdm_params.argtypes = [C.c_int, C.c_void_p]
+        L.dabgpu_ofdm_demod_frames_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_ofdm_phase_update_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p]
         _lib = L
     return _lib
 
@@ -276,6 +282,15 @@ class Context:
         check(lib().dabgpu_ofdm_demod_frames_raw(self._h, _ptr(raw), int(fmt), n_frames, _ptr(freq_offset), _ptr(bits),
                                                  _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, bits_frame_stride,
                                                  self._stream(stream)), "dabgpu_ofdm_demod_frames_raw")
+
+    def ofdm_demod_frames_mode(self, mode, iq, n_frames, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0, stream=None):
+        """frame-aligned frames of transmission mode 1..4 through the size-generic kernel"""
+        check(lib().dabgpu_ofdm_demod_frames_mode(self._h, int(mode), _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
+                                                  _ptr(fft), symbols_per_block, self._stream(stream)), "dabgpu_ofdm_demod_frames_mode")
+
+    def ofdm_phase_update_mode(self, mode, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):
+        check(lib().dabgpu_ofdm_phase_update_mode(self._h, int(mode), _ptr(cp_corr), n_frames, beta, _ptr(total_phase), _ptr(fine_freq),
+                                                  self._stream(stream)), "dabgpu_ofdm_phase_update_mode")
 
     def ofdm_phase_update(self, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):
         check(lib().dabgpu_ofdm_phase_update(self._h, _ptr(cp_corr), n_frames, beta, _ptr(total_phase),
@@ -453,6 +468,22 @@ def stream_cfg_default():
     c = StreamCfg()
     lib().dabgpu_stream_cfg_default(C.byref(c))
     return c
+
+
+def ofdm_params(mode):
+    """dict of the geometry of transmission mode 1..4 (host only)"""
+    out = (C.c_int * 9)()
+    check(lib().dabgpu_get_ofdm_params(int(mode), out), "dabgpu_get_ofdm_params")
+    keys = ("nb_frame_symbols", "nb_symbol_period", "nb_null_period", "nb_fft", "nb_cyclic_prefix", "nb_data_carriers",
+            "nb_frame_samples", "nb_sym_bits", "nb_frame_bits")
+    return dict(zip(keys, list(out)))
+
+
+def carrier_mapper(mode):
+    import numpy as np
+    m = np.zeros(ofdm_params(mode)["nb_data_carriers"], np.int32)
+    check(lib().dabgpu_get_carrier_mapper(int(mode), _ptr(m)), "dabgpu_get_carrier_mapper")
+    return m
 
 
 def iq_format_from_mode(mode):

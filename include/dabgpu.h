@@ -289,6 +289,25 @@ int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream *s, int8_t *h_out);
 int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *n_out, uint64_t *path_error, int tie_rule);
 
 /* ==================================================================================================
+ * Transmission modes II, III and IV (geometries of src/ofdm/dab_ofdm_params_ref.cpp:11-60).
+ * The same demodulation pipeline, frame-aligned batches, through a size-generic kernel (FFT 512 / 256 / 1024 with the mode I
+ * butterflies and twiddle rule; PLL with apply_pll's scalar tail for symbol periods that are not a multiple of 4).  The DAB
+ * layer above the soft bits exists for mode I only in the reference (fic_decoder.cpp:61-72), and here.
+ */
+/* out9 = {nb_frame_symbols, nb_symbol_period, nb_null_period, nb_fft, nb_cyclic_prefix, nb_data_carriers,
+ *         samples per frame (symbols + NULL), soft bits per symbol, soft bits per frame}; host only */
+int dabgpu_get_ofdm_params(int transmission_mode, int *out9);
+/*   d_iq   [n_frames][samples per frame] complex float, layout as for mode I (symbols, PRS first, then the NULL symbol)
+ *   d_bits [n_frames][soft bits per frame] int8;  d_cp_corr [n_frames][nb_frame_symbols] complex float, may be NULL
+ *   d_fft  [n_frames][nb_frame_symbols + 1][nb_fft] complex float, may be NULL.  transmission_mode 1 is accepted too
+ *   (cross-check of the two kernels). */
+int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx *ctx, int transmission_mode, const float *d_iq, size_t n_frames,
+                                  const float *d_freq_offset, int8_t *d_bits, float *d_cp_corr, float *d_fft, int symbols_per_block,
+                                  void *stream);
+int dabgpu_ofdm_phase_update_mode(dabgpu_ctx *ctx, int transmission_mode, const float *d_cp_corr, size_t n_frames,
+                                  float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
+
+/* ==================================================================================================
  * Unsynchronised front end on the device: a bank of n independent receivers whose state between
  * calls -- signal level, NULL-search flags, circular NULL buffer, correlation window, frame buffer, frequency
  * offsets, counters (src/ofdm/ofdm_demodulator.h:131-176) -- lives in HBM.  One dabgpu_stream_bank_process() is one

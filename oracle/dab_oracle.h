@@ -260,6 +260,21 @@ void dab_aac_destroy(dab_aac_frame_processor *p);
  * superframe_done; returns 0, or -1 when the reference rejects the buffer (empty / shorter than 11 bytes) */
 int dab_aac_process(dab_aac_frame_processor *p, const uint8_t *frame, int n, dab_superframe_result *res, uint8_t *sf_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Transmission modes II-IV
+ */
+typedef struct {
+    int mode, nb_frame_symbols, nb_symbol_period, nb_null_period, nb_fft, nb_cp, nb_carriers;
+    int nb_frame_samples, nb_sym_bits, nb_frame_bits;
+} dab_ofdm_geometry;
+int dab_ofdm_geometry_get(int mode, dab_ofdm_geometry *g);
+void dab_mapper_n(int nb_fft, int nb_carriers, int *out);
+void dab_fft_n(int n, const dab_cf32 *in, dab_cf32 *out, int inverse);      /* n in {256, 512, 1024, 2048} */
+dab_cf32 dab_cp_correlation_n(const dab_cf32 *sym, int nb_fft, int nb_cp);
+float dab_demod_frame_mode(int mode, const dab_cf32 *frame, float f, const int *mapper, int8_t *bits, dab_cf32 *cp_corr,
+                           float *cp_phase, dab_cf32 *fft_out);
+float dab_update_fine_freq_mode(int mode, float fine, float total_phase_error, float beta);
+
 #ifdef __cplusplus
 }
 #endif

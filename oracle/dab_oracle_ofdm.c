@@ -555,3 +555,143 @@ int dab_fine_time_sync(const dab_cf32 *prs_sym, const dab_cf32 *prs_fft_conj, co
     *offset = max_index - DAB_NB_CYCLIC_PREFIX;                 /* :536 */
     return 1;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Transmission modes II, III, IV: the same demodulator over the other geometries  */
+/* (src/ofdm/dab_ofdm_params_ref.cpp:11-60).  Mode I goes through the functions above; the         */
+/* generic ones reproduce them exactly for mode I (tests/test_oracle_modes.py).                     */
+/* ------------------------------------------------------------------------------------------ */
+
+int dab_ofdm_geometry_get(int mode, dab_ofdm_geometry *g) {
+    static const int T[5][5] = { {0, 0, 0, 0, 0}, {76, 2552, 2656, 2048, 1536}, {76, 638, 664, 512, 384},
+                                 {153, 319, 345, 256, 192}, {76, 1276, 1328, 1024, 768} };
+    if (mode < 1 || mode > 4) return -1;
+    g->mode = mode;
+    g->nb_frame_symbols = T[mode][0]; g->nb_symbol_period = T[mode][1]; g->nb_null_period = T[mode][2];
+    g->nb_fft = T[mode][3]; g->nb_carriers = T[mode][4];
+    g->nb_cp = g->nb_symbol_period - g->nb_fft;
+    g->nb_frame_samples = g->nb_frame_symbols * g->nb_symbol_period + g->nb_null_period;
+    g->nb_sym_bits = 2 * g->nb_carriers;
+    g->nb_frame_bits = (g->nb_frame_symbols - 1) * g->nb_sym_bits;
+    return 0;
+}
+
+/* get_DAB_mapper_ref for any (nb_fft, nb_carriers), src/ofdm/dab_mapper_ref.cpp:10-51 */
+void dab_mapper_n(int nb_fft, int nb_carriers, int *out) {
+    const int N = nb_fft, dc = N / 2, lo = dc - nb_carriers / 2, hi = dc + nb_carriers / 2;
+    int v = 0, n = 0;
+    for (int i = 0; i < N; i++) {
+        if (i > 0) v = (13 * v + N / 4 - 1) % N;
+        if (v < lo || v > hi || v == dc) continue;
+        out[n++] = (v < dc) ? (v - lo) : (v - lo - 1);
+    }
+}
+
+/* FFT contract for n = r1 * 8^k (2048 = 4.8.8.8, 1024 = 2.8.8.8, 512 = 8.8.8, 256 = 4.8.8): Stockham autosort, decimation
+ * in frequency, one radix-r1 pass then radix-8 passes; twiddle w_n^m = g_tw[m * 2048 / n]; output 0 of a butterfly is not
+ * multiplied, the last pass has no twiddles */
+void dab_fft_n(int n, const dab_cf32 *in, dab_cf32 *out, int inverse) {
+    ensure_tw();
+    dab_cf32 bufs[2][DAB_NB_FFT];
+    int radix[4], n_pass = 0;
+    { int rem = n; if (n == 2048 || n == 256) { radix[n_pass++] = 4; rem /= 4; } else if (n == 1024) { radix[n_pass++] = 2; rem /= 2; }
+      while (rem > 1) { radix[n_pass++] = 8; rem /= 8; } }
+    const dab_cf32 *src = in;
+    int cur_n = n, s = 1;
+    for (int ps = 0; ps < n_pass; ps++) {
+        const int r = radix[ps], m = cur_n / r, last = (ps == n_pass - 1), first = (ps == 0);
+        dab_cf32 *dst = last ? out : bufs[ps & 1];
+        const int tw_step = DAB_NB_FFT / cur_n;
+        for (int p = 0; p < m; p++)
+            for (int q = 0; q < s; q++) {
+                dab_cf32 a[8], b[8];
+                for (int j = 0; j < r; j++) {
+                    a[j] = src[q + s * (p + m * j)];
+                    if (first && inverse) a[j].im = -a[j].im;
+                }
+                if (r == 8) dft8(a, b);
+                else if (r == 4) dft4(a, b);
+                else { b[0] = cadd(a[0], a[1]); b[1] = csub(a[0], a[1]); }
+                for (int k = 0; k < r; k++) {
+                    dab_cf32 v = (k == 0 || last) ? b[k] : cmul(b[k], g_tw[tw_step * p * k]);
+                    if (last && inverse) v.im = -v.im;
+                    dst[q + s * (r * p + k)] = v;
+                }
+            }
+        src = dst;
+        cur_n = m;
+        s *= r;
+    }
+}
+
+/* cyclic-prefix correlation: mode I keeps its 256-leaf tree (above); the other modes take one leaf per sample,
+ * L = the power of two >= nb_cp, and halve with strides L/2 .. 1 */
+dab_cf32 dab_cp_correlation_n(const dab_cf32 *sym, int nb_fft, int nb_cp) {
+    if (nb_fft == DAB_NB_FFT) return dab_cp_correlation(sym);
+    float pr[256], pi[256];
+    int L = 1;
+    while (L < nb_cp) L <<= 1;
+    for (int j = 0; j < L; j++) {
+        if (j < nb_cp) { const dab_cf32 p = conj_mul(sym[nb_fft + j], sym[j]); pr[j] = p.re; pi[j] = p.im; }
+        else { pr[j] = 0.0f; pi[j] = 0.0f; }
+    }
+    for (int h = L / 2; h >= 1; h >>= 1)
+        for (int i = 0; i < h; i++) { pr[i] += pr[i + h]; pi[i] += pi[i + h]; }
+    dab_cf32 r = { pr[0], pi[0] };
+    return r;
+}
+
+float dab_demod_frame_mode(int mode, const dab_cf32 *frame, float f, const int *mapper, int8_t *bits, dab_cf32 *cp_corr,
+                           float *cp_phase, dab_cf32 *fft_out) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return 0.0f;
+    dab_cf32 sym[DAB_NB_SYMBOL_PERIOD];
+    static __thread dab_cf32 X[2][DAB_NB_FFT];
+    const int N = g.nb_fft, NC = g.nb_carriers, M = NC / 2;
+    float total = 0.0f;
+    for (int i = 0; i <= g.nb_frame_symbols; i++) {
+        const dab_cf32 *src = frame + (size_t)i * g.nb_symbol_period;
+        const float dt0 = (float)(i * g.nb_symbol_period) * f;
+        dab_apply_pll(src, sym, (size_t)g.nb_symbol_period, f, dt0);
+        if (i < g.nb_frame_symbols) {
+            const dab_cf32 c = dab_cp_correlation_n(sym, N, g.nb_cp);
+            const float ph = dab_atan2f(c.im, c.re);
+            if (cp_corr) cp_corr[i] = c;
+            if (cp_phase) cp_phase[i] = ph;
+            total += ph;
+        }
+        if (i == g.nb_frame_symbols && !fft_out) break;
+        dab_cf32 *cur = X[i & 1];
+        dab_fft_n(N, sym + g.nb_cp, cur, 0);
+        if (fft_out) memcpy(fft_out + (size_t)i * N, cur, sizeof(dab_cf32) * (size_t)N);
+        if (i >= 1 && i < g.nb_frame_symbols) {
+            const dab_cf32 *prev = X[(i - 1) & 1];
+            int8_t *o = bits + (size_t)(i - 1) * g.nb_sym_bits;
+            for (int n = 0; n < NC; n++) {
+                const int c = mapper[n];
+                const int k = (c < M) ? (c - M) : (c - M + 1);
+                const int bin = (N + k) % N;
+                const dab_cf32 d = conj_mul(prev[bin], cur[bin]);
+                const float ar = fabsf(d.re), ai = fabsf(d.im);
+                const float A = (ar < ai) ? ai : ar;
+                o[n] = to_vbit(+(d.re / A));
+                o[n + NC] = to_vbit(-(d.im / A));
+            }
+        }
+    }
+    return total;
+}
+
+/* ofdm_demodulator.cpp:606-618 + :779-840 for any mode */
+float dab_update_fine_freq_mode(int mode, float fine, float total_phase_error, float beta) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return fine;
+    const float TWO_PI = (float)M_PI * 2.0f;
+    const float avg = total_phase_error / (float)g.nb_frame_symbols;
+    const float spacing = 1.0f / (float)g.nb_fft;
+    const float err = spacing * avg / TWO_PI;
+    const float delta = -beta * err;
+    const float wrap = 0.5f * spacing * 1.01f;
+    fine += delta;
+    return fmodf(fine, wrap);
+}

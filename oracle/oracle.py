@@ -222,6 +222,54 @@ class AacFrameProcessor:
             pass
 
 
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mode", "nb_frame_symbols", "nb_symbol_period", "nb_null_period", "nb_fft", "nb_cp",
+                                       "nb_carriers", "nb_frame_samples", "nb_sym_bits", "nb_frame_bits")]
+
+
+def geometry(mode):
+    g = Geometry()
+    assert lib().dab_ofdm_geometry_get(int(mode), C.byref(g)) == 0
+    return g
+
+
+def mapper_n(nb_fft, nb_carriers):
+    out = np.zeros(nb_carriers, np.int32)
+    lib().dab_mapper_n(int(nb_fft), int(nb_carriers), _p(out))
+    return out
+
+
+def fft_n(x, inverse=False):
+    x = c64(x)
+    out = np.empty_like(x)
+    lib().dab_fft_n(x.size, _p(x), _p(out), int(inverse))
+    return out
+
+
+def demod_frame_mode(mode, frame, freq_offset=0.0, want_fft=False, m=None):
+    g = geometry(mode)
+    frame = c64(frame)
+    assert frame.size == g.nb_frame_samples
+    m = mapper_n(g.nb_fft, g.nb_carriers) if m is None else np.ascontiguousarray(m, dtype=np.int32)
+    bits = np.empty(g.nb_frame_bits, np.int8)
+    corr = np.empty(g.nb_frame_symbols, np.complex64)
+    phase = np.empty(g.nb_frame_symbols, np.float32)
+    fft = np.empty((g.nb_frame_symbols + 1) * g.nb_fft, np.complex64) if want_fft else None
+    L = lib()
+    L.dab_demod_frame_mode.restype = C.c_float
+    L.dab_demod_frame_mode.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    total = L.dab_demod_frame_mode(int(mode), _p(frame), np.float32(freq_offset), _p(m), _p(bits), _p(corr), _p(phase),
+                                   _p(fft) if want_fft else None)
+    return {"bits": bits, "cp_corr": corr, "cp_phase": phase, "total_phase": np.float32(total), "fft": fft}
+
+
+def update_fine_freq_mode(mode, fine, total_phase, beta=0.9):
+    L = lib()
+    L.dab_update_fine_freq_mode.restype = C.c_float
+    L.dab_update_fine_freq_mode.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    return np.float32(L.dab_update_fine_freq_mode(int(mode), np.float32(fine), np.float32(total_phase), np.float32(beta)))
+
+
 def wav_parse_header(image):
     """-> None where the reference throws, else dict(format, code, channels, rate, bits, data_size, data_offset)"""
     image = np.ascontiguousarray(image, dtype=np.uint8)

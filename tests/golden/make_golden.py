@@ -24,6 +24,9 @@ def main():
     p = np.zeros(2048, np.complex64); R.ref_get_prs(1, p.ctypes.data, 2048); out["prs_fft"] = p
     op = np.zeros(6, np.uint64); R.ref_get_ofdm_params(1, op.ctypes.data); out["ofdm_params_mode1"] = op
     dp = np.zeros(13, np.int32); R.ref_get_dab_params(1, dp.ctypes.data); out["dab_params_mode1"] = dp
+    for mode in (2, 3, 4):                                   # transmission modes II-IV: geometry and frequency interleaver
+        opm = np.zeros(6, np.uint64); R.ref_get_ofdm_params(mode, opm.ctypes.data); out[f"ofdm_params_mode{mode}"] = opm
+        mm = np.zeros(int(opm[5]), np.int32); R.ref_get_mapper(mm.ctypes.data, int(opm[5]), int(opm[4])); out[f"mapper_mode{mode}"] = mm.astype(np.int16)
     pi = np.zeros(192, np.uint8); px = np.zeros(6, np.uint8); R.ref_puncture_tables(pi.ctypes.data, px.ctypes.data)
     out["pi_table"] = pi.reshape(24, 8); out["pi_x"] = px
     b = np.zeros(1024, np.uint8); R.ref_scrambler_bytes(b.ctypes.data, 1024); out["prbs_1024"] = b

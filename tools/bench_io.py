@@ -59,6 +59,18 @@ def main():
         ms = timed(lambda: ctx.ofdm_demod_frames_raw(raw, fmt, args.frames, bits, cp_corr=corr), args.reps)
         res["demod"][name] = {"ms": ms, "frames_per_s": args.frames / ms * 1e3}
         del raw
+    # transmission modes II-IV through the size-generic kernel (24 ms / 24 ms / 48 ms of signal per frame)
+    res["modes"] = {}
+    for mode in (2, 3, 4):
+        p = dabgpu.ofdm_params(mode)
+        F = 4 * args.frames
+        x = torch.randn((F * p["nb_frame_samples"] * 2,), dtype=torch.float32, device="cuda")
+        b = torch.empty((F, p["nb_frame_bits"]), dtype=torch.int8, device="cuda")
+        ms = timed(lambda: ctx.ofdm_demod_frames_mode(mode, x, F, b), args.reps)
+        algo = F * (p["nb_frame_samples"] * 8 + p["nb_frame_bits"])
+        res["modes"][f"mode_{mode}"] = {"frames": F, "ms": ms, "frames_per_s": F / ms * 1e3, "GB_per_s": algo / ms / 1e6,
+                                        "x_realtime": F / ms * 1e3 * p["nb_frame_samples"] / 2.048e6}
+        del x, b
     nb = args.frames * dabgpu.NB_FRAME_BITS // 8
     soft = torch.randint(-128, 128, (8 * nb,), dtype=torch.int8, device="cuda")
     hard = torch.empty(nb, dtype=torch.uint8, device="cuda")
