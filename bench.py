@@ -108,7 +108,17 @@ def cpu_baseline(seconds_target=12.0):
     per_thread = int(max(8, min(8 * seconds_target / probe, 4 * seconds_target / (dt1 / n1))))
     dt = run(per_thread)
     done = per_thread * cores
-    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "host_logical_cpus": os.cpu_count(),
             "single_thread_value": n1 / dt1,
             "sample": f"{done} frame demods (PLL+CP-phase+76xFFT2048+DQPSK+demap) cycling 4 distinct synthetic frames, "
                       f"{cores} host threads x {per_thread} frames, oracle/dab_oracle_ofdm.c dab_demod_frame "

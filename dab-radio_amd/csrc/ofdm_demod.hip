@@ -352,7 +352,9 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
-    const size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
+    size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
+    if (g_dabgpu_variant == 2) lds += 14 * 1024;      // development: 3 instead of 4 workgroups per CU (occupancy sensitivity)
+    if (g_dabgpu_variant == 3) lds += 42 * 1024;      // development: 2 workgroups per CU
     const dim3 grid((unsigned)(n_frames * chunks));
 #define DABGPU_LAUNCH(PF, SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC, BANK>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
