@@ -52,14 +52,22 @@ int dabgpu_device_count(void) {
     return usable;
 }
 
-// ---- built-in Mode I tables ----
-// ETSI EN 300 401 14.3.2 tables 23/24, Mode I (replaces get_DAB_PRS_reference, src/ofdm/dab_prs_ref.cpp:140-195)
-static const signed char PRS_ROW_I[48] = {
-    0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,
-    0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 };
-static const signed char PRS_ROW_N[48] = {
-    1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,
-    3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 };
+// ---- built-in tables ----
+// ETSI EN 300 401 14.3.2 tables 23/24 (mode I) and the mode II-IV tables of docs/DAB_implementation_in_SDR_detailed.pdf
+// appendix B, as (row of the h table, offset n) per block of 32 carriers, lowest carrier first
+// (replaces get_DAB_PRS_reference, src/ofdm/dab_prs_ref.cpp:25-195)
+static const signed char PRS_ROW_I[4][48] = {
+    { 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 },
+    { 0,1,2,3,0,1,  2,1,0,3,2,1 },
+    { 0,1,2,  3,2,1 },
+    { 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1 },
+};
+static const signed char PRS_ROW_N[4][48] = {
+    { 1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,  3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 },
+    { 2,3,2,2,1,2,  0,2,2,1,0,3 },
+    { 2,3,0,  2,2,2 },
+    { 0,1,1,2, 2,2,0,3, 3,1,3,2,  0,1,0,2, 0,1,2,2, 2,1,3,0 },
+};
 static const signed char PRS_H_TABLE[4][32] = {
     {0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1,0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1},
     {0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0,0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0},
@@ -69,15 +77,17 @@ static const signed char PRS_H_TABLE[4][32] = {
 
 int dabgpu_get_prs_fft_ref(int mode, float* out) {
     if (!out) return DABGPU_ERR_INVALID_ARG;
-    if (mode != 1) { dabgpu_set_error("transmission mode %d: only Mode I tables are built in", mode); return DABGPU_ERR_UNSUPPORTED; }
-    memset(out, 0, sizeof(float) * 2 * DABGPU_NB_FFT);
-    for (int row = 0; row < 48; row++) {
-        const int k_min = (row < 24) ? (-768 + 32 * row) : (1 + 32 * (row - 24));
+    int geom[9];
+    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
+    const int N = geom[3], nb = geom[5], rows = nb / 32, half = rows / 2;
+    memset(out, 0, sizeof(float) * 2 * (size_t)N);
+    for (int row = 0; row < rows; row++) {
+        const int k_min = (row < half) ? (-nb / 2 + 32 * row) : (1 + 32 * (row - half));
         for (int j = 0; j < 32; j++) {
             const int k = k_min + j;
-            const int h = PRS_H_TABLE[(int)PRS_ROW_I[row]][j];
-            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_ROW_N[row]);
-            const int bin = (k < 0) ? (DABGPU_NB_FFT + k) : k;
+            const int h = PRS_H_TABLE[(int)PRS_ROW_I[mode - 1][row]][j];
+            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_ROW_N[mode - 1][row]);
+            const int bin = (k < 0) ? (N + k) : k;
             out[2 * bin] = cosf(phi);
             out[2 * bin + 1] = sinf(phi);
         }
@@ -161,7 +171,7 @@ int dabgpu_create(dabgpu_ctx** out, int device, const float* h_prs, const int* h
     CK(hipMemcpy(c->d_inv_map, inv.data(), sizeof(uint16_t) * inv.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(c->d_prs, c->prs.data(), sizeof(float) * c->prs.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&c->d_prs_time_ref, sizeof(float) * 2 * DABGPU_NB_FFT));
-    CK(dabgpu_launch_sync_init(c->d_prs, c->d_tw, c->d_prs_time_ref, c->stream));     // ofdm_demodulator.cpp:134-140
+    CK(dabgpu_launch_sync_init(c->d_prs, c->d_tw, c->d_prs_time_ref, DABGPU_NB_FFT, c->stream));     // ofdm_demodulator.cpp:134-140
     CK(hipStreamSynchronize(c->stream));
 #undef CK
     *out = c;
@@ -177,6 +187,8 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     if (c->d_prs_time_ref) (void)hipFree(c->d_prs_time_ref);
     if (c->d_vit_tables) (void)hipFree(c->d_vit_tables);
     for (int* p : c->d_mode_mapper) if (p) (void)hipFree(p);
+    for (float* p : c->d_mode_prs) if (p) (void)hipFree(p);
+    for (float* p : c->d_mode_prs_time_ref) if (p) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -335,7 +347,19 @@ int dabgpu_ofdm_sync(dabgpu_ctx* c, const float* d_prs_syms, size_t n_streams, s
     if (n_streams == 0) return DABGPU_OK;
     if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
     return dabgpu_check_hip(dabgpu_launch_sync(d_prs_syms, stride_samples, (int)n_streams, cfg, d_states, d_impulse, d_freq,
-                                               c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, (hipStream_t)stream), "ofdm_sync_kernel launch");
+                                               c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, 1, (hipStream_t)stream), "ofdm_sync_kernel launch");
+}
+
+int dabgpu_ofdm_sync_mode(dabgpu_ctx* c, int mode, const float* d_prs_syms, size_t n_streams, size_t stride_samples, const dabgpu_sync_cfg* cfg,
+                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, void* stream) {
+    if (!c || !d_prs_syms || !cfg || !d_states) { dabgpu_set_error("ofdm_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_streams == 0) return DABGPU_OK;
+    if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync_mode: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
+    const float *d_prs, *d_ref;
+    int st = dabgpu_mode_sync_tables(c, mode, &d_prs, &d_ref);
+    if (st) return st;
+    return dabgpu_check_hip(dabgpu_launch_sync(d_prs_syms, stride_samples, (int)n_streams, cfg, d_states, d_impulse, d_freq,
+                                               c->d_tw, d_prs, d_ref, nullptr, mode, (hipStream_t)stream), "ofdm_sync_kernel launch");
 }
 
 int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* h_state,
@@ -362,6 +386,29 @@ int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabg
 }
 
 }  // extern "C"
+
+// PRS spectrum and coarse-sync reference of modes II-IV on the device, built on first use (ofdm_demodulator.cpp:128-140)
+int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const float** d_prs_time_ref) {
+    int geom[9];
+    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
+    if (mode == 1) { *d_prs = c->d_prs; *d_prs_time_ref = c->d_prs_time_ref; return DABGPU_OK; }
+    if (!c->d_mode_prs[mode]) {
+        const size_t bytes = sizeof(float) * 2 * (size_t)geom[3];
+        std::vector<float> prs(2 * (size_t)geom[3]);
+        int st = dabgpu_get_prs_fft_ref(mode, prs.data());
+        if (st) return st;
+        (void)hipSetDevice(c->device);
+        float *dp = nullptr, *dr = nullptr;
+        if ((st = dabgpu_check_hip(hipMalloc(&dp, bytes), "hipMalloc(mode prs)"))) return st;
+        if ((st = dabgpu_check_hip(hipMalloc(&dr, bytes), "hipMalloc(mode prs ref)"))) { (void)hipFree(dp); return st; }
+        if ((st = dabgpu_check_hip(hipMemcpy(dp, prs.data(), bytes, hipMemcpyHostToDevice), "hipMemcpy(mode prs)")) ||
+            (st = dabgpu_check_hip(dabgpu_launch_sync_init(dp, c->d_tw, dr, geom[3], c->stream), "sync_init_kernel launch")) ||
+            (st = dabgpu_check_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize"))) { (void)hipFree(dp); (void)hipFree(dr); return st; }
+        c->d_mode_prs[mode] = dp; c->d_mode_prs_time_ref[mode] = dr;
+    }
+    *d_prs = c->d_mode_prs[mode]; *d_prs_time_ref = c->d_mode_prs_time_ref[mode];
+    return DABGPU_OK;
+}
 
 // grow-only scratch slots owned by the context (never shrinks; freed in dabgpu_destroy)
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out) {

@@ -19,6 +19,8 @@ struct dabgpu_ctx {
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
     int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
+    float* d_mode_prs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // PRS spectra and coarse-sync references of modes II-IV
+    float* d_mode_prs_time_ref[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
 };
@@ -26,6 +28,8 @@ struct dabgpu_ctx {
 void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
+// device PRS spectrum / coarse-sync time reference of a transmission mode (mode I: the context's own tables)
+int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const float** d_prs_time_ref);
 
 // per-stream work item of a stream bank round (ofdm_stream.hip -> ofdm_demod.hip)
 struct dabgpu_frame_desc {
@@ -69,9 +73,10 @@ extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, hipStream_t stream);
 
 // ---- sync ----
-extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
                                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
-                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, hipStream_t stream);
+                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, int mode,
+                                         hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_cif_deinterleave(const int8_t* d_ring, int n_bits, int n_slots, int newest_slot,
                                                      int8_t* d_out, hipStream_t stream);

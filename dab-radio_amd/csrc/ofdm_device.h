@@ -135,4 +135,53 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- transmission-mode geometry (src/ofdm/dab_ofdm_params_ref.cpp:11-60) ----
+struct ModeGeom { int n_sym, period, null_period, n_fft, n_cp, n_carriers, frame_samples, sym_bits, frame_bits; };
+
+__host__ __device__ inline bool mode_geometry(int mode, ModeGeom& g) {
+    switch (mode) {
+    case 1: g.n_sym = 76; g.period = 2552; g.null_period = 2656; g.n_fft = 2048; g.n_carriers = 1536; break;
+    case 2: g.n_sym = 76; g.period = 638; g.null_period = 664; g.n_fft = 512; g.n_carriers = 384; break;
+    case 3: g.n_sym = 153; g.period = 319; g.null_period = 345; g.n_fft = 256; g.n_carriers = 192; break;
+    case 4: g.n_sym = 76; g.period = 1276; g.null_period = 1328; g.n_fft = 1024; g.n_carriers = 768; break;
+    default: return false;
+    }
+    g.n_cp = g.period - g.n_fft;
+    g.frame_samples = g.n_sym * g.period + g.null_period;
+    g.sym_bits = 2 * g.n_carriers;
+    g.frame_bits = (g.n_sym - 1) * g.sym_bits;
+    return true;
+}
+
+// ---- size-generic Stockham autosort passes through LDS (modes II-IV; same butterflies and twiddle rule as mode I) ----
+template <int R>
+__device__ __forceinline__ void butterfly(f2 (&a)[8]) {
+    if constexpr (R == 8) {
+        dft8(a);
+    } else if constexpr (R == 4) {
+        f2 b0, b1, b2, b3;
+        dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
+        a[0] = b0; a[1] = b1; a[2] = b2; a[3] = b3;
+    } else {
+        const f2 s = a[0] + a[1], d = a[0] - a[1];
+        a[0] = s; a[1] = d;
+    }
+}
+
+// one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst`
+template <int R>
+__device__ __forceinline__ void stockham_pass(const f2* __restrict__ src, f2* __restrict__ dst, int n_total, int cur_n, int s, bool last,
+                                              const f2* __restrict__ tw, int t) {
+    const int m = cur_n / R, tw_step = NB_FFT / cur_n;
+    for (int u = t; u < n_total / R; u += 256) {
+        const int q = u % s, p = u / s;
+        f2 a[8];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = src[q + s * (p + m * j)];
+        butterfly<R>(a);
+#pragma unroll
+        for (int k = 0; k < R; k++) dst[q + s * (R * p + k)] = (k == 0 || last) ? a[k] : cmul(a[k], tw[tw_step * p * k]);
+    }
+}
+
 }  // namespace dabgpu

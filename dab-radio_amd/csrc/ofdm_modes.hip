@@ -17,23 +17,6 @@
 
 namespace dabgpu {
 
-struct ModeGeom { int n_sym, period, null_period, n_fft, n_cp, n_carriers, frame_samples, sym_bits, frame_bits; };
-
-__host__ __device__ inline bool mode_geometry(int mode, ModeGeom& g) {
-    switch (mode) {
-    case 1: g.n_sym = 76; g.period = 2552; g.null_period = 2656; g.n_fft = 2048; g.n_carriers = 1536; break;
-    case 2: g.n_sym = 76; g.period = 638; g.null_period = 664; g.n_fft = 512; g.n_carriers = 384; break;
-    case 3: g.n_sym = 153; g.period = 319; g.null_period = 345; g.n_fft = 256; g.n_carriers = 192; break;
-    case 4: g.n_sym = 76; g.period = 1276; g.null_period = 1328; g.n_fft = 1024; g.n_carriers = 768; break;
-    default: return false;
-    }
-    g.n_cp = g.period - g.n_fft;
-    g.frame_samples = g.n_sym * g.period + g.null_period;
-    g.sym_bits = 2 * g.n_carriers;
-    g.frame_bits = (g.n_sym - 1) * g.sym_bits;
-    return true;
-}
-
 // scalar Chebyshev of apply_pll_scalar (chebyshev_sine.h:22-41, no fused operations)
 __device__ __forceinline__ float cheb_scalar(float x) {
     const float z = x * x;
@@ -60,36 +43,6 @@ __device__ __forceinline__ f2 pll_any(f2 v, int n, int period, float f, float dt
     dt_cos = dt_cos - __builtin_roundf(dt_cos);
     const float c = cheb_scalar(dt_cos), s = cheb_scalar(dt_sin);
     return mk2(v.x * c - v.y * s, v.x * s + v.y * c);
-}
-
-template <int R>
-__device__ __forceinline__ void butterfly(f2 (&a)[8]) {
-    if constexpr (R == 8) {
-        dft8(a);
-    } else if constexpr (R == 4) {
-        f2 b0, b1, b2, b3;
-        dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
-        a[0] = b0; a[1] = b1; a[2] = b2; a[3] = b3;
-    } else {
-        const f2 s = a[0] + a[1], d = a[0] - a[1];
-        a[0] = s; a[1] = d;
-    }
-}
-
-// one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst`
-template <int R>
-__device__ __forceinline__ void stockham_pass(const f2* __restrict__ src, f2* __restrict__ dst, int n_total, int cur_n, int s, bool last,
-                                              const f2* __restrict__ tw, int t) {
-    const int m = cur_n / R, tw_step = NB_FFT / cur_n;
-    for (int u = t; u < n_total / R; u += 256) {
-        const int q = u % s, p = u / s;
-        f2 a[8];
-#pragma unroll
-        for (int j = 0; j < R; j++) a[j] = src[q + s * (p + m * j)];
-        butterfly<R>(a);
-#pragma unroll
-        for (int k = 0; k < R; k++) dst[q + s * (R * p + k)] = (k == 0 || last) ? a[k] : cmul(a[k], tw[tw_step * p * k]);
-    }
 }
 
 __global__ __launch_bounds__(256)
@@ -242,5 +195,65 @@ int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, si
                        c->d_mode_mapper[mode], (int)n_frames, symbols_per_block, chunks);
     return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_mode_kernel launch");
 }
+
+// ---- single-stream, host-buffer forms for the OFDM_Demod mirror class in modes II-IV ----
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+
+int dabgpu_ofdm_demod_stream_frame_sync_mode(dabgpu_ctx* c, int mode, const float* h_iq, float freq_coarse, float* h_freq_fine, float beta,
+                                             int8_t* h_bits, float* h_total_phase, float* h_fft) {
+    ModeGeom g;
+    if (!c || !h_iq || !h_bits || !h_freq_fine) { dabgpu_set_error("ofdm_demod_stream_frame_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_stream_frame_sync_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    if (mode == 1) return dabgpu_ofdm_demod_stream_frame_sync(c, h_iq, freq_coarse, h_freq_fine, beta, h_bits, h_total_phase, h_fft, nullptr);
+    int st;
+    (void)hipSetDevice(c->device);
+    const size_t iq_bytes = (size_t)g.frame_samples * 2 * sizeof(float);
+    const size_t fft_bytes = (size_t)(g.n_sym + 1) * g.n_fft * 2 * sizeof(float);
+    float *d_iq, *d_small, *d_corr, *d_fft = nullptr; int8_t* d_bits;
+    if ((st = dabgpu_scratch(c, 1, iq_bytes, (void**)&d_iq))) return st;
+    if ((st = dabgpu_scratch(c, 2, (size_t)g.frame_bits, (void**)&d_bits))) return st;
+    if ((st = dabgpu_scratch(c, 3, 4 * sizeof(float), (void**)&d_small))) return st;       // [0] net freq, [1] fine, [2] total phase
+    if ((st = dabgpu_scratch(c, 4, (size_t)g.n_sym * 2 * sizeof(float), (void**)&d_corr))) return st;
+    if (h_fft && (st = dabgpu_scratch(c, 6, fft_bytes, (void**)&d_fft))) return st;
+    hipStream_t s = c->stream;
+    const float h_small[2] = { freq_coarse + *h_freq_fine, *h_freq_fine };
+    CK(hipMemcpyAsync(d_iq, h_iq, iq_bytes, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_small, h_small, sizeof(h_small), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_ofdm_demod_frames_mode(c, mode, d_iq, 1, d_small, d_bits, d_corr, d_fft, 0, s))) return st;
+    if ((st = dabgpu_ofdm_phase_update_mode(c, mode, d_corr, 1, beta, d_small + 2, d_small + 1, s))) return st;
+    CK(hipMemcpyAsync(h_bits, d_bits, (size_t)g.frame_bits, hipMemcpyDeviceToHost, s));
+    float back[2];
+    CK(hipMemcpyAsync(back, d_small + 1, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h_fft) CK(hipMemcpyAsync(h_fft, d_fft, fft_bytes, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    *h_freq_fine = back[0];
+    if (h_total_phase) *h_total_phase = back[1];
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_sync_host_sync_mode(dabgpu_ctx* c, int mode, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* h_state,
+                                    float* h_impulse, float* h_freq) {
+    ModeGeom g;
+    if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_sync_host_sync_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    int st;
+    const size_t N = (size_t)g.n_fft;
+    float *d_sym, *d_imp, *d_frq; dabgpu_sync_state* d_st;
+    if ((st = dabgpu_scratch(c, 7, sizeof(float) * 2 * DABGPU_NB_FFT, (void**)&d_sym))) return st;
+    if ((st = dabgpu_scratch(c, 8, sizeof(dabgpu_sync_state), (void**)&d_st))) return st;
+    if ((st = dabgpu_scratch(c, 9, sizeof(float) * 2 * DABGPU_NB_FFT, (void**)&d_imp))) return st;
+    d_frq = d_imp + DABGPU_NB_FFT;
+    hipStream_t s = c->stream;
+    CK(hipMemcpyAsync(d_sym, h_prs_sym, sizeof(float) * 2 * N, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_st, h_state, sizeof(dabgpu_sync_state), hipMemcpyHostToDevice, s));
+    if ((st = dabgpu_ofdm_sync_mode(c, mode, d_sym, 1, N, cfg, d_st, d_imp, d_frq, s))) return st;
+    CK(hipMemcpyAsync(h_state, d_st, sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, s));
+    if (h_impulse) CK(hipMemcpyAsync(h_impulse, d_imp, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+    if (h_freq) CK(hipMemcpyAsync(h_freq, d_frq, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    return DABGPU_OK;
+}
+#undef CK
 
 }  // extern "C"

@@ -469,7 +469,7 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
                            stream_stride_samples);
         CK(hipGetLastError());
         CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
-                              nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, s));
+                              nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, 1, s));
         CK(dabgpu_launch_ofdm_demod(b->view.frame, 0, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
                                     n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,

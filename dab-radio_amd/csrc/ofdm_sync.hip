@@ -57,8 +57,8 @@ __device__ __forceinline__ float undb20_det(float db) {
 }
 
 // UpdateFineFrequencyOffset (ofdm_demodulator.cpp:829-840)
-__device__ __forceinline__ float fine_freq_add(float fine, float delta) {
-    const float spacing = 1.0f / (float)NB_FFT;
+__device__ __forceinline__ float fine_freq_add(float fine, float delta, int n_fft) {
+    const float spacing = 1.0f / (float)n_fft;
     const float wrap = 0.5f * spacing * 1.01f;
     fine += delta;
     return fmodf(fine, wrap);
@@ -118,6 +118,29 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
     __syncthreads();
 }
 
+// transform of any supported length between natural-order LDS arrays: the register-resident 2048-point version above, or
+// Stockham passes r1 x 8 x 8 [x 8] alternating between `tmp` and `y` so that the last pass lands in `y`
+__device__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __restrict__ tw, bool conj_io) {
+    if (N == NB_FFT) { fft2048_lds(x, y, tmp, patch0, tw, conj_io); return; }
+    const int t = threadIdx.x;
+    if (conj_io) { for (int i = t; i < N; i += 256) x[i].y = -x[i].y; __syncthreads(); }
+    const int r1 = (N == 256) ? 4 : (N == 1024 ? 2 : 8);
+    const int n_pass = (N == 1024) ? 4 : 3;
+    const f2* src = x;
+    int cur_n = N, s = 1;
+    for (int ps = 0; ps < n_pass; ps++) {
+        const int r = (ps == 0) ? r1 : 8;
+        const bool last = (ps == n_pass - 1);
+        f2* dst = (((n_pass - 1 - ps) & 1) == 0) ? y : tmp;
+        if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t);
+        else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t);
+        else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t);
+        __syncthreads();
+        src = dst; cur_n /= r; s *= r;
+    }
+    if (conj_io) { for (int i = t; i < N; i += 256) y[i].y = -y[i].y; __syncthreads(); }
+}
+
 struct SyncLds {
     f2 X[NB_FFT];
     f2 Y[NB_FFT];
@@ -151,22 +174,22 @@ __device__ __forceinline__ void argmax_reduce(float& v, int& i, SyncLds* S) {
 
 // constructor-time reference of the coarse sync (ofdm_demodulator.cpp:134-140): conj(IFFT(relative_phase(PRS)))
 __global__ __launch_bounds__(256)
-void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2* __restrict__ prs_time_ref) {
+void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2* __restrict__ prs_time_ref, int N) {
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
     const int t = threadIdx.x;
-    for (int i = t; i < NB_FFT; i += 256)
-        S->X[i] = (i < NB_FFT - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);      // CalculateRelativePhase :901-909
+    for (int i = t; i < N; i += 256)
+        S->X[i] = (i < N - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);           // CalculateRelativePhase :901-909
     __syncthreads();
-    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);
-    for (int i = t; i < NB_FFT; i += 256) prs_time_ref[i] = mk2(S->Y[i].x, -S->Y[i].y);
+    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);
+    for (int i = t; i < N; i += 256) prs_time_ref[i] = mk2(S->Y[i].x, -S->Y[i].y);
 }
 
 __global__ __launch_bounds__(256)
 void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, int n_streams, dabgpu_sync_cfg cfg,
                       dabgpu_sync_state* __restrict__ states, float* __restrict__ impulse_out, float* __restrict__ freq_out,
                       const f2* __restrict__ tw, const f2* __restrict__ prs_fft, const f2* __restrict__ prs_time_ref,
-                      const int* __restrict__ active)
+                      const int* __restrict__ active, ModeGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
@@ -176,20 +199,20 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     if (active != nullptr && active[sidx] == 0) return;        // stream banks: only streams whose PRS window just filled
     const f2* prs_sym = prs_syms + (size_t)sidx * stride_samples;
     dabgpu_sync_state st = states[sidx];
-    const int N = NB_FFT, M = N / 2;
+    const int N = g.n_fft, M = N / 2;
 
     // ================= coarse frequency sync (:360-471) =================
     if (cfg.is_coarse_freq_correction) {
         for (int i = t; i < N; i += 256) S->X[i] = prs_sym[i];
         __syncthreads();
-        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                              // :377
+        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                               // :377
         for (int i = t; i < N; i += 256)
             S->X[i] = (i < N - 1) ? conj_mul(S->Y[i + 1], S->Y[i]) : mk2(0.0f, 0.0f);       // :380
         __syncthreads();
-        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);                               // :383
+        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);                                // :383
         for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], prs_time_ref[i]);          // :387-389
         __syncthreads();
-        fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                              // :392
+        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                               // :392
         for (int i = t; i < N; i += 256) {                                                  // :911-920
             const float r = db20_det(cabs_det(S->Y[(i + M) % N]));
             S->R[i] = r;
@@ -234,7 +257,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
             const float delta = beta * error;
             st.freq_coarse += delta;                                                        // :461
             st.is_found_coarse = 1;
-            st.freq_fine = fine_freq_add(st.freq_fine, -delta);                             // :467
+            st.freq_fine = fine_freq_add(st.freq_fine, -delta, N);                          // :467
             S->reds[0] = st.freq_coarse; S->reds[1] = st.freq_fine;
         }
         __syncthreads();
@@ -253,10 +276,10 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         S->X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
     }
     __syncthreads();
-    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, false);                                  // :487
+    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                                   // :487
     for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], mk2(prs_fft[i].x, -prs_fft[i].y));   // :488-490
     __syncthreads();
-    fft2048_lds(S->X, S->Y, S->bufA, S->patch, tw, true);                                   // :493
+    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);                                    // :493
     for (int i = t; i < N; i += 256) {                                                      // :494-498
         const float r = db20_det(cabs_det(S->Y[i]));
         S->R[i] = r;
@@ -267,13 +290,12 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     const float decay = 1.0f - cfg.impulse_peak_distance_probability;
     float bv = -__builtin_inff(); int bi = 0x7FFFFFFF;
     float leaf = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < N / 256; j++) {
         const int i = t + 256 * j;
         const float r = S->R[i];
         leaf = (j == 0) ? r : (leaf + r);
-        const int dist = abs(NB_CP - i);
-        const float norm_dist = (float)dist / (float)NB_SYMBOL_PERIOD;
+        const int dist = abs(g.n_cp - i);
+        const float norm_dist = (float)dist / (float)g.period;
         const float prob = 1.0f - decay * norm_dist;
         const float w = prob * r;
         if (w > bv || (w == bv && i < bi)) { bv = w; bi = i; }
@@ -290,26 +312,29 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         if (bv > r0) { max_value = bv; max_index = bi; }
         const bool valid = !((max_value - avg) < cfg.impulse_peak_threshold_db);            // :529
         st.sync_valid = valid ? 1 : 0;
-        if (valid) st.fine_time_offset = max_index - NB_CP;                                 // :536
+        if (valid) st.fine_time_offset = max_index - g.n_cp;                               // :536
         states[sidx] = st;
     }
 }
 
 }  // namespace dabgpu
 
-extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, hipStream_t stream) {
+extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream) {
     using namespace dabgpu;
     hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(256), sizeof(SyncLds), stream,
-                       reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_tw), reinterpret_cast<f2*>(d_prs_time_ref));
+                       reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_tw), reinterpret_cast<f2*>(d_prs_time_ref), n_fft);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,
                                          dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, const float* d_tw,
-                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, hipStream_t stream) {
+                                         const float* d_prs, const float* d_prs_time_ref, const int* d_active, int mode,
+                                         hipStream_t stream) {
     using namespace dabgpu;
+    ModeGeom g;
+    if (!mode_geometry(mode, g)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ofdm_sync_kernel, dim3((unsigned)n_streams), dim3(256), sizeof(SyncLds), stream,
                        reinterpret_cast<const f2*>(d_prs_syms), stride_samples, n_streams, *cfg, d_states, d_impulse, d_freq,
-                       reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref), d_active);
+                       reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref), d_active, g);
     return hipGetLastError();
 }

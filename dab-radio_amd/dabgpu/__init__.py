@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
     "dabgpu_dabplus_process_frame_host_sync",
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
+    "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -186,6 +187,9 @@ def lib():
                                                   C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_dabplus_process_frame_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                              C.c_void_p, C.c_void_p]
+        L.dabgpu_ofdm_sync_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        L.dabgpu_ofdm_sync_host_sync_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_get_ofdm_params.argtypes = [C.c_int, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -287,6 +291,19 @@ class Context:
         """frame-aligned frames of transmission mode 1..4 through the size-generic kernel"""
         check(lib().dabgpu_ofdm_demod_frames_mode(self._h, int(mode), _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
                                                   _ptr(fft), symbols_per_block, self._stream(stream)), "dabgpu_ofdm_demod_frames_mode")
+
+    def ofdm_sync_host_mode(self, mode, prs_sym, state, cfg=None):
+        """numpy convenience over dabgpu_ofdm_sync_host_sync_mode: returns (impulse_db[nb_fft], freq_response_db[nb_fft])"""
+        import numpy as np
+        n = ofdm_params(mode)["nb_fft"]
+        cfg = cfg or sync_cfg_default()
+        sym = np.ascontiguousarray(prs_sym, dtype=np.complex64).reshape(-1)
+        assert sym.size == n
+        imp = np.empty(n, dtype=np.float32)
+        frq = np.empty(n, dtype=np.float32)
+        check(lib().dabgpu_ofdm_sync_host_sync_mode(self._h, int(mode), _ptr(sym), C.byref(cfg), C.byref(state), _ptr(imp), _ptr(frq)),
+              "dabgpu_ofdm_sync_host_sync_mode")
+        return imp, frq
 
     def ofdm_phase_update_mode(self, mode, cp_corr, n_frames, total_phase=None, fine_freq=None, beta=0.9, stream=None):
         check(lib().dabgpu_ofdm_phase_update_mode(self._h, int(mode), _ptr(cp_corr), n_frames, beta, _ptr(total_phase), _ptr(fine_freq),

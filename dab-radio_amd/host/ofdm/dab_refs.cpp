@@ -1,6 +1,5 @@
 // ofdm/dab_refs.cpp -- Mode parameters, PRS spectrum and carrier map, host side.
-// Mode I tables come from the C ABI (the same tables the device context uses); modes II-IV are geometry only
-// (the kernels are Mode I; see DESIGN.md "out of scope").
+// All tables come from the C ABI (the same tables the device context uses), transmission modes I-IV.
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,20 +27,23 @@ OFDM_Params get_DAB_OFDM_params(const int transmission_mode) {
 }
 
 void get_DAB_PRS_reference(const int transmission_mode, tcb::span<std::complex<float>> buf) {
-    if (transmission_mode < 1 || transmission_mode > 4)
+    int g[9];
+    if (dabgpu_get_ofdm_params(transmission_mode, g) != DABGPU_OK)
         throw std::runtime_error("Invalid transmission mode " + std::to_string(transmission_mode));
-    if (transmission_mode != 1)
-        throw std::runtime_error("dabgpu: only the Mode I phase reference symbol is built in");
-    if (buf.size() < DABGPU_NB_DATA_CARRIERS + 1)
-        throw std::runtime_error("FFT buffer not large enough to fit phase reference symbol");
-    std::vector<float> tmp(2 * DABGPU_NB_FFT);
-    if (buf.size() != DABGPU_NB_FFT || dabgpu_get_prs_fft_ref(1, tmp.data()) != DABGPU_OK)
-        throw std::runtime_error("dabgpu: Mode I PRS needs a 2048-bin buffer");
+    if ((int)buf.size() < g[5] + 1) throw std::runtime_error("FFT buffer not large enough to fit phase reference symbol");
+    if ((int)buf.size() != g[3]) throw std::runtime_error("dabgpu: the PRS of a transmission mode needs a buffer of its FFT size");
+    std::vector<float> tmp(2 * (size_t)g[3]);
+    if (dabgpu_get_prs_fft_ref(transmission_mode, tmp.data()) != DABGPU_OK) throw std::runtime_error(dabgpu_last_error());
     for (size_t i = 0; i < buf.size(); i++) buf[i] = std::complex<float>(tmp[2 * i], tmp[2 * i + 1]);
 }
 
 void get_DAB_mapper_ref(tcb::span<int> carrier_map, const size_t nb_fft) {
-    if (nb_fft != DABGPU_NB_FFT || carrier_map.size() != DABGPU_NB_DATA_CARRIERS ||
-        dabgpu_get_carrier_mapper(1, carrier_map.data()) != DABGPU_OK)
-        throw std::runtime_error("dabgpu: only the Mode I carrier map (2048 bins, 1536 carriers) is built in");
+    for (int mode = 1; mode <= 4; mode++) {
+        int g[9];
+        if (dabgpu_get_ofdm_params(mode, g) == DABGPU_OK && (size_t)g[3] == nb_fft && (size_t)g[5] == carrier_map.size()) {
+            if (dabgpu_get_carrier_mapper(mode, carrier_map.data()) != DABGPU_OK) throw std::runtime_error(dabgpu_last_error());
+            return;
+        }
+    }
+    throw std::runtime_error("dabgpu: carrier maps exist for the DAB transmission modes I-IV (fft size / carrier count pairs) only");
 }

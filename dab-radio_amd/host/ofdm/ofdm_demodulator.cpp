@@ -19,19 +19,35 @@ namespace {
 OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::complex<float>> prs_fft_ref,
                        const tcb::span<const int> carrier_mapper, int /*nb_desired_threads*/)
     : m_params(params) {
-    if (params.nb_fft != DABGPU_NB_FFT || params.nb_frame_symbols != DABGPU_NB_FRAME_SYMBOLS ||
-        params.nb_symbol_period != DABGPU_NB_SYMBOL_PERIOD || params.nb_null_period != DABGPU_NB_NULL_PERIOD ||
-        params.nb_data_carriers != DABGPU_NB_DATA_CARRIERS)
-        throw std::runtime_error("OFDM_Demod: the MI355X kernels implement transmission mode I only");
+    // the kernels exist for the four DAB geometries (src/ofdm/dab_ofdm_params_ref.cpp:11-60); anything else has no device path
+    for (int mode = 1; mode <= 4 && m_mode == 0; mode++) {
+        int g[9];
+        if (dabgpu_get_ofdm_params(mode, g) != DABGPU_OK) continue;
+        if ((int)params.nb_frame_symbols == g[0] && (int)params.nb_symbol_period == g[1] && (int)params.nb_null_period == g[2] &&
+            (int)params.nb_fft == g[3] && (int)params.nb_cyclic_prefix == g[4] && (int)params.nb_data_carriers == g[5]) m_mode = mode;
+    }
+    if (m_mode == 0) throw std::runtime_error("OFDM_Demod: the MI355X kernels implement the DAB transmission modes I-IV only");
     if (prs_fft_ref.size() < params.nb_fft || carrier_mapper.size() < params.nb_data_carriers)
         throw std::runtime_error("OFDM_Demod: PRS reference / carrier mapper too small");
     const char* dev = std::getenv("DABGPU_DEVICE");
-    const int st = dabgpu_create(&m_ctx, dev ? std::atoi(dev) : 0, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+    int st;
+    if (m_mode == 1) {
+        st = dabgpu_create(&m_ctx, dev ? std::atoi(dev) : 0, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+    } else {
+        // modes II-IV run on the library's built-in tables of that mode: a caller-supplied table must be that table
+        std::vector<float> prs(2 * params.nb_fft);
+        std::vector<int> map(params.nb_data_carriers);
+        if (dabgpu_get_prs_fft_ref(m_mode, prs.data()) != DABGPU_OK || dabgpu_get_carrier_mapper(m_mode, map.data()) != DABGPU_OK ||
+            std::memcmp(prs.data(), prs_fft_ref.data(), prs.size() * sizeof(float)) != 0 ||
+            std::memcmp(map.data(), carrier_mapper.data(), map.size() * sizeof(int)) != 0)
+            throw std::runtime_error("OFDM_Demod: custom PRS / carrier tables are only supported in transmission mode I");
+        st = dabgpu_create(&m_ctx, dev ? std::atoi(dev) : 0, nullptr, nullptr);
+    }
     if (st != DABGPU_OK) fail("dabgpu_create", st);       // no CPU fallback: a missing GPU is a construction error
     m_ring.assign(params.nb_null_period, {0.0f, 0.0f});
     m_corr.assign(params.nb_null_period + params.nb_symbol_period, {0.0f, 0.0f});
-    m_frame.assign(DABGPU_NB_FRAME_SAMPLES, {0.0f, 0.0f});
-    m_frame_bits.assign(DABGPU_NB_FRAME_BITS, 0);
+    m_frame.assign(params.nb_frame_symbols * params.nb_symbol_period + params.nb_null_period, {0.0f, 0.0f});
+    m_frame_bits.assign((params.nb_frame_symbols - 1) * params.nb_data_carriers * 2, 0);
     m_frame_fft.assign((params.nb_frame_symbols + 1) * params.nb_fft, {0.0f, 0.0f});
     m_frame_dqpsk.assign((params.nb_frame_symbols - 1) * params.nb_fft, {0.0f, 0.0f});
     m_impulse_response.assign(params.nb_fft, 0.0f);
@@ -141,9 +157,10 @@ void OFDM_Demod::RunSync() {
     st.reserved = 0;
     m_state = RUNNING_FINE_TIME_SYNC;
     const auto* prs_sym = &m_corr[m_params.nb_null_period];
-    const int rc = dabgpu_ofdm_sync_host_sync(m_ctx, reinterpret_cast<const float*>(prs_sym), &cfg, &st, m_impulse_response.data(),
-                                              cfg.is_coarse_freq_correction ? m_frequency_response.data() : nullptr);
-    if (rc != DABGPU_OK) fail("dabgpu_ofdm_sync_host_sync", rc);
+    const int rc = dabgpu_ofdm_sync_host_sync_mode(m_ctx, m_mode, reinterpret_cast<const float*>(prs_sym), &cfg, &st,
+                                                   m_impulse_response.data(),
+                                                   cfg.is_coarse_freq_correction ? m_frequency_response.data() : nullptr);
+    if (rc != DABGPU_OK) fail("dabgpu_ofdm_sync_host_sync_mode", rc);
     m_freq_coarse = st.freq_coarse;
     m_freq_fine = st.freq_fine;
     m_is_found_coarse = st.is_found_coarse != 0;
@@ -179,10 +196,15 @@ size_t OFDM_Demod::ReadSymbols(tcb::span<const std::complex<float>> buf) {
 // :581-639 (coordinator) + :650-766 (pipelines) for one frame
 void OFDM_Demod::DemodulateFrame() {
     float fine = m_freq_fine;
-    const int rc = dabgpu_ofdm_demod_stream_frame_sync(
-        m_ctx, reinterpret_cast<const float*>(m_frame.data()), m_freq_coarse, &fine, m_cfg.sync.fine_freq_update_beta,
-        m_frame_bits.data(), nullptr, m_fetch_debug ? reinterpret_cast<float*>(m_frame_fft.data()) : nullptr,
-        m_fetch_debug ? reinterpret_cast<float*>(m_frame_dqpsk.data()) : nullptr);
+    // mode I: the register-resident kernel (also fills GetFrameDataVec); modes II-IV: the size-generic kernel
+    const int rc = (m_mode == 1)
+        ? dabgpu_ofdm_demod_stream_frame_sync(
+              m_ctx, reinterpret_cast<const float*>(m_frame.data()), m_freq_coarse, &fine, m_cfg.sync.fine_freq_update_beta,
+              m_frame_bits.data(), nullptr, m_fetch_debug ? reinterpret_cast<float*>(m_frame_fft.data()) : nullptr,
+              m_fetch_debug ? reinterpret_cast<float*>(m_frame_dqpsk.data()) : nullptr)
+        : dabgpu_ofdm_demod_stream_frame_sync_mode(
+              m_ctx, m_mode, reinterpret_cast<const float*>(m_frame.data()), m_freq_coarse, &fine, m_cfg.sync.fine_freq_update_beta,
+              m_frame_bits.data(), nullptr, m_fetch_debug ? reinterpret_cast<float*>(m_frame_fft.data()) : nullptr);
     if (rc != DABGPU_OK) fail("dabgpu_ofdm_demod_stream_frame_sync", rc);
     m_freq_fine = fine;
     m_total_frames_read++;

@@ -99,6 +99,7 @@ private:
     OFDM_Demod_Config m_cfg;
     State m_state = FINDING_NULL_POWER_DIP;
     const OFDM_Params m_params;
+    int m_mode = 0;                          // transmission mode 1..4 matching m_params
     dabgpu_ctx* m_ctx = nullptr;
     int m_total_frames_read = 0;
     int m_total_frames_desync = 0;

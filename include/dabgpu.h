@@ -306,6 +306,17 @@ int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx *ctx, int transmission_mode, const 
                                   void *stream);
 int dabgpu_ofdm_phase_update_mode(dabgpu_ctx *ctx, int transmission_mode, const float *d_cp_corr, size_t n_frames,
                                   float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
+/* PRS synchronisation (dabgpu_ofdm_sync) for any mode: d_prs_syms = nb_fft samples per stream; d_impulse / d_freq_response
+ * [n_streams][nb_fft].  The PRS spectrum of the mode (get_DAB_PRS_reference, src/ofdm/dab_prs_ref.cpp:140-195) and the
+ * coarse-sync reference are built on the context at first use. */
+int dabgpu_ofdm_sync_mode(dabgpu_ctx *ctx, int transmission_mode, const float *d_prs_syms, size_t n_streams, size_t stride_samples,
+                          const dabgpu_sync_cfg *cfg, dabgpu_sync_state *d_states, float *d_impulse, float *d_freq_response, void *stream);
+/* single-stream host-buffer forms used by the OFDM_Demod mirror class in modes II-IV (h_fft [nb_frame_symbols+1][nb_fft]) */
+int dabgpu_ofdm_demod_stream_frame_sync_mode(dabgpu_ctx *ctx, int transmission_mode, const float *h_iq, float freq_coarse,
+                                             float *h_freq_fine, float fine_freq_update_beta, int8_t *h_bits, float *h_total_phase,
+                                             float *h_fft);
+int dabgpu_ofdm_sync_host_sync_mode(dabgpu_ctx *ctx, int transmission_mode, const float *h_prs_sym, const dabgpu_sync_cfg *cfg,
+                                    dabgpu_sync_state *h_state, float *h_impulse, float *h_freq_response);
 
 /* ==================================================================================================
  * Unsynchronised front end on the device: a bank of n independent receivers whose state between

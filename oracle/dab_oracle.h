@@ -274,6 +274,14 @@ dab_cf32 dab_cp_correlation_n(const dab_cf32 *sym, int nb_fft, int nb_cp);
 float dab_demod_frame_mode(int mode, const dab_cf32 *frame, float f, const int *mapper, int8_t *bits, dab_cf32 *cp_corr,
                            float *cp_phase, dab_cf32 *fft_out);
 float dab_update_fine_freq_mode(int mode, float fine, float total_phase_error, float beta);
+/* get_DAB_PRS_reference (src/ofdm/dab_prs_ref.cpp:140-195) and the PRS synchronisation of OFDM_Demod for any mode; the mode I
+ * instances equal dab_get_prs_fft / dab_sync_refs / dab_coarse_freq_sync / dab_fine_time_sync bit for bit */
+int dab_get_prs_fft_mode(int mode, dab_cf32 *prs /*[nb_fft]*/);
+void dab_sync_refs_mode(int mode, const dab_cf32 *prs_fft, dab_cf32 *prs_fft_conj, dab_cf32 *prs_time_ref);
+void dab_coarse_freq_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32 *prs_time_ref, const dab_sync_cfg *cfg,
+                               dab_sync_state *st, float *freq_response);
+int dab_fine_time_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32 *prs_fft_conj, const dab_sync_cfg *cfg,
+                            float freq_offset, int *offset, float *impulse_response);
 
 #ifdef __cplusplus
 }

@@ -695,3 +695,152 @@ float dab_update_fine_freq_mode(int mode, float fine, float total_phase_error, f
     fine += delta;
     return fmodf(fine, wrap);
 }
+
+/* ---- phase reference symbol and PRS synchronisation for any mode ---- */
+
+/* ETSI EN 300 401 clause 14.3.2 (tables for modes II-IV: docs/DAB_implementation_in_SDR_detailed.pdf appendix B; the same
+ * data as src/ofdm/dab_prs_ref.cpp:25-120): per 32-carrier block the row i of the h table and the offset n */
+static const signed char PRS_ROWS_I[4][48] = {
+    { 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 },
+    { 0,1,2,3,0,1,  2,1,0,3,2,1 },
+    { 0,1,2,  3,2,1 },
+    { 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1 },
+};
+static const signed char PRS_ROWS_N[4][48] = {
+    { 1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,  3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 },
+    { 2,3,2,2,1,2,  0,2,2,1,0,3 },
+    { 2,3,0,  2,2,2 },
+    { 0,1,1,2, 2,2,0,3, 3,1,3,2,  0,1,0,2, 0,1,2,2, 2,1,3,0 },
+};
+
+int dab_get_prs_fft_mode(int mode, dab_cf32 *prs) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return -1;
+    const int N = g.nb_fft, rows = g.nb_carriers / 32, half = rows / 2;
+    memset(prs, 0, sizeof(dab_cf32) * (size_t)N);
+    for (int row = 0; row < rows; row++) {
+        const int k_min = (row < half) ? (-g.nb_carriers / 2 + 32 * row) : (1 + 32 * (row - half));
+        for (int j = 0; j < 32; j++) {
+            const int k = k_min + j;
+            const int h = PRS_H[(int)PRS_ROWS_I[mode - 1][row]][j];
+            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_ROWS_N[mode - 1][row]);
+            const int bin = (k < 0) ? (N + k) : k;
+            prs[bin].re = cosf(phi);
+            prs[bin].im = sinf(phi);
+        }
+    }
+    return 0;
+}
+
+static void relative_phase_n(int n, const dab_cf32 *in, dab_cf32 *out) {
+    for (int i = 0; i < n - 1; i++) out[i] = conj_mul(in[i + 1], in[i]);
+    out[n - 1].re = 0.0f; out[n - 1].im = 0.0f;
+}
+
+void dab_sync_refs_mode(int mode, const dab_cf32 *prs_fft, dab_cf32 *prs_fft_conj, dab_cf32 *prs_time_ref) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return;
+    const int N = g.nb_fft;
+    dab_cf32 tmp[DAB_NB_FFT];
+    for (int i = 0; i < N; i++) { prs_fft_conj[i].re = prs_fft[i].re; prs_fft_conj[i].im = -prs_fft[i].im; }
+    relative_phase_n(N, prs_fft, tmp);
+    dab_fft_n(N, tmp, prs_time_ref, 1);
+    for (int i = 0; i < N; i++) prs_time_ref[i].im = -prs_time_ref[i].im;
+}
+
+/* leaf t sums elements t, t+256, ... sequentially, then the 256-leaf tree (n >= 256) */
+static float tree_sum_n(int n, const float *v) {
+    float a[256];
+    for (int t = 0; t < 256; t++) {
+        float s = v[t];
+        for (int j = 1; j < n / 256; j++) s += v[t + 256 * j];
+        a[t] = s;
+    }
+    return tree256(a);
+}
+
+static float fine_freq_add_n(int n, float fine, float delta) {
+    const float spacing = 1.0f / (float)n;
+    const float wrap = 0.5f * spacing * 1.01f;
+    fine += delta;
+    return fmodf(fine, wrap);
+}
+
+void dab_coarse_freq_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32 *prs_time_ref, const dab_sync_cfg *cfg,
+                               dab_sync_state *st, float *freq_response) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return;
+    if (!cfg->is_coarse_freq_correction) { st->freq_coarse = 0.0f; return; }
+    const int N = g.nb_fft, M = N / 2;
+    dab_cf32 A[DAB_NB_FFT], B[DAB_NB_FFT];
+    float resp[DAB_NB_FFT];
+    dab_fft_n(N, prs_sym, A, 0);
+    relative_phase_n(N, A, B);
+    dab_fft_n(N, B, A, 1);
+    for (int i = 0; i < N; i++) A[i] = cmul(A[i], prs_time_ref[i]);
+    dab_fft_n(N, A, B, 0);
+    for (int i = 0; i < N; i++) resp[i] = dab_db20f(dab_cabsf(B[(i + M) % N]));
+    if (freq_response) memcpy(freq_response, resp, sizeof(float) * (size_t)N);
+    int max_off = (int)(cfg->max_coarse_freq_correction_norm * (float)N);
+    if (max_off < 0) max_off = 0;
+    if (max_off > M) max_off = M;
+    int max_index = -max_off;
+    float max_value = resp[max_index + M];
+    for (int i = -max_off; i <= max_off; i++) {
+        const int idx = i + M;
+        if (idx == N) continue;
+        if (resp[idx] > max_value) { max_value = resp[idx]; max_index = i; }
+    }
+    int pidx[3]; float pmag[3];
+    for (int j = 0; j < 3; j++) {
+        int index = max_index - 1 + j;
+        if (index < -max_off) index = -max_off;
+        if (index > max_off) index = max_off;
+        int fi = index + M;
+        if (fi >= N) fi = N - 1;
+        pidx[j] = fi - M;
+        pmag[j] = dab_undb20f(resp[fi]);
+    }
+    float peak_sum = 0.0f, lerp = 0.0f;
+    for (int j = 0; j < 3; j++) peak_sum += pmag[j];
+    for (int j = 0; j < 3; j++) lerp += (float)pidx[j] * pmag[j] / peak_sum;
+    const float predicted = -lerp / (float)N;
+    const float error = predicted - st->freq_coarse;
+    const float large_thresh = 1.5f / (float)N;
+    const int is_large = fabsf(error) > large_thresh;
+    const int is_fast = is_large || !st->is_found_coarse;
+    const float beta = is_fast ? 1.0f : cfg->coarse_freq_slow_beta;
+    const float delta = beta * error;
+    st->freq_coarse += delta;
+    st->is_found_coarse = 1;
+    st->freq_fine = fine_freq_add_n(N, st->freq_fine, -delta);
+}
+
+int dab_fine_time_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32 *prs_fft_conj, const dab_sync_cfg *cfg,
+                            float freq_offset, int *offset, float *impulse_response) {
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return 0;
+    const int N = g.nb_fft;
+    dab_cf32 A[DAB_NB_FFT], B[DAB_NB_FFT];
+    float ir[DAB_NB_FFT];
+    dab_apply_pll(prs_sym, A, (size_t)N, freq_offset, 0.0f);
+    dab_fft_n(N, A, B, 0);
+    for (int i = 0; i < N; i++) B[i] = cmul(B[i], prs_fft_conj[i]);
+    dab_fft_n(N, B, A, 1);
+    for (int i = 0; i < N; i++) ir[i] = dab_db20f(dab_cabsf(A[i]));
+    if (impulse_response) memcpy(impulse_response, ir, sizeof(float) * (size_t)N);
+    float max_value = ir[0];
+    int max_index = 0;
+    const float decay = 1.0f - cfg->impulse_peak_distance_probability;
+    for (int i = 0; i < N; i++) {
+        const int dist = abs(g.nb_cp - i);
+        const float norm_dist = (float)dist / (float)g.nb_symbol_period;
+        const float prob = 1.0f - decay * norm_dist;
+        const float w = prob * ir[i];
+        if (w > max_value) { max_value = w; max_index = i; }
+    }
+    const float avg = tree_sum_n(N, ir) / (float)N;
+    if ((max_value - avg) < cfg->impulse_peak_threshold_db) return 0;
+    *offset = max_index - g.nb_cp;
+    return 1;
+}

@@ -263,6 +263,49 @@ def demod_frame_mode(mode, frame, freq_offset=0.0, want_fft=False, m=None):
     return {"bits": bits, "cp_corr": corr, "cp_phase": phase, "total_phase": np.float32(total), "fft": fft}
 
 
+def prs_fft_mode(mode):
+    g = geometry(mode)
+    out = np.zeros(g.nb_fft, np.complex64)
+    assert lib().dab_get_prs_fft_mode(int(mode), _p(out)) == 0
+    return out
+
+
+def sync_refs_mode(mode):
+    g = geometry(mode)
+    p = prs_fft_mode(mode)
+    conj_ref, time_ref = np.zeros(g.nb_fft, np.complex64), np.zeros(g.nb_fft, np.complex64)
+    lib().dab_sync_refs_mode(int(mode), _p(p), _p(conj_ref), _p(time_ref))
+    return conj_ref, time_ref
+
+
+def coarse_freq_sync_mode(mode, prs_sym, state, cfg=None, prs_time_ref=None):
+    g = geometry(mode)
+    cfg = sync_cfg_default() if cfg is None else cfg
+    if prs_time_ref is None:
+        prs_time_ref = sync_refs_mode(mode)[1]
+    prs_sym = c64(prs_sym)
+    resp = np.zeros(g.nb_fft, np.float32)
+    L = lib()
+    L.dab_coarse_freq_sync_mode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dab_coarse_freq_sync_mode(int(mode), _p(prs_sym), _p(prs_time_ref), C.byref(cfg), C.byref(state), _p(resp))
+    return resp
+
+
+def fine_time_sync_mode(mode, prs_sym, freq_offset, cfg=None, prs_fft_conj=None):
+    g = geometry(mode)
+    cfg = sync_cfg_default() if cfg is None else cfg
+    if prs_fft_conj is None:
+        prs_fft_conj = sync_refs_mode(mode)[0]
+    prs_sym = c64(prs_sym)
+    ir = np.zeros(g.nb_fft, np.float32)
+    off = C.c_int(0)
+    L = lib()
+    L.dab_fine_time_sync_mode.restype = C.c_int
+    L.dab_fine_time_sync_mode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    ok = L.dab_fine_time_sync_mode(int(mode), _p(prs_sym), _p(prs_fft_conj), C.byref(cfg), np.float32(freq_offset), C.byref(off), _p(ir))
+    return bool(ok), off.value, ir
+
+
 def update_fine_freq_mode(mode, fine, total_phase, beta=0.9):
     L = lib()
     L.dab_update_fine_freq_mode.restype = C.c_float

@@ -33,7 +33,10 @@ int main(int argc, char** argv) {
     if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
 
     const DAB_Parameters dab = get_dab_parameters(1);
-    auto demod = Create_OFDM_Demodulator(1);
+    const char* mode_env = std::getenv("DABGPU_HARNESS_MODE");
+    const int tx_mode = mode_env ? std::atoi(mode_env) : 1;
+    auto demod = Create_OFDM_Demodulator(tx_mode);
+    if (const char* thr = std::getenv("DABGPU_HARNESS_PEAK_DB")) demod->GetConfig().sync.impulse_peak_threshold_db = (float)std::atof(thr);
     demod->EnableDebugBuffers(true);
     FIC_Decoder fic((size_t)dab.nb_fib_cif_bits, (size_t)dab.nb_fibs_per_cif);
     fic.OnFIB().Attach([&](tcb::span<const uint8_t> fib) { append(out + "/fibs.bin", fib.data(), fib.size()); });
@@ -62,8 +65,10 @@ int main(int argc, char** argv) {
         const float st[4] = {demod->GetCoarseFrequencyOffset(), demod->GetFineFrequencyOffset(), (float)demod->GetFineTimeOffset(),
                              (float)demod->GetTotalFramesDesync()};
         append(out + "/states.bin", st, sizeof(st));
+        const size_t nb_fft = demod->GetOFDMParams().nb_fft;
         auto fft = demod->GetFrameFFT();
-        append(out + "/fft_sym1.bin", fft.data() + 2048, 2048 * sizeof(std::complex<float>));
+        append(out + "/fft_sym1.bin", fft.data() + nb_fft, nb_fft * sizeof(std::complex<float>));
+        if (tx_mode != 1) return;                       // the DAB layer above the soft bits is mode I only (fic_decoder.cpp:61-72)
         auto dq = demod->GetFrameDataVec();
         append(out + "/dqpsk_sym0.bin", dq.data(), 1536 * sizeof(std::complex<float>));
         auto fic_bits = bits.subspan(0, (size_t)dab.nb_fic_bits);

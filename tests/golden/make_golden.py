@@ -27,6 +27,7 @@ def main():
     for mode in (2, 3, 4):                                   # transmission modes II-IV: geometry and frequency interleaver
         opm = np.zeros(6, np.uint64); R.ref_get_ofdm_params(mode, opm.ctypes.data); out[f"ofdm_params_mode{mode}"] = opm
         mm = np.zeros(int(opm[5]), np.int32); R.ref_get_mapper(mm.ctypes.data, int(opm[5]), int(opm[4])); out[f"mapper_mode{mode}"] = mm.astype(np.int16)
+        pm = np.zeros(int(opm[4]), np.complex64); R.ref_get_prs(mode, pm.ctypes.data, int(opm[4])); out[f"prs_fft_mode{mode}"] = pm
     pi = np.zeros(192, np.uint8); px = np.zeros(6, np.uint8); R.ref_puncture_tables(pi.ctypes.data, px.ctypes.data)
     out["pi_table"] = pi.reshape(24, 8); out["pi_x"] = px
     b = np.zeros(1024, np.uint8); R.ref_scrambler_bytes(b.ctypes.data, 1024); out["prbs_1024"] = b

@@ -5,7 +5,15 @@ II-IV tests.  The first symbol is a random unit-magnitude reference (the differe
 import numpy as np
 
 
-def make_frame(oracle, mode, bits01, rng):
+def make_tx_frame(oracle, mode, bits01, rng):
+    """transmission order (NULL first, then PRS and the data symbols), PRS = the mode's phase reference symbol"""
+    g = oracle.geometry(mode)
+    f = make_frame(oracle, mode, bits01, rng, prs=True)
+    body = f[:g.nb_frame_symbols * g.nb_symbol_period]
+    return np.concatenate([np.zeros(g.nb_null_period, np.complex64), body])
+
+
+def make_frame(oracle, mode, bits01, rng, prs=False):
     g = oracle.geometry(mode)
     N, NC, M = g.nb_fft, g.nb_carriers, g.nb_carriers // 2
     mapper = oracle.mapper_n(N, NC)
@@ -15,7 +23,10 @@ def make_frame(oracle, mode, bits01, rng):
     k = np.where(carriers < M, carriers - M, carriers - M + 1)
     bins = (N + k) % N                                          # carrier index c -> FFT bin
     spec = np.zeros((g.nb_frame_symbols, N), np.complex128)
-    cur = np.exp(2j * np.pi * rng.integers(0, 4, NC) / 4)       # reference symbol, carrier order
+    if prs:
+        cur = oracle.prs_fft_mode(mode)[bins].astype(np.complex128)
+    else:
+        cur = np.exp(2j * np.pi * rng.integers(0, 4, NC) / 4)   # reference symbol, carrier order
     spec[0, bins] = cur
     a = np.sqrt(0.5)
     for s in range(n_data):

@@ -16,21 +16,23 @@ def l1_average(block):
 class StreamModel:
     """states: 0 FINDING_NULL_POWER_DIP, 1 READING_NULL_AND_PRS, 2/3 sync, 4 READING_SYMBOLS"""
 
-    def __init__(self, oracle):
+    def __init__(self, oracle, mode=1):
         self.O = oracle
+        self.mode = mode
+        self.g = oracle.geometry(mode)
         self.cfg = oracle.sync_cfg_default()
-        self.conj_ref, self.time_ref = oracle.sync_refs()
-        self.mapper = oracle.mapper()
+        self.conj_ref, self.time_ref = oracle.sync_refs_mode(mode)
+        self.mapper = oracle.mapper_n(self.g.nb_fft, self.g.nb_carriers)
         self.state = 0
         self.signal_avg = F32(0)
         self.null_start = False
         self.null_end = False
-        self.ring = np.zeros(oracle.NB_NULL_PERIOD, np.complex64)
+        self.ring = np.zeros(self.g.nb_null_period, np.complex64)
         self.ring_index = 0
         self.ring_length = 0
-        self.corr = np.zeros(oracle.NB_NULL_PERIOD + oracle.NB_SYMBOL_PERIOD, np.complex64)
+        self.corr = np.zeros(self.g.nb_null_period + self.g.nb_symbol_period, np.complex64)
         self.corr_length = 0
-        self.frame = np.zeros(oracle.NB_FRAME_SAMPLES, np.complex64)
+        self.frame = np.zeros(self.g.nb_frame_samples, np.complex64)
         self.frame_length = 0
         self.sync = oracle.SyncState(0.0, 0.0, 0, 0, 0, 0)
         self.fine_time_offset = 0
@@ -93,15 +95,15 @@ class StreamModel:
         return take
 
     def run_sync(self):                                          # :360-548
-        O = self.O
-        prs_sym = self.corr[O.NB_NULL_PERIOD:O.NB_NULL_PERIOD + O.NB_FFT]
-        O.coarse_freq_sync(prs_sym, self.sync, self.cfg, self.time_ref)
+        O, g = self.O, self.g
+        prs_sym = self.corr[g.nb_null_period:g.nb_null_period + g.nb_fft]
+        O.coarse_freq_sync_mode(self.mode, prs_sym, self.sync, self.cfg, self.time_ref)
         f = F32(F32(self.sync.freq_coarse) + F32(self.sync.freq_fine))
-        ok, off, _ = O.fine_time_sync(prs_sym, f, self.cfg, self.conj_ref)
+        ok, off, _ = O.fine_time_sync_mode(self.mode, prs_sym, f, self.cfg, self.conj_ref)
         if not ok:
             self.reset()
             return
-        start = O.NB_NULL_PERIOD + off
+        start = g.nb_null_period + off
         count = self.corr.size - start
         self.frame[:count] = self.corr[start:]
         self.frame_length = count
@@ -110,18 +112,18 @@ class StreamModel:
         self.state = 4
 
     def read_symbols(self, buf):                                 # :550-577
-        O = self.O
+        O, g = self.O, self.g
         take = min(self.frame.size - self.frame_length, buf.size)
         self.frame[self.frame_length:self.frame_length + take] = buf[:take]
         self.frame_length += take
         if self.frame_length < self.frame.size:
             return take
-        null_at = 76 * O.NB_SYMBOL_PERIOD
-        self.corr[:O.NB_NULL_PERIOD] = self.frame[null_at:null_at + O.NB_NULL_PERIOD]
-        self.corr_length = O.NB_NULL_PERIOD
+        null_at = g.nb_frame_symbols * g.nb_symbol_period
+        self.corr[:g.nb_null_period] = self.frame[null_at:null_at + g.nb_null_period]
+        self.corr_length = g.nb_null_period
         f = F32(F32(self.sync.freq_coarse) + F32(self.sync.freq_fine))
-        r = O.demod_frame(self.frame, f, want_fft=True, m=self.mapper)
-        self.sync.freq_fine = float(O.update_fine_freq(self.sync.freq_fine, r["total_phase"]))
+        r = O.demod_frame_mode(self.mode, self.frame, f, want_fft=True, m=self.mapper)
+        self.sync.freq_fine = float(O.update_fine_freq_mode(self.mode, self.sync.freq_fine, r["total_phase"], 0.9))
         self.frames_read += 1
         self.out_frames.append(dict(bits=r["bits"].copy(), coarse=F32(self.sync.freq_coarse), fine=F32(self.sync.freq_fine),
                                     offset=self.fine_time_offset, desync=self.frames_desync, fft=r["fft"].copy()))

@@ -45,7 +45,8 @@ def test_host_tables_match_oracle(dabgpu, oracle):
 def test_unsupported_mode_and_null_args(dabgpu):
     L = dabgpu.lib()
     buf = np.zeros(4096, np.float32)
-    assert L.dabgpu_get_prs_fft_ref(2, buf.ctypes.data) == 5          # DABGPU_ERR_UNSUPPORTED
+    assert L.dabgpu_get_prs_fft_ref(2, buf.ctypes.data) == 0          # modes II-IV have tables too
+    assert L.dabgpu_get_prs_fft_ref(5, buf.ctypes.data) == 2          # DABGPU_ERR_INVALID_ARG: no such transmission mode
     assert L.dabgpu_get_prs_fft_ref(1, None) == 2                      # DABGPU_ERR_INVALID_ARG
     assert L.dabgpu_ofdm_demod_frames(None, None, 1, None, None, None, None, None, 0, 0, None) == 2
 

@@ -91,3 +91,91 @@ def test_invalid_mode_is_rejected(ctx):
     b = torch.zeros(16, dtype=torch.int8, device="cuda")
     with pytest.raises(dabgpu.DabGpuError):
         ctx.ofdm_demod_frames_mode(5, x, 1, b)
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_prs_sync_of_other_modes_matches_oracle(ctx, oracle, mode):
+    """coarse frequency + fine time synchronisation on the mode's own phase reference symbol: state and both dB responses"""
+    import dabgpu
+    import modes_model as MM
+    rng = np.random.default_rng(50 + mode)
+    g = oracle.geometry(mode)
+    prs_o = oracle.prs_fft_mode(mode)
+    assert np.array_equal(u32(prs_o), u32(np.frombuffer(_prs_bytes(dabgpu, mode, g.nb_fft), np.complex64)))
+    tx = np.concatenate([MM.make_tx_frame(oracle, mode, rng.integers(0, 2, g.nb_frame_bits, dtype=np.uint8), rng) for _ in range(2)])
+    for cfo_bins, toff, noise in [(0.0, 0, 0.0), (2.4, 17, 0.05), (-5.25, -30, 0.1)]:
+        x = oracle.apply_pll(tx, cfo_bins / g.nb_fft, 0.1)
+        x = (x + noise * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64) / np.float32(39.2)
+        start = g.nb_null_period - toff
+        sym = x[start:start + g.nb_fft].copy()
+        ost = oracle.SyncState(0.0, 0.0, 0, 0, 0, 0)
+        gst = dabgpu.SyncState(0.0, 0.0, 0, 0, 0, 0)
+        cfg_o = oracle.sync_cfg_default(); cfg_o.impulse_peak_threshold_db = 8.0
+        cfg_g = dabgpu.sync_cfg_default(); cfg_g.impulse_peak_threshold_db = 8.0
+        for it in range(2):                                  # second pass exercises the slow-beta branch of the coarse loop
+            resp = oracle.coarse_freq_sync_mode(mode, sym, ost, cfg_o)
+            f = np.float32(np.float32(ost.freq_coarse) + np.float32(ost.freq_fine))
+            ok, off, ir = oracle.fine_time_sync_mode(mode, sym, f, cfg_o)
+            imp, frq = ctx.ofdm_sync_host_mode(mode, sym, gst, cfg_g)
+            assert np.array_equal(u32(frq), u32(resp)) and np.array_equal(u32(imp), u32(ir)), (mode, cfo_bins, it)
+            assert u32(np.float32(gst.freq_coarse))[()] == u32(np.float32(ost.freq_coarse))[()]
+            assert u32(np.float32(gst.freq_fine))[()] == u32(np.float32(ost.freq_fine))[()]
+            assert bool(gst.sync_valid) == ok and (not ok or gst.fine_time_offset == off), (mode, cfo_bins, it)
+        assert abs(ost.freq_coarse * g.nb_fft + cfo_bins) < 1.0
+
+
+def _prs_bytes(dabgpu, mode, n):
+    buf = np.zeros(2 * n, np.float32)
+    dabgpu.check(dabgpu.lib().dabgpu_get_prs_fft_ref(mode, buf.ctypes.data), "get_prs_fft_ref")
+    return buf.tobytes()
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_cpp_mirror_stream_in_other_modes(oracle, tmp_path, mode):
+    """OFDM_Demod mirror class constructed for mode II / III / IV on an unsynchronised stream vs the oracle state machine"""
+    import os
+    import subprocess
+    import modes_model as MM
+    import stream_model as SM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    harness = os.path.join(root, "tests", "cpp", "mirror_harness")
+    if not os.path.exists(harness):
+        import __graft_entry__ as gr
+        gr.build()
+    rng = np.random.default_rng(mode)
+    g = oracle.geometry(mode)
+    sent = [rng.integers(0, 2, g.nb_frame_bits, dtype=np.uint8) for _ in range(8)]
+    tx = oracle.apply_pll(np.concatenate([MM.make_tx_frame(oracle, mode, b, rng) for b in sent]), 2.1 / g.nb_fft, 0.2)
+    stream = np.concatenate([tx[g.nb_null_period:g.nb_null_period + 6000 + 77], tx])
+    stream = ((stream + 0.05 * (rng.standard_normal(stream.size) + 1j * rng.standard_normal(stream.size))) / 39.2).astype(np.complex64)
+    (tmp_path / "iq.c32").write_bytes(stream.tobytes())
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(root, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    env["DABGPU_HARNESS_MODE"] = str(mode)
+    env["DABGPU_HARNESS_PEAK_DB"] = "8"          # the reference's default 20 dB rarely passes with the short symbols of modes II / III
+    res = subprocess.run([harness, str(tmp_path / "iq.c32"), str(out), "16384"], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    model = SM.StreamModel(oracle, mode)
+    model.cfg.impulse_peak_threshold_db = 8.0
+    for k in range(0, stream.size, 16384):
+        model.process(stream[k:k + 16384])
+    nf = len(model.out_frames)
+    assert nf >= 4
+    assert f"frames={nf} read={nf} desync={model.frames_desync} state={model.state}" in res.stdout, res.stdout
+    bits = np.fromfile(out / "frame_bits.bin", dtype=np.int8).reshape(nf, g.nb_frame_bits)
+    states = np.fromfile(out / "states.bin", dtype=np.float32).reshape(nf, 4)
+    fft1 = np.fromfile(out / "fft_sym1.bin", dtype=np.complex64).reshape(nf, g.nb_fft)
+    good = 0
+    for k, fr in enumerate(model.out_frames):
+        assert np.array_equal(bits[k], fr["bits"]), (mode, k)
+        assert u32(states[k, 0:1])[0] == u32(np.array([fr["coarse"]], np.float32))[0]
+        assert u32(states[k, 1:2])[0] == u32(np.array([fr["fine"]], np.float32))[0]
+        assert int(states[k, 2]) == fr["offset"] and int(states[k, 3]) == fr["desync"]
+        assert np.array_equal(u32(fft1[k]), u32(fr["fft"][g.nb_fft:2 * g.nb_fft]))
+        good += any(np.array_equal((bits[k] >= 0).astype(np.uint8), b) for b in sent)
+    # the reference's loop settles within a few frames in modes III and IV; with mode II's 512-point PRS its coarse / fine
+    # estimates keep jittering on this noisy stream (same behaviour in the oracle: parity is the criterion there)
+    if mode != 2:
+        assert good >= 1, "once locked, the hard bits are the transmitted bits"

@@ -27,6 +27,8 @@ def test_geometry_and_mapper_match_reference(oracle, golden):
         assert [g.nb_frame_symbols, g.nb_symbol_period, g.nb_null_period, g.nb_cp, g.nb_fft, g.nb_carriers] == \
                [int(v) for v in golden[f"ofdm_params_mode{mode}"]]
         assert np.array_equal(oracle.mapper_n(g.nb_fft, g.nb_carriers), golden[f"mapper_mode{mode}"])
+        assert np.array_equal(oracle.prs_fft_mode(mode).view(np.uint32), golden[f"prs_fft_mode{mode}"].view(np.uint32))
+    assert np.array_equal(oracle.prs_fft_mode(1).view(np.uint32), golden["prs_fft"].view(np.uint32))
 
 
 def test_product_host_tables_for_all_modes(oracle):
@@ -38,6 +40,9 @@ def test_product_host_tables_for_all_modes(oracle):
                [g.nb_frame_symbols, g.nb_symbol_period, g.nb_null_period, g.nb_fft, g.nb_cp, g.nb_carriers, g.nb_frame_samples,
                 g.nb_sym_bits, g.nb_frame_bits]
         assert np.array_equal(dabgpu.carrier_mapper(mode), oracle.mapper_n(g.nb_fft, g.nb_carriers))
+        prs = np.zeros(2 * g.nb_fft, np.float32)
+        dabgpu.check(dabgpu.lib().dabgpu_get_prs_fft_ref(mode, prs.ctypes.data), "get_prs_fft_ref")
+        assert np.array_equal(prs.view(np.uint32), oracle.prs_fft_mode(mode).view(np.uint32))
     with pytest.raises(dabgpu.DabGpuError):
         dabgpu.ofdm_params(5)
 
