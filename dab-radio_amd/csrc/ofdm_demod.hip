@@ -307,20 +307,23 @@ __device__ __forceinline__ float atan2_det(float y, float x) {
 
 // one thread per frame: sequential sum of the 76 per-symbol phase errors, then the fine-frequency IIR
 // (ofdm_demodulator.cpp:606-618, :779-824, :829-840)
+// one wave per frame: the per-symbol atan2 in parallel, then lane 0 adds them in symbol order (the reference's sequential
+// sum, ofdm_demodulator.cpp:606-618) and runs the fine-frequency IIR (:779-824, :829-840)
 __global__ __launch_bounds__(64)
 void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
                        float* __restrict__ total_phase, float* __restrict__ fine_freq, int fine_freq_stride,
                        const dabgpu_frame_desc* __restrict__ desc, int n_sym, int n_fft)
 {
-    const int fr = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float ph[160];                       // n_sym <= 153
+    const int fr = blockIdx.x, lane = threadIdx.x;
     if (fr >= n_frames) return;
     if (desc != nullptr && desc[fr].slot < 0) return;
     const f2* c = cp_corr + (size_t)fr * n_sym;
+    for (int i = lane; i < n_sym; i += 64) { const f2 v = c[i]; ph[i] = atan2_det(v.y, v.x); }
+    __syncthreads();
+    if (lane != 0) return;
     float total = 0.0f;
-    for (int i = 0; i < n_sym; i++) {
-        const f2 v = c[i];
-        total += atan2_det(v.y, v.x);
-    }
+    for (int i = 0; i < n_sym; i++) total += ph[i];
     if (total_phase) total_phase[fr] = total;
     if (fine_freq) {
         const float TWO_PI = 3.14159274101257324f * 2.0f;
@@ -380,7 +383,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_fra
                                                hipStream_t stream)
 {
     using namespace dabgpu;
-    const dim3 grid((unsigned)((n_frames + 63) / 64));
+    const dim3 grid((unsigned)n_frames);
     hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
                        reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc, n_sym, n_fft);
     return hipGetLastError();
