@@ -72,6 +72,26 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
     return f4{v.x, v.y, v.z, v.w};
 }
 
+// workgroup barrier of the kernel.  With the LDS-DMA prefetch in flight the fence inside __syncthreads() would make the compiler
+// wait for the DMA (an LDS write it counts with vmcnt) at every barrier, i.e. a quarter into the symbol instead of at the
+// next one; the staged slots are wave-private, so the barrier only has to cover this wave's own ds_ writes: wait for them,
+// then s_barrier (the asm memory clobber keeps the compiler from moving LDS accesses across it).
+template <bool PREFETCH>
+__device__ __forceinline__ void block_barrier() {
+    if constexpr (PREFETCH) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
+
+template <bool PREFETCH>
+__device__ __forceinline__ f2* stage_area() {
+    if constexpr (PREFETCH) {
+        __shared__ __attribute__((aligned(16))) f2 stage_lds[NB_FFT];
+        return stage_lds;
+    } else {
+        return nullptr;
+    }
+}
+
 template <bool PREFETCH, int SRC, bool BANK>
 __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
@@ -81,10 +101,17 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                        const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f2* bufA = reinterpret_cast<f2*>(smem);                              // 2048 x 8 B, position-indexed
-    f2* patch0 = bufA + NB_FFT;                                          // 4 x WAVE_PATCH x 8 B
-    int8_t* obuf = reinterpret_cast<int8_t*>(patch0 + 4 * WAVE_PATCH);   // 3072 B
+    // bufA: the radix-4 outputs, position-indexed, as four 512-element blocks (one per wave's 512-point problem) placed
+    // WAVE_PATCH = 576 apart; a wave's transpose patch ALIASES its own block: the wave has read its 8 inputs per lane before
+    // it writes the patch (one wave's LDS instructions execute in order) and nobody else touches the block until the
+    // end-of-symbol barrier
+    f2* bufA = reinterpret_cast<f2*>(smem);                              // 4 x 576 x 8 B
+    f2* patch0 = bufA;
+    int8_t* obuf = reinterpret_cast<int8_t*>(bufA + 4 * WAVE_PATCH);     // 3072 B
     f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 4 x 8 B
+    // PREFETCH: 2048 x 8 B, the next symbol's FFT body.  A separate LDS object on purpose: the compiler counts the DMA as a
+    // pending LDS write and would wait for it before ANY LDS read it cannot prove distinct from the staging area
+    f2* stage = stage_area<PREFETCH>();
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -134,7 +161,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     // LDS addresses (float2 element indices); every per-k term below is an instruction immediate
     f2* patch = patch0 + wave * WAVE_PATCH;
     const int la = lane & 7, lb = lane >> 3;
-    const int rd2 = lane + 512 * wave;            // pass-2 inputs: + 64 j           (stride-1 across lanes)
+    const int rd2 = lane + WAVE_PATCH * wave;     // pass-2 inputs: + 64 j           (stride-1 across lanes)
     const int ta_w = lane;                        // transpose A write: + 72 r       (element a + 8b + 72r)
     const int ta_r = la + 72 * lb;                // transpose A read : + 8 r'       (element a + 8r' + 72b')
     const int tb_w = la + 72 * lb;                // transpose B write: + 9 r        (element a + 9r + 72b)
@@ -169,12 +196,41 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             else h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
         }
     };
+    // PREFETCH: the NEXT symbol's FFT body goes from HBM straight into LDS (global_load_lds_dwordx4: lane L's 16 bytes land
+    // at M0 + 16 L, no registers involved) while this symbol is transformed; every wave stages, reads back and re-stages only
+    // its own 4 x 1 KB slots, so the staging area needs no cross-wave synchronisation.  The 504-sample cyclic-prefix head
+    // (one 16-byte load per lane) is prefetched in registers.  The DMA is issued from inline asm on purpose: the compiler
+    // counts a DMA it knows about as a pending LDS write and waits for it (vmcnt(0)) before the next LDS read it cannot prove
+    // distinct, i.e. right after the first barrier; untracked, the only wait is the explicit one at the top of the next symbol
+    // (loads return in order, so the compiler's own vmcnt(n) waits can only become more conservative, never wrong).
+    f4 h_next = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    const unsigned stage_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(stage + 128 * wave));
+    auto stage_symbol = [&](int i) {
+        const uint8_t* sym = fbase + (size_t)i * NB_SYMBOL_PERIOD * 8;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* src = sym + (size_t)(NB_CP + 2 * t + 512 * k) * 8;
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + 512 * 8 * k));
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+        }
+        const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+        h_next = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (dc && t >= 4) h_next = *reinterpret_cast<const f4*>(sym + (size_t)(2 * (t - 4)) * 8);
+    };
     f4 v[4], h;
-    if constexpr (PREFETCH) load_symbol(out0, v, h);
+    if constexpr (PREFETCH) stage_symbol(out0);
 
     for (int i = out0; i <= sym_end; i++) {
         const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
-        if constexpr (!PREFETCH) load_symbol(i, v, h);
+        if constexpr (PREFETCH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's staged symbol (and head) arrived
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f4*>(stage + 2 * t + 512 * k);
+            h = h_next;
+            if (i < sym_end) stage_symbol(i + 1);                        // (waits for the read-back before refilling the slots)
+        } else {
+            load_symbol(i, v, h);
+        }
         const bool do_corr = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
 
         // ---- PLL ----
@@ -199,8 +255,6 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             p.y = wave_tree_sum(p.y, lane);
             if (lane == 0) red[wave] = p;
         }
-        if constexpr (PREFETCH) { if (i < sym_end) load_symbol(i + 1, v, h); }
-
         // ---- pass 1: radix 4 on positions p + 512 j (p = 2t, 2t+1); outputs stay in place ----
         {
             f2 b0, b1, b2, b3, c0, c1, c2, c3;
@@ -209,12 +263,12 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             b1 = cmul(b1, w1a[0]); b2 = cmul(b2, w1a[1]); b3 = cmul(b3, w1a[2]);
             c1 = cmul(c1, w1b[0]); c2 = cmul(c2, w1b[1]); c3 = cmul(c3, w1b[2]);
             f4* dst = reinterpret_cast<f4*>(bufA + 2 * t);
-            dst[0]   = f4{b0.x, b0.y, c0.x, c0.y};
-            dst[256] = f4{b1.x, b1.y, c1.x, c1.y};
-            dst[512] = f4{b2.x, b2.y, c2.x, c2.y};
-            dst[768] = f4{b3.x, b3.y, c3.x, c3.y};
+            dst[0]                  = f4{b0.x, b0.y, c0.x, c0.y};        // block j of 512 positions starts at j * WAVE_PATCH
+            dst[WAVE_PATCH / 2]     = f4{b1.x, b1.y, c1.x, c1.y};
+            dst[WAVE_PATCH]         = f4{b2.x, b2.y, c2.x, c2.y};
+            dst[3 * WAVE_PATCH / 2] = f4{b3.x, b3.y, c3.x, c3.y};
         }
-        __syncthreads();                       // the only cross-wave exchange of the transform
+        block_barrier<PREFETCH>();             // the only cross-wave exchange of the transform
         if (do_corr && t == 0) {
             const f2 r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
             cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
@@ -272,7 +326,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                 obuf[pos[k] + 1536] = (int8_t)to_vbit(-(d.y / A));
             }
         }
-        __syncthreads();       // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
+        block_barrier<PREFETCH>();   // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
         if (emit && t < NB_SYM_BITS / 16) {
             const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
             uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
@@ -355,7 +409,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
-    size_t lds = (NB_FFT + 4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
+    size_t lds = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
     if (g_dabgpu_variant == 2) lds += 14 * 1024;      // development: 3 instead of 4 workgroups per CU (occupancy sensitivity)
     if (g_dabgpu_variant == 3) lds += 42 * 1024;      // development: 2 workgroups per CU
     const dim3 grid((unsigned)(n_frames * chunks));
