@@ -347,6 +347,8 @@ struct dabgpu_stream_bank {
     BankView view{};
     float* d_corr_out = nullptr;       // [n][76][2] cyclic-prefix correlations of the last demodulated frames
     dabgpu_stream_status* d_status = nullptr;
+    float* d_raw_scratch = nullptr;    // converted block of dabgpu_stream_bank_process_raw (grow-only)
+    size_t raw_scratch_bytes = 0;
     std::vector<void*> allocs;
 };
 
@@ -487,6 +489,38 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
     }
 #undef CK
     return DABGPU_OK;
+}
+
+// the same from blocks still in their capture format: dequantised on the device (iq_convert_kernel, reader arithmetic of
+// examples/app_helpers/app_iq_readers.h) into bank-owned scratch on `stream`, then processed as above
+int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                   int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+    if (!b || !d_raw) { dabgpu_set_error("stream_bank_process_raw: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    const size_t sb = dabgpu_iq_format_sample_bytes(format);
+    if (sb == 0) { dabgpu_set_error("stream_bank_process_raw: unknown format %d", format); return DABGPU_ERR_INVALID_ARG; }
+    if (n_samples == 0) return DABGPU_OK;
+    if (((stream_stride_samples * sb) & 15) != 0 && b->n > 1) {
+        dabgpu_set_error("stream_bank_process_raw: the byte stride between streams must be a multiple of 16"); return DABGPU_ERR_INVALID_ARG;
+    }
+    (void)hipSetDevice(b->ctx->device);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t padded = (n_samples + 1) & ~(size_t)1;                    // keeps every stream's converted block 16-byte aligned
+    const size_t need = b->n * padded * 2 * sizeof(float);
+    if (need > b->raw_scratch_bytes) {
+        int st = dabgpu_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        if (st) return st;
+        if (b->d_raw_scratch) { (void)hipFree(b->d_raw_scratch); b->allocs.erase(std::find(b->allocs.begin(), b->allocs.end(), (void*)b->d_raw_scratch)); }
+        b->d_raw_scratch = nullptr; b->raw_scratch_bytes = 0;
+        if ((st = dabgpu_check_hip(hipMalloc((void**)&b->d_raw_scratch, need), "hipMalloc(stream bank raw scratch)"))) return st;
+        b->allocs.push_back(b->d_raw_scratch);
+        b->raw_scratch_bytes = need;
+    }
+    for (size_t k = 0; k < b->n; k++) {
+        const int st = dabgpu_iq_convert(b->ctx, static_cast<const uint8_t*>(d_raw) + k * stream_stride_samples * sb, format, n_samples,
+                                         b->d_raw_scratch + k * padded * 2, stream);
+        if (st) return st;
+    }
+    return dabgpu_stream_bank_process(b, b->d_raw_scratch, padded, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
 }
 
 int dabgpu_stream_bank_status(dabgpu_stream_bank* b, dabgpu_stream_status* h_status, void* stream) {

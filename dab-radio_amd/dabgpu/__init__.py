@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "dabgpu_soft_bits_to_hard_bytes", "dabgpu_hard_bytes_to_soft_bits",
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
     "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
-    "dabgpu_stream_bank_process", "dabgpu_stream_bank_status",
+    "dabgpu_stream_bank_process", "dabgpu_stream_bank_process_raw", "dabgpu_stream_bank_status",
     "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
     "dabgpu_dabplus_process_frame_host_sync",
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
@@ -179,6 +179,8 @@ def lib():
         L.dabgpu_stream_bank_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_process_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                     C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_dabplus_bank_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.dabgpu_dabplus_bank_destroy.argtypes = [C.c_void_p]
@@ -430,6 +432,10 @@ class StreamBank:
     def process(self, iq, stream_stride_samples, n_samples, bits, max_frames, n_frames=None, stream=None):
         check(lib().dabgpu_stream_bank_process(self._h, _ptr(iq), stream_stride_samples, n_samples, _ptr(bits), max_frames,
                                                _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process")
+
+    def process_raw(self, raw, fmt, stream_stride_samples, n_samples, bits, max_frames, n_frames=None, stream=None):
+        check(lib().dabgpu_stream_bank_process_raw(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(bits), max_frames,
+                                                   _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process_raw")
 
     def status(self, stream=None):
         import numpy as np
