@@ -91,34 +91,72 @@ __device__ __forceinline__ void acs_step(uint32_t& metric, uint32_t& hist, const
     metric = (uint32_t)((cs < cp) ? cs : cp);
 }
 
-// up to 48 trellis steps; ypk[q] lane 4j = packed symbols of step t0 + 16 q + j
+// the reference's renormalisation (dab_viterbi_decoder.cpp:31-41): when metric[0] reaches the threshold, subtract the minimum
+__device__ __forceinline__ void renormalise(uint32_t& metric, uint64_t& renorm_total) {
+    uint32_t mn = metric;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+    metric -= mn;
+    renorm_total += mn;
+}
+
+template <int J, int TIE>
+__device__ __forceinline__ void acs_at(uint32_t& metric, uint32_t& hist, const LaneConst& K, const int (&ypk)[3], int lane) {
+    const int ysym = __builtin_amdgcn_readlane(ypk[J >> 4], 4 * (J & 15));
+    acs_step<J % 6, TIE>(metric, hist, K, ysym, lane);
+}
+
+// 8 trellis steps J0 .. J0+7 of a block with no per-step scalar work: the caller has established that all 8 exist and that
+// metric[0] (which grows by at most the largest branch cost, 1016, per step) cannot reach the renormalisation threshold
+template <int J0, int TIE>
+__device__ __forceinline__ void forward_group_fast(uint32_t& metric, uint32_t& hist, const LaneConst& K, const int (&ypk)[3], int t0,
+                                                   int lane, uint16_t* my_dec16) {
+    acs_at<J0, TIE>(metric, hist, K, ypk, lane);     acs_at<J0 + 1, TIE>(metric, hist, K, ypk, lane);
+    acs_at<J0 + 2, TIE>(metric, hist, K, ypk, lane); acs_at<J0 + 3, TIE>(metric, hist, K, ypk, lane);
+    acs_at<J0 + 4, TIE>(metric, hist, K, ypk, lane); acs_at<J0 + 5, TIE>(metric, hist, K, ypk, lane);
+    acs_at<J0 + 6, TIE>(metric, hist, K, ypk, lane); acs_at<J0 + 7, TIE>(metric, hist, K, ypk, lane);
+    if (((J0 + 7) & 15) == 15) my_dec16[(size_t)((t0 + J0 + 7) >> 4) * 64 + lane] = (uint16_t)hist;   // 16 steps x 64 lanes = 128 B
+}
+
+// the same 8 steps the careful way: bounds test and renormalisation check after every step.  Rare; a compact loop that is
+// generic in the step position (phase by switch) keeps the instruction-cache footprint of the unrolled fast path small
+template <int TIE>
+__device__ __forceinline__ void forward_group_slow(uint32_t& metric, uint32_t& hist, uint64_t& renorm_total, const LaneConst& K,
+                                                   int y0, int y1, int y2, int t0, int j0, int n_steps, int lane, uint16_t* my_dec16) {
+#pragma nounroll
+    for (int j = j0; j < j0 + 8 && t0 + j < n_steps; j++) {
+        const int l4 = 4 * (j & 15);
+        const int s0 = __builtin_amdgcn_readlane(y0, l4), s1 = __builtin_amdgcn_readlane(y1, l4), s2 = __builtin_amdgcn_readlane(y2, l4);
+        const int ysym = (j < 16) ? s0 : ((j < 32) ? s1 : s2);
+        switch (j % 6) {
+        case 0: acs_step<0, TIE>(metric, hist, K, ysym, lane); break;
+        case 1: acs_step<1, TIE>(metric, hist, K, ysym, lane); break;
+        case 2: acs_step<2, TIE>(metric, hist, K, ysym, lane); break;
+        case 3: acs_step<3, TIE>(metric, hist, K, ysym, lane); break;
+        case 4: acs_step<4, TIE>(metric, hist, K, ysym, lane); break;
+        default: acs_step<5, TIE>(metric, hist, K, ysym, lane); break;
+        }
+        const uint32_t m1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)metric);       // state 0 is lane 0 in every phase
+        if (m1 >= V_RENORM) renormalise(metric, renorm_total);
+        if ((j & 15) == 15) my_dec16[(size_t)((t0 + j) >> 4) * 64 + lane] = (uint16_t)hist;
+    }
+}
+
+// up to 48 trellis steps; ypk[q] lane 4j = packed symbols of step t0 + 16 q + j.  Groups of 8 steps: unrolled and free of
+// scalar work when all 8 exist and metric[0] cannot reach the threshold inside the group, else the careful loop
 template <int TIE>
 __device__ __forceinline__ void forward_block(uint32_t& metric, uint32_t& hist, uint64_t& renorm_total, const LaneConst& K,
                                               const int (&ypk)[3], int t0, int n_steps, int lane, uint16_t* my_dec16) {
-#pragma unroll
-    for (int j = 0; j < VBLOCK; j++) {
-        const int t = t0 + j;
-        if (t < n_steps) {                                                       // wave-uniform
-            const int ysym = __builtin_amdgcn_readlane(ypk[j >> 4], 4 * (j & 15));
-            switch (j % 6) {                                                     // constant after unrolling
-            case 0: acs_step<0, TIE>(metric, hist, K, ysym, lane); break;
-            case 1: acs_step<1, TIE>(metric, hist, K, ysym, lane); break;
-            case 2: acs_step<2, TIE>(metric, hist, K, ysym, lane); break;
-            case 3: acs_step<3, TIE>(metric, hist, K, ysym, lane); break;
-            case 4: acs_step<4, TIE>(metric, hist, K, ysym, lane); break;
-            default: acs_step<5, TIE>(metric, hist, K, ysym, lane); break;
-            }
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)metric);   // state 0 is lane 0 in every phase
-            if (m0 >= V_RENORM) {                                                // rare, wave-uniform
-                uint32_t mn = metric;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-                metric -= mn;
-                renorm_total += mn;
-            }
-            if ((j & 15) == 15) my_dec16[(size_t)(t >> 4) * 64 + lane] = (uint16_t)hist;   // 16 steps x 64 lanes = 128 B, coalesced
-        }
+#define VIT_GROUP(G)                                                                                                              \
+    if (t0 + 8 * (G) < n_steps) {                                                         /* wave-uniform */                      \
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)metric);                                              \
+        if (t0 + 8 * (G) + 8 <= n_steps && m0 + 8u * 1016u < V_RENORM)                                                          \
+            forward_group_fast<8 * (G), TIE>(metric, hist, K, ypk, t0, lane, my_dec16);                                          \
+        else                                                                                                                     \
+            forward_group_slow<TIE>(metric, hist, renorm_total, K, ypk[0], ypk[1], ypk[2], t0, 8 * (G), n_steps, lane, my_dec16); \
     }
+    VIT_GROUP(0) VIT_GROUP(1) VIT_GROUP(2) VIT_GROUP(3) VIT_GROUP(4) VIT_GROUP(5)
+#undef VIT_GROUP
 }
 
 // up to 48 chain-back steps t = tb+47 .. tb (those with 6 <= t < n_steps).
