@@ -201,7 +201,8 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     uint16_t* pi_tab = reinterpret_cast<uint16_t*>(vsm);            // [25][8]: count | prefix << 8
     unsigned char* prbs = vsm + 25 * 8 * 2;                         // [512]
-    unsigned char* obytes = prbs + 512;                             // decoded bytes of the current codeword
+    unsigned long long* age_off = reinterpret_cast<unsigned long long*>(prbs + 512);   // [16] ring offsets of the 16 CIF ages
+    unsigned char* obytes = reinterpret_cast<unsigned char*>(age_off + 16);             // decoded bytes of the current codeword
 
     const int lane = threadIdx.x;
     // ---- tables (host-computed constants of the context) ----
@@ -248,41 +249,60 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
             seg_pi[4] = 8; seg_in0[4] = in0; seg_end[4] = st + 6;
         }
 
+        // time de-interleaver (cif_deinterleaver.cpp:57-68): input bit i comes from the CIF that is 15 - bitrev4(i mod 16) CIFs
+        // old; the byte offset of that CIF inside the frame-history ring depends on i mod 16 only -> 16-entry table per codeword
+        __syncthreads();
+        if (lane < 16) {
+            unsigned long long off = 0;
+            if (D.n_slots != 0) {
+                const int age = 15 - (int)(__brev((unsigned)lane) >> 28);
+                int slot = (int)D.newest_slot - age;
+                if (slot < 0) slot += (int)D.n_slots;
+                const int fr = slot / (int)D.cifs_per_frame, ci = slot - fr * (int)D.cifs_per_frame;
+                off = (unsigned long long)fr * D.frame_stride + (unsigned long long)ci * D.cif_stride;
+            }
+            age_off[lane] = off;
+        }
+        __syncthreads();
+        const int8_t* src_base = reinterpret_cast<const int8_t*>(D.d_src);
+
+        // ---- de-puncturing as a running index (dab_viterbi_decoder.cpp:131-181): lane L owns mother symbols 64 q + L of every
+        // 48-step block, i.e. step offset so = (64 q + L) / 4, code bit r = L % 4.  Inside a puncturing segment the kept / dropped
+        // pattern of that position repeats every 8 steps, so from block to block the input index just advances by
+        // 6 x (8 + PI); only a lane that crosses into the next segment recomputes its position from the tables.
+        int fidx[3], finc[3], frem[3], fkeep = 0;
+        const int rbit = lane & 3;
+        auto locate = [&](int q, int step) {
+            int k = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) k += (step >= seg_end[u]) ? 1 : 0;
+            int sstart = 0, send = seg_end[0], pi = seg_pi[0], in0 = seg_in0[0];
+#pragma unroll
+            for (int u = 1; u < 5; u++) if (k == u) { sstart = seg_end[u - 1]; send = seg_end[u]; pi = seg_pi[u]; in0 = seg_in0[u]; }
+            const int sis = step - sstart;
+            const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
+            const int cnt = e & 0xFF, pre = e >> 8;
+            fidx[q] = in0 + (sis >> 3) * (8 + pi) + pre + rbit;
+            finc[q] = (VBLOCK / 8) * (8 + pi);
+            frem[q] = send - step;                        // steps from this one to the end of its segment (> 0 while inside)
+            fkeep = (fkeep & ~(1 << q)) | ((rbit < cnt) ? (1 << q) : 0);
+        };
+#pragma unroll
+        for (int q = 0; q < 3; q++) locate(q, 16 * q + (lane >> 2));
+
         uint32_t metric = (lane == (int)(D.start_state & 63u)) ? 0u : V_NONSTART;   // phase 0: lane = state
         uint64_t renorm_total = 0;
         uint32_t hist = 0;
 
         for (int t0 = 0; t0 < n_steps; t0 += VBLOCK) {
-            // ---- fetch + de-puncture + time de-interleave: lane L owns mother symbols 4*t0 + 64*q + L ----
+            // ---- fetch + time de-interleave ----
             int ypk[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const int M = 4 * t0 + 64 * q + lane;
-                const int step = M >> 2, r = M & 3;
-                int k = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) k += (step >= seg_end[u]) ? 1 : 0;
-                int sstart = 0, pi = seg_pi[0], in0 = seg_in0[0];
-#pragma unroll
-                for (int u = 1; u < 5; u++) if (k == u) { sstart = seg_end[u - 1]; pi = seg_pi[u]; in0 = seg_in0[u]; }
-                const int sis = step - sstart;
-                const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
-                const int cnt = e & 0xFF, pre = e >> 8;
-                const int idx = in0 + (sis >> 3) * (8 + pi) + pre + r;
+                const int step = t0 + 16 * q + (lane >> 2);
                 int y = 0;
-                if (step < n_steps && r < cnt) {
-                    const int8_t* p;
-                    if (D.n_slots == 0) {
-                        p = reinterpret_cast<const int8_t*>(D.d_src) + idx;
-                    } else {
-                        // cif_deinterleaver.cpp:57-68: bit i comes from the CIF that is 15 - T[i mod 16] old, T = bitrev4
-                        const int age = 15 - (int)(__brev((unsigned)idx & 15u) >> 28);
-                        int slot = (int)D.newest_slot - age;
-                        if (slot < 0) slot += (int)D.n_slots;
-                        const int fr = slot / (int)D.cifs_per_frame, ci = slot - fr * (int)D.cifs_per_frame;
-                        p = reinterpret_cast<const int8_t*>(D.d_src) + (size_t)fr * D.frame_stride + (size_t)ci * D.cif_stride + idx;
-                    }
-                    y = *p;
+                if (step < n_steps && ((fkeep >> q) & 1)) {
+                    y = src_base[age_off[fidx[q] & 15] + (unsigned long long)(unsigned)fidx[q]];
                     y = max(y, -127);          // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                 }
                 // pack the 4 symbols of a step into one dword in every lane of the quad
@@ -291,6 +311,10 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 const int y2 = __builtin_amdgcn_mov_dpp(y, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
                 const int y3 = __builtin_amdgcn_mov_dpp(y, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
                 ypk[q] = (y0 & 0xFF) | ((y1 & 0xFF) << 8) | ((y2 & 0xFF) << 16) | (y3 << 24);
+                // this lane's position in the next block
+                frem[q] -= VBLOCK;
+                fidx[q] += finc[q];
+                if (frem[q] <= 0 && step + VBLOCK < n_steps) locate(q, step + VBLOCK);      // crossed into another segment (rare)
             }
             forward_block<TIE>(metric, hist, renorm_total, K, ypk, t0, n_steps, lane, my_dec16);
         }
@@ -353,7 +377,7 @@ extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n
                                             hipStream_t stream)
 {
     using namespace dabgpu;
-    const size_t lds = 25 * 8 * 2 + 512 + (size_t)((max_out_bytes + 63 + 15) & ~15);
+    const size_t lds = 25 * 8 * 2 + 512 + 16 * 8 + (size_t)((max_out_bytes + 63 + 15) & ~15);
     if (tie_rule)
         hipLaunchKernelGGL(viterbi_kernel<1>, dim3((unsigned)n_waves), dim3(64), lds, stream,
                            d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables);
