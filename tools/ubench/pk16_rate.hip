@@ -21,6 +21,9 @@ __global__ __launch_bounds__(256) void k(unsigned* out, unsigned a) {
             if (MODE == 4) x[i] = __builtin_amdgcn_sdot4((int)x[i], (int)a, (int)x[i], false);
             if (MODE == 5) x[i] = __builtin_amdgcn_alignbit(x[i], a, 31);
             if (MODE == 6) x[i] = __builtin_amdgcn_perm(x[i], a, 0x05040100u);
+            if (MODE == 7) x[i] = __builtin_amdgcn_sad_u8(x[i], a, x[i]);
+            if (MODE == 8) x[i] = __builtin_amdgcn_ubfe(x[i], a & 31, 9) + (x[i] << 3);
+            if (MODE == 9) x[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)x[i], 0x128, 0xF, 0xF, true) ^ a;
         }
     }
     unsigned s = 0; for (int i = 0; i < N_ACC; i++) s += x[i];
@@ -42,6 +45,7 @@ int main() {
     for (int w : {2, 4}) {
         run<0>("v_add_u32", w); run<1>("v_pk_add_u16", w); run<2>("v_pk_sub_i16", w); run<3>("v_pk_min_u16+add", w);
         run<4>("v_dot4_i32_i8", w); run<5>("v_alignbit", w); run<6>("v_perm_b32", w);
+        run<7>("v_sad_u8", w); run<8>("v_bfe+lshl_add", w); run<9>("v_mov_dpp+xor", w);
     }
     return 0;
 }
