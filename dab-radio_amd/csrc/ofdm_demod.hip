@@ -38,7 +38,7 @@ template <int SRC>
 __device__ __forceinline__ f4 load_pair(const uint8_t* __restrict__ frame_base, size_t n) {
     const uint8_t* p = frame_base + n * src_bytes<SRC>::value;
     if constexpr (SRC == SRC_C32) {
-        return *reinterpret_cast<const f4*>(p);
+        return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));   // streamed once: keep it out of the way in L2 (-2 %)
     } else if constexpr (SRC == SRC_S16) {
         raw_words<2> r;
         const uint2 q = *reinterpret_cast<const uint2*>(p);
@@ -330,7 +330,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         if (emit && t < NB_SYM_BITS / 16) {
             const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
             uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
-            dst[t] = o;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(dst + t));
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) prev[k] = cur[k];
