@@ -66,11 +66,7 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
 // stream banks (ofdm_stream.hip): samples [0, split) of a frame come from the stream's frame buffer, the rest straight
 // from the caller's block (no assembly copy); split is even, the block side is only 8-byte aligned
 typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
-__device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_base, const uint8_t* __restrict__ tail_base, int split, size_t n) {
-    const uint8_t* p = (((int)n < split) ? frame_base : tail_base) + n * 8;
-    const f4u v = *reinterpret_cast<const f4u*>(p);
-    return f4{v.x, v.y, v.z, v.w};
-}
+
 
 // workgroup barrier of the kernel.  With the LDS-DMA prefetch in flight the fence inside __syncthreads() would make the compiler
 // wait for the DMA (an LDS write it counts with vmcnt) at every barrier, i.e. a quarter into the symbol instead of at the
@@ -80,6 +76,32 @@ template <bool PREFETCH>
 __device__ __forceinline__ void block_barrier() {
     if constexpr (PREFETCH) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
+}
+
+// stream banks: head of the frame from the (complex float) frame buffer, tail from the caller's block in its capture format SRC
+// (tail_base is pre-biased so that frame sample n sits at tail_base + n * bytes per sample; only naturally 2/4/8-byte aligned)
+template <int SRC>
+__device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_base, const uint8_t* __restrict__ tail_base, int split, size_t n) {
+    if constexpr (SRC == SRC_C32) {
+        const uint8_t* p = (((int)n < split) ? frame_base : tail_base) + n * 8;
+        const f4u v = *reinterpret_cast<const f4u*>(p);
+        return f4{v.x, v.y, v.z, v.w};
+    } else {
+        if ((int)n < split) return *reinterpret_cast<const f4*>(frame_base + n * 8);
+        const uint8_t* p = tail_base + n * src_bytes<SRC>::value;
+        if constexpr (SRC == SRC_S16) {
+            typedef uint32_t u32a4 __attribute__((aligned(4)));
+            raw_words<2> r;
+            r.w[0] = reinterpret_cast<const u32a4*>(p)[0]; r.w[1] = reinterpret_cast<const u32a4*>(p)[1];
+            return f4{decode<K_S16, 2, false>(r, 0), decode<K_S16, 2, false>(r, 1), decode<K_S16, 2, false>(r, 2), decode<K_S16, 2, false>(r, 3)};
+        } else {
+            constexpr comp_kind K = (SRC == SRC_U8) ? K_U8 : K_S8;
+            typedef uint32_t u32a2 __attribute__((aligned(2)));
+            raw_words<1> r;
+            r.w[0] = *reinterpret_cast<const u32a2*>(p);
+            return f4{decode<K, 1, false>(r, 0), decode<K, 1, false>(r, 1), decode<K, 1, false>(r, 2), decode<K, 1, false>(r, 3)};
+        }
+    }
 }
 
 template <bool PREFETCH>
@@ -128,7 +150,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         if (d.slot < 0) return;
         out_frame = (size_t)d.slot;
         split = d.split;
-        tbase = static_cast<const uint8_t*>(tail) + ((long long)frame * (long long)tail_stride + d.tail_off - (long long)d.split) * 8;
+        tbase = static_cast<const uint8_t*>(tail) + ((long long)frame * (long long)tail_stride + d.tail_off - (long long)d.split) * src_bytes<SRC>::value;
     }
 
     // DQPSK outputs [out0, out1) need FFTs of symbols [out0, out1]; the last chunk also owns the
@@ -139,7 +161,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int sym_end = (last_chunk && fft_out != nullptr) ? NB_FRAME_SYMBOLS : out1;   // inclusive
 
     const float f = freq_offset ? freq_offset[frame] : 0.0f;
-    const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * NB_FRAME_SAMPLES * src_bytes<SRC>::value;
+    // (stream banks: iq = the complex-float frame buffers, SRC describes the tail source only)
+    const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * NB_FRAME_SAMPLES * (BANK ? 8 : src_bytes<SRC>::value);
 
     // PLL constants: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
     const int k0 = 2 * (t & 1);
@@ -186,13 +209,13 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if constexpr (BANK) v[k] = load_pair_bank(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
+            if constexpr (BANK) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
             else v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
         }
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
         h = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if (dc && t >= 4) {
-            if constexpr (BANK) h = load_pair_bank(fbase, tbase, split, sym + 2 * (t - 4));
+            if constexpr (BANK) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * (t - 4));
             else h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
         }
     };
@@ -424,9 +447,9 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
         else if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32, false);
         else DABGPU_LAUNCH(false, SRC_C32, false);
         break;
-    case SRC_U8: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_U8, false); break;
-    case SRC_S8: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_S8, false); break;
-    case SRC_S16: if (d_desc != nullptr) return hipErrorInvalidValue; DABGPU_LAUNCH(false, SRC_S16, false); break;
+    case SRC_U8: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_U8, true); else DABGPU_LAUNCH(false, SRC_U8, false); break;
+    case SRC_S8: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_S8, true); else DABGPU_LAUNCH(false, SRC_S8, false); break;
+    case SRC_S16: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_S16, true); else DABGPU_LAUNCH(false, SRC_S16, false); break;
     default: return hipErrorInvalidValue;
     }
 #undef DABGPU_LAUNCH

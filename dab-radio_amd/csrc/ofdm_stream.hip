@@ -27,6 +27,7 @@
 
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
+#include "iq_decode.h"
 #include "ofdm_device.h"
 
 namespace dabgpu {
@@ -69,10 +70,36 @@ struct BankView {
 
 constexpr int COPY_WGS = 16;         // workgroups per stream of the bulk copy
 
-__device__ __forceinline__ float l1_window(const f2* p, int k) {           // CalculateL1Average :922-932
+// The caller's block in its capture format: SRC 0 = complex float, 1 = raw_u8, 2 = raw_s8, 3 = raw_s16l (the formats the
+// demodulation kernel reads by itself); sample i dequantised with the reader arithmetic of iq_decode.h
+template <int SRC> struct src_sample_bytes { static constexpr int value = (SRC == 0) ? 8 : (SRC == 3) ? 4 : 2; };
+template <int SRC>
+__device__ __forceinline__ f2 sample_at(const uint8_t* __restrict__ base, long long i) {
+    const uint8_t* p = base + i * src_sample_bytes<SRC>::value;
+    if constexpr (SRC == 0) {
+        return *reinterpret_cast<const f2*>(p);
+    } else if constexpr (SRC == 3) {
+        typedef uint32_t u32a2 __attribute__((aligned(2)));
+        raw_words<1> r; r.w[0] = *reinterpret_cast<const u32a2*>(p);
+        return mk2(decode<K_S16, 2, false>(r, 0), decode<K_S16, 2, false>(r, 1));
+    } else {
+        constexpr comp_kind K = (SRC == 1) ? K_U8 : K_S8;
+        typedef uint16_t u16a1 __attribute__((aligned(1)));
+        raw_words<1> r; r.w[0] = *reinterpret_cast<const u16a1*>(p);
+        return mk2(decode<K, 1, false>(r, 0), decode<K, 1, false>(r, 1));
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ float l1_window(const uint8_t* base, long long first, int k) {           // CalculateL1Average :922-932
     float acc = 0.0f;
-    for (int i = 0; i < k; i++) { const f2 v = p[i]; acc += __builtin_fabsf(v.x) + __builtin_fabsf(v.y); }
+    for (int i = 0; i < k; i++) { const f2 v = sample_at<SRC>(base, first + i); acc += __builtin_fabsf(v.x) + __builtin_fabsf(v.y); }
     return acc / (float)k;
+}
+
+template <int SRC>
+__device__ __forceinline__ void copy_block_samples(f2* __restrict__ dst, const uint8_t* __restrict__ base, long long first, long long n, int t) {
+    for (long long i = t; i < n; i += 256) dst[i] = sample_at<SRC>(base, first + i);
 }
 
 __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __restrict__ src, long long n, int t) {
@@ -84,8 +111,9 @@ __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __r
     for (; i < n; i += 256) dst[i] = src[i];
 }
 
+template <int SRC>
 __global__ __launch_bounds__(256)
-void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq, size_t stream_stride, long long n_samples,
+void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
                            dabgpu_stream_cfg cfg, int max_frames, int first_round)
 {
     __shared__ StreamState S;
@@ -96,7 +124,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
     if (s >= n_streams) return;
     if (t == 0) S = B.st[s];
     __syncthreads();
-    const f2* block = iq + (size_t)s * stream_stride;
+    const uint8_t* block = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
     f2* ring = B.ring + (size_t)s * NB_NULL_PERIOD;
     f2* corr = B.corr + (size_t)s * NB_CORR;
     f2* frame = B.frame + (size_t)s * NB_FRAME_SAMPLES;
@@ -161,7 +189,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
 
     // ---- the Process() loop (:241-274) up to the next device-kernel request ----
     while (S.pos < n_samples && S.pending == PEND_NONE) {
-        const f2* buf = block + S.pos;
+        const long long bpos = S.pos;                                               // buf[i] of the reference = block sample bpos + i
         const long long rest = n_samples - S.pos;
         if (S.state == ST_FINDING_NULL) {
             // FindNullPowerDip :291-347
@@ -173,7 +201,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
             __syncthreads();
             for (long long w0 = 0; w0 < n_win; w0 += 256) {
                 const long long w = w0 + t;
-                if (w < n_win) win[t] = l1_window(buf + w * k, k);
+                if (w < n_win) win[t] = l1_window<SRC>(block, bpos + w * k, k);
                 __syncthreads();
                 if (t == 0) {
                     const int m = (int)((n_win - w0 < 256) ? (n_win - w0) : 256);
@@ -198,7 +226,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
             const long long keep = (nb_read < cap) ? nb_read : cap;
             const long long first = nb_read - keep;
             const int ring_index = S.ring_index;
-            for (long long j = t; j < keep; j += 256) ring[(int)((ring_index + first + j) % cap)] = buf[first + j];
+            for (long long j = t; j < keep; j += 256) ring[(int)((ring_index + first + j) % cap)] = sample_at<SRC>(block, bpos + first + j);
             __syncthreads();
             const int new_index = (int)((ring_index + nb_read) % cap);
             const int new_length = (int)(((long long)S.ring_length + nb_read < cap) ? (S.ring_length + nb_read) : cap);
@@ -216,7 +244,7 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
             // ReadNullPRS :349-358
             const long long want = NB_CORR - S.corr_length;
             const long long take = (want < rest) ? want : rest;
-            copy_samples(corr + S.corr_length, buf, take, t);
+            copy_block_samples<SRC>(corr + S.corr_length, block, bpos, take, t);
             __syncthreads();
             if (t == 0) {
                 S.corr_length += (int)take; S.pos += take;
@@ -236,12 +264,12 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
             if (full) {
                 // the frame completes inside this block: no assembly, the demodulator reads [0, split) from the frame
                 // buffer and the rest from the block; one sample is moved over when the boundary would split a pair
-                if ((have & 1) && t == 0) frame[have] = buf[0];
+                if ((have & 1) && t == 0) frame[have] = sample_at<SRC>(block, bpos);
                 // the NULL symbol at the end of this frame heads the next correlation window (:558-562)
                 const int null_at = NB_FRAME_SYMBOLS * NB_SYMBOL_PERIOD;
                 for (int j = t; j < NB_NULL_PERIOD; j += 256) {
                     const int idx = null_at + j;
-                    corr[j] = (idx < have) ? frame[idx] : buf[idx - have];
+                    corr[j] = (idx < have) ? frame[idx] : sample_at<SRC>(block, bpos + (idx - have));
                 }
             } else if (t == 0) {
                 B.copy_src[s] = S.pos; B.copy_dst[s] = have; B.copy_cnt[s] = (int)take;      // carried over by stream_copy_kernel
@@ -283,17 +311,18 @@ void stream_advance_kernel(BankView B, int n_streams, const f2* __restrict__ iq,
 // reduced to |re| + |im| into LDS; one lane per window then adds its k terms in the reference's sequential order.
 constexpr int L1_WINDOWS = 64;
 constexpr int L1_MAX_K = 128;
+template <int SRC>
 __global__ __launch_bounds__(256)
-void stream_l1_kernel(BankView B, const f2* __restrict__ iq, size_t stream_stride, long long n_win, int k, long long stride) {
+void stream_l1_kernel(BankView B, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_win, int k, long long stride) {
     __shared__ float term[L1_WINDOWS * (L1_MAX_K + 1)];
     const long long w0 = (long long)blockIdx.x * L1_WINDOWS;
     const int s = blockIdx.y, t = threadIdx.x;
-    const f2* base = iq + (size_t)s * stream_stride;
+    const uint8_t* base = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
     const int m = (int)((n_win - w0 < L1_WINDOWS) ? (n_win - w0) : L1_WINDOWS);
     if (k <= L1_MAX_K) {
         for (int e = t; e < m * k; e += 256) {
             const int w = e / k, i = e - w * k;
-            const f2 v = base[(w0 + w) * stride + i];
+            const f2 v = sample_at<SRC>(base, (w0 + w) * stride + i);
             term[w * (k + 1) + i] = __builtin_fabsf(v.x) + __builtin_fabsf(v.y);
         }
         __syncthreads();
@@ -303,22 +332,24 @@ void stream_l1_kernel(BankView B, const f2* __restrict__ iq, size_t stream_strid
             B.win[(size_t)s * B.win_cap + w0 + t] = acc / (float)k;
         }
     } else if (t < m) {
-        B.win[(size_t)s * B.win_cap + w0 + t] = l1_window(base + (w0 + t) * stride, k);
+        B.win[(size_t)s * B.win_cap + w0 + t] = l1_window<SRC>(base, (w0 + t) * stride, k);
     }
 }
 
 // the round's bulk copy block -> frame buffer (the unfinished frame at the end of a block), COPY_WGS workgroups per stream
+template <int SRC>
 __global__ __launch_bounds__(256)
-void stream_copy_kernel(BankView B, const f2* __restrict__ iq, size_t stream_stride) {
+void stream_copy_kernel(BankView B, const uint8_t* __restrict__ iq, size_t stream_stride) {
     const int s = blockIdx.y;
     const int cnt = B.copy_cnt[s];
     if (cnt == 0) return;
-    const f2* src = iq + (size_t)s * stream_stride + B.copy_src[s];
+    const uint8_t* src = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
+    const long long first = B.copy_src[s];
     f2* dst = B.frame + (size_t)s * NB_FRAME_SAMPLES + B.copy_dst[s];
     const int per = (((cnt + COPY_WGS - 1) / COPY_WGS) + 255) & ~255;
     const int a = blockIdx.x * per;
     const int b = (a + per < cnt) ? (a + per) : cnt;
-    for (int i = a + threadIdx.x; i < b; i += 256) dst[i] = src[i];
+    for (int i = a + threadIdx.x; i < b; i += 256) dst[i] = sample_at<SRC>(src, first + i);
 }
 
 __global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status) {
@@ -423,8 +454,11 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
     return DABGPU_OK;
 }
 
-int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t stream_stride_samples, size_t n_samples,
-                               int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+}  // extern "C"
+
+template <int SRC>
+static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t stream_stride_samples, size_t n_samples,
+                             int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
     if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
     // a frame needs at least 76 symbols + a NULL minus the sync's pull-back of new samples
@@ -433,7 +467,7 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
         dabgpu_set_error("stream_bank_process: max_frames_per_stream must be at least %zu for %zu samples", need, n_samples);
         return DABGPU_ERR_INVALID_ARG;
     }
-    if (((uintptr_t)d_iq & 7) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("stream_bank_process: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
+    if (((uintptr_t)d_iq & (src_sample_bytes<SRC>::value - 1)) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("stream_bank_process: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
     hipStream_t s = (hipStream_t)stream;
@@ -454,8 +488,8 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
             b->view.win_cap = n_win;
         }
         if (n_win > 0) {
-            hipLaunchKernelGGL(stream_l1_kernel, dim3((unsigned)((n_win + L1_WINDOWS - 1) / L1_WINDOWS), (unsigned)n), dim3(256), 0, s,
-                               b->view, reinterpret_cast<const f2*>(d_iq), stream_stride_samples, n_win, k, stride);
+            hipLaunchKernelGGL(stream_l1_kernel<SRC>, dim3((unsigned)((n_win + L1_WINDOWS - 1) / L1_WINDOWS), (unsigned)n), dim3(256), 0, s,
+                               b->view, static_cast<const uint8_t*>(d_iq), stream_stride_samples, n_win, k, stride);
             CK(hipGetLastError());
         }
     }
@@ -464,15 +498,15 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
     int h_not_done = 1;
     for (int round = 0; h_not_done != 0; round++) {
         CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
-        hipLaunchKernelGGL(stream_advance_kernel, dim3((unsigned)n), dim3(256), 0, s, b->view, n, reinterpret_cast<const f2*>(d_iq),
+        hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)n), dim3(256), 0, s, b->view, n, static_cast<const uint8_t*>(d_iq),
                            stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0);
         CK(hipGetLastError());
-        hipLaunchKernelGGL(stream_copy_kernel, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, reinterpret_cast<const f2*>(d_iq),
+        hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, static_cast<const uint8_t*>(d_iq),
                            stream_stride_samples);
         CK(hipGetLastError());
         CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
                               nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, 1, s));
-        CK(dabgpu_launch_ofdm_demod(b->view.frame, 0, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
+        CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
                                     n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
                                     (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, NB_FRAME_SYMBOLS, NB_FFT, s));
@@ -491,6 +525,13 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t 
     return DABGPU_OK;
 }
 
+extern "C" {
+
+int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t stream_stride_samples, size_t n_samples,
+                               int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+    return bank_process_impl<0>(b, d_iq, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
+}
+
 // the same from blocks still in their capture format: dequantised on the device (iq_convert_kernel, reader arithmetic of
 // examples/app_helpers/app_iq_readers.h) into bank-owned scratch on `stream`, then processed as above
 int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
@@ -499,6 +540,18 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int
     const size_t sb = dabgpu_iq_format_sample_bytes(format);
     if (sb == 0) { dabgpu_set_error("stream_bank_process_raw: unknown format %d", format); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
+    // formats the kernels read by themselves: no conversion pass, 2-4 bytes per sample from HBM instead of 8
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32:
+        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8:
+        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
+    case DABGPU_IQ_RAW_S8:
+        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16:
+        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
+    default: break;
+    }
     if (((stream_stride_samples * sb) & 15) != 0 && b->n > 1) {
         dabgpu_set_error("stream_bank_process_raw: the byte stride between streams must be a multiple of 16"); return DABGPU_ERR_INVALID_ARG;
     }

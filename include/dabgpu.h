@@ -361,8 +361,10 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank *bank, void *stream);     /* eve
 int dabgpu_stream_bank_process(dabgpu_stream_bank *bank, const float *d_iq, size_t stream_stride_samples, size_t n_samples,
                                int8_t *d_bits, size_t max_frames_per_stream, int32_t *d_n_frames, void *stream);
 /* The same from blocks still in a capture format (dabgpu_iq_format): d_raw holds n_samples IQ pairs per stream, stream s at
- * byte offset s * stream_stride_samples * sample_bytes (a multiple of 16).  The block is dequantised on the device with the
- * reader arithmetic (dabgpu_iq_convert) into bank-owned scratch, then processed as above. */
+ * byte offset s * stream_stride_samples * sample_bytes.  raw_u8 / raw_s8 / raw_s16l (and wav PCM8 / PCM16 / float32) blocks are
+ * read by the bank's kernels themselves -- level windows, NULL search, buffering and the demodulator's frame tails dequantise
+ * on the fly with the reader arithmetic, 2-4 bytes per sample instead of 8 and no conversion pass; any other format is first
+ * dequantised (dabgpu_iq_convert) into bank-owned scratch (then d_raw and the byte offset between streams must be multiples of 16). */
 int dabgpu_stream_bank_process_raw(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
                                    size_t n_samples, int8_t *d_bits, size_t max_frames_per_stream, int32_t *d_n_frames, void *stream);
 /* snapshot of every stream's getters (GetState, GetSignalAverage, Get*FrequencyOffset, ...) into host memory; synchronous */

@@ -101,41 +101,58 @@ def test_stream_bank_reset_and_argument_checks(oracle):
     bank.close()
 
 
-def test_stream_bank_from_u8_capture(oracle):
-    """rtl_sdr style u8 streams: the bank dequantises on the device; frames equal the oracle state machine fed
-    oracle.iq_convert(raw) in the same blocks"""
+@pytest.mark.parametrize("name", ["raw_u8", "raw_s8", "raw_s16l", "raw_u16l"])
+def test_stream_bank_from_capture_formats(oracle, name):
+    """SDR-style quantised streams: u8 / s8 / s16l blocks are read by the bank's kernels themselves (no conversion pass),
+    other formats are dequantised into bank scratch first; frames equal the oracle state machine fed oracle.iq_convert(raw)
+    in the same blocks"""
     import dabgpu
     import stream_model as SM
     import torch
     ctx = dabgpu.Context(0)
-    E, block = 2, 65536
+    fmt = dabgpu.IQ_FORMATS.index(name)
+    # fused formats: any block boundary (+2 samples: odd byte alignments inside the raw data); converted formats: 16-byte aligned blocks
+    E, block = 2, (65536 + 2 if name != "raw_u16l" else 65536)
     streams = [make_stream(oracle, 21, 3, 1.1e-3, 500, 2.0), make_stream(oracle, 22, 3, -0.7e-3, 1700, 4.0)]
     n = min(s.size for s in streams) // 8 * 8
     raws = []
     for s in streams:
         x = np.stack([s[:n].real, s[:n].imag], axis=-1).reshape(-1)
-        raws.append(np.clip(np.rint(x / np.abs(x).max() * 127.0 + 127.5), 0, 255).astype(np.uint8))
-    raw = np.stack(raws)                                                    # [E][2 n] bytes
+        x = x / np.abs(x).max()
+        if name == "raw_u8":
+            raws.append(np.clip(np.rint(x * 127.0 + 127.5), 0, 255).astype(np.uint8))
+        elif name == "raw_s8":
+            raws.append(np.clip(np.rint(x * 127.0), -128, 127).astype(np.int8).view(np.uint8))
+        elif name == "raw_s16l":
+            raws.append(np.clip(np.rint(x * 30000.0), -32768, 32767).astype("<i2").view(np.uint8))
+        else:
+            raws.append((np.clip(np.rint(x * 30000.0), -32768, 32767).astype(np.int32) + 32768).astype("<u2").view(np.uint8))
+    raw = np.stack(raws)                                                    # [E][n * sample bytes]
+    sb = dabgpu.iq_format_sample_bytes(fmt)
     d_raw = torch.from_numpy(raw).cuda()
     bank = dabgpu.StreamBank(ctx, E)
     max_frames = block // 191400 + 2
     d_bits = torch.zeros((E, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")
     d_nf = torch.zeros(E, dtype=torch.int32, device="cuda")
     models = [SM.StreamModel(oracle) for _ in range(E)]
-    iq = [oracle.iq_convert(raw[e], 0).view(np.complex64) for e in range(E)]
+    iq = [oracle.iq_convert(raw[e], fmt).view(np.complex64) for e in range(E)]
     got = 0
     for k in range(0, n, block):
         m = min(block, n - k)
-        bank.process_raw(d_raw[:, 2 * k:].data_ptr(), 0, n, m, d_bits, max_frames, d_nf)
+        bank.process_raw(d_raw[:, sb * k:].data_ptr(), fmt, n, m, d_bits, max_frames, d_nf)
         torch.cuda.synchronize()
         nf = d_nf.cpu().numpy()
         for e in range(E):
             before = len(models[e].out_frames)
             models[e].process(iq[e][k:k + m])
             new = models[e].out_frames[before:]
-            assert nf[e] == len(new), (k, e)
+            assert nf[e] == len(new), (name, k, e)
             for j, fr in enumerate(new):
-                assert np.array_equal(d_bits[e, j].cpu().numpy(), fr["bits"]), (k, e, j)
+                assert np.array_equal(d_bits[e, j].cpu().numpy(), fr["bits"]), (name, k, e, j)
             got += len(new)
+    st = bank.status()
+    for e in range(E):
+        assert st["freq_fine"][e].view(np.uint32) == np.float32(models[e].sync.freq_fine).view(np.uint32)
+        assert st["signal_l1_average"][e].view(np.uint32) == np.float32(models[e].signal_avg).view(np.uint32)
     assert got >= 3
     bank.close()

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--block-frames", type=int, default=2)
     ap.add_argument("--calls", type=int, default=6)
+    ap.add_argument("--format", type=str, default="c32", help="c32 | raw_u8 | raw_s16l : capture format of the blocks")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = dabgpu.Context(0)
@@ -69,12 +70,24 @@ def main():
     bits = torch.zeros((E, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev)
     nf = torch.zeros(E, dtype=torch.int32, device=dev)
     sv = torch.view_as_real(stream)
+    fmt = None
+    if args.format != "c32":
+        fmt = dabgpu.IQ_FORMATS.index(args.format)
+        peak = float(sv.abs().max().item())
+        if args.format == "raw_u8":
+            raw = torch.clamp(torch.round(sv / peak * 127.0 + 127.5), 0, 255).to(torch.uint8)
+        else:
+            raw = torch.clamp(torch.round(sv / peak * 30000.0), -32768, 32767).to(torch.int16)
+        del stream, sv
+        sb = dabgpu.iq_format_sample_bytes(fmt)
     frames_total, times = 0, []
     for k in range(args.calls):
-        blk = sv[:, k * n_block:(k + 1) * n_block]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        bank.process(blk, total, n_block, bits, max_frames, nf)
+        if fmt is None:
+            bank.process(sv[:, k * n_block:(k + 1) * n_block], total, n_block, bits, max_frames, nf)
+        else:
+            bank.process_raw(raw.data_ptr() + k * n_block * sb, fmt, total, n_block, bits, max_frames, nf)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         got = int(nf.sum().item())
@@ -83,7 +96,7 @@ def main():
     st = bank.status()
     steady = times[2:] if len(times) > 3 else times
     fps = sum(g_ for _, g_ in steady) / sum(t for t, _ in steady)
-    print(json.dumps({"streams": E, "block_samples": n_block, "calls": args.calls, "frames_total": frames_total,
+    print(json.dumps({"streams": E, "format": args.format, "block_samples": n_block, "calls": args.calls, "frames_total": frames_total,
                       "frames_desync_total": int(st["total_frames_desync"].sum()), "steady_frames_per_s": fps,
                       "steady_x_realtime_per_stream": fps / E / (2.048e6 / 196608),
                       "per_call_ms": [round(t * 1e3, 3) for t, _ in times], "per_call_frames": [g_ for _, g_ in times]}))
