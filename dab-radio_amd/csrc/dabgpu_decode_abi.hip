@@ -158,8 +158,8 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
 }
 
-extern "C" int dabgpu_fic_decode_frames(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride,
-                                        uint8_t* d_fib_bytes, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride, const int32_t* d_slots,
+                          uint8_t* d_fib_bytes, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
     if (!c || !d_bits || !d_fib_bytes || !d_results) { dabgpu_set_error("fic_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (frame_stride < DABGPU_NB_FIC_BITS) { dabgpu_set_error("fic_decode_frames: frame_stride %zu < 9216", frame_stride); return DABGPU_ERR_INVALID_ARG; }
@@ -169,14 +169,25 @@ extern "C" int dabgpu_fic_decode_frames(dabgpu_ctx* c, const int8_t* d_bits, siz
     dabgpu_cw_desc* d_descs = nullptr;
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
-    st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, s), "fic_build_descs launch");
+    st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
     return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s);
 }
 
-extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
-                                        int newest_frame_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
-                                        size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+extern "C" int dabgpu_fic_decode_frames(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride,
+                                        uint8_t* d_fib_bytes, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    return fic_decode_any(c, d_bits, n_frames, frame_stride, nullptr, d_fib_bytes, d_results, tie_rule, stream);
+}
+
+extern "C" int dabgpu_fic_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, const int32_t* d_newest_slot,
+                                      uint8_t* d_fib_bytes, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    if (!d_newest_slot) { dabgpu_set_error("fic_decode_ring: null slot array"); return DABGPU_ERR_INVALID_ARG; }
+    return fic_decode_any(c, d_hist, n_ens, ens_stride, d_newest_slot, d_fib_bytes, d_results, tie_rule, stream);
+}
+
+static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                          int newest_frame_slot, const int32_t* d_slots, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                          size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
     if (!c || !d_hist || !h_sub || !d_out || !d_results) { dabgpu_set_error("msc_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_ens == 0 || n_sub == 0) return DABGPU_OK;
     if (hist_frames < 5 || newest_frame_slot < 0 || newest_frame_slot >= hist_frames || n_sub < 0) {
@@ -214,8 +225,23 @@ extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, siz
     if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
     if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                       d_out, out_ens_stride, (int)off, s), "msc_build_descs launch"))) return st;
+                                                       d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
+}
+
+extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                        int newest_frame_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                                        size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, nullptr, h_sub, n_sub, d_out, out_ens_stride,
+                          d_results, tie_rule, stream);
+}
+
+extern "C" int dabgpu_msc_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                      const int32_t* d_newest_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                                      size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+    if (!d_newest_slot) { dabgpu_set_error("msc_decode_ring: null slot array"); return DABGPU_ERR_INVALID_ARG; }
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, 0, d_newest_slot, h_sub, n_sub, d_out, out_ens_stride, d_results,
+                          tie_rule, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -67,10 +67,11 @@ extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
                                             hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
-                                              size_t frame_stride, uint8_t* d_out, hipStream_t stream);
+                                              size_t frame_stride, uint8_t* d_out, const int32_t* d_slots, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
-                                              uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, hipStream_t stream);
+                                              uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
+                                              hipStream_t stream);
 
 // ---- sync ----
 extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream);

@@ -153,11 +153,15 @@ __global__ __launch_bounds__(64)
 void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ frames, const unsigned long long* __restrict__ stream_offsets,
                     size_t frame_stride, const uint32_t* __restrict__ frame_bytes, int n_frames, uint8_t* __restrict__ sf_acc,
                     uint8_t* __restrict__ sf_out, size_t sf_out_stride, dabgpu_superframe_result* __restrict__ results, int max_sf,
-                    int32_t* __restrict__ counts, int n_streams)
+                    int32_t* __restrict__ counts, int n_streams, const int32_t* __restrict__ active, int active_divisor)
 {
     __shared__ DpLds L;
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= n_streams) return;
+    if (active != nullptr && active[s / active_divisor] < 0) {           // nothing new for this stream's ensemble in this call
+        if (lane == 0) { counts[4 * s] = 0; counts[4 * s + 1] = 0; counts[4 * s + 2] = 0; counts[4 * s + 3] = states[s].curr_dab_frame; }
+        return;
+    }
     for (int k = lane; k < 512; k += 64) L.exp[k] = GF_TABLES.exp[k];
     for (int k = lane; k < 256; k += 64) {
         L.log[k] = GF_TABLES.log[k];
@@ -384,9 +388,18 @@ int dabgpu_dabplus_bank_create(dabgpu_ctx* c, size_t n_streams, dabgpu_dabplus_b
 int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank* b, const uint8_t* d_frames, const uint64_t* d_stream_offsets, size_t frame_stride_bytes,
                                 const uint32_t* d_frame_bytes, int n_frames, uint8_t* d_superframes, size_t superframe_stride_bytes,
                                 dabgpu_superframe_result* d_results, int max_superframes, int32_t* d_counts, void* stream) {
+    return dabgpu_dabplus_bank_process_masked(b, d_frames, d_stream_offsets, frame_stride_bytes, d_frame_bytes, n_frames, d_superframes,
+                                              superframe_stride_bytes, d_results, max_superframes, d_counts, nullptr, 1, stream);
+}
+
+int dabgpu_dabplus_bank_process_masked(dabgpu_dabplus_bank* b, const uint8_t* d_frames, const uint64_t* d_stream_offsets, size_t frame_stride_bytes,
+                                       const uint32_t* d_frame_bytes, int n_frames, uint8_t* d_superframes, size_t superframe_stride_bytes,
+                                       dabgpu_superframe_result* d_results, int max_superframes, int32_t* d_counts,
+                                       const int32_t* d_active, int streams_per_flag, void* stream) {
     if (!b || !d_frames || !d_stream_offsets || !d_frame_bytes || !d_superframes || !d_results || !d_counts) {
         dabgpu_set_error("dabplus_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG;
     }
+    if (streams_per_flag < 1) { dabgpu_set_error("dabplus_bank_process_masked: streams_per_flag must be positive"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames <= 0) return DABGPU_OK;
     if (max_superframes < (n_frames + 4) / 5 || superframe_stride_bytes == 0) {
         dabgpu_set_error("dabplus_bank_process: max_superframes must be at least ceil(n_frames / 5)"); return DABGPU_ERR_INVALID_ARG;
@@ -394,7 +407,7 @@ int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank* b, const uint8_t* d_frames,
     (void)hipSetDevice(b->ctx->device);
     hipLaunchKernelGGL(dabplus_kernel, dim3((unsigned)b->n), dim3(64), 0, (hipStream_t)stream, b->d_states, d_frames,
                        reinterpret_cast<const unsigned long long*>(d_stream_offsets), frame_stride_bytes, d_frame_bytes, n_frames, b->d_acc,
-                       d_superframes, superframe_stride_bytes, d_results, max_superframes, d_counts, (int)b->n);
+                       d_superframes, superframe_stride_bytes, d_results, max_superframes, d_counts, (int)b->n, d_active, streams_per_flag);
     return dabgpu_check_hip(hipGetLastError(), "dabplus_kernel launch");
 }
 

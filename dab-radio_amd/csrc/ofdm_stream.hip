@@ -114,7 +114,7 @@ __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __r
 template <int SRC>
 __global__ __launch_bounds__(256)
 void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
-                           dabgpu_stream_cfg cfg, int max_frames, int first_round)
+                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode)
 {
     __shared__ StreamState S;
     __shared__ float win[256];
@@ -283,7 +283,8 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
                     const dabgpu_sync_state y = B.sync[s];
                     B.freq[s] = y.freq_coarse + y.freq_fine;
                     // a frame beyond the caller's capacity is demodulated into the last slot (and reported through n_frames)
-                    const int slot = (S.n_out < max_frames) ? S.n_out : (max_frames - 1);
+                    // (ring mode: slot of the stream's frame-history ring = frames demodulated so far mod ring length)
+                    const int slot = ring_mode ? (S.total_frames_read % max_frames) : ((S.n_out < max_frames) ? S.n_out : (max_frames - 1));
                     dabgpu_frame_desc d;
                     d.slot = s * max_frames + slot;
                     d.split = have + (have & 1);
@@ -352,11 +353,12 @@ void stream_copy_kernel(BankView B, const uint8_t* __restrict__ iq, size_t strea
     for (int i = a + threadIdx.x; i < b; i += 256) dst[i] = sample_at<SRC>(src, first + i);
 }
 
-__global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status) {
+__global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status,
+                                     int ring_frames) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
     const StreamState S = B.st[s];
-    if (n_frames) n_frames[s] = S.n_out;
+    if (n_frames) n_frames[s] = (ring_frames > 0) ? ((S.n_out > 0) ? ((S.total_frames_read - 1) % ring_frames) : -1) : S.n_out;
     if (status) {
         const dabgpu_sync_state y = B.sync[s];
         dabgpu_stream_status o;
@@ -456,13 +458,19 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
 
 }  // extern "C"
 
+// ring_mode: d_bits = [n_streams][max_frames_per_stream = ring length][230400], a completed frame goes to slot
+// (frames demodulated so far) mod ring length, d_n_frames receives the slot written in this call or -1
 template <int SRC>
 static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t stream_stride_samples, size_t n_samples,
-                             int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+                             int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream, int ring_mode = 0) {
     if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
     // a frame needs at least 76 symbols + a NULL minus the sync's pull-back of new samples
-    const size_t need = n_samples / (size_t)(NB_FRAME_SAMPLES - NB_CORR) + 2;
+    const size_t need = ring_mode ? 1 : (n_samples / (size_t)(NB_FRAME_SAMPLES - NB_CORR) + 2);
+    if (ring_mode && n_samples > (size_t)(NB_FRAME_SAMPLES - NB_CORR)) {
+        dabgpu_set_error("stream_bank_process_ring: at most %d samples per call (one frame per stream per call)", NB_FRAME_SAMPLES - NB_CORR);
+        return DABGPU_ERR_INVALID_ARG;
+    }
     if (max_frames_per_stream < need || max_frames_per_stream > (size_t)(1 << 20) || b->n * max_frames_per_stream > (size_t)0x7FFFFFFF) {
         dabgpu_set_error("stream_bank_process: max_frames_per_stream must be at least %zu for %zu samples", need, n_samples);
         return DABGPU_ERR_INVALID_ARG;
@@ -499,7 +507,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     for (int round = 0; h_not_done != 0; round++) {
         CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
         hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)n), dim3(256), 0, s, b->view, n, static_cast<const uint8_t*>(d_iq),
-                           stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0);
+                           stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0, ring_mode);
         CK(hipGetLastError());
         hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, static_cast<const uint8_t*>(d_iq),
                            stream_stride_samples);
@@ -518,7 +526,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     }
     if (d_n_frames) {
         hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, d_n_frames,
-                           (dabgpu_stream_status*)nullptr);
+                           (dabgpu_stream_status*)nullptr, ring_mode ? (int)max_frames_per_stream : 0);
         CK(hipGetLastError());
     }
 #undef CK
@@ -576,13 +584,33 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int
     return dabgpu_stream_bank_process(b, b->d_raw_scratch, padded, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream);
 }
 
+// frames go straight into per-stream frame-history rings (the layout dabgpu_fic_decode_ring / dabgpu_msc_decode_ring read)
+int dabgpu_stream_bank_process_ring(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                    int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, void* stream) {
+    if (!b || !d_raw || !d_hist || !d_newest_slot) { dabgpu_set_error("stream_bank_process_ring: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (hist_frames < 5) { dabgpu_set_error("stream_bank_process_ring: the ring needs at least 5 frames"); return DABGPU_ERR_INVALID_ARG; }
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32:
+        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8:
+        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+    case DABGPU_IQ_RAW_S8:
+        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16:
+        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+    default:
+        dabgpu_set_error("stream_bank_process_ring: format %d is not read directly (use raw_f32l, raw_u8, raw_s8 or raw_s16l)", format);
+        return DABGPU_ERR_UNSUPPORTED;
+    }
+}
+
 int dabgpu_stream_bank_status(dabgpu_stream_bank* b, dabgpu_stream_status* h_status, void* stream) {
     if (!b || !h_status) { dabgpu_set_error("stream_bank_status: null argument"); return DABGPU_ERR_INVALID_ARG; }
     (void)hipSetDevice(b->ctx->device);
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)b->n;
     int st;
-    hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, (int*)nullptr, b->d_status);
+    hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, (int*)nullptr, b->d_status, 0);
     if ((st = dabgpu_check_hip(hipGetLastError(), "stream_report_kernel launch"))) return st;
     if ((st = dabgpu_check_hip(hipMemcpyAsync(h_status, b->d_status, b->n * sizeof(dabgpu_stream_status), hipMemcpyDeviceToHost, s), "hipMemcpyAsync"))) return st;
     return dabgpu_check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");

@@ -234,6 +234,10 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
     for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
         const dabgpu_cw_desc D = descs[cw];
         const int n_steps = (int)D.n_steps;
+        if (n_steps < 7) {                            // skipped work item (ring decode of an ensemble without a new frame)
+            if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; results[cw] = R; }
+            continue;
+        }
         // segment boundaries in trellis steps; the 6 tail steps use PI_8 == PI_X
         int seg_end[5], seg_pi[5], seg_in0[5];
         {
@@ -391,14 +395,22 @@ extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n
 namespace dabgpu {
 
 // FIC: 4 FIB groups per frame, PI_16 x 21 blocks, PI_15 x 3 blocks, tail (fic_decoder.cpp:53-84)
+// slots != nullptr: frame fr is slot slots[fr] of ensemble fr's frame-history ring (frame_stride = bytes per ensemble),
+// a negative slot = no new frame for that ensemble (descriptor with n_steps = 0: the decoder skips it)
 __global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits, size_t n_frames, size_t frame_stride,
-                                       uint8_t* out)
+                                       uint8_t* out, const int32_t* slots)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_frames * 4) return;
     const size_t fr = i >> 2, g = i & 3;
     dabgpu_cw_desc D = {};
-    D.d_src = (uint64_t)(uintptr_t)(bits + fr * frame_stride + g * 2304);
+    const int8_t* base = bits + fr * frame_stride;
+    if (slots != nullptr) {
+        const int sl = slots[fr];
+        if (sl < 0) { descs[i] = D; return; }
+        base += (size_t)sl * 230400;
+    }
+    D.d_src = (uint64_t)(uintptr_t)(base + g * 2304);
     D.d_out = (uint64_t)(uintptr_t)(out + i * 96);
     D.n_steps = 768 + 6;
     D.seg_pi[0] = 16; D.seg_steps[0] = 32 * 21;
@@ -411,7 +423,7 @@ __global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits
 // straight out of the history of demodulated frames (msc_decoder.cpp:46-75 + cif_deinterleaver.cpp:36-71)
 __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride,
                                        int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub,
-                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes)
+                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_ens = (size_t)4 * n_sub;
@@ -420,6 +432,10 @@ __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist
     const int rem = (int)(i - e * per_ens), c = rem / n_sub, s = rem - c * n_sub;
     const dabgpu_msc_plan P = plans[s];
     dabgpu_cw_desc D = {};
+    if (slots != nullptr) {                           // per-ensemble ring position; negative = nothing new for this ensemble
+        newest_frame_slot = slots[e];
+        if (newest_frame_slot < 0) { descs[i] = D; return; }
+    }
     D.d_src = (uint64_t)(uintptr_t)(hist + e * ens_stride + 9216 + (size_t)P.start_address * 64);
     D.d_out = (uint64_t)(uintptr_t)(out + e * out_ens_stride + (size_t)c * cif_out_bytes + P.out_offset);
     D.n_steps = P.n_steps;
@@ -456,21 +472,22 @@ extern "C" hipError_t dabgpu_launch_cif_deinterleave(const int8_t* d_ring, int n
 }
 
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
-                                              size_t frame_stride, uint8_t* d_out, hipStream_t stream)
+                                              size_t frame_stride, uint8_t* d_out, const int32_t* d_slots, hipStream_t stream)
 {
     const size_t n = n_frames * 4;
     hipLaunchKernelGGL(dabgpu::fic_build_descs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       d_descs, d_bits, n_frames, frame_stride, d_out);
+                       d_descs, d_bits, n_frames, frame_stride, d_out, d_slots);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
-                                              uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, hipStream_t stream)
+                                              uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
+                                              hipStream_t stream)
 {
     const size_t n = n_ens * 4 * (size_t)n_sub;
     hipLaunchKernelGGL(dabgpu::msc_build_descs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub, d_out,
-                       out_ens_stride, cif_out_bytes);
+                       out_ens_stride, cif_out_bytes, d_slots);
     return hipGetLastError();
 }

@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "dabgpu_dabplus_process_frame_host_sync",
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
+    "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -181,6 +182,14 @@ def lib():
                                                  C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                      C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_process_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
+                                                      C.c_void_p, C.c_void_p]
+        L.dabgpu_fic_decode_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p]
+        L.dabgpu_msc_decode_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_dabplus_bank_process_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
+                                                         C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.dabgpu_stream_bank_status.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_dabplus_bank_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.dabgpu_dabplus_bank_destroy.argtypes = [C.c_void_p]
@@ -358,6 +367,18 @@ class Context:
         check(lib().dabgpu_fic_decode_frames(self._h, _ptr(bits), n_frames, frame_stride, _ptr(fib_bytes), _ptr(results),
                                              tie_rule, self._stream(stream)), "dabgpu_fic_decode_frames")
 
+    def fic_decode_ring(self, history, n_ensembles, ensemble_stride, newest_slot, fib_bytes, results, tie_rule=0, stream=None):
+        check(lib().dabgpu_fic_decode_ring(self._h, _ptr(history), n_ensembles, ensemble_stride, _ptr(newest_slot), _ptr(fib_bytes),
+                                           _ptr(results), tie_rule, self._stream(stream)), "dabgpu_fic_decode_ring")
+
+    def msc_decode_ring(self, history, n_ensembles, ensemble_stride, history_frames, newest_slot, subchannels, out, out_ensemble_stride,
+                        results, tie_rule=0, stream=None):
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels)
+        check(lib().dabgpu_msc_decode_ring(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, _ptr(newest_slot), arr, n,
+                                           _ptr(out), out_ensemble_stride, _ptr(results), tie_rule, self._stream(stream)),
+              "dabgpu_msc_decode_ring")
+
     def msc_decode_frames(self, history, n_ensembles, ensemble_stride, history_frames, newest_frame_slot, subchannels,
                           out, out_ensemble_stride, results, tie_rule=0, stream=None):
         n = len(subchannels)
@@ -437,6 +458,10 @@ class StreamBank:
         check(lib().dabgpu_stream_bank_process_raw(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(bits), max_frames,
                                                    _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process_raw")
 
+    def process_ring(self, raw, fmt, stream_stride_samples, n_samples, hist, hist_frames, newest_slot, stream=None):
+        check(lib().dabgpu_stream_bank_process_ring(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(hist), hist_frames,
+                                                    _ptr(newest_slot), Context._stream(stream)), "dabgpu_stream_bank_process_ring")
+
     def status(self, stream=None):
         import numpy as np
         out = np.zeros(self.n, dtype=np.dtype(STREAM_STATUS_DTYPE))
@@ -472,6 +497,13 @@ class DabPlusBank:
         check(lib().dabgpu_dabplus_bank_process(self._h, _ptr(frames), _ptr(stream_offsets), frame_stride, _ptr(frame_bytes),
                                                 n_frames, _ptr(superframes), superframe_stride, _ptr(results), max_superframes,
                                                 _ptr(counts), Context._stream(stream)), "dabgpu_dabplus_bank_process")
+
+    def process_masked(self, frames, stream_offsets, frame_stride, frame_bytes, n_frames, superframes, superframe_stride, results,
+                       max_superframes, counts, active, streams_per_flag, stream=None):
+        check(lib().dabgpu_dabplus_bank_process_masked(self._h, _ptr(frames), _ptr(stream_offsets), frame_stride, _ptr(frame_bytes),
+                                                       n_frames, _ptr(superframes), superframe_stride, _ptr(results), max_superframes,
+                                                       _ptr(counts), _ptr(active), streams_per_flag, Context._stream(stream)),
+              "dabgpu_dabplus_bank_process_masked")
 
     def process_frame_host(self, frame):
         """one-stream bank: -> (superframe_done, firecode_wait_failed, result record, super frame bytes or None)"""

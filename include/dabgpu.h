@@ -263,6 +263,16 @@ int dabgpu_msc_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits_history, size
                              int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
                              dabgpu_codeword_result *d_results, int tie_rule, void *stream);
 
+/* Ring forms: ensemble e decodes the frame in slot d_newest_slot[e] of its own frame-history ring d_hist + e*ensemble_stride
+ * (each ensemble at its own ring position, as dabgpu_stream_bank_process_ring leaves them); a negative slot skips the ensemble
+ * (its result records come back with n_out_bytes = 0).  FIB bytes [n_ensembles][4][96], results [n_ensembles][4]. */
+int dabgpu_fic_decode_ring(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride,
+                           const int32_t *d_newest_slot, uint8_t *d_fib_bytes, dabgpu_codeword_result *d_results, int tie_rule,
+                           void *stream);
+int dabgpu_msc_decode_ring(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride, int history_frames,
+                           const int32_t *d_newest_slot, const dabgpu_subchannel *subchannels, int n_subchannels, uint8_t *d_out,
+                           size_t out_ensemble_stride, dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Single-stream, host-buffer, synchronous forms used by the C++ mirror classes (one codeword per call).
  */
@@ -367,6 +377,13 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank *bank, const float *d_iq, size
  * dequantised (dabgpu_iq_convert) into bank-owned scratch (then d_raw and the byte offset between streams must be multiples of 16). */
 int dabgpu_stream_bank_process_raw(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
                                    size_t n_samples, int8_t *d_bits, size_t max_frames_per_stream, int32_t *d_n_frames, void *stream);
+/* Ring form for a device-resident pipeline: a completed frame of stream s is written to slot (frames demodulated so far) mod
+ * hist_frames of d_hist [n_streams][hist_frames][230400] -- the per-ensemble frame-history ring dabgpu_fic_decode_ring /
+ * dabgpu_msc_decode_ring read -- and d_newest_slot[s] receives that slot, or -1 when the stream completed no frame in this
+ * call.  At most 191400 samples per call (so that a stream completes at most one frame); format must be one the kernels read
+ * directly (raw_f32l, raw_u8, raw_s8, raw_s16l, wav PCM8/PCM16/float32). */
+int dabgpu_stream_bank_process_ring(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
+                                    size_t n_samples, int8_t *d_hist, int hist_frames, int32_t *d_newest_slot, void *stream);
 /* snapshot of every stream's getters (GetState, GetSignalAverage, Get*FrequencyOffset, ...) into host memory; synchronous */
 int dabgpu_stream_bank_status(dabgpu_stream_bank *bank, dabgpu_stream_status *h_status, void *stream);
 
@@ -412,6 +429,12 @@ int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank *bank, const uint8_t *d_fram
                                 size_t frame_stride_bytes, const uint32_t *d_frame_bytes, int n_frames, uint8_t *d_superframes,
                                 size_t superframe_stride_bytes, dabgpu_superframe_result *d_results, int max_superframes,
                                 int32_t *d_counts, void *stream);
+/* the same, skipping every stream whose flag d_active[s / streams_per_flag] is negative (e.g. the newest-slot array of
+ * dabgpu_stream_bank_process_ring with streams ordered ensemble-major: streams_per_flag = DAB+ sub-channels per ensemble) */
+int dabgpu_dabplus_bank_process_masked(dabgpu_dabplus_bank *bank, const uint8_t *d_frames, const uint64_t *d_stream_offsets,
+                                       size_t frame_stride_bytes, const uint32_t *d_frame_bytes, int n_frames, uint8_t *d_superframes,
+                                       size_t superframe_stride_bytes, dabgpu_superframe_result *d_results, int max_superframes,
+                                       int32_t *d_counts, const int32_t *d_active, int streams_per_flag, void *stream);
 /* one Process(buf) of a one-stream bank with host buffers (the AAC_Frame_Processor mirror class); h_superframe [5*n_bytes] */
 int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank *bank, const uint8_t *h_frame, uint32_t n_bytes, int *superframe_done,
                                            int *firecode_wait_failed, uint32_t *firecode_wait_rx_calc /* may be NULL */,

@@ -147,7 +147,7 @@ class StreamModel:
                 pos += self.read_symbols(rest)
 
 
-def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=1234, noise=3.0, amplitude=1.0 / 39.2):
+def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=1234, noise=3.0, amplitude=1.0 / 39.2, payload=None):
     """n_frames transmission frames: FIC = 4 groups of 3 CRC-valid random FIBs, MSC = the listed EEP sub-channels
     (random payload, time interleaved across CIFs), other capacity units random bits; then CFO, noise, a lead-in of
     noise-only samples so that the NULL detector has a level to compare with.
@@ -155,7 +155,8 @@ def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=12
     rng = np.random.default_rng(seed)
     n_cif = 4 * n_frames
     plans = [oracle.subchannel_plan(s) for s in subs]
-    payload = [rng.integers(0, 256, (n_cif, p[2]), dtype=np.uint8) for p in plans]
+    if payload is None:
+        payload = [rng.integers(0, 256, (n_cif, p[2]), dtype=np.uint8) for p in plans]
     cif_bits = rng.integers(0, 2, (n_cif, oracle.NB_CIF_BITS), dtype=np.uint8)
     for s, p, pay in zip(subs, plans, payload):
         lf = np.stack([oracle.msc_encode_logical(s, pay[t]) for t in range(n_cif)])
