@@ -115,6 +115,34 @@ static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, u
                                                   tie_rule ? 1 : 0, c->d_vit_tables, s), "viterbi_kernel launch");
 }
 
+extern "C" int dabgpu_viterbi_set_mapping(dabgpu_ctx* c, int mapping) {
+    if (!c || mapping < DABGPU_VIT_MAP_AUTO || mapping > DABGPU_VIT_MAP_LANE) { dabgpu_set_error("viterbi_set_mapping: bad argument"); return DABGPU_ERR_INVALID_ARG; }
+    c->vit_mapping = mapping;
+    return DABGPU_OK;
+}
+
+static bool use_lane_mapping(const dabgpu_ctx* c, size_t n_cw) {
+    if (c->vit_mapping == DABGPU_VIT_MAP_LANE) return true;
+    if (c->vit_mapping == DABGPU_VIT_MAP_WAVE) return false;
+    return n_cw >= DABGPU_VIT_LANE_MIN_CODEWORDS;
+}
+
+// lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (LANES_MAX_ROWS rows of
+// 768 bytes = 6 GiB), larger batches run as several launches over consecutive groups (each group's offsets are rebased
+// by the builder kernels through row_base)
+static const size_t LANES_MAX_ROWS = (size_t)8 << 20;
+
+static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
+                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s) {
+    int st = ensure_vit_tables(c);
+    if (st) return st;
+    uint32_t *d_sym = nullptr, *d_dec = nullptr;
+    if ((st = dabgpu_scratch(c, 18, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
+    if ((st = dabgpu_scratch(c, 19, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+    return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
+                                                        tie_rule ? 1 : 0, c->d_vit_tables, s), "vit_lanes_kernel launch");
+}
+
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
     uint64_t steps = 0;
     for (int k = 0; k < 4; k++) {
@@ -155,6 +183,25 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     st = dabgpu_check_hip(hipMemcpyAsync(d_descs, h_cw, n * sizeof(dabgpu_cw_desc), hipMemcpyHostToDevice, s), "hipMemcpyAsync(descs)");
     if (st) return st;
     // pageable host memory: the copy above has consumed h_cw when it returns, the caller may reuse it
+    bool uniform = true;                                  // one puncturing schedule for the whole batch?
+    for (size_t i = 1; i < n && uniform; i++)
+        uniform = h_cw[i].n_steps == h_cw[0].n_steps && !memcmp(h_cw[i].seg_pi, h_cw[0].seg_pi, sizeof(h_cw[0].seg_pi)) &&
+                  !memcmp(h_cw[i].seg_steps, h_cw[0].seg_steps, sizeof(h_cw[0].seg_steps));
+    for (size_t i = 0; i < n && uniform; i++)             // the lane mapping keeps ring offsets in 32 bits
+        uniform = h_cw[i].n_slots == 0 || (uint64_t)(h_cw[i].n_slots / h_cw[i].cifs_per_frame + 1) * h_cw[i].frame_stride +
+                                          (uint64_t)h_cw[i].cifs_per_frame * h_cw[i].cif_stride < ((uint64_t)1 << 32);
+    if (uniform && use_lane_mapping(c, n)) {
+        const uint32_t rows = dabgpu_vit_alloc_steps(max_steps);
+        const size_t slice_groups = std::max<size_t>(1, LANES_MAX_ROWS / rows);
+        for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
+            const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
+            dabgpu_vit_group* d_groups = nullptr;
+            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, s), "vit_groups launch"))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, d_results + cw0, s))) return st;
+        }
+        return DABGPU_OK;
+    }
     return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
 }
 
@@ -171,6 +218,20 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     if (st) return st;
     st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
+    if (use_lane_mapping(c, n)) {
+        // one schedule for every FIB group: groups of 64 consecutive codewords, processed in bounded slices
+        const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
+        const uint32_t rows = dabgpu_vit_alloc_steps(774);
+        const size_t slice_groups = std::max<size_t>(1, LANES_MAX_ROWS / rows);
+        for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
+            const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
+            dabgpu_vit_group* d_groups = nullptr;
+            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, d_results + cw0, s))) return st;
+        }
+        return DABGPU_OK;
+    }
     return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s);
 }
 
@@ -226,6 +287,30 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
+    if (use_lane_mapping(c, n)) {
+        // group (s, gq) = sub-channel s of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch stays
+        // inside the scratch bound
+        size_t rows_per_gq = 0;
+        std::vector<uint64_t> prefix((size_t)n_sub);
+        for (int k = 0; k < n_sub; k++) { prefix[(size_t)k] = rows_per_gq; rows_per_gq += dabgpu_vit_alloc_steps(plans[(size_t)k].n_steps); }
+        const size_t max_gq = std::max<size_t>(1, LANES_MAX_ROWS / rows_per_gq);
+        const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
+        uint64_t* d_prefix = nullptr;
+        if ((st = dabgpu_scratch(c, 24, prefix.size() * sizeof(uint64_t), (void**)&d_prefix))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s), "hipMemcpyAsync(prefix)"))) return st;
+        for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
+            const size_t ne = std::min(n_ens - e0, ens_per_slice);
+            const uint32_t gps = (uint32_t)((ne * 4 + 63) / 64);
+            const size_t n_groups = (size_t)n_sub * gps;
+            dabgpu_vit_group* d_groups = nullptr;
+            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_prefix, n_sub, ne, gps, s), "vit_groups launch"))) return st;
+            const size_t cw0 = e0 * 4 * (size_t)n_sub;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(max_steps),
+                                        tie_rule, d_results + cw0, s))) return st;
+        }
+        return DABGPU_OK;
+    }
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
 }
 

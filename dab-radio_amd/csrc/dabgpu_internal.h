@@ -18,6 +18,7 @@ struct dabgpu_ctx {
     float* d_prs = nullptr;          // PRS spectrum
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
+    int vit_mapping = 0;             // DABGPU_VIT_MAP_* (dabgpu_viterbi_set_mapping)
     int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
     float* d_mode_prs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // PRS spectra and coarse-sync references of modes II-IV
     float* d_mode_prs_time_ref[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -62,6 +63,28 @@ struct dabgpu_vit_tables {          // constant tables of the Viterbi kernel, bu
     uint16_t pi_tab[25 * 8];        // [PI][group]: kept count | running prefix << 8 (puncture_codes.h:42-67)
     unsigned char prbs[512];        // energy-dispersal bytes, period 511 (additive_scrambler.h:16-35)
 };
+// lane-per-codeword decoder (viterbi_lanes.hip): a GROUP = up to 64 codewords with one puncturing schedule
+struct dabgpu_vit_group {
+    uint32_t first, stride, count;  // lane L decodes descs[first + L * stride], L < count
+    uint32_t n_steps;               // trellis steps incl. tail
+    uint32_t alloc_steps;           // rows of the group's symbol / decision areas (dabgpu_vit_alloc_steps)
+    uint32_t seg_pi[4];
+    uint32_t seg_steps[4];
+    uint32_t pad_;
+    uint64_t sym_off;               // dwords into the symbol scratch   [alloc_steps][64]
+    uint64_t dec_off;               // dwords into the decision scratch [alloc_steps][64][2]
+};
+// the forward pass prefetches one 6-step block past the end; the gather kernel works in tiles of 64 steps
+static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_steps) { return (n_steps + 6u + 63u) & ~63u; }
+extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
+                                                       const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const struct dabgpu_msc_plan* d_plans,
+                                                   const uint64_t* d_plan_step_prefix, int n_sub, size_t n_ens,
+                                                   uint32_t groups_per_sub, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
+                                                  const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
+                                                  dabgpu_cw_result* d_results, int tie_rule, const struct dabgpu_vit_tables* d_tables,
+                                                  hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,

@@ -1,0 +1,439 @@
+// viterbi_lanes.hip -- gfx950 kernels of the batch form of the channel decoder: ONE LANE per codeword.
+//
+// viterbi.hip spreads the 64 trellis states of one codeword over the lanes of a wavefront (12 VALU instructions and one
+// cross-lane exchange per trellis step and codeword).  When a batch holds thousands of codewords with the SAME puncturing
+// schedule (one sub-channel of many ensembles, the FIB groups of many frames) the transposed mapping is ~3.5x cheaper:
+//   lane              = one codeword; a wavefront = a GROUP of 64 codewords that share n_steps / PI segments
+//   metrics           = all 64 states of the lane's codeword in 32 VGPRs, two u16 metrics per register, biased by 0x8000 so
+//                       that signed packed ops (v_pk_min_i16, v_pk_sub_i16 clamp) order them like the reference's unsigned
+//                       u16 compares; wrap-around of v_pk_add_u16 = the reference's u16 wrap (dab_viterbi_decoder.cpp:31-41)
+//   layout            = ROTATING: in layout L_q register idx holds the two states that differ in state bit q (idx = state
+//                       with bit q removed).  A trellis step shifts every state bit up by one, so step phase q (= layout L_q,
+//                       q = 0..4) reads X = M[i] (states b0,b1 < 32) and Y = M[i+16] (b0+32, b1+32) and writes the two packed
+//                       survivors straight into N[2i], N[2i+1] of layout L_{q+1}: no cross-lane traffic, no shuffles, the
+//                       same register pattern in every phase; only the branch-cost pairing differs.  In L_5 a register holds
+//                       (s, s+32), i.e. both predecessors of one butterfly: that phase costs two extra ops per register.
+//   branch costs      = e = 508 - (+-(y0+y3) +- y1 +- y2) (polynomials 0 and 3 are equal): 8 values per step, packed into
+//                       8 registers C[sigma] = (e(sigma), e(sigma x f_q)); the complement pattern is C[7 - sigma]
+//   decisions         = sign bits of the saturated candidate differences, gathered with v_perm_b32 + v_bfi_b32 into
+//                       2 dwords per step and lane, streamed to HBM ([step][lane], 512 B per wavefront and step)
+//   chain-back        = per lane, reading the lane's own decision words back (coalesced across the wavefront),
+//                       MSB-first bytes, energy-dispersal XOR, FIB CRC16 -- same outputs as viterbi.hip
+//   input             = vit_prep_kernel gathers the soft bits of a group through the time de-interleaver and the
+//                       puncturing tables into [step][lane] dwords (4 mother-code symbols, 0 = punctured), so the
+//                       forward pass streams 256 B per step
+// Arithmetic and tie rules are those of viterbi.hip / oracle/dab_oracle_decode.c (bit-exact, incl. path_error).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dabgpu_internal.h"
+
+namespace dabgpu {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+constexpr int VL_TILE = 64;                 // steps per prep tile
+constexpr int VL_PRBS = 511;
+
+__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ s2 add16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
+__device__ __forceinline__ s2 sub16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
+__device__ __forceinline__ s2 min16(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s2 satsub16(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ s2 swap16(s2 v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ s2 lo_hi(s2 lo_src, s2 hi_src) { return __builtin_shufflevector(lo_src, hi_src, 0, 3); }
+
+// ---- compile-time trellis tables ----
+__host__ __device__ constexpr int vl_parity(unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return (int)(v & 1u); }
+// sign pattern of butterfly b (input bit 0): bit 0 = polynomials 0 and 3 (109), bit 1 = polynomial 1 (79), bit 2 = polynomial 2 (83)
+// expect +127 (dab_viterbi_decoder.cpp:25, ViterbiBranchTable)
+__host__ __device__ constexpr int vl_sigma(int b) {
+    return vl_parity((2u * (unsigned)b) & 109u) | (vl_parity((2u * (unsigned)b) & 79u) << 1) | (vl_parity((2u * (unsigned)b) & 83u) << 2);
+}
+__host__ __device__ constexpr int vl_ins_zero(int i, int q) { return ((i >> q) << (q + 1)) | (i & ((1 << q) - 1)); }
+// pattern flip between the two butterflies of a register pair in phase q: b1 = b0 | 1 << q (q < 5); phase 5: lower vs upper predecessor
+__host__ __device__ constexpr int vl_flip(int q) { return q < 5 ? (vl_sigma(0) ^ vl_sigma(1 << q)) : 7; }
+
+// ---- decision gather: sign bytes of 32 difference registers -> 2 dwords ----
+// word w bit 8 j + 7 - k  <-  D[2 (8 w + k) + (j >> 1)] half (j & 1)
+__device__ __forceinline__ void vl_gather(const s2 (&D)[32], uint32_t& w0, uint32_t& w1) {
+    uint32_t G[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) G[g] = __builtin_amdgcn_perm(as_u32(D[2 * g + 1]), as_u32(D[2 * g]), 0x07050301u);
+    uint32_t a0 = G[7], a1 = G[15];
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+        a0 = (G[k] & 0x80808080u) | ((a0 >> 1) & 0x7F7F7F7Fu);
+        a1 = (G[8 + k] & 0x80808080u) | ((a1 >> 1) & 0x7F7F7F7Fu);
+    }
+    w0 = a0; w1 = a1;
+}
+
+// bit position (0..63) of the decision of state n inside the 64-bit decision word of a step that ends in layout L_q
+__device__ __forceinline__ uint32_t vl_decision_pos(uint32_t n, uint32_t q) {
+    const uint32_t r = ((n >> (q + 1)) << q) | (n & ((1u << q) - 1u));
+    const uint32_t h = (n >> q) & 1u;
+    return ((r >> 4) << 5) + ((r & 1u) << 4) + (h << 3) + 7u - ((r >> 1) & 7u);
+}
+
+// 8 packed branch-cost registers of one step: C[s] = (e(s), e(s ^ flip)), e(s) = 508 - (+-a +- y1 +- y2), bit set = '+'
+template <int FLIP>
+__device__ __forceinline__ void vl_costs(uint32_t ysym, s2 (&C)[8]) {
+    const int y0 = (int)(int8_t)(ysym & 0xFF), y1 = (int)(int8_t)((ysym >> 8) & 0xFF), y2 = (int)(int8_t)((ysym >> 16) & 0xFF),
+              y3 = (int)(int8_t)(ysym >> 24);
+    const int a = y0 + y3;
+    int E[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) E[s] = 508 - (((s & 1) ? a : -a) + ((s & 2) ? y1 : -y1) + ((s & 4) ? y2 : -y2));
+#pragma unroll
+    for (int s = 0; s < 8; s++) C[s] = as_s2((uint32_t)E[s] | ((uint32_t)E[s ^ FLIP] << 16));
+}
+
+// one trellis step in phase Q: layout L_Q (M) -> L_{(Q+1) mod 6} (N)
+template <int Q, int TIE>
+__device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t ysym, uint32_t& w0, uint32_t& w1) {
+    s2 C[8], D[32];
+    vl_costs<vl_flip(Q)>(ysym, C);
+    if constexpr (Q < 5) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int s = vl_sigma(vl_ins_zero(i, Q));
+            const s2 c1 = C[s], c2 = C[7 - s];
+            const s2 t1 = add16(M[i], c1), t2 = add16(M[i + 16], c2);         // new state 2b:   lower + e | upper + (1016 - e)
+            const s2 t3 = add16(M[i], c2), t4 = add16(M[i + 16], c1);         // new state 2b+1: lower + (1016 - e) | upper + e
+            N[2 * i] = min16(t1, t2);
+            N[2 * i + 1] = min16(t3, t4);
+            // decision 1 = upper predecessor: TIE 0 iff lower > upper (sign of upper - lower); TIE 1 iff !(lower < upper)
+            D[2 * i] = TIE ? satsub16(t1, t2) : satsub16(t2, t1);
+            D[2 * i + 1] = TIE ? satsub16(t3, t4) : satsub16(t4, t3);
+        }
+    } else {
+        // L_5: M[b] = (old[b], old[b+32]) and C[s] = (e, 1016 - e): broadcasting a half (op_sel, free) gives the packed
+        // candidates of the new states (2b, 2b+1) directly
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const int s = vl_sigma(b);
+            const s2 lower = add16(__builtin_shufflevector(M[b], M[b], 0, 0), C[s]);          // (old[b] + e, old[b] + 1016 - e)
+            const s2 upper = add16(__builtin_shufflevector(M[b], M[b], 1, 1), C[7 - s]);      // (old[b+32] + 1016 - e, old[b+32] + e)
+            N[b] = min16(lower, upper);
+            D[b] = TIE ? satsub16(lower, upper) : satsub16(upper, lower);
+        }
+    }
+    vl_gather(D, w0, w1);
+    if constexpr (TIE != 0) { w0 = ~w0; w1 = ~w1; }
+}
+
+// the reference's renormalisation (dab_viterbi_decoder.cpp:31-41) for the lanes whose metric[0] reached the threshold
+__device__ __forceinline__ void vl_renorm(s2 (&N)[32], uint32_t& total) {
+    if ((int)N[0].x >= (int)(60455 - 32768)) {
+        s2 red[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[r] = min16(N[r], N[r + 16]);
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1) {
+#pragma unroll
+            for (int r = 0; r < w; r++) red[r] = min16(red[r], red[r + w]);
+        }
+        s2 mn = red[0];
+        mn = min16(mn, swap16(mn));
+        const uint32_t mu = ((uint32_t)(uint16_t)mn.x) ^ 0x8000u;            // unbiased minimum
+        const s2 sub = as_s2(mu | (mu << 16));
+#pragma unroll
+        for (int r = 0; r < 32; r++) N[r] = sub16(N[r], sub);
+        total += mu;
+    }
+}
+
+template <int TIE>
+__global__ __launch_bounds__(64)
+void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
+                      const uint32_t* __restrict__ sym, uint32_t* __restrict__ dec, dabgpu_cw_result* __restrict__ results,
+                      const dabgpu_vit_tables* __restrict__ tables)
+{
+    __shared__ unsigned char prbs[512];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 512; e += 64) prbs[e] = tables->prbs[e];
+    __syncthreads();
+
+    const dabgpu_vit_group Gd = groups[blockIdx.x];
+    const int T = (int)Gd.n_steps;
+    const bool valid = lane < (int)Gd.count;
+    const size_t cw = (size_t)Gd.first + (size_t)Gd.stride * (size_t)(valid ? lane : 0);
+    const dabgpu_cw_desc Dd = descs[cw];
+    const bool live = valid && Dd.n_steps != 0;              // n_steps == 0: skipped work item of a ring decode
+
+    const uint32_t* my_sym = sym + Gd.sym_off + lane;        // [step][64]
+    uint32_t* my_dec = dec + Gd.dec_off + 2 * lane;          // [step][64][2]
+
+    // ---- forward pass.  The LAST step runs in phase 5, so the metrics end in layout L_0; the first block is partial ----
+    const int q0 = (6 - T % 6) % 6;
+    s2 M[32], N[32];
+    {
+        // start state ss in layout L_q0: register idx_q0(ss), half bit q0 of ss
+        const uint32_t ss = Dd.start_state & 63u;
+        const uint32_t r0 = ((ss >> (q0 + 1)) << q0) | (ss & ((1u << q0) - 1u)), h0 = (ss >> q0) & 1u;
+        const uint32_t non = (5080u ^ 0x8000u), st = 0x8000u;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const uint32_t lo = ((uint32_t)r == r0 && h0 == 0) ? st : non, hi = ((uint32_t)r == r0 && h0 == 1) ? st : non;
+            M[r] = as_s2(lo | (hi << 16));
+        }
+    }
+    uint32_t total = 0;
+    const int n_blocks = (T + 5) / 6;
+    uint32_t ynext[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { const int t = q - q0; ynext[q] = my_sym[(size_t)(t < 0 ? 0 : t) * 64]; }
+    for (int blk = 0; blk < n_blocks; blk++) {
+        uint32_t y[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) y[q] = ynext[q];
+        const int tb = blk * 6 - q0;                          // step index of phase 0 of this block
+#pragma unroll
+        for (int q = 0; q < 6; q++) ynext[q] = my_sym[(size_t)(tb + 6 + q) * 64];     // the buffer is padded by one block
+        const bool first = (blk == 0);
+#define VL_PHASE(Q, SRC, DST)                                                                        \
+        if (!first || (Q) >= q0) {                                        /* wave-uniform */          \
+            uint32_t w0, w1;                                                                          \
+            vl_step<Q, TIE>(SRC, DST, y[Q], w0, w1);                                                  \
+            vl_renorm(DST, total);                                                                    \
+            uint2 wv; wv.x = w0; wv.y = w1;                                                           \
+            *reinterpret_cast<uint2*>(my_dec + (size_t)(tb + (Q)) * 128) = wv;                        \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int r = 0; r < 32; r++) DST[r] = SRC[r];                           \
+        }
+        VL_PHASE(0, M, N) VL_PHASE(1, N, M) VL_PHASE(2, M, N) VL_PHASE(3, N, M) VL_PHASE(4, M, N) VL_PHASE(5, N, M)
+#undef VL_PHASE
+    }
+
+    // ---- end metric (layout L_0: register es >> 1, half es & 1) ----
+    const uint32_t es = Dd.end_state & 63u;
+    uint32_t endm = 0;
+#pragma unroll
+    for (int r = 0; r < 32; r++) endm = ((es >> 1) == (uint32_t)r) ? as_u32(M[r]) : endm;
+    endm = (((es & 1u) ? (endm >> 16) : endm) & 0xFFFFu) ^ 0x8000u;
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);               // decision words are re-read by this same lane: drain its stores first
+
+    // ---- chain-back over steps T-1 .. 6 (dab_viterbi_decoder.cpp:124-129): decoded bit t-6 = decision of the survivor at step t ----
+    const bool raw = (Dd.flags & DABGPU_CW_RAW) != 0;
+    unsigned char* out = reinterpret_cast<unsigned char*>(Dd.d_out);
+    uint32_t n = es;
+    uint32_t acc = 0;
+    int ql = 0;                                  // layout after step t: (t + 1 + q0) % 6, = 0 after the last step
+    // decision words do not depend on the survivor: 16 steps are fetched ahead of the 16 being walked
+    constexpr int CB = 16;
+    uint32_t cx[CB], cy[CB], nx[CB], ny[CB];
+#pragma unroll
+    for (int u = 0; u < CB; u++) {
+        const int t = T - 1 - u;
+        const uint2 v = *reinterpret_cast<const uint2*>(my_dec + (size_t)(t < 0 ? 0 : t) * 128);
+        cx[u] = v.x; cy[u] = v.y;
+    }
+    for (int th = T - 1; th >= 6; th -= CB) {
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int t = th - CB - u;
+            const uint2 v = *reinterpret_cast<const uint2*>(my_dec + (size_t)(t < 0 ? 0 : t) * 128);
+            nx[u] = v.x; ny[u] = v.y;
+        }
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int t = th - u;
+            if (t >= 6) {                                                  // wave-uniform
+                const uint32_t pos = vl_decision_pos(n, (uint32_t)ql);
+                const uint32_t word = (pos & 32u) ? cy[u] : cx[u];
+                const uint32_t d = (word >> (pos & 31u)) & 1u;
+                n = (n >> 1) | (d << 5);
+                const int bit = t - 6;
+                acc |= d << (7 - (bit & 7));
+                if ((bit & 7) == 0) {
+                    const int k = bit >> 3;
+                    const unsigned char pb = raw ? (unsigned char)0 : prbs[k % VL_PRBS];
+                    if (live) out[k] = (unsigned char)(acc ^ pb);
+                    acc = 0;
+                }
+                ql = (ql == 0) ? 5 : ql - 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CB; u++) { cx[u] = nx[u]; cy[u] = ny[u]; }
+    }
+
+    // ---- optional FIB CRC16 (fic_decoder.cpp:19-31,103-116) over the lane's own bytes + result record ----
+    const int n_out = (T - 6) >> 3;
+    uint32_t crc_mask = 0;
+    if (live && Dd.n_crc_blocks) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_s_waitcnt(0);
+        const int blk_bytes = n_out / (int)Dd.n_crc_blocks;
+        for (int b = 0; b < (int)Dd.n_crc_blocks && b < 32; b++) {
+            const unsigned char* fib = out + b * blk_bytes;
+            unsigned crc = 0xFFFFu;
+            for (int i = 0; i < blk_bytes - 2; i++) {
+                crc ^= (unsigned)__builtin_nontemporal_load(&fib[i]) << 8;
+                for (int qq = 0; qq < 8; qq++) crc = (crc & 0x8000u) ? (((crc << 1) ^ 0x1021u) & 0xFFFFu) : ((crc << 1) & 0xFFFFu);
+            }
+            crc ^= 0xFFFFu;
+            const unsigned rx = ((unsigned)__builtin_nontemporal_load(&fib[blk_bytes - 2]) << 8) | __builtin_nontemporal_load(&fib[blk_bytes - 1]);
+            if (rx == crc) crc_mask |= 1u << b;
+        }
+    }
+    if (valid) {
+        dabgpu_cw_result R;
+        R.path_error = live ? (uint64_t)total + endm : 0;
+        R.crc_ok_mask = crc_mask;
+        R.n_out_bytes = live ? (uint32_t)n_out : 0u;
+        results[cw] = R;
+    }
+}
+
+// ---- input gather: soft bits of a group -> [step][lane] dwords ----
+// grid (n_groups, ceil(alloc_steps / 64)), 256 threads: wave v handles codewords v, v+4, ... of the group, lane = step of the tile
+__global__ __launch_bounds__(256)
+void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
+                     uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+{
+    __shared__ uint32_t tile[VL_TILE][65];
+    __shared__ uint16_t pi_tab[25 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const dabgpu_vit_group Gd = groups[blockIdx.x];
+    const int t0 = blockIdx.y * VL_TILE;
+    if (t0 >= (int)Gd.alloc_steps) return;
+    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
+    __syncthreads();
+
+    // position of step t in the punctured input (dab_viterbi_decoder.cpp:131-181): the same for every codeword of the group
+    const int T = (int)Gd.n_steps;
+    const int t = t0 + lane;
+    int idx0 = 0, cnt = 0;
+    if (t < T) {
+        int sstart = 0, in0 = 0, pi = 8, k = 0;
+        for (; k < 4; k++) {
+            const int len = (int)Gd.seg_steps[k];
+            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
+            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
+            sstart += len;
+        }
+        // k == 4: the 6 tail steps, PI_X == PI_8 restricted to 6 groups
+        const int sis = t - sstart;
+        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
+        cnt = e & 0xFF;
+        idx0 = in0 + (sis >> 3) * (8 + pi) + (e >> 8);
+    }
+    for (int c = wv; c < 64; c += 4) {
+        uint32_t packed = 0;
+        const bool have = c < (int)Gd.count;                                   // wave-uniform
+        const dabgpu_cw_desc Dd = descs[(size_t)Gd.first + (size_t)Gd.stride * (size_t)(have ? c : 0)];
+        // time de-interleaver (cif_deinterleaver.cpp:57-68): input bit i lives in the CIF that is 15 - bitrev4(i mod 16) CIFs old;
+        // lane L holds the ring offset of class i mod 16 == L mod 16 (the ring of one ensemble is < 4 GiB)
+        uint32_t aoff = 0;
+        if (Dd.n_slots != 0) {
+            const int age = 15 - (int)(__brev((unsigned)lane & 15u) >> 28);
+            int slot = (int)Dd.newest_slot - age;
+            if (slot < 0) slot += (int)Dd.n_slots;
+            const int fr = slot / (int)Dd.cifs_per_frame, ci = slot - fr * (int)Dd.cifs_per_frame;
+            aoff = (uint32_t)fr * Dd.frame_stride + (uint32_t)ci * Dd.cif_stride;
+        }
+        const int8_t* src = reinterpret_cast<const int8_t*>(Dd.d_src);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned i = (unsigned)(idx0 + r);
+            const uint32_t off = (uint32_t)__shfl((int)aoff, (int)(i & 15u));
+            if (have && Dd.n_steps != 0 && r < cnt) {
+                int yv = src[(size_t)off + i];
+                yv = max(yv, -127);                                            // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
+                packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
+            }
+        }
+        tile[lane][c] = packed;
+    }
+    __syncthreads();
+    uint32_t* dst = sym + Gd.sym_off;
+    for (int s = wv; s < VL_TILE; s += 4) {
+        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+    }
+}
+
+// ---- group tables ----
+// FIC: all codewords share one schedule; group g = codewords 64 g .. 64 g + 63
+__global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw, uint32_t n_steps, uint32_t alloc_steps,
+                                          uint32_t pi0, uint32_t st0, uint32_t pi1, uint32_t st1, uint32_t pi2, uint32_t st2,
+                                          uint32_t pi3, uint32_t st3)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * 64 >= n_cw) return;
+    dabgpu_vit_group G = {};
+    G.first = (uint32_t)(g * 64); G.stride = 1;
+    G.count = (uint32_t)((n_cw - g * 64 < 64) ? (n_cw - g * 64) : 64);
+    G.n_steps = n_steps; G.alloc_steps = alloc_steps;
+    G.seg_pi[0] = pi0; G.seg_steps[0] = st0; G.seg_pi[1] = pi1; G.seg_steps[1] = st1;
+    G.seg_pi[2] = pi2; G.seg_steps[2] = st2; G.seg_pi[3] = pi3; G.seg_steps[3] = st3;
+    G.sym_off = g * (size_t)alloc_steps * 64;
+    G.dec_off = g * (size_t)alloc_steps * 128;
+    groups[g] = G;
+}
+
+// MSC: codeword index = (4 e + c) * n_sub + s (msc_build_descs_kernel); group (s, gq) = sub-channel s of ensemble-CIFs 64 gq ..
+__global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc_plan* plans, const uint64_t* plan_step_prefix,
+                                      int n_sub, size_t n_ens, uint32_t groups_per_sub)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (size_t)n_sub * groups_per_sub) return;
+    const int s = (int)(g / groups_per_sub);
+    const uint32_t gq = (uint32_t)(g - (size_t)s * groups_per_sub);
+    const dabgpu_msc_plan P = plans[s];
+    const size_t n_j = n_ens * 4;
+    dabgpu_vit_group G = {};
+    G.first = (uint32_t)((size_t)s + (size_t)n_sub * 64 * gq); G.stride = (uint32_t)n_sub;
+    G.count = (uint32_t)((n_j - (size_t)gq * 64 < 64) ? (n_j - (size_t)gq * 64) : 64);
+    G.n_steps = P.n_steps;
+    G.alloc_steps = dabgpu_vit_alloc_steps(P.n_steps);
+    for (int k = 0; k < 4; k++) { G.seg_pi[k] = P.seg_pi[k]; G.seg_steps[k] = P.seg_steps[k]; }
+    const size_t steps_before = (size_t)plan_step_prefix[s] * groups_per_sub + (size_t)gq * G.alloc_steps;
+    G.sym_off = steps_before * 64;
+    G.dec_off = steps_before * 128;
+    groups[g] = G;
+}
+
+}  // namespace dabgpu
+
+extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
+                                                       const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream)
+{
+    const size_t n_groups = (n_cw + 63) / 64;
+    hipLaunchKernelGGL(dabgpu::vit_groups_uniform_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
+                       d_groups, n_cw, n_steps, dabgpu_vit_alloc_steps(n_steps), seg_pi[0], seg_steps[0], seg_pi[1], seg_steps[1],
+                       seg_pi[2], seg_steps[2], seg_pi[3], seg_steps[3]);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const dabgpu_msc_plan* d_plans,
+                                                   const uint64_t* d_plan_step_prefix, int n_sub, size_t n_ens,
+                                                   uint32_t groups_per_sub, hipStream_t stream)
+{
+    const size_t n_groups = (size_t)n_sub * groups_per_sub;
+    hipLaunchKernelGGL(dabgpu::vit_groups_msc_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
+                       d_groups, d_plans, d_plan_step_prefix, n_sub, n_ens, groups_per_sub);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
+                                                  const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
+                                                  dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
+                                                  hipStream_t stream)
+{
+    using namespace dabgpu;
+    const unsigned tiles = (max_alloc_steps + VL_TILE - 1) / VL_TILE;
+    hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+    if (tie_rule)
+        hipLaunchKernelGGL(vit_lanes_kernel<1>, dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, d_descs, d_sym, d_dec,
+                           d_results, d_tables);
+    else
+        hipLaunchKernelGGL(vit_lanes_kernel<0>, dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, d_descs, d_sym, d_dec,
+                           d_results, d_tables);
+    return hipGetLastError();
+}

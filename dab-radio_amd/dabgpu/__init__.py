@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync", "dabgpu_ofdm_demod_stream_frame_sync",
     "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",
-    "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
+    "dabgpu_viterbi_set_mapping", "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
     "dabgpu_fic_decode_group_host_sync", "dabgpu_viterbi_decode_host_sync", "dabgpu_msc_stream_create",
     "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
     "dabgpu_msc_stream_decode_sync",
@@ -158,6 +158,7 @@ def lib():
         L.dabgpu_ofdm_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_sync_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_viterbi_set_mapping.argtypes = [C.c_void_p, C.c_int]
         L.dabgpu_viterbi_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_fic_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p]
@@ -356,6 +357,10 @@ class Context:
         return state, imp, frq
 
     # ---- channel decode ----
+    def viterbi_set_mapping(self, mapping):
+        """0 = auto, 1 = one wavefront per codeword, 2 = one lane per codeword (include/dabgpu.h DABGPU_VIT_MAP_*)."""
+        check(lib().dabgpu_viterbi_set_mapping(self._h, int(mapping)), "dabgpu_viterbi_set_mapping")
+
     def viterbi_decode_batch(self, codewords, results, tie_rule=0, stream=None):
         """codewords: list/ctypes array of Codeword (host); results: device buffer of n CodewordResult"""
         n = len(codewords)

@@ -216,6 +216,21 @@ typedef struct {
     uint32_t n_out_bytes;
 } dabgpu_codeword_result;
 
+/*
+ * Two device mappings of the same decoder (identical results, bit for bit):
+ *   WAVE  one wavefront per codeword, the 64 trellis states across its lanes (viterbi.hip) -- any batch, any mix of schedules
+ *   LANE  one lane per codeword, wavefronts of 64 codewords that share a puncturing schedule (viterbi_lanes.hip) -- ~3x the
+ *         throughput once a batch holds thousands of codewords per schedule; needs 768 bytes of scratch per trellis step
+ *         and 64 codewords
+ * AUTO (default) picks LANE for batches of at least DABGPU_VIT_LANE_MIN_CODEWORDS codewords (dabgpu_viterbi_decode_batch:
+ * only when every codeword of the batch has the same n_steps / segments); forcing LANE on a mixed generic batch runs WAVE.
+ */
+#define DABGPU_VIT_MAP_AUTO 0
+#define DABGPU_VIT_MAP_WAVE 1
+#define DABGPU_VIT_MAP_LANE 2
+#define DABGPU_VIT_LANE_MIN_CODEWORDS 8192
+int dabgpu_viterbi_set_mapping(dabgpu_ctx *ctx, int mapping);
+
 /* generic batch: h_codewords is a HOST array (copied to the device on `stream`); d_results a DEVICE array [n] */
 int dabgpu_viterbi_decode_batch(dabgpu_ctx *ctx, const dabgpu_codeword *h_codewords, size_t n, int tie_rule,
                                 dabgpu_codeword_result *d_results, void *stream);

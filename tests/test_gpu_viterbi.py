@@ -26,8 +26,16 @@ def results_np(t):
     return t.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(-1)
 
 
+@pytest.fixture(params=[1, 2], ids=["wave", "lane"])
+def mapping(ctx, request):
+    """both device mappings of the decoder (include/dabgpu.h DABGPU_VIT_MAP_*), forced"""
+    ctx.viterbi_set_mapping(request.param)
+    yield request.param
+    ctx.viterbi_set_mapping(0)
+
+
 @pytest.mark.parametrize("tie_rule", [0, 1])
-def test_fic_frames_match_oracle(ctx, oracle, tie_rule):
+def test_fic_frames_match_oracle(ctx, oracle, tie_rule, mapping):
     import torch
     rng = np.random.default_rng(100 + tie_rule)
     n_frames = 9
@@ -101,7 +109,7 @@ def test_generic_batch_direct_mode_all_puncture_vectors(ctx, oracle):
     assert saw_renorm, "no codeword was long/noisy enough to pass the renormalisation threshold"
 
 
-def test_edge_inputs(ctx, oracle):
+def test_edge_inputs(ctx, oracle, mapping):
     """all-erased codeword (every metric ties), -128 soft bits (read as -127), rejected descriptors"""
     import dabgpu
     import torch
@@ -131,7 +139,7 @@ def test_edge_inputs(ctx, oracle):
 
 
 @pytest.mark.parametrize("tie_rule", [0, 1])
-def test_msc_frames_with_history_ring(ctx, oracle, tie_rule):
+def test_msc_frames_with_history_ring(ctx, oracle, tie_rule, mapping):
     """3 ensembles x mixed multiplex (EEP-A, EEP-B, 2-A special, UEP) through 7 frames (28 CIFs): the kernel's
     de-interleave-by-index over the frame-history ring must equal CIF_Deinterleaver + MSC_Decoder of the oracle"""
     import dabgpu
@@ -182,3 +190,114 @@ def test_msc_frames_with_history_ring(ctx, oracle, tie_rule):
                         checked += 1
                     off += p[2]
     assert checked == n_ens * len(subs) * (n_cif - 15)
+
+
+@pytest.mark.parametrize("tie_rule", [0, 1])
+def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule):
+    """a batch large enough for several full and one ragged group per schedule: FIC of 333 frames (1332 codewords) and an
+    MSC multiplex of seven sub-channels (DAB sub-channel sizes always give n_steps mod 6 = 0; the other start phases of the
+    rotating layout are covered by test_uniform_generic_batch_through_both_mappings), with skipped
+    ensembles (ring decode), clean / noisy / saturated / all-erased inputs -- bytes, CRC masks and path errors identical"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(77 + tie_rule)
+    n_frames = 333
+    frames = rng.integers(-127, 128, (n_frames, oracle.NB_FRAME_BITS), dtype=np.int8)
+    for f in range(0, n_frames, 3):
+        for g in range(4):
+            enc = oracle.fic_encode_group(rng.integers(0, 256, 90, dtype=np.uint8))
+            frames[f, g * 2304:(g + 1) * 2304] = noisy(oracle, enc, rng, sigma=[0.0, 25.0, 45.0][(f // 3 + g) % 3] + 1e-3)
+    frames[1, :2304] = 0
+    frames[4, :2304] = -128
+    frames[7, :9216] = 127
+    d_bits = torch.from_numpy(frames).cuda()
+    got = {}
+    for m in (1, 2):
+        ctx.viterbi_set_mapping(m)
+        d_out = torch.zeros((n_frames, 4, 96), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((n_frames * 4, 16), dtype=torch.uint8, device="cuda")
+        ctx.fic_decode_frames(d_bits, n_frames, d_out, d_res, tie_rule=tie_rule)
+        torch.cuda.synchronize()
+        got[m] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+    ctx.viterbi_set_mapping(0)
+    assert np.array_equal(got[1][0], got[2][0]) and np.array_equal(got[1][1], got[2][1])
+    assert 0 < int((results_np(torch.from_numpy(got[2][1]))["crc_ok_mask"] == 7).sum()) < n_frames * 4
+
+    subs = [dabgpu.SubChannel(0, 48, False, 0, 2, 0), dabgpu.SubChannel(48, 8, False, 0, 1, 0), dabgpu.SubChannel(60, 27, False, 0, 0, 1),
+            dabgpu.SubChannel(100, 35, True, 4, 0, 0), dabgpu.SubChannel(700, 164, False, 0, 3, 0), dabgpu.SubChannel(300, 4, False, 0, 3, 0), dabgpu.SubChannel(310, 8, False, 0, 3, 0)]
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    n_ens, H = 37, 6
+    hist = torch.from_numpy(rng.integers(-127, 128, (n_ens, H, oracle.NB_FRAME_BITS), dtype=np.int8)).cuda()
+    hist[3] = 0
+    hist[5] = 127
+    slots = torch.from_numpy(rng.integers(-1, H, n_ens).astype(np.int32)).cuda()
+    got = {}
+    for m in (1, 2):
+        ctx.viterbi_set_mapping(m)
+        for ring in (False, True):
+            d_out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+            if ring:
+                ctx.msc_decode_ring(hist, n_ens, H * oracle.NB_FRAME_BITS, H, slots, subs, d_out, 4 * cif_out, d_res, tie_rule=tie_rule)
+            else:
+                ctx.msc_decode_frames(hist, n_ens, H * oracle.NB_FRAME_BITS, H, 2, subs, d_out, 4 * cif_out, d_res, tie_rule=tie_rule)
+            torch.cuda.synchronize()
+            got[(m, ring)] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+    ctx.viterbi_set_mapping(0)
+    for ring in (False, True):
+        assert np.array_equal(got[(1, ring)][0], got[(2, ring)][0]), ring
+        assert np.array_equal(got[(1, ring)][1], got[(2, ring)][1]), ring
+
+
+@pytest.mark.parametrize("tie_rule", [0, 1])
+@pytest.mark.parametrize("segs", [((3, 40), (0, 0), (24, 24), (11, 72)), ((17, 80),), ((8, 8),), ((1, 2048),)],
+                         ids=["T142", "T86", "T14", "T2054"])
+def test_uniform_generic_batch_through_both_mappings(ctx, oracle, tie_rule, segs):
+    """70 codewords of ONE schedule (segments in 8-step units, an empty segment, n_steps mod 6 = 4 / 2 / 2 / 2), random
+    soft bits (every decision is a near tie), random start / end states, raw and descrambled outputs: oracle == WAVE == LANE"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(500 + tie_rule + len(segs))
+    n_cw = 70
+    n_bits = sum(st for _, st in segs)
+    n_in = sum(st // 8 * (8 + pi) for pi, st in segs) + 12
+    soft = rng.integers(-128, 128, (n_cw, n_in), dtype=np.int8)
+    soft[3] = 0
+    soft[4, ::2] = 127
+    starts, ends = rng.integers(0, 64, n_cw), rng.integers(0, 64, n_cw)
+    raws = rng.integers(0, 2, n_cw)
+    d_in = torch.from_numpy(soft).cuda()
+    expect = []
+    for i in range(n_cw):
+        v = oracle.Viterbi(n_bits, tie_rule)
+        v.reset(int(starts[i]))
+        x = np.maximum(soft[i], -127)
+        used = 0
+        for pi, st in segs:
+            if st:
+                used += v.update(x[used:], oracle.puncture_code(pi), 4 * st)
+        used += v.update(x[used:], oracle.puncture_code_tail(), 24)
+        assert used == n_in
+        ob, oe = v.chainback(n_bits // 8, int(ends[i]))
+        if not raws[i]:
+            ob = ob ^ oracle.scrambler_bytes(n_bits // 8)
+        expect.append((ob, oe))
+    for m in (1, 2):
+        ctx.viterbi_set_mapping(m)
+        d_o = torch.zeros((n_cw, n_bits // 8), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((n_cw, 16), dtype=torch.uint8, device="cuda")
+        cws = []
+        for i in range(n_cw):
+            cw = dabgpu.Codeword()
+            cw.d_src, cw.d_out, cw.n_steps = d_in[i].data_ptr(), d_o[i].data_ptr(), n_bits + 6
+            for k, (pi, st) in enumerate(segs):
+                cw.seg_pi[k], cw.seg_steps[k] = pi, st
+            cw.start_state, cw.end_state, cw.flags = int(starts[i]), int(ends[i]), int(raws[i])
+            cws.append(cw)
+        ctx.viterbi_decode_batch(cws, d_res, tie_rule=tie_rule)
+        torch.cuda.synchronize()
+        out, res = d_o.cpu().numpy(), results_np(d_res)
+        for i, (ob, oe) in enumerate(expect):
+            assert np.array_equal(out[i], ob), (m, i)
+            assert int(res[i]["path_error"]) == oe and int(res[i]["n_out_bytes"]) == n_bits // 8, (m, i)
+    ctx.viterbi_set_mapping(0)
