@@ -133,14 +133,15 @@ static bool use_lane_mapping(const dabgpu_ctx* c, size_t n_cw) {
 static const size_t LANES_MAX_ROWS = (size_t)8 << 20;
 
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
-                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s) {
+                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, bool ring4, dabgpu_codeword_result* d_results,
+                             hipStream_t s) {
     int st = ensure_vit_tables(c);
     if (st) return st;
     uint32_t *d_sym = nullptr, *d_dec = nullptr;
     if ((st = dabgpu_scratch(c, 18, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
     if ((st = dabgpu_scratch(c, 19, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, c->d_vit_tables, s), "vit_lanes_kernel launch");
+                                                        tie_rule ? 1 : 0, ring4 ? 1 : 0, c->d_vit_tables, s), "vit_lanes_kernel launch");
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
@@ -198,7 +199,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, d_results + cw0, s))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s))) return st;
         }
         return DABGPU_OK;
     }
@@ -228,7 +229,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, d_results + cw0, s))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s))) return st;
         }
         return DABGPU_OK;
     }
@@ -306,8 +307,10 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_prefix, n_sub, ne, gps, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
+            // the staged gather reads the ring rows in aligned 16-byte chunks
+            const bool ring4 = ((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0);
             if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(max_steps),
-                                        tie_rule, d_results + cw0, s))) return st;
+                                        tie_rule, ring4, d_results + cw0, s))) return st;
         }
         return DABGPU_OK;
     }

@@ -83,8 +83,8 @@ extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, c
                                                    uint32_t groups_per_sub, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
-                                                  dabgpu_cw_result* d_results, int tie_rule, const struct dabgpu_vit_tables* d_tables,
-                                                  hipStream_t stream);
+                                                  dabgpu_cw_result* d_results, int tie_rule, int ring4,
+                                                  const struct dabgpu_vit_tables* d_tables, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,

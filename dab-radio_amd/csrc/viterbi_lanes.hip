@@ -358,6 +358,109 @@ void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_c
     }
 }
 
+// ---- input gather, MSC form: lane 4 k + c of a group = CIF c of ensemble k (16 ensembles), all read through a frame-history
+// ring with 4 CIFs per frame.  Output CIFs c = 0..3 with ages 0..15 touch the 19 ring slots 4 nf - 15 .. 4 nf + 3; per ensemble
+// the tile's byte range of those 19 rows is staged in LDS with 16-byte loads (the byte-granular gather of vit_prep_kernel
+// costs one address-coalescer slot per BYTE), then thread (step, c) picks its <= 4 soft bits from LDS.
+// grid (n_groups, ceil(alloc_steps / 64)), 256 threads = 64 steps x 4 CIFs
+constexpr int VR_ROWS = 19, VR_CHUNKS = 17, VR_PITCH = VR_CHUNKS * 16 + 16;
+__global__ __launch_bounds__(256)
+void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
+                           uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+{
+    __shared__ uint32_t tile[VL_TILE][65];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[2][VR_ROWS][VR_PITCH];
+    __shared__ uint16_t pi_tab[25 * 8];
+    const int tid = threadIdx.x, step = tid & 63, c = tid >> 6;
+    const dabgpu_vit_group Gd = groups[blockIdx.x];
+    const int t0 = blockIdx.y * VL_TILE;
+    if (t0 >= (int)Gd.alloc_steps) return;
+    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
+    __syncthreads();
+
+    const int T = (int)Gd.n_steps;
+    // input index of the first kept bit of step t (dab_viterbi_decoder.cpp:131-181) and the total input length
+    auto locate = [&](int t, int& cnt) {
+        int sstart = 0, in0 = 0, pi = 8, k = 0;
+        for (; k < 4; k++) {
+            const int len = (int)Gd.seg_steps[k];
+            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
+            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
+            sstart += len;
+        }
+        const int sis = t - sstart;
+        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
+        cnt = e & 0xFF;
+        return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
+    };
+    int n_in = 12;
+    for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);
+    int dummy;
+    const int i_lo = (t0 < T ? locate(t0, dummy) : n_in) & ~15;            // wave-uniform: first byte of the tile, 16-byte aligned
+    const int t = t0 + step;
+    int cnt = 0, idx0 = 0;
+    if (t < T) idx0 = locate(t, cnt);
+    // LDS address of the thread's r-th kept bit: row = c - age + 15, column = i - i_lo  (the same for every ensemble)
+    int lds_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned i = (unsigned)(idx0 + r);
+        const int age = 15 - (int)(__brev(i & 15u) >> 28);
+        lds_off[r] = (c - age + 15) * VR_PITCH + ((int)i - i_lo);
+    }
+    // staging loads: chunk q = tid, tid + 256 of the 19 x 17 sixteen-byte chunks of one ensemble
+    auto fetch = [&](int k, uint4 (&v)[2]) {
+        const bool have = 4 * k < (int)Gd.count;
+        const dabgpu_cw_desc Dd = descs[(size_t)Gd.first + (size_t)Gd.stride * (size_t)(have ? 4 * k : 0)];
+        const bool on = have && Dd.n_steps != 0;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(Dd.d_src);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q = tid + 256 * h, row = q / VR_CHUNKS, ch = q - row * VR_CHUNKS;
+            v[h] = make_uint4(0, 0, 0, 0);
+            if (on && row < VR_ROWS && i_lo + 16 * ch < n_in) {
+                int slot = (int)Dd.newest_slot - 15 + row;                 // lane 4 k is CIF 0: its newest slot is 4 nf
+                if (slot < 0) slot += (int)Dd.n_slots;
+                if (slot >= (int)Dd.n_slots) slot -= (int)Dd.n_slots;
+                const size_t off = (size_t)(slot >> 2) * Dd.frame_stride + (size_t)(slot & 3) * Dd.cif_stride + (size_t)(i_lo + 16 * ch);
+                v[h] = *reinterpret_cast<const uint4*>(src + off);
+            }
+        }
+    };
+    auto stash = [&](int buf, const uint4 (&v)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int q = tid + 256 * h, row = q / VR_CHUNKS, ch = q - row * VR_CHUNKS;
+            if (row < VR_ROWS) *reinterpret_cast<uint4*>(&rows[buf][row][16 * ch]) = v[h];
+        }
+    };
+    uint4 v[2];
+    fetch(0, v);
+    stash(0, v);
+    __syncthreads();
+    for (int k = 0; k < 16; k++) {
+        if (k + 1 < 16) fetch(k + 1, v);
+        const unsigned char* rb = &rows[k & 1][0][0];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (r < cnt) {
+                int yv = (int)(signed char)rb[lds_off[r]];
+                yv = max(yv, -127);                                        // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
+                packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
+            }
+        }
+        tile[step][4 * k + c] = packed;
+        if (k + 1 < 16) stash((k + 1) & 1, v);
+        __syncthreads();
+    }
+    uint32_t* dst = sym + Gd.sym_off;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int s = wv; s < VL_TILE; s += 4) {
+        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+    }
+}
+
 // ---- group tables ----
 // FIC: all codewords share one schedule; group g = codewords 64 g .. 64 g + 63
 __global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw, uint32_t n_steps, uint32_t alloc_steps,
@@ -423,12 +526,15 @@ extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, c
 
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
-                                                  dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
+                                                  dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
                                                   hipStream_t stream)
 {
     using namespace dabgpu;
     const unsigned tiles = (max_alloc_steps + VL_TILE - 1) / VL_TILE;
-    hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+    if (ring4)
+        hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+    else
+        hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
     if (tie_rule)
         hipLaunchKernelGGL(vit_lanes_kernel<1>, dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, d_descs, d_sym, d_dec,
                            d_results, d_tables);

@@ -88,9 +88,11 @@ def main():
     ap.add_argument("--ensembles", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--tie-rule", type=int, default=0)
+    ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword (DABGPU_VIT_MAP_*)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = dabgpu.Context(0)
+    ctx.viterbi_set_mapping(args.mapping)
     prs, mapper, _ = dabgpu.host_tables()
     E, H = args.ensembles, 5
     g = torch.Generator(device=dev)
@@ -182,7 +184,7 @@ def main():
     msc_eq = bool(torch.equal(msc_out.view(E, 4, n_sub, 192), payload.unsqueeze(1).expand(E, 4, n_sub, 192)))
     fic_steps, msc_steps = 4 * 774, 4 * n_sub * 1542
     out = {
-        "ensembles": E, "multiplex": "18 x 48 CU EEP 3-A (864 CU)", "tie_rule": args.tie_rule,
+        "ensembles": E, "multiplex": "18 x 48 CU EEP 3-A (864 CU)", "tie_rule": args.tie_rule, "viterbi_mapping": args.mapping,
         "config3_demod_plus_fic": {"ms_per_frame_step": t_demod + t_fic, "frames_per_s": E / (t_demod + t_fic) * 1e3,
                                    "fic_trellis_steps_per_s": E * fic_steps / t_fic * 1e3},
         "config4_full": {"ms_per_frame_step_sum_of_kernels": t_demod + t_fic + t_msc, "ms_per_frame_step_wall": t_all,
