@@ -16,7 +16,7 @@
 //   branch costs      = e = 508 - (+-(y0+y3) +- y1 +- y2) (polynomials 0 and 3 are equal): 8 values per step, packed into
 //                       8 registers C[sigma] = (e(sigma), e(sigma x f_q)); the complement pattern is C[7 - sigma]
 //   decisions         = sign bits of the saturated candidate differences, gathered with v_perm_b32 + v_bfi_b32 into
-//                       2 dwords per step and lane, streamed to HBM ([step][lane], 512 B per wavefront and step)
+//                       2 dwords per step and lane, streamed to HBM two steps at a time ([step / 2][lane][4], 1 KB per store)
 //   chain-back        = per lane, reading the lane's own decision words back (coalesced across the wavefront),
 //                       MSB-first bytes, energy-dispersal XOR, FIB CRC16 -- same outputs as viterbi.hip
 //   input             = vit_prep_kernel gathers the soft bits of a group through the time de-interleaver and the
@@ -45,6 +45,13 @@ __device__ __forceinline__ s2 satsub16(s2 a, s2 b) { return __builtin_elementwis
 __device__ __forceinline__ s2 swap16(s2 v) { return __builtin_shufflevector(v, v, 1, 0); }
 __device__ __forceinline__ s2 lo_hi(s2 lo_src, s2 hi_src) { return __builtin_shufflevector(lo_src, hi_src, 0, 3); }
 
+// (a & mask) | (b & ~mask) in one instruction (the compiler splits the expression into v_and + v_and_or)
+__device__ __forceinline__ uint32_t vl_bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 // ---- compile-time trellis tables ----
 __host__ __device__ constexpr int vl_parity(unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return (int)(v & 1u); }
 // sign pattern of butterfly b (input bit 0): bit 0 = polynomials 0 and 3 (109), bit 1 = polynomial 1 (79), bit 2 = polynomial 2 (83)
@@ -57,38 +64,56 @@ __host__ __device__ constexpr int vl_ins_zero(int i, int q) { return ((i >> q) <
 __host__ __device__ constexpr int vl_flip(int q) { return q < 5 ? (vl_sigma(0) ^ vl_sigma(1 << q)) : 7; }
 
 // ---- decision gather: sign bytes of 32 difference registers -> 2 dwords ----
-// word w bit 8 j + 7 - k  <-  D[2 (8 w + k) + (j >> 1)] half (j & 1)
+// The decision of new state n (layout L_QN after the step: register idx_QN(n), half = bit QN of n) goes to bit
+// pos = rotr6(n, QN - 3) of the step's 64-bit word.  The half bit then is bit 3 of pos, so the 4 bytes of one v_perm_b32 (pos bits
+// 4:3) come from two registers, and walking back one step (n' = n >> 1 | d << 5, QN' = QN - 1) changes exactly ONE bit of pos:
+// bit (3 - QN) mod 6 := d.  The chain-back never computes a layout.
+__host__ __device__ constexpr int vl_rotl6(int v, int s) { return ((v << s) | (v >> (6 - s))) & 63; }
+__host__ __device__ constexpr int vl_idx(int n, int q) { return ((n >> (q + 1)) << q) | (n & ((1 << q) - 1)); }
+
+template <int QN>
 __device__ __forceinline__ void vl_gather(const s2 (&D)[32], uint32_t& w0, uint32_t& w1) {
+    constexpr int S = (QN + 3) % 6;                                  // (QN - 3) mod 6
     uint32_t G[16];
 #pragma unroll
-    for (int g = 0; g < 16; g++) G[g] = __builtin_amdgcn_perm(as_u32(D[2 * g + 1]), as_u32(D[2 * g]), 0x07050301u);
-    uint32_t a0 = G[7], a1 = G[15];
+    for (int g = 0; g < 16; g++) {
+        // bits pos = 32 w + 8 j + k, g = 8 w + k: bytes j = 0,1 are the two halves of one register, j = 2,3 of another
+        const int base = ((g >> 3) << 5) | (g & 7);
+        const int r_lo = vl_idx(vl_rotl6(base, S), QN), r_hi = vl_idx(vl_rotl6(base | 16, S), QN);
+        G[g] = __builtin_amdgcn_perm(as_u32(D[r_hi]), as_u32(D[r_lo]), 0x07050301u);
+    }
+    uint32_t a0 = G[0], a1 = G[8];
 #pragma unroll
-    for (int k = 6; k >= 0; k--) {
-        a0 = (G[k] & 0x80808080u) | ((a0 >> 1) & 0x7F7F7F7Fu);
-        a1 = (G[8 + k] & 0x80808080u) | ((a1 >> 1) & 0x7F7F7F7Fu);
+    for (int k = 1; k < 8; k++) {                                    // bit k of every byte <- sign byte of G[k]
+        a0 = vl_bfi(0x80808080u, G[k], a0 >> 1);
+        a1 = vl_bfi(0x80808080u, G[8 + k], a1 >> 1);
     }
     w0 = a0; w1 = a1;
 }
 
-// bit position (0..63) of the decision of state n inside the 64-bit decision word of a step that ends in layout L_q
-__device__ __forceinline__ uint32_t vl_decision_pos(uint32_t n, uint32_t q) {
-    const uint32_t r = ((n >> (q + 1)) << q) | (n & ((1u << q) - 1u));
-    const uint32_t h = (n >> q) & 1u;
-    return ((r >> 4) << 5) + ((r & 1u) << 4) + (h << 3) + 7u - ((r >> 1) & 7u);
-}
-
-// 8 packed branch-cost registers of one step: C[s] = (e(s), e(s ^ flip)), e(s) = 508 - (+-a +- y1 +- y2), bit set = '+'
+// 8 packed branch-cost registers of one step: C[s] = (e(s), e(s ^ FLIP)), e(s) = 508 - (+-a +- y1 +- y2) with a = y0 + y3
+// (polynomials 0 and 3 are equal), bit k of s set = '+' for a / y1 / y2.  Two v_dot4 give a + y1 and a - y1, six packed adds
+// the 8 values as pairs, 8 v_perm_b32 pair them up for this phase
 template <int FLIP>
 __device__ __forceinline__ void vl_costs(uint32_t ysym, s2 (&C)[8]) {
-    const int y0 = (int)(int8_t)(ysym & 0xFF), y1 = (int)(int8_t)((ysym >> 8) & 0xFF), y2 = (int)(int8_t)((ysym >> 16) & 0xFF),
-              y3 = (int)(int8_t)(ysym >> 24);
-    const int a = y0 + y3;
-    int E[8];
+    const int p = __builtin_amdgcn_sdot4((int)ysym, 0x01000101, 0, false);            // y0 + y1 + y3
+    const int q = __builtin_amdgcn_sdot4((int)ysym, 0x0100FF01, 0, false);            // y0 - y1 + y3
+    const int y2 = (int)(int8_t)((ysym >> 16) & 0xFF);
+    const s2 w1 = as_s2(__builtin_amdgcn_perm((uint32_t)q, (uint32_t)p, 0x05040100u));
+    const s2 w2 = as_s2(__builtin_amdgcn_perm((uint32_t)y2, (uint32_t)y2, 0x05040100u));
+    const s2 K = as_s2(508u | (508u << 16));
+    const s2 x1 = sub16(K, w1), x2 = add16(K, w1);                         // (e[a+ b+], e[a+ b-]) / (e[a- b-], e[a- b+]) before y2
+    uint32_t R[4];                                                         // pairs of e(): {7,5} {3,1} {4,6} {0,2}
+    R[0] = as_u32(sub16(x1, w2)); R[1] = as_u32(add16(x1, w2));
+    R[2] = as_u32(sub16(x2, w2)); R[3] = as_u32(add16(x2, w2));
 #pragma unroll
-    for (int s = 0; s < 8; s++) E[s] = 508 - (((s & 1) ? a : -a) + ((s & 2) ? y1 : -y1) + ((s & 4) ? y2 : -y2));
-#pragma unroll
-    for (int s = 0; s < 8; s++) C[s] = as_s2((uint32_t)E[s] | ((uint32_t)E[s ^ FLIP] << 16));
+    for (int s = 0; s < 8; s++) {
+        constexpr int reg_of[8] = {3, 1, 3, 1, 2, 0, 2, 0}, half_of[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+        const int v0 = s, v1 = s ^ FLIP;
+        // result low half = e(v0), high half = e(v1): v_perm_b32 selects bytes 0-3 from its second, 4-7 from its first operand
+        const uint32_t sel = (uint32_t)(half_of[v0] ? 0x0302 : 0x0100) | ((uint32_t)(half_of[v1] ? 0x0706 : 0x0504) << 16);
+        C[s] = as_s2(__builtin_amdgcn_perm(R[reg_of[v1]], R[reg_of[v0]], sel));
+    }
 }
 
 // one trellis step in phase Q: layout L_Q (M) -> L_{(Q+1) mod 6} (N)
@@ -121,7 +146,7 @@ __device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t
             D[b] = TIE ? satsub16(lower, upper) : satsub16(upper, lower);
         }
     }
-    vl_gather(D, w0, w1);
+    vl_gather<(Q + 1) % 6>(D, w0, w1);
     if constexpr (TIE != 0) { w0 = ~w0; w1 = ~w1; }
 }
 
@@ -147,7 +172,7 @@ __device__ __forceinline__ void vl_renorm(s2 (&N)[32], uint32_t& total) {
 }
 
 template <int TIE>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
                       const uint32_t* __restrict__ sym, uint32_t* __restrict__ dec, dabgpu_cw_result* __restrict__ results,
                       const dabgpu_vit_tables* __restrict__ tables)
@@ -164,10 +189,11 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
     const dabgpu_cw_desc Dd = descs[cw];
     const bool live = valid && Dd.n_steps != 0;              // n_steps == 0: skipped work item of a ring decode
 
-    const uint32_t* my_sym = sym + Gd.sym_off + lane;        // [step][64]
-    uint32_t* my_dec = dec + Gd.dec_off + 2 * lane;          // [step][64][2]
+    const uint32_t* grp_sym = sym + Gd.sym_off;              // [step][64]          (wave-uniform bases: scalar address + lane offset)
+    uint32_t* grp_dec = dec + Gd.dec_off;                    // [step / 2][64][4]
 
-    // ---- forward pass.  The LAST step runs in phase 5, so the metrics end in layout L_0; the first block is partial ----
+    // ---- forward pass.  The LAST step runs in phase 5, so the metrics end in layout L_0.  n_steps = 8 m + 6 is even: the first,
+    // partial block starts in phase q0 = 0, 2 or 4, and steps pair up (even phase, odd phase) into one 16-byte decision store ----
     const int q0 = (6 - T % 6) % 6;
     s2 M[32], N[32];
     {
@@ -182,31 +208,41 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
         }
     }
     uint32_t total = 0;
-    const int n_blocks = (T + 5) / 6;
+    // two trellis steps t, t + 1 (t even) in phases Q, Q + 1: M -> N -> M
+#define VL_PAIR(Q, TT, YA, YB)                                                                        \
+    {                                                                                                 \
+        uint4 wv;                                                                                     \
+        vl_step<Q, TIE>(M, N, YA, wv.x, wv.y);                                                        \
+        vl_renorm(N, total);                                                                          \
+        vl_step<(Q) + 1, TIE>(N, M, YB, wv.z, wv.w);                                                  \
+        vl_renorm(M, total);                                                                          \
+        reinterpret_cast<uint4*>(grp_dec + (size_t)((TT) >> 1) * 256)[lane] = wv;                     \
+    }
+    int t = 0;
+    if (q0 == 2) {
+        const uint32_t ya = (grp_sym + (size_t)t * 64)[lane], yb = (grp_sym + (size_t)(t + 1) * 64)[lane];
+        VL_PAIR(2, t, ya, yb)
+        t += 2;
+    }
+    if (q0 != 0) {
+        const uint32_t ya = (grp_sym + (size_t)t * 64)[lane], yb = (grp_sym + (size_t)(t + 1) * 64)[lane];
+        VL_PAIR(4, t, ya, yb)
+        t += 2;
+    }
     uint32_t ynext[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) { const int t = q - q0; ynext[q] = my_sym[(size_t)(t < 0 ? 0 : t) * 64]; }
-    for (int blk = 0; blk < n_blocks; blk++) {
+    for (int q = 0; q < 6; q++) ynext[q] = (grp_sym + (size_t)(t + q) * 64)[lane];
+    for (; t < T; t += 6) {
         uint32_t y[6];
 #pragma unroll
         for (int q = 0; q < 6; q++) y[q] = ynext[q];
-        const int tb = blk * 6 - q0;                          // step index of phase 0 of this block
 #pragma unroll
-        for (int q = 0; q < 6; q++) ynext[q] = my_sym[(size_t)(tb + 6 + q) * 64];     // the buffer is padded by one block
-        const bool first = (blk == 0);
-#define VL_PHASE(Q, SRC, DST)                                                                        \
-        if (!first || (Q) >= q0) {                                        /* wave-uniform */          \
-            uint32_t w0, w1;                                                                          \
-            vl_step<Q, TIE>(SRC, DST, y[Q], w0, w1);                                                  \
-            vl_renorm(DST, total);                                                                    \
-            uint2 wv; wv.x = w0; wv.y = w1;                                                           \
-            *reinterpret_cast<uint2*>(my_dec + (size_t)(tb + (Q)) * 128) = wv;                        \
-        } else {                                                                                      \
-            _Pragma("unroll") for (int r = 0; r < 32; r++) DST[r] = SRC[r];                           \
-        }
-        VL_PHASE(0, M, N) VL_PHASE(1, N, M) VL_PHASE(2, M, N) VL_PHASE(3, N, M) VL_PHASE(4, M, N) VL_PHASE(5, N, M)
-#undef VL_PHASE
+        for (int q = 0; q < 6; q++) ynext[q] = (grp_sym + (size_t)(t + 6 + q) * 64)[lane];     // the buffer is padded by one block
+        VL_PAIR(0, t, y[0], y[1])
+        VL_PAIR(2, t + 2, y[2], y[3])
+        VL_PAIR(4, t + 4, y[4], y[5])
     }
+#undef VL_PAIR
 
     // ---- end metric (layout L_0: register es >> 1, half es & 1) ----
     const uint32_t es = Dd.end_state & 63u;
@@ -221,42 +257,39 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
     // ---- chain-back over steps T-1 .. 6 (dab_viterbi_decoder.cpp:124-129): decoded bit t-6 = decision of the survivor at step t ----
     const bool raw = (Dd.flags & DABGPU_CW_RAW) != 0;
     unsigned char* out = reinterpret_cast<unsigned char*>(Dd.d_out);
-    uint32_t n = es;
-    uint32_t acc = 0;
-    int ql = 0;                                  // layout after step t: (t + 1 + q0) % 6, = 0 after the last step
-    // decision words do not depend on the survivor: 16 steps are fetched ahead of the 16 being walked
-    constexpr int CB = 16;
+    // The walk is done on pos = rotr6(state, QN - 3) (vl_gather).  Chunks of 24 steps: n_steps = 8 m + 6 and the last step ends in
+    // layout L_0, so every chunk starts in layout L_0 at bit 7 of a byte -- phases and byte boundaries are compile-time.
+    // Decision words do not depend on the survivor: 24 steps are fetched ahead of the 24 being walked.
+    uint32_t pos = ((es >> 3) | (es << 3)) & 63u;                  // rotr6(es, 3): layout L_0 after the last step
+    constexpr int CB = 24;
     uint32_t cx[CB], cy[CB], nx[CB], ny[CB];
+    // words of steps th - u, u = 0..23, th odd: pair (th - 2 v) >> 1 holds step th - 2 v - 1 in .x .y and step th - 2 v in .z .w
+    auto fetch = [&](int th, uint32_t (&ax)[CB], uint32_t (&ay)[CB]) {
 #pragma unroll
-    for (int u = 0; u < CB; u++) {
-        const int t = T - 1 - u;
-        const uint2 v = *reinterpret_cast<const uint2*>(my_dec + (size_t)(t < 0 ? 0 : t) * 128);
-        cx[u] = v.x; cy[u] = v.y;
-    }
-    for (int th = T - 1; th >= 6; th -= CB) {
-#pragma unroll
-        for (int u = 0; u < CB; u++) {
-            const int t = th - CB - u;
-            const uint2 v = *reinterpret_cast<const uint2*>(my_dec + (size_t)(t < 0 ? 0 : t) * 128);
-            nx[u] = v.x; ny[u] = v.y;
+        for (int v = 0; v < CB / 2; v++) {
+            const int pr = (th >> 1) - v;
+            const uint4 q4 = reinterpret_cast<const uint4*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256)[lane];
+            ax[2 * v] = q4.z; ay[2 * v] = q4.w; ax[2 * v + 1] = q4.x; ay[2 * v + 1] = q4.y;
         }
+    };
+    fetch(T - 1, cx, cy);
+    for (int th = T - 1; th >= 6; th -= CB) {
+        fetch(th - CB, nx, ny);
 #pragma unroll
-        for (int u = 0; u < CB; u++) {
-            const int t = th - u;
-            if (t >= 6) {                                                  // wave-uniform
-                const uint32_t pos = vl_decision_pos(n, (uint32_t)ql);
-                const uint32_t word = (pos & 32u) ? cy[u] : cx[u];
-                const uint32_t d = (word >> (pos & 31u)) & 1u;
-                n = (n >> 1) | (d << 5);
-                const int bit = t - 6;
-                acc |= d << (7 - (bit & 7));
-                if ((bit & 7) == 0) {
-                    const int k = bit >> 3;
-                    const unsigned char pb = raw ? (unsigned char)0 : prbs[k % VL_PRBS];
-                    if (live) out[k] = (unsigned char)(acc ^ pb);
-                    acc = 0;
+        for (int ub = 0; ub < CB; ub += 8) {
+            if (th - ub >= 6) {                                            // wave-uniform; steps come in whole bytes
+                uint32_t acc = 0;
+#pragma unroll
+                for (int u = ub; u < ub + 8; u++) {
+                    const uint32_t word = (pos & 32u) ? cy[u] : cx[u];
+                    const uint32_t d = (word >> (pos & 31u)) & 1u;
+                    const int b = (3 + u) % 6;                             // (3 - QN) mod 6 with QN = (-u) mod 6
+                    pos = (pos & ~(1u << b)) | (d << b);
+                    acc |= d << (u - ub);                                  // bit index (t - 6) & 7 = 7 - (u - ub), MSB first
                 }
-                ql = (ql == 0) ? 5 : ql - 1;
+                const int k = (th - ub - 7 - 6) >> 3;                      // byte of bits t-6 for t = th-ub-7 .. th-ub
+                const unsigned char pb = raw ? (unsigned char)0 : prbs[k % VL_PRBS];
+                if (live) out[k] = (unsigned char)(acc ^ pb);
             }
         }
 #pragma unroll
@@ -393,10 +426,12 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
         cnt = e & 0xFF;
         return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
     };
-    int n_in = 12;
+    int n_in = 12;                                                         // total input bytes: sub-channel size, a multiple of 64
     for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);
     int dummy;
     const int i_lo = (t0 < T ? locate(t0, dummy) : n_in) & ~15;            // wave-uniform: first byte of the tile, 16-byte aligned
+    int i_hi = i_lo;                                                       // one past the last byte any step of the tile reads
+    if (t0 < T) { const int tl = min(t0 + VL_TILE, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
     const int t = t0 + step;
     int cnt = 0, idx0 = 0;
     if (t < T) idx0 = locate(t, cnt);
@@ -418,7 +453,7 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
         for (int h = 0; h < 2; h++) {
             const int q = tid + 256 * h, row = q / VR_CHUNKS, ch = q - row * VR_CHUNKS;
             v[h] = make_uint4(0, 0, 0, 0);
-            if (on && row < VR_ROWS && i_lo + 16 * ch < n_in) {
+            if (on && row < VR_ROWS && i_lo + 16 * ch < i_hi) {
                 int slot = (int)Dd.newest_slot - 15 + row;                 // lane 4 k is CIF 0: its newest slot is 4 nf
                 if (slot < 0) slot += (int)Dd.n_slots;
                 if (slot >= (int)Dd.n_slots) slot -= (int)Dd.n_slots;
@@ -434,12 +469,14 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
             if (row < VR_ROWS) *reinterpret_cast<uint4*>(&rows[buf][row][16 * ch]) = v[h];
         }
     };
-    uint4 v[2];
-    fetch(0, v);
-    stash(0, v);
+    // four ensembles of loads in flight: with one, every ensemble costs a full memory round trip per workgroup
+    uint4 v[4][2];
+    fetch(0, v[0]); fetch(1, v[1]); fetch(2, v[2]); fetch(3, v[3]);
+    stash(0, v[0]);
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < 16; k++) {
-        if (k + 1 < 16) fetch(k + 1, v);
+        if (k + 4 < 16) fetch(k + 4, v[k & 3]);
         const unsigned char* rb = &rows[k & 1][0][0];
         uint32_t packed = 0;
 #pragma unroll
@@ -451,7 +488,7 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
             }
         }
         tile[step][4 * k + c] = packed;
-        if (k + 1 < 16) stash((k + 1) & 1, v);
+        if (k + 1 < 16) stash((k + 1) & 1, v[(k + 1) & 3]);
         __syncthreads();
     }
     uint32_t* dst = sym + Gd.sym_off;

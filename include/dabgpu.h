@@ -228,7 +228,7 @@ typedef struct {
 #define DABGPU_VIT_MAP_AUTO 0
 #define DABGPU_VIT_MAP_WAVE 1
 #define DABGPU_VIT_MAP_LANE 2
-#define DABGPU_VIT_LANE_MIN_CODEWORDS 8192
+#define DABGPU_VIT_LANE_MIN_CODEWORDS 12288
 int dabgpu_viterbi_set_mapping(dabgpu_ctx *ctx, int mapping);
 
 /* generic batch: h_codewords is a HOST array (copied to the device on `stream`); d_results a DEVICE array [n] */
