@@ -1,6 +1,7 @@
 // dabgpu_decode_abi.hip -- channel-decode entry points of the C ABI (include/dabgpu.h): protection-profile
 // tables, codeword descriptors, scratch sizing and launches.  Host side only; the arithmetic is in viterbi.hip.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -127,10 +128,14 @@ static bool use_lane_mapping(const dabgpu_ctx* c, size_t n_cw) {
     return n_cw >= DABGPU_VIT_LANE_MIN_CODEWORDS;
 }
 
-// lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (LANES_MAX_ROWS rows of
-// 768 bytes = 6 GiB), larger batches run as several launches over consecutive groups (each group's offsets are rebased
-// by the builder kernels through row_base)
-static const size_t LANES_MAX_ROWS = (size_t)8 << 20;
+// lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (768 bytes per row:
+// 6 GiB by default, DABGPU_VIT_SCRATCH_MB in the environment overrides), larger batches run as several launches over
+// consecutive groups
+static size_t lanes_max_rows() {
+    size_t mb = 6144;
+    if (const char* e = getenv("DABGPU_VIT_SCRATCH_MB")) { const long v = atol(e); if (v > 0) mb = (size_t)v; }
+    return std::max<size_t>(mb * 1024 * 1024 / 768, 1);
+}
 
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
                              size_t total_rows, uint32_t max_alloc_steps, int tie_rule, bool ring4, dabgpu_codeword_result* d_results,
@@ -193,7 +198,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
                                           (uint64_t)h_cw[i].cifs_per_frame * h_cw[i].cif_stride < ((uint64_t)1 << 32);
     if (uniform && use_lane_mapping(c, n)) {
         const uint32_t rows = dabgpu_vit_alloc_steps(max_steps);
-        const size_t slice_groups = std::max<size_t>(1, LANES_MAX_ROWS / rows);
+        const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / rows);
         for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
             const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
             dabgpu_vit_group* d_groups = nullptr;
@@ -223,7 +228,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
         // one schedule for every FIB group: groups of 64 consecutive codewords, processed in bounded slices
         const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
         const uint32_t rows = dabgpu_vit_alloc_steps(774);
-        const size_t slice_groups = std::max<size_t>(1, LANES_MAX_ROWS / rows);
+        const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / rows);
         for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
             const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
             dabgpu_vit_group* d_groups = nullptr;
@@ -294,7 +299,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         size_t rows_per_gq = 0;
         std::vector<uint64_t> prefix((size_t)n_sub);
         for (int k = 0; k < n_sub; k++) { prefix[(size_t)k] = rows_per_gq; rows_per_gq += dabgpu_vit_alloc_steps(plans[(size_t)k].n_steps); }
-        const size_t max_gq = std::max<size_t>(1, LANES_MAX_ROWS / rows_per_gq);
+        const size_t max_gq = std::max<size_t>(1, lanes_max_rows() / rows_per_gq);
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
         uint64_t* d_prefix = nullptr;
         if ((st = dabgpu_scratch(c, 24, prefix.size() * sizeof(uint64_t), (void**)&d_prefix))) return st;

@@ -192,8 +192,18 @@ def test_msc_frames_with_history_ring(ctx, oracle, tie_rule, mapping):
     assert checked == n_ens * len(subs) * (n_cif - 15)
 
 
+@pytest.fixture(params=[0, 2], ids=["one_launch", "sliced"])
+def scratch_mb(request):
+    """DABGPU_VIT_SCRATCH_MB = 2 forces the lane mapping to run the batch as several launches over slices of it"""
+    import os
+    if request.param:
+        os.environ["DABGPU_VIT_SCRATCH_MB"] = str(request.param)
+    yield request.param
+    os.environ.pop("DABGPU_VIT_SCRATCH_MB", None)
+
+
 @pytest.mark.parametrize("tie_rule", [0, 1])
-def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule):
+def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scratch_mb):
     """a batch large enough for several full and one ragged group per schedule: FIC of 333 frames (1332 codewords) and an
     MSC multiplex of seven sub-channels (DAB sub-channel sizes always give n_steps mod 6 = 0; the other start phases of the
     rotating layout are covered by test_uniform_generic_batch_through_both_mappings), with skipped
