@@ -48,6 +48,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_fra
                                                float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
                                                hipStream_t stream);
 
+// size-generic demodulation (ofdm_modes.hip); d_desc != nullptr = stream bank round (frame = stream, split input)
+int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+                                  float* d_fft, int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
+                                  size_t block_stride, hipStream_t s);
+
 // ---- channel decode ----
 typedef dabgpu_codeword dabgpu_cw_desc;
 typedef dabgpu_codeword_result dabgpu_cw_result;

@@ -13,6 +13,7 @@
 
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
+#include "iq_sample.h"
 #include "ofdm_device.h"
 
 namespace dabgpu {
@@ -45,10 +46,15 @@ __device__ __forceinline__ f2 pll_any(f2 v, int n, int period, float f, float dt
     return mk2(v.x * c - v.y * s, v.x * s + v.y * c);
 }
 
+// BANK (stream bank rounds, ofdm_stream.hip): frame = stream; desc[frame].slot < 0 = nothing to do, else samples [0, split) of
+// the frame come from the stream's frame buffer (iq, complex float) and the rest from the caller's block in capture format SRC
+// (block + frame * block_stride samples, first at tail_off); the soft bits go to frame slot desc[frame].slot
+template <int SRC, bool BANK>
 __global__ __launch_bounds__(256)
 void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __restrict__ freq_offset, int8_t* __restrict__ bits,
                             f2* __restrict__ cp_corr, f2* __restrict__ fft_out, const f2* __restrict__ tw,
-                            const int* __restrict__ mapper, int n_frames, int sym_per_chunk, int chunks_per_frame)
+                            const int* __restrict__ mapper, int n_frames, int sym_per_chunk, int chunks_per_frame,
+                            const dabgpu_frame_desc* __restrict__ desc, const uint8_t* __restrict__ block, size_t block_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char msm[];
     ModeGeom g;
@@ -69,6 +75,16 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
     const int sym_end = (last_chunk && fft_out != nullptr) ? g.n_sym : out1;     // inclusive
     const float f = freq_offset ? freq_offset[frame] : 0.0f;
     const f2* fbase = iq + (size_t)frame * g.frame_samples;
+    size_t out_frame = (size_t)frame;
+    int split = g.frame_samples;
+    long long tail_off = 0;
+    const uint8_t* tail = nullptr;
+    if constexpr (BANK) {
+        const dabgpu_frame_desc d = desc[frame];
+        if (d.slot < 0) return;
+        out_frame = (size_t)d.slot; split = d.split; tail_off = d.tail_off;
+        tail = block + (size_t)frame * block_stride * src_sample_bytes<SRC>::value;
+    }
     int L = 1;
     while (L < g.n_cp) L <<= 1;
     int prev = 0;                                       // index of the buffer holding the previous symbol's spectrum
@@ -76,7 +92,16 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
     for (int i = out0; i <= sym_end; i++) {
         const float dt0 = (float)(i * g.period) * f;
         const f2* sym = fbase + (size_t)i * g.period;
-        for (int n = t; n < g.period; n += 256) Y[n] = pll_any(sym[n], n, g.period, f, dt0);
+        for (int n = t; n < g.period; n += 256) {
+            f2 v;
+            if constexpr (BANK) {
+                const int j = i * g.period + n;
+                v = (j < split) ? fbase[j] : sample_at<SRC>(tail, tail_off + (j - split));
+            } else {
+                v = sym[n];
+            }
+            Y[n] = pll_any(v, n, g.period, f, dt0);
+        }
         __syncthreads();
         const bool do_corr = (i < g.n_sym) && (i < out1 || i == g.n_sym - 1);
         if (do_corr) {                                                           // uniform per workgroup
@@ -133,7 +158,7 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
         if (i > out0 && i < g.n_sym) {
             // ---- DQPSK + frequency de-interleave + soft bits (ofdm_demodulator.cpp:842-889) ----
             const int NC = g.n_carriers, M = NC / 2;
-            int8_t* o = bits + (size_t)frame * g.frame_bits + (size_t)(i - 1) * g.sym_bits;
+            int8_t* o = bits + out_frame * g.frame_bits + (size_t)(i - 1) * g.sym_bits;
             for (int n = t; n < NC; n += 256) {
                 const int c = mapper[n];
                 const int k = (c < M) ? (c - M) : (c - M + 1);
@@ -153,6 +178,43 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
 }  // namespace dabgpu
 
 using namespace dabgpu;
+
+// size-generic demodulation launch shared by dabgpu_ofdm_demod_frames_mode and the stream bank (d_desc != nullptr: bank round,
+// frame = stream, input split between the bank's frame buffers d_iq and the caller's block d_block in capture format src)
+int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+                                  float* d_fft, int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
+                                  size_t block_stride, hipStream_t s) {
+    ModeGeom g;
+    if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    int st;
+    // per-mode carrier mapper on the device, built on first use (get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
+    if (!c->d_mode_mapper[mode]) {
+        std::vector<int> m((size_t)g.n_carriers);
+        if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
+        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_mapper[mode], m.size() * sizeof(int)), "hipMalloc(mode mapper)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_mapper[mode], m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode mapper)"))) return st;
+    }
+    if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
+    const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
+    const size_t lds = ((size_t)g.period + 3 * (size_t)g.n_fft) * sizeof(f2) + 512 * sizeof(float);
+#define MODE_GO(SRC, BANK)                                                                                                          \
+    do {                                                                                                                            \
+        if (lds > 48 * 1024 && (st = dabgpu_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ofdm_demod_mode_kernel<SRC, BANK>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),                   \
+                                                      "hipFuncSetAttribute(ofdm_demod_mode_kernel)"))) return st;                  \
+        hipLaunchKernelGGL((ofdm_demod_mode_kernel<SRC, BANK>), dim3((unsigned)((size_t)n_frames * chunks)), dim3(256), lds, s, mode, \
+                           reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr),                    \
+                           reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(c->d_tw), c->d_mode_mapper[mode], n_frames,     \
+                           symbols_per_block, chunks, d_desc, static_cast<const uint8_t*>(d_block), block_stride);                  \
+    } while (0)
+    if (!d_desc) MODE_GO(0, false);
+    else if (src == 0) MODE_GO(0, true);
+    else if (src == 1) MODE_GO(1, true);
+    else if (src == 2) MODE_GO(2, true);
+    else MODE_GO(3, true);
+#undef MODE_GO
+    return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_mode_kernel launch");
+}
 
 extern "C" {
 
@@ -175,25 +237,9 @@ int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, si
     (void)hipSetDevice(c->device);
     hipStream_t s = (hipStream_t)stream;
     int st;
-    // per-mode carrier mapper on the device, built on first use (get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
-    if (!c->d_mode_mapper[mode]) {
-        std::vector<int> m((size_t)g.n_carriers);
-        if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
-        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_mapper[mode], m.size() * sizeof(int)), "hipMalloc(mode mapper)"))) return st;
-        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_mapper[mode], m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode mapper)"))) return st;
-    }
     float* corr = d_cp_corr;
     if (!corr && (st = dabgpu_scratch(c, 23, n_frames * (size_t)g.n_sym * 2 * sizeof(float), (void**)&corr))) return st;
-    if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
-    const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
-    const size_t lds = ((size_t)g.period + 3 * (size_t)g.n_fft) * sizeof(f2) + 512 * sizeof(float);
-    if (lds > 48 * 1024 && (st = dabgpu_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ofdm_demod_mode_kernel),
-                                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                                   "hipFuncSetAttribute(ofdm_demod_mode_kernel)"))) return st;
-    hipLaunchKernelGGL(ofdm_demod_mode_kernel, dim3((unsigned)(n_frames * chunks)), dim3(256), lds, s, mode, reinterpret_cast<const f2*>(d_iq),
-                       d_freq, d_bits, reinterpret_cast<f2*>(corr), reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(c->d_tw),
-                       c->d_mode_mapper[mode], (int)n_frames, symbols_per_block, chunks);
-    return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_mode_kernel launch");
+    return dabgpu_launch_ofdm_demod_mode(c, mode, d_iq, 0, d_freq, d_bits, corr, d_fft, (int)n_frames, symbols_per_block, nullptr, nullptr, 0, s);
 }
 
 // ---- single-stream, host-buffer forms for the OFDM_Demod mirror class in modes II-IV ----

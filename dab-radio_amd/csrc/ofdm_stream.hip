@@ -28,12 +28,13 @@
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
 #include "iq_decode.h"
+#include "iq_sample.h"
 #include "ofdm_device.h"
 
 namespace dabgpu {
 
-constexpr int NB_NULL_PERIOD = 2656;
-constexpr int NB_CORR = NB_NULL_PERIOD + NB_SYMBOL_PERIOD;      // 5208
+// geometry of the bank's transmission mode (src/ofdm/dab_ofdm_params_ref.cpp:11-60); mode I: 2656 / 2552 / 76 / 196608 / 5208
+struct BankGeom { int mode, null_period, period, n_sym, n_fft, frame_samples, n_corr, frame_bits; };
 enum { ST_FINDING_NULL = 0, ST_READING_NULL_PRS = 1, ST_RUNNING_COARSE = 2, ST_RUNNING_FINE = 3, ST_READING_SYMBOLS = 4 };
 enum { PEND_NONE = 0, PEND_SYNC = 1, PEND_DEMOD = 2 };
 
@@ -52,11 +53,12 @@ struct StreamState {
 };
 
 struct BankView {
+    BankGeom g;
     StreamState* st;
     dabgpu_sync_state* sync;
-    f2* ring;                        // [n][2656]
-    f2* corr;                        // [n][5208]
-    f2* frame;                       // [n][196608]
+    f2* ring;                        // [n][null_period]
+    f2* corr;                        // [n][null_period + period]
+    f2* frame;                       // [n][frame_samples]
     float* freq;                     // [n] coarse + fine handed to the PLL
     int* sync_active;                // [n]
     dabgpu_frame_desc* desc;         // [n] demodulation request of the round
@@ -69,26 +71,6 @@ struct BankView {
 };
 
 constexpr int COPY_WGS = 16;         // workgroups per stream of the bulk copy
-
-// The caller's block in its capture format: SRC 0 = complex float, 1 = raw_u8, 2 = raw_s8, 3 = raw_s16l (the formats the
-// demodulation kernel reads by itself); sample i dequantised with the reader arithmetic of iq_decode.h
-template <int SRC> struct src_sample_bytes { static constexpr int value = (SRC == 0) ? 8 : (SRC == 3) ? 4 : 2; };
-template <int SRC>
-__device__ __forceinline__ f2 sample_at(const uint8_t* __restrict__ base, long long i) {
-    const uint8_t* p = base + i * src_sample_bytes<SRC>::value;
-    if constexpr (SRC == 0) {
-        return *reinterpret_cast<const f2*>(p);
-    } else if constexpr (SRC == 3) {
-        typedef uint32_t u32a2 __attribute__((aligned(2)));
-        raw_words<1> r; r.w[0] = *reinterpret_cast<const u32a2*>(p);
-        return mk2(decode<K_S16, 2, false>(r, 0), decode<K_S16, 2, false>(r, 1));
-    } else {
-        constexpr comp_kind K = (SRC == 1) ? K_U8 : K_S8;
-        typedef uint16_t u16a1 __attribute__((aligned(1)));
-        raw_words<1> r; r.w[0] = *reinterpret_cast<const u16a1*>(p);
-        return mk2(decode<K, 1, false>(r, 0), decode<K, 1, false>(r, 1));
-    }
-}
 
 template <int SRC>
 __device__ __forceinline__ float l1_window(const uint8_t* base, long long first, int k) {           // CalculateL1Average :922-932
@@ -125,6 +107,7 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
     if (t == 0) S = B.st[s];
     __syncthreads();
     const uint8_t* block = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
+    const int NB_NULL_PERIOD = B.g.null_period, NB_CORR = B.g.n_corr, NB_FRAME_SAMPLES = B.g.frame_samples;
     f2* ring = B.ring + (size_t)s * NB_NULL_PERIOD;
     f2* corr = B.corr + (size_t)s * NB_CORR;
     f2* frame = B.frame + (size_t)s * NB_FRAME_SAMPLES;
@@ -266,7 +249,7 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
                 // buffer and the rest from the block; one sample is moved over when the boundary would split a pair
                 if ((have & 1) && t == 0) frame[have] = sample_at<SRC>(block, bpos);
                 // the NULL symbol at the end of this frame heads the next correlation window (:558-562)
-                const int null_at = NB_FRAME_SYMBOLS * NB_SYMBOL_PERIOD;
+                const int null_at = B.g.n_sym * B.g.period;
                 for (int j = t; j < NB_NULL_PERIOD; j += 256) {
                     const int idx = null_at + j;
                     corr[j] = (idx < have) ? frame[idx] : sample_at<SRC>(block, bpos + (idx - have));
@@ -346,7 +329,7 @@ void stream_copy_kernel(BankView B, const uint8_t* __restrict__ iq, size_t strea
     if (cnt == 0) return;
     const uint8_t* src = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
     const long long first = B.copy_src[s];
-    f2* dst = B.frame + (size_t)s * NB_FRAME_SAMPLES + B.copy_dst[s];
+    f2* dst = B.frame + (size_t)s * B.g.frame_samples + B.copy_dst[s];
     const int per = (((cnt + COPY_WGS - 1) / COPY_WGS) + 255) & ~255;
     const int a = blockIdx.x * per;
     const int b = (a + per < cnt) ? (a + per) : cnt;
@@ -378,7 +361,7 @@ struct dabgpu_stream_bank {
     size_t n = 0;
     dabgpu_stream_cfg cfg{};
     BankView view{};
-    float* d_corr_out = nullptr;       // [n][76][2] cyclic-prefix correlations of the last demodulated frames
+    float* d_corr_out = nullptr;       // [n][n_sym][2] cyclic-prefix correlations of the last demodulated frames
     dabgpu_stream_status* d_status = nullptr;
     float* d_raw_scratch = nullptr;    // converted block of dabgpu_stream_bank_process_raw (grow-only)
     size_t raw_scratch_bytes = 0;
@@ -413,15 +396,21 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     CK(hipMemsetAsync(b->view.sync_active, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.desc, 0xFF, b->n * sizeof(dabgpu_frame_desc), s));
     CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
-    CK(hipMemsetAsync(b->view.ring, 0, b->n * NB_NULL_PERIOD * sizeof(f2), s));
-    CK(hipMemsetAsync(b->view.corr, 0, b->n * NB_CORR * sizeof(f2), s));
+    CK(hipMemsetAsync(b->view.ring, 0, b->n * (size_t)b->view.g.null_period * sizeof(f2), s));
+    CK(hipMemsetAsync(b->view.corr, 0, b->n * (size_t)b->view.g.n_corr * sizeof(f2), s));
     CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
 #undef CK
     return DABGPU_OK;
 }
 
 int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stream_cfg* cfg, dabgpu_stream_bank** out) {
+    return dabgpu_stream_bank_create_mode(c, 1, n_streams, cfg, out);
+}
+
+int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, const dabgpu_stream_cfg* cfg, dabgpu_stream_bank** out) {
     if (!c || !out || n_streams == 0 || n_streams > (size_t)(1 << 20)) { dabgpu_set_error("stream_bank_create: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
+    ModeGeom mg;
+    if (!mode_geometry(mode, mg)) { dabgpu_set_error("stream_bank_create: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_stream_cfg k;
     if (cfg) k = *cfg; else dabgpu_stream_cfg_default(&k);
     if (k.signal_l1_nb_samples <= 0 || k.signal_l1_nb_decimate <= 0) { dabgpu_set_error("stream_bank_create: invalid L1 window"); return DABGPU_ERR_INVALID_ARG; }
@@ -429,6 +418,9 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
     dabgpu_stream_bank* b = new (std::nothrow) dabgpu_stream_bank();
     if (!b) return DABGPU_ERR_HIP;
     b->ctx = c; b->n = n_streams; b->cfg = k;
+    BankGeom& G = b->view.g;
+    G.mode = mode; G.null_period = mg.null_period; G.period = mg.period; G.n_sym = mg.n_sym; G.n_fft = mg.n_fft;
+    G.frame_samples = mg.frame_samples; G.n_corr = mg.null_period + mg.period; G.frame_bits = mg.frame_bits;
     int st = DABGPU_OK;
     auto alloc = [&](void** p, size_t bytes) {
         if (st) return;
@@ -437,9 +429,9 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
     };
     alloc((void**)&b->view.st, n_streams * sizeof(StreamState));
     alloc((void**)&b->view.sync, n_streams * sizeof(dabgpu_sync_state));
-    alloc((void**)&b->view.ring, n_streams * NB_NULL_PERIOD * sizeof(f2));
-    alloc((void**)&b->view.corr, n_streams * NB_CORR * sizeof(f2));
-    alloc((void**)&b->view.frame, n_streams * (size_t)NB_FRAME_SAMPLES * sizeof(f2));
+    alloc((void**)&b->view.ring, n_streams * (size_t)G.null_period * sizeof(f2));
+    alloc((void**)&b->view.corr, n_streams * (size_t)G.n_corr * sizeof(f2));
+    alloc((void**)&b->view.frame, n_streams * (size_t)G.frame_samples * sizeof(f2));
     alloc((void**)&b->view.freq, n_streams * sizeof(float));
     alloc((void**)&b->view.sync_active, n_streams * sizeof(int));
     alloc((void**)&b->view.desc, n_streams * sizeof(dabgpu_frame_desc));
@@ -447,7 +439,7 @@ int dabgpu_stream_bank_create(dabgpu_ctx* c, size_t n_streams, const dabgpu_stre
     alloc((void**)&b->view.copy_dst, n_streams * sizeof(int));
     alloc((void**)&b->view.copy_cnt, n_streams * sizeof(int));
     alloc((void**)&b->view.not_done, sizeof(int));
-    alloc((void**)&b->d_corr_out, n_streams * NB_FRAME_SYMBOLS * 2 * sizeof(float));
+    alloc((void**)&b->d_corr_out, n_streams * (size_t)G.n_sym * 2 * sizeof(float));
     alloc((void**)&b->d_status, n_streams * sizeof(dabgpu_stream_status));
     if (!st) st = dabgpu_stream_bank_reset(b, c->stream);
     if (!st) st = dabgpu_check_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
@@ -465,7 +457,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
                              int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream, int ring_mode = 0) {
     if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
-    // a frame needs at least 76 symbols + a NULL minus the sync's pull-back of new samples
+    const BankGeom& G = b->view.g;
+    const int NB_FRAME_SAMPLES = G.frame_samples, NB_CORR = G.n_corr, NB_NULL_PERIOD = G.null_period;
+    // a frame needs at least n_sym symbols + a NULL minus the sync's pull-back of new samples
     const size_t need = ring_mode ? 1 : (n_samples / (size_t)(NB_FRAME_SAMPLES - NB_CORR) + 2);
     if (ring_mode && n_samples > (size_t)(NB_FRAME_SAMPLES - NB_CORR)) {
         dabgpu_set_error("stream_bank_process_ring: at most %d samples per call (one frame per stream per call)", NB_FRAME_SAMPLES - NB_CORR);
@@ -501,6 +495,8 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
             CK(hipGetLastError());
         }
     }
+    const float *d_prs = nullptr, *d_prs_time_ref = nullptr;               // PRS spectrum / coarse-sync reference of the bank's mode
+    if ((st = dabgpu_mode_sync_tables(c, G.mode, &d_prs, &d_prs_time_ref))) return st;
     // rounds every locked stream needs: (sync, demod) per frame that can complete inside this block, plus one to drain
     const int blind_rounds = 2 * (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
     int h_not_done = 1;
@@ -513,11 +509,16 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
                            stream_stride_samples);
         CK(hipGetLastError());
         CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
-                              nullptr, nullptr, c->d_tw, c->d_prs, c->d_prs_time_ref, b->view.sync_active, 1, s));
-        CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
-                                    n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
+                              nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active, G.mode, s));
+        if (G.mode == 1) {
+            CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
+                                        n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
+        } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
+                                                       b->view.desc, d_iq, stream_stride_samples, s))) {
+            return st;
+        }
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
-                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, NB_FRAME_SYMBOLS, NB_FFT, s));
+                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, G.n_sym, G.n_fft, s));
         if (round + 1 >= blind_rounds) {
             CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
             CK(hipStreamSynchronize(s));

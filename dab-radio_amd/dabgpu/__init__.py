@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "dabgpu_iq_convert", "dabgpu_iq_convert_host_sync", "dabgpu_ofdm_demod_frames_raw",
     "dabgpu_soft_bits_to_hard_bytes", "dabgpu_hard_bytes_to_soft_bits",
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
-    "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
+    "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_create_mode", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
     "dabgpu_stream_bank_process", "dabgpu_stream_bank_process_raw", "dabgpu_stream_bank_status",
     "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
     "dabgpu_dabplus_process_frame_host_sync",
@@ -177,6 +177,7 @@ def lib():
         L.dabgpu_hard_bytes_to_soft_bits_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.dabgpu_stream_cfg_default.argtypes = [C.c_void_p]
         L.dabgpu_stream_bank_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dabgpu_stream_bank_create_mode.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]
         L.dabgpu_stream_bank_destroy.argtypes = [C.c_void_p]
         L.dabgpu_stream_bank_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -434,12 +435,13 @@ class Context:
 class StreamBank:
     """dabgpu_stream_bank: n unsynchronised receivers resident on the device (one OFDM_Demod each)"""
 
-    def __init__(self, ctx, n_streams, cfg=None):
+    def __init__(self, ctx, n_streams, cfg=None, mode=1):
         self._ctx = ctx
         self.n = n_streams
+        self.mode = mode
         self._h = C.c_void_p()
-        check(lib().dabgpu_stream_bank_create(ctx._h, n_streams, C.byref(cfg) if cfg is not None else None, C.byref(self._h)),
-              "dabgpu_stream_bank_create")
+        check(lib().dabgpu_stream_bank_create_mode(ctx._h, int(mode), n_streams, C.byref(cfg) if cfg is not None else None, C.byref(self._h)),
+              "dabgpu_stream_bank_create_mode")
 
     def close(self):
         if self._h:

@@ -374,6 +374,10 @@ typedef struct {
 typedef struct dabgpu_stream_bank dabgpu_stream_bank;
 /* cfg NULL = the reference's defaults. Device memory: 1.64 MB per stream. */
 int dabgpu_stream_bank_create(dabgpu_ctx *ctx, size_t n_streams, const dabgpu_stream_cfg *cfg, dabgpu_stream_bank **out);
+/* the same for transmission mode 1..4 (get_DAB_OFDM_params, src/ofdm/dab_ofdm_params_ref.cpp:11-60): frames are
+ * dabgpu_get_ofdm_params(mode)[8] soft bits each, ring / block limits scale with the mode's frame length; modes II-IV run the
+ * size-generic demodulation kernel (dabgpu_ofdm_demod_frames_mode) */
+int dabgpu_stream_bank_create_mode(dabgpu_ctx *ctx, int mode, size_t n_streams, const dabgpu_stream_cfg *cfg, dabgpu_stream_bank **out);
 void dabgpu_stream_bank_destroy(dabgpu_stream_bank *bank);
 int dabgpu_stream_bank_reset(dabgpu_stream_bank *bank, void *stream);     /* every stream back to its constructed state */
 /*

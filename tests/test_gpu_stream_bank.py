@@ -156,3 +156,79 @@ def test_stream_bank_from_capture_formats(oracle, name):
         assert st["signal_l1_average"][e].view(np.uint32) == np.float32(models[e].signal_avg).view(np.uint32)
     assert got >= 3
     bank.close()
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+@pytest.mark.parametrize("fmt", ["c32", "raw_s16l"])
+def test_stream_bank_in_other_transmission_modes(oracle, mode, fmt):
+    """dabgpu_stream_bank_create_mode: three receivers of transmission mode II / III / IV (different offsets, one with a signal
+    drop-out) vs the oracle state machine of that mode (tests/stream_model.py), blocks in complex float or raw s16 capture
+    bytes -- every frame's soft bits and every status field after every call, floats as bit patterns"""
+    import dabgpu
+    import modes_model as MM
+    import stream_model as SM
+    import torch
+    ctx = dabgpu.Context(0)
+    g = oracle.geometry(mode)
+
+    def make(seed, n_frames, cfo_bins, pad, noise, dropout=None):
+        rng = np.random.default_rng(1000 * mode + seed)
+        sent = [rng.integers(0, 2, g.nb_frame_bits, dtype=np.uint8) for _ in range(n_frames)]
+        tx = oracle.apply_pll(np.concatenate([MM.make_tx_frame(oracle, mode, b, rng) for b in sent]), cfo_bins / g.nb_fft, 0.2)
+        s = np.concatenate([tx[g.nb_null_period:g.nb_null_period + 6000 + pad], tx])
+        if dropout is not None:
+            s[dropout[0]:dropout[1]] = 0
+        s = (s + noise * (rng.standard_normal(s.size) + 1j * rng.standard_normal(s.size))) / 39.2
+        return s.astype(np.complex64)
+
+    fs = g.nb_frame_samples
+    streams = [make(1, 7, 2.1, 77, 0.05), make(2, 7, -3.4, 311, 0.1), make(3, 7, 0.3, 5, 0.05, dropout=(2 * fs + 9000, 2 * fs + 9000 + fs // 3))]
+    n = min(s.size for s in streams)
+    n -= n % 5
+    streams = [s[:n] for s in streams]
+    fnum = dabgpu.IQ_FORMATS.index("raw_s16l")
+    if fmt == "raw_s16l":                                # quantise first: model and bank must see the same samples
+        q = [np.clip(np.rint(s.view(np.float32) * 32767.0 * 8.0), -32768, 32767).astype("<i2") for s in streams]
+        streams = [oracle.iq_convert(x.view(np.uint8), fnum).view(np.complex64) for x in q]
+    E = len(streams)
+    cfg = dabgpu.StreamCfg()
+    dabgpu.lib().dabgpu_stream_cfg_default(dabgpu.C.byref(cfg))
+    cfg.sync.impulse_peak_threshold_db = 8.0             # the reference's default 20 dB rarely passes with the short symbols of modes II / III
+    bank = dabgpu.StreamBank(ctx, E, cfg, mode=mode)
+    models = [SM.StreamModel(oracle, mode) for _ in range(E)]
+    for m in models:
+        m.cfg.impulse_peak_threshold_db = 8.0
+    block = 40000
+    max_frames = block // (fs - g.nb_null_period - g.nb_symbol_period) + 2
+    d_bits = torch.zeros((E, max_frames, g.nb_frame_bits), dtype=torch.int8, device="cuda")
+    d_nf = torch.zeros(E, dtype=torch.int32, device="cuda")
+    total = [0] * E
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        blk = np.stack([s[k:k + m] for s in streams])
+        d_bits.zero_()
+        if fmt == "c32":
+            bank.process(torch.view_as_real(torch.from_numpy(blk).cuda()), m, m, d_bits, max_frames, d_nf)
+        else:
+            raw = np.stack([x[2 * k:2 * (k + m)] for x in q])
+            bank.process_raw(torch.from_numpy(raw.view(np.uint8)).cuda(), fnum, m, m, d_bits, max_frames, d_nf)
+        torch.cuda.synchronize()
+        nf = d_nf.cpu().numpy()
+        st = bank.status()
+        for e in range(E):
+            before = len(models[e].out_frames)
+            models[e].process(blk[e])
+            new = models[e].out_frames[before:]
+            assert nf[e] == len(new), (mode, k, e, nf[e], len(new))
+            for j, fr in enumerate(new):
+                assert np.array_equal(d_bits[e, j].cpu().numpy(), fr["bits"]), (mode, k, e, j)
+            total[e] += len(new)
+            mo = models[e]
+            assert int(st["state"][e]) == mo.state, (mode, k, e)
+            assert st["signal_l1_average"][e].view(np.uint32) == np.float32(mo.signal_avg).view(np.uint32), (mode, k, e)
+            assert st["freq_coarse"][e].view(np.uint32) == np.float32(mo.sync.freq_coarse).view(np.uint32), (mode, k, e)
+            assert st["freq_fine"][e].view(np.uint32) == np.float32(mo.sync.freq_fine).view(np.uint32), (mode, k, e)
+            assert int(st["fine_time_offset"][e]) == mo.fine_time_offset
+            assert int(st["total_frames_read"][e]) == mo.frames_read and int(st["total_frames_desync"][e]) == mo.frames_desync
+    assert sum(total) >= 6, total
+    bank.close()
