@@ -293,7 +293,8 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
-    if (use_lane_mapping(c, n)) {
+    // (the lane mapping keeps ring offsets in 32 bits: one ensemble's ring must stay below 4 GiB)
+    if (use_lane_mapping(c, n) && (uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32)) {
         // group (s, gq) = sub-channel s of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch stays
         // inside the scratch bound
         size_t rows_per_gq = 0;

@@ -32,6 +32,7 @@ namespace dabgpu {
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 constexpr int VL_TILE = 64;                 // steps per prep tile
 constexpr int VL_PRBS = 511;
@@ -216,7 +217,7 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
         vl_renorm(N, total);                                                                          \
         vl_step<(Q) + 1, TIE>(N, M, YB, wv.z, wv.w);                                                  \
         vl_renorm(M, total);                                                                          \
-        reinterpret_cast<uint4*>(grp_dec + (size_t)((TT) >> 1) * 256)[lane] = wv;                     \
+        __builtin_nontemporal_store(u4v{wv.x, wv.y, wv.z, wv.w}, reinterpret_cast<u4v*>(grp_dec + (size_t)((TT) >> 1) * 256) + lane); \
     }
     int t = 0;
     if (q0 == 2) {
@@ -268,7 +269,7 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
 #pragma unroll
         for (int v = 0; v < CB / 2; v++) {
             const int pr = (th >> 1) - v;
-            const uint4 q4 = reinterpret_cast<const uint4*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256)[lane];
+            const u4v q4 = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256) + lane);
             ax[2 * v] = q4.z; ay[2 * v] = q4.w; ax[2 * v + 1] = q4.x; ay[2 * v + 1] = q4.y;
         }
     };
