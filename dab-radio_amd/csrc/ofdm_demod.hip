@@ -335,6 +335,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         const bool emit = (i > out0) && (i < NB_FRAME_SYMBOLS);
         if (emit) {
             // ---- DQPSK (X_{i-1} * conj(X_i)) + soft bits, scattered to their de-interleaved positions ----
+            f2 dq[6];
+            float An[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 const f2 d = conj_mul(prev[k], cur[k]);
@@ -344,9 +346,35 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                     dqpsk_out[((size_t)frame * (NB_FRAME_SYMBOLS - 1) + (i - 1)) * 1536 + c] = d;
                 }
                 const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
-                const float A = (ar < ai) ? ai : ar;                     // std::max, ofdm_demodulator.cpp:882
-                obuf[pos[k]] = (int8_t)to_vbit(d.x / A);
-                obuf[pos[k] + 1536] = (int8_t)to_vbit(-(d.y / A));
+                dq[k] = d;
+                An[k] = (ar < ai) ? ai : ar;                             // std::max, ofdm_demodulator.cpp:882
+            }
+            // Two IEEE divisions per carrier are 1/7 of the kernel's instructions.  For A in [2^-60, 2^60] and |n| <= A the
+            // compiler's expansion of n / A (v_div_scale x2, v_rcp, 2 + 4 fma, v_div_fmas, v_div_fixup) never scales where it
+            // matters: the scaled cases (quotient below 2^-43) end as soft bit 0 either way.  The reciprocal refinement then
+            // depends on A only and is shared by both quotients; outside the range (or NaN) the plain expressions run.
+            const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(An[0], An[1]), __builtin_fminf(An[2], An[3])), __builtin_fminf(An[4], An[5]));
+            const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(An[0], An[1]), __builtin_fmaxf(An[2], An[3])), __builtin_fmaxf(An[4], An[5]));
+            if (amin >= 0x1p-60f && amax <= 0x1p60f) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const float A = An[k], nx = dq[k].x, ny = -dq[k].y;
+                    float r = __builtin_amdgcn_rcpf(A);
+                    r = __builtin_fmaf(__builtin_fmaf(-A, r, 1.0f), r, r);
+                    float qx = nx * r, qy = ny * r;
+                    qx = __builtin_fmaf(__builtin_fmaf(-A, qx, nx), r, qx);
+                    qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
+                    qx = __builtin_fmaf(__builtin_fmaf(-A, qx, nx), r, qx);
+                    qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
+                    obuf[pos[k]] = (int8_t)to_vbit(qx);
+                    obuf[pos[k] + 1536] = (int8_t)to_vbit(qy);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    obuf[pos[k]] = (int8_t)to_vbit(dq[k].x / An[k]);
+                    obuf[pos[k] + 1536] = (int8_t)to_vbit(-(dq[k].y / An[k]));
+                }
             }
         }
         block_barrier<PREFETCH>();   // obuf complete; also every wave is past its bufA reads before the next pass-1 writes

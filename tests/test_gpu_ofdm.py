@@ -112,6 +112,32 @@ def test_edge_inputs(ctx, oracle):
     assert got0.shape == (0, oracle.NB_FRAME_BITS)
 
 
+def test_soft_bit_division_paths(ctx, oracle):
+    """the kernel divides by the L-inf norm through a shared-reciprocal expansion when every norm of a thread's six carriers lies
+    in [2^-60, 2^60] and through plain IEEE divisions otherwise: spectra whose per-carrier amplitudes are log-uniform over
+    2^-45 .. 2^38 (products of consecutive symbols from 2^-90 to 2^76, quotients down to 2^-80) put threads on both sides of
+    both bounds, with tiny and exact-zero numerators; soft bits must equal the oracle's true divisions everywhere"""
+    rng = np.random.default_rng(99)
+    N, CP, P = 2048, 504, 2552
+    frames = np.zeros((3, oracle.NB_FRAME_SAMPLES), np.complex64)
+    for f in range(3):
+        lo, hi = [(-45, 38), (-32, -28), (28, 31)][f]              # frame 1 / 2 sit astride the lower / upper bound
+        for sym in range(76):
+            amp = np.exp2(rng.uniform(lo, hi, N))
+            spec = amp * np.exp(2j * np.pi * rng.uniform(0, 1, N))
+            if sym % 7 == 3:
+                spec[::5] = spec[::5].real                         # purely real bins: near-zero imaginary parts after the FFT
+            t = (np.fft.ifft(spec)).astype(np.complex64)
+            frames[f, sym * P + CP:(sym + 1) * P] = t
+            frames[f, sym * P:sym * P + CP] = t[N - CP:]
+    freqs = np.array([0.0, 7e-4, -1.3e-3], dtype=np.float32)
+    got, total, _ = ctx.ofdm_demod_frames_host(frames, freqs)
+    for k in range(3):
+        exp = oracle.demod_frame(frames[k], freqs[k])
+        assert np.array_equal(got[k], exp["bits"]), f"frame {k}: {int((got[k] != exp['bits']).sum())} soft bits differ"
+    assert len(np.unique(got[0])) > 200
+
+
 def test_full_size_batch_properties(ctx, oracle):
     """BASELINE config 2 size (1024 frames) checked through size-independent properties: the batch is 16
     distinct oracle-checked frames tiled 64x with per-copy frequency offsets; de-rotated copies must decode
