@@ -103,14 +103,17 @@ static int ensure_vit_tables(dabgpu_ctx* c) {
     return dabgpu_check_hip(hipMemcpy(c->d_vit_tables, &T, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(vit tables)");
 }
 
+// slot_off: the FIC entry points keep their device scratch in slots of their own (+ FIC_SLOTS), so that one context can decode the
+// FIC and the MSC of a batch concurrently on two streams
+static const int FIC_SLOTS = 20;
 static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t max_steps, uint32_t max_out_bytes,
-                       int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s) {
+                       int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
     int st0 = ensure_vit_tables(c);
     if (st0) return st0;
     const int n_waves = (int)std::min<size_t>(n, (size_t)device_waves(c));
     const size_t words = ((size_t)max_steps + 63) & ~(size_t)63;
     uint64_t* d_scratch = nullptr;
-    int st = dabgpu_scratch(c, 11, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch);
+    int st = dabgpu_scratch(c, 11 + slot_off, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch);
     if (st) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi(d_descs, (int)n, d_scratch, words, n_waves, (int)max_out_bytes, d_results,
                                                   tie_rule ? 1 : 0, c->d_vit_tables, s), "viterbi_kernel launch");
@@ -139,12 +142,12 @@ static size_t lanes_max_rows() {
 
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
                              size_t total_rows, uint32_t max_alloc_steps, int tie_rule, bool ring4, dabgpu_codeword_result* d_results,
-                             hipStream_t s) {
+                             hipStream_t s, int slot_off = 0) {
     int st = ensure_vit_tables(c);
     if (st) return st;
     uint32_t *d_sym = nullptr, *d_dec = nullptr;
-    if ((st = dabgpu_scratch(c, 18, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
-    if ((st = dabgpu_scratch(c, 19, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+    if ((st = dabgpu_scratch(c, 18 + slot_off, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
+    if ((st = dabgpu_scratch(c, 19 + slot_off, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
                                                         tie_rule ? 1 : 0, ring4 ? 1 : 0, c->d_vit_tables, s), "vit_lanes_kernel launch");
 }
@@ -220,7 +223,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     hipStream_t s = (hipStream_t)stream;
     const size_t n = n_frames * 4;
     dabgpu_cw_desc* d_descs = nullptr;
-    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    int st = dabgpu_scratch(c, 10 + FIC_SLOTS, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
     st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
@@ -232,13 +235,13 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
         for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
             const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
             dabgpu_vit_group* d_groups = nullptr;
-            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_scratch(c, 17 + FIC_SLOTS, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s, FIC_SLOTS))) return st;
         }
         return DABGPU_OK;
     }
-    return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s);
+    return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s, FIC_SLOTS);
 }
 
 extern "C" int dabgpu_fic_decode_frames(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride,

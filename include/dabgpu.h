@@ -243,6 +243,8 @@ int dabgpu_viterbi_decode_batch(dabgpu_ctx *ctx, const dabgpu_codeword *h_codewo
  *   d_bits       frame f starts at d_bits + f * frame_stride (bytes); pass DABGPU_NB_FRAME_BITS for packed frames
  *   d_fib_bytes  [n_frames][4][96]: 3 x (30 data bytes + 2 CRC bytes) per group
  *   d_results    [n_frames][4]
+ * dabgpu_fic_decode_* keep their device scratch apart from dabgpu_msc_decode_* / dabgpu_viterbi_decode_batch: one context may
+ * decode the FIC and the MSC of a batch concurrently on two streams (the FIC fits into the SIMD time the MSC leaves idle).
  */
 int dabgpu_fic_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits, size_t n_frames, size_t frame_stride,
                              uint8_t *d_fib_bytes, dabgpu_codeword_result *d_results, int tie_rule, void *stream);
