@@ -114,14 +114,18 @@ __device__ __forceinline__ f2* stage_area() {
     }
 }
 
-template <bool PREFETCH, int SRC, bool BANK>
+// VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
+// GetFrameFFT() / GetFrameDataVec()): their stores and per-carrier branches leave the symbol loop
+template <bool PREFETCH, int SRC, bool BANK, bool VIEWS = true>
 __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
-                       int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out,
-                       f2* __restrict__ dqpsk_out, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
+                       int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
+                       f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
                        const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride)
 {
+    f2* const fft_out = VIEWS ? fft_out_ : nullptr;
+    f2* const dqpsk_out = VIEWS ? dqpsk_out_ : nullptr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // bufA: the radix-4 outputs, position-indexed, as four 512-element blocks (one per wave's 512-point problem) placed
     // WAVE_PATCH = 576 apart; a wave's transpose patch ALIASES its own block: the wave has read its 8 inputs per lane before
@@ -465,10 +469,12 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     if (g_dabgpu_variant == 2) lds += 14 * 1024;      // development: 3 instead of 4 workgroups per CU (occupancy sensitivity)
     if (g_dabgpu_variant == 3) lds += 42 * 1024;      // development: 2 workgroups per CU
     const dim3 grid((unsigned)(n_frames * chunks));
-#define DABGPU_LAUNCH(PF, SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC, BANK>), grid, dim3(256), lds, stream, \
+#define DABGPU_LAUNCH_V(PF, SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
+    const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
+#define DABGPU_LAUNCH(PF, SRC, BANK) do { if (views || (PF)) DABGPU_LAUNCH_V(PF, SRC, BANK, true); else DABGPU_LAUNCH_V(PF, SRC, BANK, false); } while (0)
     switch (src) {
     case SRC_C32:
         if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_C32, true);
@@ -481,6 +487,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     default: return hipErrorInvalidValue;
     }
 #undef DABGPU_LAUNCH
+#undef DABGPU_LAUNCH_V
     return hipGetLastError();
 }
 
