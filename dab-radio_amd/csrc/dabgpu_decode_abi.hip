@@ -125,10 +125,22 @@ extern "C" int dabgpu_viterbi_set_mapping(dabgpu_ctx* c, int mapping) {
     return DABGPU_OK;
 }
 
-static bool use_lane_mapping(const dabgpu_ctx* c, size_t n_cw) {
+// AUTO: a cost model of the two mappings on this part (profiles/r01/ab_notes.md; microseconds).
+//   WAVE  one wavefront per codeword keeps every SIMD busy: t = sum over codewords of (0.0189 ns x steps + 0.038 us)
+//   LANE  a group of 64 codewords is one wavefront that needs 0.5 us per trellis step however many of its lanes are used, and
+//         a SIMD works through its groups at that same rate: t = 0.5 us x max(longest schedule, rounds x mean steps) with
+//         rounds = ceil(groups / SIMDs), + the gather pass (3.3e-3 / 8.5e-3 us per codeword-kilostep, staged / byte-wise)
+// n_cw codewords in n_groups groups; sums and maximum of their trellis steps
+static bool use_lane_mapping(dabgpu_ctx* c, size_t n_cw, size_t n_groups, double sum_cw_steps, double sum_group_steps, double max_steps,
+                             bool staged_gather) {
     if (c->vit_mapping == DABGPU_VIT_MAP_LANE) return true;
-    if (c->vit_mapping == DABGPU_VIT_MAP_WAVE) return false;
-    return n_cw >= DABGPU_VIT_LANE_MIN_CODEWORDS;
+    if (c->vit_mapping == DABGPU_VIT_MAP_WAVE || n_groups == 0) return false;
+    const double n_simd = (double)device_waves(c) / 8.0;
+    const double t_wave = 0.0189e-3 * sum_cw_steps + 0.038 * (double)n_cw;
+    const double rounds = (double)((n_groups + (size_t)n_simd - 1) / (size_t)n_simd);
+    const double t_lane = 0.5 * std::max(max_steps, rounds * (sum_group_steps / (double)n_groups)) +
+                          (staged_gather ? 3.3e-6 : 8.5e-6) * sum_cw_steps;
+    return t_lane < t_wave;
 }
 
 // lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (768 bytes per row:
@@ -199,7 +211,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     for (size_t i = 0; i < n && uniform; i++)             // the lane mapping keeps ring offsets in 32 bits
         uniform = h_cw[i].n_slots == 0 || (uint64_t)(h_cw[i].n_slots / h_cw[i].cifs_per_frame + 1) * h_cw[i].frame_stride +
                                           (uint64_t)h_cw[i].cifs_per_frame * h_cw[i].cif_stride < ((uint64_t)1 << 32);
-    if (uniform && use_lane_mapping(c, n)) {
+    if (uniform && use_lane_mapping(c, n, (n + 63) / 64, (double)n * max_steps, (double)((n + 63) / 64) * max_steps, (double)max_steps, false)) {
         const uint32_t rows = dabgpu_vit_alloc_steps(max_steps);
         const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / rows);
         for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
@@ -227,7 +239,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     if (st) return st;
     st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
-    if (use_lane_mapping(c, n)) {
+    if (use_lane_mapping(c, n, (n + 63) / 64, (double)n * 774.0, (double)((n + 63) / 64) * 774.0, 774.0, false)) {
         // one schedule for every FIB group: groups of 64 consecutive codewords, processed in bounded slices
         const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
         const uint32_t rows = dabgpu_vit_alloc_steps(774);
@@ -297,7 +309,12 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
     // (the lane mapping keeps ring offsets in 32 bits: one ensemble's ring must stay below 4 GiB)
-    if (use_lane_mapping(c, n) && (uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32)) {
+    double sum_plan_steps = 0.0;
+    for (int k = 0; k < n_sub; k++) sum_plan_steps += (double)plans[(size_t)k].n_steps;
+    const size_t groups_per_sub_all = (n_ens * 4 + 63) / 64;
+    if ((uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32) &&
+        use_lane_mapping(c, n, groups_per_sub_all * (size_t)n_sub, sum_plan_steps * (double)(n_ens * 4), sum_plan_steps * (double)groups_per_sub_all,
+                         (double)max_steps, true)) {
         // group (s, gq) = sub-channel s of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch stays
         // inside the scratch bound
         size_t rows_per_gq = 0;
