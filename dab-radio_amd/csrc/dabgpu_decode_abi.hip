@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "dabgpu.h"
@@ -161,7 +162,7 @@ static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const
     if ((st = dabgpu_scratch(c, 18 + slot_off, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
     if ((st = dabgpu_scratch(c, 19 + slot_off, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, ring4 ? 1 : 0, c->d_vit_tables, s), "vit_lanes_kernel launch");
+                                                        tie_rule ? 1 : 0, ring4 ? 1 : 0, c->d_vit_tables, device_waves(c) / 32, s), "vit_lanes_kernel launch");
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
@@ -308,37 +309,76 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
+    // Which sub-channels go to the lane-per-codeword kernel?  Its critical path is the LONGEST schedule (0.5 us per step), so a
+    // multiplex with one long sub-channel among short ones is decoded as a hybrid: the k longest by viterbi_kernel (one wavefront
+    // per codeword), the rest by vit_lanes_kernel, k = the minimum of the cost model of use_lane_mapping().
     // (the lane mapping keeps ring offsets in 32 bits: one ensemble's ring must stay below 4 GiB)
-    double sum_plan_steps = 0.0;
-    for (int k = 0; k < n_sub; k++) sum_plan_steps += (double)plans[(size_t)k].n_steps;
-    const size_t groups_per_sub_all = (n_ens * 4 + 63) / 64;
-    if ((uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32) &&
-        use_lane_mapping(c, n, groups_per_sub_all * (size_t)n_sub, sum_plan_steps * (double)(n_ens * 4), sum_plan_steps * (double)groups_per_sub_all,
-                         (double)max_steps, true)) {
-        // group (s, gq) = sub-channel s of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch stays
-        // inside the scratch bound
+    std::vector<int> order((size_t)n_sub);
+    for (int k = 0; k < n_sub; k++) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return plans[(size_t)a].n_steps > plans[(size_t)b].n_steps; });
+    const size_t gps_all = (n_ens * 4 + 63) / 64;
+    const double n_simd = (double)device_waves(c) / 8.0;
+    int k_wave = n_sub;                                        // number of (longest) sub-channels left to viterbi_kernel
+    if ((uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32) && c->vit_mapping != DABGPU_VIT_MAP_WAVE) {
+        if (c->vit_mapping == DABGPU_VIT_MAP_LANE) {
+            k_wave = 0;
+        } else {
+            double best = 1e300;
+            for (int k = 0; k <= n_sub; k++) {
+                double t = 0.0, lane_sum = 0.0, lane_max = 0.0;
+                for (int j = 0; j < n_sub; j++) {
+                    const double steps = (double)plans[(size_t)order[(size_t)j]].n_steps;
+                    if (j < k) t += (double)(n_ens * 4) * (0.0189e-3 * steps + 0.038);
+                    else { lane_sum += steps; lane_max = std::max(lane_max, steps); }
+                }
+                if (k < n_sub) {
+                    const double groups = (double)(n_sub - k) * (double)gps_all;
+                    const double rounds = std::ceil(groups / n_simd);
+                    t += 0.5 * std::max(lane_max, rounds * lane_sum / (double)(n_sub - k)) + 3.3e-6 * lane_sum * (double)(n_ens * 4);
+                }
+                if (t < best) { best = t; k_wave = k; }
+            }
+            if (const char* e = getenv("DABGPU_VIT_HYBRID_K")) { const int v = atoi(e); if (v >= 0 && v <= n_sub) k_wave = v; }   // tests
+        }
+    }
+    const int n_lane = n_sub - k_wave;
+    if (n_lane > 0) {
+        // flag the lane-mapped sub-channels in the plans the descriptor builder read: rebuild the descriptors with the flags
+        for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
+        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
+        if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
+                                                           d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
+        // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
+        // stays inside the scratch bound
         size_t rows_per_gq = 0;
-        std::vector<uint64_t> prefix((size_t)n_sub);
-        for (int k = 0; k < n_sub; k++) { prefix[(size_t)k] = rows_per_gq; rows_per_gq += dabgpu_vit_alloc_steps(plans[(size_t)k].n_steps); }
+        uint32_t lane_max_steps = 0;
+        std::vector<uint64_t> lane_subs((size_t)2 * n_lane);
+        for (int j = 0; j < n_lane; j++) {
+            const int sidx = order[(size_t)(k_wave + j)];
+            lane_subs[(size_t)2 * j] = (uint64_t)sidx;
+            lane_subs[(size_t)2 * j + 1] = rows_per_gq;
+            rows_per_gq += dabgpu_vit_alloc_steps(plans[(size_t)sidx].n_steps);
+            lane_max_steps = std::max(lane_max_steps, plans[(size_t)sidx].n_steps);
+        }
         const size_t max_gq = std::max<size_t>(1, lanes_max_rows() / rows_per_gq);
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
-        uint64_t* d_prefix = nullptr;
-        if ((st = dabgpu_scratch(c, 24, prefix.size() * sizeof(uint64_t), (void**)&d_prefix))) return st;
-        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s), "hipMemcpyAsync(prefix)"))) return st;
+        uint64_t* d_lane_subs = nullptr;
+        if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s), "hipMemcpyAsync(lane subs)"))) return st;
         for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
             const size_t ne = std::min(n_ens - e0, ens_per_slice);
             const uint32_t gps = (uint32_t)((ne * 4 + 63) / 64);
-            const size_t n_groups = (size_t)n_sub * gps;
+            const size_t n_groups = (size_t)n_lane * gps;
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
-            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_prefix, n_sub, ne, gps, s), "vit_groups launch"))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
             // the staged gather reads the ring rows in aligned 16-byte chunks
             const bool ring4 = ((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0);
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(max_steps),
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(lane_max_steps),
                                         tie_rule, ring4, d_results + cw0, s))) return st;
         }
-        return DABGPU_OK;
+        if (k_wave == 0) return DABGPU_OK;
     }
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
 }

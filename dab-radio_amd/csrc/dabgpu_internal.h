@@ -63,7 +63,9 @@ struct dabgpu_msc_plan {            // device-side sub-channel plan (one per sub
     uint32_t seg_steps[4];
     uint32_t out_offset;            // byte offset of this sub-channel inside one CIF's output record
     uint32_t n_out_bytes;
+    uint32_t lane_mapped;           // this call decodes the sub-channel with the lane-per-codeword kernel: viterbi_kernel skips it
 };
+#define DABGPU_CW_LANE_MAPPED 0x80000000u      // internal flag bit of dabgpu_codeword.flags (set by msc_build_descs_kernel)
 struct dabgpu_vit_tables {          // constant tables of the Viterbi kernel, built on the host at context creation
     uint16_t pi_tab[25 * 8];        // [PI][group]: kept count | running prefix << 8 (puncture_codes.h:42-67)
     unsigned char prbs[512];        // energy-dispersal bytes, period 511 (additive_scrambler.h:16-35)
@@ -84,12 +86,12 @@ static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_ste
 extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
                                                        const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const struct dabgpu_msc_plan* d_plans,
-                                                   const uint64_t* d_plan_step_prefix, int n_sub, size_t n_ens,
+                                                   const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
                                                    uint32_t groups_per_sub, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4,
-                                                  const struct dabgpu_vit_tables* d_tables, hipStream_t stream);
+                                                  const struct dabgpu_vit_tables* d_tables, int n_cu, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,

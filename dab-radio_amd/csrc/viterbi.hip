@@ -234,6 +234,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
     for (int cw = blockIdx.x; cw < n_cw; cw += gridDim.x) {
         const dabgpu_cw_desc D = descs[cw];
         const int n_steps = (int)D.n_steps;
+        if (D.flags & DABGPU_CW_LANE_MAPPED) continue;        // decoded by vit_lanes_kernel in this call (hybrid MSC batches)
         if (n_steps < 7) {                            // skipped work item (ring decode of an ensemble without a new frame)
             if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; results[cw] = R; }
             continue;
@@ -445,6 +446,7 @@ __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist
     D.cifs_per_frame = 4;
     D.frame_stride = 230400;
     D.cif_stride = 55296;
+    if (P.lane_mapped) D.flags |= DABGPU_CW_LANE_MAPPED;
     descs[i] = D;
 }
 

@@ -172,18 +172,24 @@ __device__ __forceinline__ void vl_renorm(s2 (&N)[32], uint32_t& total) {
     }
 }
 
-template <int TIE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
+// Workgroups of FOUR wavefronts = four groups: the hardware puts the wavefronts of a workgroup on the four SIMDs of one CU, so
+// up to 1024 groups get a SIMD each.  Single-wavefront workgroups are placed one by one and a few per cent of them double up on
+// a SIMD -- and one doubled SIMD (1.4 ms instead of 0.9) sets the time of the whole launch (tools/ubench/hwid_probe.hip).
+// With at most one group per CU, or more groups than SIMDs, single-wavefront workgroups are ~5 % faster (no CU-level sharing).
+template <int TIE, int VL_WAVES>
+__global__ __launch_bounds__(64 * VL_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups, const dabgpu_cw_desc* __restrict__ descs,
                       const uint32_t* __restrict__ sym, uint32_t* __restrict__ dec, dabgpu_cw_result* __restrict__ results,
                       const dabgpu_vit_tables* __restrict__ tables)
 {
     __shared__ unsigned char prbs[512];
-    const int lane = threadIdx.x;
-    for (int e = lane; e < 512; e += 64) prbs[e] = tables->prbs[e];
+    const int lane = threadIdx.x & 63;
+    for (int e = threadIdx.x; e < 512; e += 64 * VL_WAVES) prbs[e] = tables->prbs[e];
     __syncthreads();
+    const int group = (int)blockIdx.x * VL_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform
+    if (group >= n_groups) return;
 
-    const dabgpu_vit_group Gd = groups[blockIdx.x];
+    const dabgpu_vit_group Gd = groups[group];
     const int T = (int)Gd.n_steps;
     const bool valid = lane < (int)Gd.count;
     const size_t cw = (size_t)Gd.first + (size_t)Gd.stride * (size_t)(valid ? lane : 0);
@@ -518,14 +524,16 @@ __global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw,
     groups[g] = G;
 }
 
-// MSC: codeword index = (4 e + c) * n_sub + s (msc_build_descs_kernel); group (s, gq) = sub-channel s of ensemble-CIFs 64 gq ..
-__global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc_plan* plans, const uint64_t* plan_step_prefix,
-                                      int n_sub, size_t n_ens, uint32_t groups_per_sub)
+// MSC: codeword index = (4 e + c) * n_sub + s (msc_build_descs_kernel); group (li, gq) = the li-th lane-mapped sub-channel
+// s = lane_subs[2 li] (row prefix lane_subs[2 li + 1]) of ensemble-CIFs 64 gq .. 64 gq + 63
+__global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc_plan* plans, const uint64_t* lane_subs,
+                                      int n_lane_sub, int n_sub, size_t n_ens, uint32_t groups_per_sub)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (size_t)n_sub * groups_per_sub) return;
-    const int s = (int)(g / groups_per_sub);
-    const uint32_t gq = (uint32_t)(g - (size_t)s * groups_per_sub);
+    if (g >= (size_t)n_lane_sub * groups_per_sub) return;
+    const int li = (int)(g / groups_per_sub);
+    const uint32_t gq = (uint32_t)(g - (size_t)li * groups_per_sub);
+    const int s = (int)lane_subs[2 * li];
     const dabgpu_msc_plan P = plans[s];
     const size_t n_j = n_ens * 4;
     dabgpu_vit_group G = {};
@@ -534,7 +542,7 @@ __global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc
     G.n_steps = P.n_steps;
     G.alloc_steps = dabgpu_vit_alloc_steps(P.n_steps);
     for (int k = 0; k < 4; k++) { G.seg_pi[k] = P.seg_pi[k]; G.seg_steps[k] = P.seg_steps[k]; }
-    const size_t steps_before = (size_t)plan_step_prefix[s] * groups_per_sub + (size_t)gq * G.alloc_steps;
+    const size_t steps_before = (size_t)lane_subs[2 * li + 1] * groups_per_sub + (size_t)gq * G.alloc_steps;
     G.sym_off = steps_before * 64;
     G.dec_off = steps_before * 128;
     groups[g] = G;
@@ -553,19 +561,19 @@ extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_group
 }
 
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const dabgpu_msc_plan* d_plans,
-                                                   const uint64_t* d_plan_step_prefix, int n_sub, size_t n_ens,
+                                                   const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
                                                    uint32_t groups_per_sub, hipStream_t stream)
 {
-    const size_t n_groups = (size_t)n_sub * groups_per_sub;
+    const size_t n_groups = (size_t)n_lane_sub * groups_per_sub;
     hipLaunchKernelGGL(dabgpu::vit_groups_msc_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
-                       d_groups, d_plans, d_plan_step_prefix, n_sub, n_ens, groups_per_sub);
+                       d_groups, d_plans, d_lane_subs, n_lane_sub, n_sub, n_ens, groups_per_sub);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
-                                                  hipStream_t stream)
+                                                  int n_cu, hipStream_t stream)
 {
     using namespace dabgpu;
     const unsigned tiles = (max_alloc_steps + VL_TILE - 1) / VL_TILE;
@@ -573,11 +581,11 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
         hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
     else
         hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
-    if (tie_rule)
-        hipLaunchKernelGGL(vit_lanes_kernel<1>, dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, d_descs, d_sym, d_dec,
-                           d_results, d_tables);
-    else
-        hipLaunchKernelGGL(vit_lanes_kernel<0>, dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, d_descs, d_sym, d_dec,
-                           d_results, d_tables);
+#define VL_GO(TIE, W) hipLaunchKernelGGL((vit_lanes_kernel<TIE, W>), dim3((unsigned)((n_groups + (W) - 1) / (W))), dim3(64 * (W)), 0, stream, \
+                                         d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables)
+    const bool four = n_groups > (size_t)n_cu && n_groups <= (size_t)4 * n_cu;
+    if (tie_rule) { if (four) VL_GO(1, 4); else VL_GO(1, 1); }
+    else { if (four) VL_GO(0, 4); else VL_GO(0, 1); }
+#undef VL_GO
     return hipGetLastError();
 }

@@ -242,8 +242,11 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
     hist[5] = 127
     slots = torch.from_numpy(rng.integers(-1, H, n_ens).astype(np.int32)).cuda()
     got = {}
-    for m in (1, 2):
+    import os
+    for m in (1, 2, 0):                                   # 0 = AUTO with a forced hybrid: the 3 longest sub-channels by WAVE, 4 by LANE
         ctx.viterbi_set_mapping(m)
+        if m == 0:
+            os.environ["DABGPU_VIT_HYBRID_K"] = "3"
         for ring in (False, True):
             d_out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda")
             d_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
@@ -254,9 +257,11 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
             torch.cuda.synchronize()
             got[(m, ring)] = (d_out.cpu().numpy(), d_res.cpu().numpy())
     ctx.viterbi_set_mapping(0)
+    os.environ.pop("DABGPU_VIT_HYBRID_K", None)
     for ring in (False, True):
-        assert np.array_equal(got[(1, ring)][0], got[(2, ring)][0]), ring
-        assert np.array_equal(got[(1, ring)][1], got[(2, ring)][1]), ring
+        for m in (2, 0):
+            assert np.array_equal(got[(1, ring)][0], got[(m, ring)][0]), (m, ring)
+            assert np.array_equal(got[(1, ring)][1], got[(m, ring)][1]), (m, ring)
 
 
 @pytest.mark.parametrize("tie_rule", [0, 1])
