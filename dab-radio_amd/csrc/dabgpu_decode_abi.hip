@@ -309,9 +309,10 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
-    // Which sub-channels go to the lane-per-codeword kernel?  Its critical path is the LONGEST schedule (0.5 us per step), so a
-    // multiplex with one long sub-channel among short ones is decoded as a hybrid: the k longest by viterbi_kernel (one wavefront
-    // per codeword), the rest by vit_lanes_kernel, k = the minimum of the cost model of use_lane_mapping().
+    // Which sub-channels go to the lane-per-codeword kernel?  The k longest can be left to viterbi_kernel (one wavefront per
+    // codeword) and the rest given to vit_lanes_kernel in the same call; AUTO only compares the two pure choices k = 0 and
+    // k = n_sub with the cost model of use_lane_mapping() -- a partial viterbi_kernel launch is a single lockstep round of
+    // wavefronts and measured 2x its share of a full one, so hybrids did not pay (DABGPU_VIT_HYBRID_K forces one, for the tests).
     // (the lane mapping keeps ring offsets in 32 bits: one ensemble's ring must stay below 4 GiB)
     std::vector<int> order((size_t)n_sub);
     for (int k = 0; k < n_sub; k++) order[(size_t)k] = k;
@@ -324,7 +325,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             k_wave = 0;
         } else {
             double best = 1e300;
-            for (int k = 0; k <= n_sub; k++) {
+            for (int k = 0; k <= n_sub; k += n_sub) {
                 double t = 0.0, lane_sum = 0.0, lane_max = 0.0;
                 for (int j = 0; j < n_sub; j++) {
                     const double steps = (double)plans[(size_t)order[(size_t)j]].n_steps;
