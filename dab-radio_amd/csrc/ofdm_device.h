@@ -91,6 +91,27 @@ __device__ __forceinline__ int to_vbit(float x) {
     return (int)v;
 }
 
+// soft bits of one DQPSK product d: to_vbit(d.x / A), to_vbit(-(d.y / A)), A = max(|d.x|, |d.y|) (ofdm_demodulator.cpp:867-889).
+// Inside [2^-60, 2^60] the two correctly rounded quotients share the reciprocal refinement of the compiler's own expansion
+// (ofdm_demod.hip explains why the result is bit-identical); outside, or for NaN, the plain divisions run.
+__device__ __forceinline__ void soft_bit_pair(f2 d, int& bx, int& by) {
+    const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
+    const float A = (ar < ai) ? ai : ar;                         // std::max, ofdm_demodulator.cpp:882
+    if (A >= 0x1p-60f && A <= 0x1p60f) {
+        const float nx = d.x, ny = -d.y;
+        float r = __builtin_amdgcn_rcpf(A);
+        r = fma_(fma_(-A, r, 1.0f), r, r);
+        float qx = nx * r, qy = ny * r;
+        qx = fma_(fma_(-A, qx, nx), r, qx);
+        qy = fma_(fma_(-A, qy, ny), r, qy);
+        qx = fma_(fma_(-A, qx, nx), r, qx);
+        qy = fma_(fma_(-A, qy, ny), r, qy);
+        bx = to_vbit(qx); by = to_vbit(qy);
+    } else {
+        bx = to_vbit(d.x / A); by = to_vbit(-(d.y / A));
+    }
+}
+
 // value of `v` held by lane (lane ^ XORMASK), XORMASK in {32,16,8,4,2,1}, without touching the LDS crossbar:
 // v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row_ror:8 / bank-masked row shifts / quad_perm
 template <int XORMASK>

@@ -164,10 +164,10 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
                 const int k = (c < M) ? (c - M) : (c - M + 1);
                 const int bin = (N + k) % N;
                 const f2 d = conj_mul(W[prev][bin], W[cur][bin]);
-                const float ar = __builtin_fabsf(d.x), ai = __builtin_fabsf(d.y);
-                const float A = (ar < ai) ? ai : ar;
-                o[n] = (int8_t)to_vbit(d.x / A);
-                o[n + NC] = (int8_t)to_vbit(-(d.y / A));
+                int bx, by;
+                soft_bit_pair(d, bx, by);
+                o[n] = (int8_t)bx;
+                o[n + NC] = (int8_t)by;
             }
         }
         __syncthreads();
