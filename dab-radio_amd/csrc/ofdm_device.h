@@ -192,9 +192,9 @@ __device__ __forceinline__ void butterfly(f2 (&a)[8]) {
 // one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst`
 template <int R>
 __device__ __forceinline__ void stockham_pass(const f2* __restrict__ src, f2* __restrict__ dst, int n_total, int cur_n, int s, bool last,
-                                              const f2* __restrict__ tw, int t) {
+                                              const f2* __restrict__ tw, int t, int n_threads) {
     const int m = cur_n / R, tw_step = NB_FFT / cur_n;
-    for (int u = t; u < n_total / R; u += 256) {
+    for (int u = t; u < n_total / R; u += n_threads) {
         const int q = u % s, p = u / s;
         f2 a[8];
 #pragma unroll

@@ -9,6 +9,8 @@
 // the soft bits here as they do there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 #include "dabgpu.h"
@@ -65,7 +67,8 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
     float* red = reinterpret_cast<float*>(W0 + 3 * N);  // 2 x 256 reduction leaves
     f2* W[3] = {W0, W0 + N, W0 + 2 * N};
 
-    const int t = threadIdx.x;
+    // the workgroup size is the launcher's choice (128 threads for FFT 512 / 256, else 256)
+    const int t = threadIdx.x, NT = blockDim.x;
     const int unit = blockIdx.x;
     const int frame = unit / chunks_per_frame, chunk = unit % chunks_per_frame;
     if (frame >= n_frames) return;
@@ -92,7 +95,7 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
     for (int i = out0; i <= sym_end; i++) {
         const float dt0 = (float)(i * g.period) * f;
         const f2* sym = fbase + (size_t)i * g.period;
-        for (int n = t; n < g.period; n += 256) {
+        for (int n = t; n < g.period; n += NT) {
             f2 v;
             if constexpr (BANK) {
                 const int j = i * g.period + n;
@@ -124,11 +127,14 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
                                                                        (red[256] + red[320]) + (red[384] + red[448]));
             } else {
                 // modes II-IV: one leaf per sample, L = power of two >= n_cp (<= 256), strides L/2 .. 1
-                if (t < g.n_cp) { const f2 p = conj_mul(Y[N + t], Y[t]); pr = p.x; pi = p.y; }
-                red[t] = pr; red[256 + t] = pi;
+                for (int n = t; n < L; n += NT) {
+                    float lr = 0.0f, li = 0.0f;
+                    if (n < g.n_cp) { const f2 p = conj_mul(Y[N + n], Y[n]); lr = p.x; li = p.y; }
+                    red[n] = lr; red[256 + n] = li;
+                }
                 __syncthreads();
                 for (int h = L / 2; h >= 1; h >>= 1) {
-                    if (t < h) { red[t] += red[t + h]; red[256 + t] += red[256 + t + h]; }
+                    for (int n = t; n < h; n += NT) { red[n] += red[n + h]; red[256 + n] += red[256 + n + h]; }
                     __syncthreads();
                 }
                 if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2(red[0], red[256]);
@@ -144,22 +150,22 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
             const int r = (pass == 0) ? r1 : 8;
             const bool last = (rem == r);
             f2* dst = W[(pass & 1) ? wb : wa];
-            if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t);
-            else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t);
-            else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t);
+            if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t, NT);
+            else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t, NT);
+            else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t, NT);
             __syncthreads();
             src = dst; cur = (pass & 1) ? wb : wa;
             cur_n /= r; s *= r; rem /= r; pass++;
         }
         if (fft_out != nullptr) {
             f2* dst = fft_out + ((size_t)frame * (g.n_sym + 1) + i) * N;
-            for (int k = t; k < N; k += 256) dst[k] = W[cur][k];
+            for (int k = t; k < N; k += NT) dst[k] = W[cur][k];
         }
         if (i > out0 && i < g.n_sym) {
             // ---- DQPSK + frequency de-interleave + soft bits (ofdm_demodulator.cpp:842-889) ----
             const int NC = g.n_carriers, M = NC / 2;
             int8_t* o = bits + out_frame * g.frame_bits + (size_t)(i - 1) * g.sym_bits;
-            for (int n = t; n < NC; n += 256) {
+            for (int n = t; n < NC; n += NT) {
                 const int c = mapper[n];
                 const int k = (c < M) ? (c - M) : (c - M + 1);
                 const int bin = (N + k) % N;
@@ -197,12 +203,15 @@ int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int
     if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
     const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
     const size_t lds = ((size_t)g.period + 3 * (size_t)g.n_fft) * sizeof(f2) + 512 * sizeof(float);
+    // measured (tools/bench_io.py, 2048 frames): FFT 512 / 256 run best with 128 threads (0.94 / 1.01 ms; 256 threads 1.03 / 1.47, 64 threads
+    // 1.19 / 1.01), FFT 1024 with 256 (1.93 ms; 128 threads 2.58): fewer idle butterfly lanes against fewer resident wavefronts
+    const int n_threads = (mode == 2 || mode == 3) ? 128 : 256;
 #define MODE_GO(SRC, BANK)                                                                                                          \
     do {                                                                                                                            \
         if (lds > 48 * 1024 && (st = dabgpu_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(ofdm_demod_mode_kernel<SRC, BANK>), \
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),                   \
                                                       "hipFuncSetAttribute(ofdm_demod_mode_kernel)"))) return st;                  \
-        hipLaunchKernelGGL((ofdm_demod_mode_kernel<SRC, BANK>), dim3((unsigned)((size_t)n_frames * chunks)), dim3(256), lds, s, mode, \
+        hipLaunchKernelGGL((ofdm_demod_mode_kernel<SRC, BANK>), dim3((unsigned)((size_t)n_frames * chunks)), dim3((unsigned)n_threads), lds, s, mode, \
                            reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr),                    \
                            reinterpret_cast<f2*>(d_fft), reinterpret_cast<const f2*>(c->d_tw), c->d_mode_mapper[mode], n_frames,     \
                            symbols_per_block, chunks, d_desc, static_cast<const uint8_t*>(d_block), block_stride);                  \

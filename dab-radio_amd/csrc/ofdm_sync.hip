@@ -132,9 +132,9 @@ __device__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __re
         const int r = (ps == 0) ? r1 : 8;
         const bool last = (ps == n_pass - 1);
         f2* dst = (((n_pass - 1 - ps) & 1) == 0) ? y : tmp;
-        if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t);
-        else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t);
-        else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t);
+        if (r == 8) stockham_pass<8>(src, dst, N, cur_n, s, last, tw, t, 256);
+        else if (r == 4) stockham_pass<4>(src, dst, N, cur_n, s, last, tw, t, 256);
+        else stockham_pass<2>(src, dst, N, cur_n, s, last, tw, t, 256);
         __syncthreads();
         src = dst; cur_n /= r; s *= r;
     }
