@@ -126,18 +126,24 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
                 if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2((red[0] + red[64]) + (red[128] + red[192]),
                                                                        (red[256] + red[320]) + (red[384] + red[448]));
             } else {
-                // modes II-IV: one leaf per sample, L = power of two >= n_cp (<= 256), strides L/2 .. 1
-                for (int n = t; n < L; n += NT) {
-                    float lr = 0.0f, li = 0.0f;
-                    if (n < g.n_cp) { const f2 p = conj_mul(Y[N + n], Y[n]); lr = p.x; li = p.y; }
-                    red[n] = lr; red[256 + n] = li;
+                // modes II-IV: one leaf per sample, L = power of two >= n_cp (64, 128 or 256), the binary tree red[n] += red[n + h] for
+                // h = L/2 .. 1.  The first wavefront does all of it without a barrier: lane n holds leaves n, n + 64, ... (the strides
+                // >= 64 are adds inside the lane, in the tree's order), strides 32 .. 1 are lane exchanges; the other wavefronts go on
+                if (t < 64) {
+                    float lr[4], li[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int n = t + 64 * j;
+                        lr[j] = 0.0f; li[j] = 0.0f;
+                        if (n < g.n_cp) { const f2 p = conj_mul(Y[N + n], Y[n]); lr[j] = p.x; li[j] = p.y; }
+                    }
+                    float xr, xi;
+                    if (L == 256) { xr = (lr[0] + lr[2]) + (lr[1] + lr[3]); xi = (li[0] + li[2]) + (li[1] + li[3]); }
+                    else if (L == 128) { xr = lr[0] + lr[1]; xi = li[0] + li[1]; }
+                    else { xr = lr[0]; xi = li[0]; }
+                    xr = wave_tree_sum(xr, t); xi = wave_tree_sum(xi, t);
+                    if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2(xr, xi);
                 }
-                __syncthreads();
-                for (int h = L / 2; h >= 1; h >>= 1) {
-                    for (int n = t; n < h; n += NT) { red[n] += red[n + h]; red[256 + n] += red[256 + n + h]; }
-                    __syncthreads();
-                }
-                if (t == 0) cp_corr[(size_t)frame * g.n_sym + i] = mk2(red[0], red[256]);
             }
         }
         // ---- FFT: Y[cp .. cp + N) -> W[cur]; the two buffers other than `prev` alternate as source and destination ----
