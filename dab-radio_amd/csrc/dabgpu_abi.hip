@@ -187,6 +187,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     if (c->d_prs_time_ref) (void)hipFree(c->d_prs_time_ref);
     if (c->d_vit_tables) (void)hipFree(c->d_vit_tables);
     for (int* p : c->d_mode_mapper) if (p) (void)hipFree(p);
+    for (int* p : c->d_mode_inv_map) if (p) (void)hipFree(p);
     for (float* p : c->d_mode_prs) if (p) (void)hipFree(p);
     for (float* p : c->d_mode_prs_time_ref) if (p) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);

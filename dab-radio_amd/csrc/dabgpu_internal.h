@@ -20,6 +20,7 @@ struct dabgpu_ctx {
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
     int vit_mapping = 0;             // DABGPU_VIT_MAP_* (dabgpu_viterbi_set_mapping)
     int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
+    int* d_mode_inv_map[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // their inverses (ofdm_wave512.hip)
     float* d_mode_prs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};    // PRS spectra and coarse-sync references of modes II-IV
     float* d_mode_prs_time_ref[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> scratch;      // grow-only device scratch slots
@@ -51,6 +52,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_fra
 // size-generic demodulation (ofdm_modes.hip); d_desc != nullptr = stream bank round (frame = stream, split input)
 int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                   float* d_fft, int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
+                                  size_t block_stride, hipStream_t s);
+
+// register-resident demodulation of modes II / IV (ofdm_wave512.hip), same arguments
+int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+                                  int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
                                   size_t block_stride, hipStream_t s);
 
 // ---- channel decode ----

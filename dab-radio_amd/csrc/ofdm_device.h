@@ -48,6 +48,34 @@ __device__ __forceinline__ f2 pll1(f2 v, float base, f2 step) {
     return mk2(fma_(cs.x, v.x, -b0x), fma_(cs.x, v.y, b0y));
 }
 
+// scalar Chebyshev of apply_pll_scalar (chebyshev_sine.h:22-41, no fused operations)
+__device__ __forceinline__ float cheb_scalar(float x) {
+    const float z = x * x;
+    const float b4 = 3.20396066f * z + -14.07150173f;
+    const float b3 = b4 * z + 38.50016403f;
+    const float b2 = b3 * z + -67.07687378f;
+    const float b1 = b2 * z + 64.83583069f;
+    const float b0 = b1 * z + -25.13274193f;
+    return b0 * (z - 0.25f) * x;
+}
+
+// sample n of a symbol of `period` samples: the vector body in groups of 4, then the scalar tail (apply_pll.cpp:12-30)
+__device__ __forceinline__ f2 pll_any(f2 v, int n, int period, float f, float dt0) {
+    const int nv = period & ~3;
+    if (n < nv) {
+        const int k = n & 3;
+        const float ss = (float)k * f;
+        return pll1(v, dt0 + (float)(n & ~3) * f, mk2(ss + 0.25f, ss));
+    }
+    const float dt_scalar = dt0 + (float)nv * f;
+    float dt_sin = dt_scalar + (float)(n - nv) * f;
+    float dt_cos = dt_sin + 0.25f;
+    dt_sin = dt_sin - __builtin_roundf(dt_sin);
+    dt_cos = dt_cos - __builtin_roundf(dt_cos);
+    const float c = cheb_scalar(dt_cos), s = cheb_scalar(dt_sin);
+    return mk2(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+
 // x0 * conj(x1), FMA form of x86/c32_conj_mul.h:12-44
 __device__ __forceinline__ f2 conj_mul(f2 x0, f2 x1) {
     const float a = x0.x, b = x0.y, c = x1.x, d = x1.y;

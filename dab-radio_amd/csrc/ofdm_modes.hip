@@ -20,34 +20,6 @@
 
 namespace dabgpu {
 
-// scalar Chebyshev of apply_pll_scalar (chebyshev_sine.h:22-41, no fused operations)
-__device__ __forceinline__ float cheb_scalar(float x) {
-    const float z = x * x;
-    const float b4 = 3.20396066f * z + -14.07150173f;
-    const float b3 = b4 * z + 38.50016403f;
-    const float b2 = b3 * z + -67.07687378f;
-    const float b1 = b2 * z + 64.83583069f;
-    const float b0 = b1 * z + -25.13274193f;
-    return b0 * (z - 0.25f) * x;
-}
-
-// sample n of a symbol of `period` samples: the vector body in groups of 4, then the scalar tail (apply_pll.cpp:12-30)
-__device__ __forceinline__ f2 pll_any(f2 v, int n, int period, float f, float dt0) {
-    const int nv = period & ~3;
-    if (n < nv) {
-        const int k = n & 3;
-        const float ss = (float)k * f;
-        return pll1(v, dt0 + (float)(n & ~3) * f, mk2(ss + 0.25f, ss));
-    }
-    const float dt_scalar = dt0 + (float)nv * f;
-    float dt_sin = dt_scalar + (float)(n - nv) * f;
-    float dt_cos = dt_sin + 0.25f;
-    dt_sin = dt_sin - __builtin_roundf(dt_sin);
-    dt_cos = dt_cos - __builtin_roundf(dt_cos);
-    const float c = cheb_scalar(dt_cos), s = cheb_scalar(dt_sin);
-    return mk2(v.x * c - v.y * s, v.x * s + v.y * c);
-}
-
 // BANK (stream bank rounds, ofdm_stream.hip): frame = stream; desc[frame].slot < 0 = nothing to do, else samples [0, split) of
 // the frame come from the stream's frame buffer (iq, complex float) and the rest from the caller's block in capture format SRC
 // (block + frame * block_stride samples, first at tail_off); the soft bits go to frame slot desc[frame].slot
@@ -199,6 +171,10 @@ int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int
     ModeGeom g;
     if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     int st;
+    // modes II and IV without the GUI view run register-resident, one wavefront per run of symbols (ofdm_wave512.hip);
+    // DABGPU_MODE_GENERIC=1 keeps them on this file's kernel (the tests cross-check the two)
+    if ((mode == 2 || mode == 4) && !d_fft && !getenv("DABGPU_MODE_GENERIC"))
+        return dabgpu_launch_ofdm_demod_wave(c, mode, d_iq, src, d_freq, d_bits, d_cp_corr, n_frames, symbols_per_block, d_desc, d_block, block_stride, s);
     // per-mode carrier mapper on the device, built on first use (get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
     if (!c->d_mode_mapper[mode]) {
         std::vector<int> m((size_t)g.n_carriers);

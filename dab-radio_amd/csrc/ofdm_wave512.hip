@@ -1,0 +1,238 @@
+// ofdm_wave512.hip -- register-resident OFDM demodulation for transmission modes II (FFT 512) and IV (FFT 1024): ONE WAVEFRONT
+// per run of symbols, no workgroup barrier anywhere.
+//
+// The transform contract of the modes (r1 x 8 x 8 x 8 with the twiddles w_n^m = tw2048[m 2048 / n], ofdm_modes.hip /
+// oracle dab_fft_n) makes the 512-point transform of mode II identical, operation for operation, to what ONE wavefront of the
+// mode I kernel does after that kernel's radix-4 pass (ofdm_demod.hip passes 2-4: 8 points per lane, two 8 x 8 lane<->register
+// transposes through a wave-private LDS patch); mode IV adds a radix-2 pass whose two inputs p, p + 512 both belong to lane
+// p mod 64, i.e. it runs inside the lane, and then two such 512-point transforms (even / odd outputs).  So here a wavefront
+// loads its symbol (8 / 16 samples per lane, 512-byte rows), applies the PLL (apply_pll.cpp incl. the scalar tail of mode II's
+// 638-sample period), correlates the cyclic prefix (one leaf per sample, the binary tree of the modes' contract: in-lane adds
+// for strides >= 64, lane exchanges below), transforms, multiplies with the previous symbol's six (twelve) active bins it kept
+// in registers, and scatters the soft bits to their frequency-de-interleaved positions in a wave-private LDS row that leaves
+// as 16-byte stores.  Four independent wavefronts per workgroup; the size-generic LDS-Stockham kernel of ofdm_modes.hip
+// (1 TB/s, barrier-bound) remains for mode III, for the GUI views (fft_out) and as the cross-check of this one in the tests.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+#include "iq_sample.h"
+#include "ofdm_device.h"
+
+namespace dabgpu {
+
+template <int MODE> struct W512Geom;
+template <> struct W512Geom<2> { static constexpr int N = 512, CP = 126, PERIOD = 638, NSYM = 76, NC = 384, NULLP = 664; };
+template <> struct W512Geom<4> { static constexpr int N = 1024, CP = 252, PERIOD = 1276, NSYM = 76, NC = 768, NULLP = 1328; };
+
+// the 512-point transform of one wavefront: a[j] = input lane + 64 j  ->  a[k] = bin (lane >> 3) + 8 (lane & 7) + 64 k
+__device__ __forceinline__ void fft512_wave(f2 (&a)[8], f2* patch, const f2 (&w2)[7], const f2 (&w3)[7], int lane) {
+    const int la = lane & 7, lb = lane >> 3;
+    const int ta_w = lane, ta_r = la + 72 * lb, tb_w = la + 72 * lb, tb_r = 9 * la + 72 * lb;
+    dft8(a);
+    patch[ta_w] = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
+    wave_lds_fence();
+    dft8(a);
+    patch[tb_w] = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3[k - 1]);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
+    wave_lds_fence();
+    dft8(a);
+}
+
+template <int MODE, int SRC, bool BANK>
+__global__ __launch_bounds__(256)
+void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset, int8_t* __restrict__ bits,
+                            f2* __restrict__ cp_corr, const f2* __restrict__ tw, const int* __restrict__ inv_map, int n_frames,
+                            int sym_per_chunk, int chunks_per_frame, const dabgpu_frame_desc* __restrict__ desc,
+                            const uint8_t* __restrict__ block, size_t block_stride)
+{
+    using G = W512Geom<MODE>;
+    constexpr int N = G::N, CP = G::CP, PERIOD = G::PERIOD, NSYM = G::NSYM, NC = G::NC;
+    constexpr int P = N / 64;                       // samples per lane
+    constexpr int Q = N / 512;                      // 512-point sub-transforms (mode IV: even / odd outputs of the radix-2 pass)
+    constexpr int SYM_BITS = 2 * NC, FRAME_BITS = (NSYM - 1) * SYM_BITS, FRAME_SAMPLES = NSYM * PERIOD + G::NULLP;
+    constexpr int LEAVES = (CP + 63) / 64;          // correlation leaves per lane: the tree has 64 LEAVES leaves (128 / 256)
+    constexpr int TAIL0 = N - CP;                   // body index of the sample that pairs with cyclic-prefix sample 0
+
+    __shared__ __attribute__((aligned(16))) f2 patches[4][WAVE_PATCH];
+    __shared__ __attribute__((aligned(16))) int8_t obufs[4][SYM_BITS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    f2* patch = patches[wave];
+    int8_t* obuf = obufs[wave];
+
+    const int unit = (int)blockIdx.x * 4 + wave;
+    const int frame = unit / chunks_per_frame, chunk = unit % chunks_per_frame;
+    if (frame >= n_frames) return;
+    const f2* fbase = iq + (size_t)frame * FRAME_SAMPLES;
+    size_t out_frame = (size_t)frame;
+    int split = FRAME_SAMPLES;
+    long long tail_off = 0;
+    const uint8_t* tail = nullptr;
+    if constexpr (BANK) {
+        const dabgpu_frame_desc d = desc[frame];
+        if (d.slot < 0) return;
+        out_frame = (size_t)d.slot; split = d.split; tail_off = d.tail_off;
+        tail = block + (size_t)frame * block_stride * src_sample_bytes<SRC>::value;
+    }
+    auto fetch = [&](int j) -> f2 {                 // sample j of the frame
+        if constexpr (BANK) return (j < split) ? fbase[j] : sample_at<SRC>(tail, tail_off + (j - split));
+        else return fbase[j];
+    };
+
+    const int out0 = chunk * sym_per_chunk;
+    const int out1 = min(out0 + sym_per_chunk, NSYM - 1);
+    const float f = freq_offset ? freq_offset[frame] : 0.0f;
+
+    // twiddles resident in registers: pass r1 (mode IV) w_1024^{p}, p = lane + 64 j; then w_512^{lane k}, w_64^{(lane & 7) k}
+    f2 w0[8], w2[7], w3[7];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w0[j] = (Q == 2) ? tw[2 * (lane + 64 * j)] : mk2(1.0f, 0.0f);
+#pragma unroll
+    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
+
+    // soft-bit positions of the lane's active bins.  Sub-transform q leaves bin q + Q (Ks + 64 k) in register k, Ks = (lane >> 3) +
+    // 8 (lane & 7); carriers -NC/2 .. -1, 1 .. NC/2 are bins N - NC/2 .. N - 1 and 1 .. NC/2 = registers 5, 6, 7 and 0, 1, 2 (+ register 3
+    // for bin NC/2 itself, which takes the place of the DC bin in the lane that holds both); carrier index c = bin - (N - NC/2) or
+    // bin + NC/2 - 1
+    const int Ks = (lane >> 3) + 8 * (lane & 7);
+    int pos[Q][6];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const int b0 = q + Q * Ks;                  // bin of register 0
+        pos[q][0] = inv_map[(b0 == 0) ? (NC - 1) : (b0 + NC / 2 - 1)];
+        pos[q][1] = inv_map[b0 + Q * 64 + NC / 2 - 1];
+        pos[q][2] = inv_map[b0 + Q * 128 + NC / 2 - 1];
+        pos[q][3] = inv_map[b0 + Q * 320 - (N - NC / 2)];
+        pos[q][4] = inv_map[b0 + Q * 384 - (N - NC / 2)];
+        pos[q][5] = inv_map[b0 + Q * 448 - (N - NC / 2)];
+    }
+    f2 prev[Q][6];
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[q][k] = mk2(0.0f, 0.0f);
+
+    for (int i = out0; i <= out1; i++) {
+        const float dt0 = (float)(i * PERIOD) * f;                       // ofdm_demodulator.cpp:675-676
+        const int s0 = i * PERIOD;
+        // ---- load + PLL: lane holds body samples lane + 64 j ----
+        f2 x[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) { const int n = CP + lane + 64 * j; x[j] = pll_any(fetch(s0 + n), n, PERIOD, f, dt0); }
+
+        // ---- cyclic prefix correlation: leaf n = prefix sample n x conj... (CalculateCyclicPhaseError :768-777), n = lane + 64 m ----
+        const bool do_corr = (i < out1 || i == NSYM - 1);
+        if (do_corr) {                                                   // wave-uniform
+            constexpr int SH = TAIL0 & 63, RB = TAIL0 >> 6;              // the partner of prefix sample n is body sample TAIL0 + n
+            const int src = (lane + SH) & 63;
+            const bool wrap = lane + SH >= 64;
+            float lr[LEAVES], li[LEAVES];
+#pragma unroll
+            for (int m = 0; m < LEAVES; m++) {
+                const int n = lane + 64 * m;
+                // body sample TAIL0 + n lives in lane `src`, register RB + m (+ 1 when the lane index wrapped)
+                const float ax = __shfl(x[RB + m].x, src), ay = __shfl(x[RB + m].y, src);
+                float bx = 0.0f, by = 0.0f;
+                if (RB + m + 1 < P) { bx = __shfl(x[(RB + m + 1 < P) ? (RB + m + 1) : 0].x, src); by = __shfl(x[(RB + m + 1 < P) ? (RB + m + 1) : 0].y, src); }
+                const f2 tl = wrap ? mk2(bx, by) : mk2(ax, ay);
+                lr[m] = 0.0f; li[m] = 0.0f;
+                if (n < CP) {
+                    const f2 hd = pll_any(fetch(s0 + n), n, PERIOD, f, dt0);
+                    const f2 p = conj_mul(tl, hd);
+                    lr[m] = p.x; li[m] = p.y;
+                }
+            }
+            float xr, xi;
+            if constexpr (LEAVES == 4) { xr = (lr[0] + lr[2]) + (lr[1] + lr[3]); xi = (li[0] + li[2]) + (li[1] + li[3]); }
+            else { xr = lr[0] + lr[1]; xi = li[0] + li[1]; }
+            xr = wave_tree_sum(xr, lane); xi = wave_tree_sum(xi, lane);
+            if (lane == 0) cp_corr[(size_t)frame * NSYM + i] = mk2(xr, xi);
+        }
+
+        // ---- transform(s) + DQPSK + soft bits ----
+        const bool emit = (i > out0);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            f2 a[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if constexpr (Q == 1) a[j] = x[j];
+                else a[j] = (q == 0) ? (x[j] + x[j + 8]) : cmul(x[j] - x[j + 8], w0[j]);     // radix-2 pass, inside the lane
+            }
+            fft512_wave(a, patch, w2, w3, lane);
+            f2 cur[6];
+            cur[0] = (q == 0 && Ks == 0) ? a[3] : a[0];
+            cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
+            if (emit) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    int bx, by;
+                    soft_bit_pair(conj_mul(prev[q][k], cur[k]), bx, by);
+                    obuf[pos[q][k]] = (int8_t)bx;
+                    obuf[pos[q][k] + NC] = (int8_t)by;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) prev[q][k] = cur[k];
+        }
+        wave_lds_fence();
+        if (emit) {
+            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * FRAME_BITS + (size_t)(i - 1) * SYM_BITS);
+#pragma unroll
+            for (int c = lane; c < SYM_BITS / 16; c += 64) dst[c] = reinterpret_cast<const uint4*>(obuf)[c];
+        }
+        wave_lds_fence();
+    }
+}
+
+}  // namespace dabgpu
+
+using namespace dabgpu;
+
+// modes II and IV without the GUI views; frame = stream when d_desc != nullptr (stream bank rounds)
+int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
+                                  int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
+                                  size_t block_stride, hipStream_t s) {
+    ModeGeom g;
+    if ((mode != 2 && mode != 4) || !mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_wave: mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    int st;
+    // inverse of the frequency interleaver on the device, built on first use: carrier c carries soft bit inv[c] (get_DAB_mapper_ref)
+    if (!c->d_mode_inv_map[mode]) {
+        std::vector<int> m((size_t)g.n_carriers), inv((size_t)g.n_carriers);
+        if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
+        for (int n = 0; n < g.n_carriers; n++) inv[(size_t)m[(size_t)n]] = n;
+        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_inv_map[mode], inv.size() * sizeof(int)), "hipMalloc(mode inverse mapper)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_inv_map[mode], inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode inverse mapper)"))) return st;
+    }
+    if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
+    const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
+    const size_t units = (size_t)n_frames * chunks;
+    const dim3 grid((unsigned)((units + 3) / 4));
+#define WAVE_GO(MODE, SRC, BANK)                                                                                                   \
+    hipLaunchKernelGGL((ofdm_demod_wave_kernel<MODE, SRC, BANK>), grid, dim3(256), 0, s, reinterpret_cast<const f2*>(d_iq), d_freq, d_bits, \
+                       reinterpret_cast<f2*>(d_cp_corr), reinterpret_cast<const f2*>(c->d_tw), c->d_mode_inv_map[mode], n_frames,    \
+                       symbols_per_block, chunks, d_desc, static_cast<const uint8_t*>(d_block), block_stride)
+#define WAVE_MODE(MODE)                                          \
+    do {                                                         \
+        if (!d_desc) WAVE_GO(MODE, 0, false);                    \
+        else if (src == 0) WAVE_GO(MODE, 0, true);               \
+        else if (src == 1) WAVE_GO(MODE, 1, true);               \
+        else if (src == 2) WAVE_GO(MODE, 2, true);               \
+        else WAVE_GO(MODE, 3, true);                             \
+    } while (0)
+    if (mode == 2) WAVE_MODE(2); else WAVE_MODE(4);
+#undef WAVE_MODE
+#undef WAVE_GO
+    return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_wave_kernel launch");
+}
