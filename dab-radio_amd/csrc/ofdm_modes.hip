@@ -171,9 +171,9 @@ int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int
     ModeGeom g;
     if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     int st;
-    // modes II and IV without the GUI view run register-resident, one wavefront per run of symbols (ofdm_wave512.hip);
+    // modes II-IV without the GUI view run register-resident, one wavefront per run of symbols (ofdm_wave512.hip);
     // DABGPU_MODE_GENERIC=1 keeps them on this file's kernel (the tests cross-check the two)
-    if ((mode == 2 || mode == 4) && !d_fft && !getenv("DABGPU_MODE_GENERIC"))
+    if (mode != 1 && !d_fft && !getenv("DABGPU_MODE_GENERIC"))
         return dabgpu_launch_ofdm_demod_wave(c, mode, d_iq, src, d_freq, d_bits, d_cp_corr, n_frames, symbols_per_block, d_desc, d_block, block_stride, s);
     // per-mode carrier mapper on the device, built on first use (get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
     if (!c->d_mode_mapper[mode]) {

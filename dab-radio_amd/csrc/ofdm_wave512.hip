@@ -1,5 +1,5 @@
-// ofdm_wave512.hip -- register-resident OFDM demodulation for transmission modes II (FFT 512) and IV (FFT 1024): ONE WAVEFRONT
-// per run of symbols, no workgroup barrier anywhere.
+// ofdm_wave512.hip -- register-resident OFDM demodulation for transmission modes II (FFT 512), III (FFT 256) and IV (FFT 1024):
+// ONE WAVEFRONT per run of symbols, no workgroup barrier anywhere.
 //
 // The transform contract of the modes (r1 x 8 x 8 x 8 with the twiddles w_n^m = tw2048[m 2048 / n], ofdm_modes.hip /
 // oracle dab_fft_n) makes the 512-point transform of mode II identical, operation for operation, to what ONE wavefront of the
@@ -10,8 +10,9 @@
 // 638-sample period), correlates the cyclic prefix (one leaf per sample, the binary tree of the modes' contract: in-lane adds
 // for strides >= 64, lane exchanges below), transforms, multiplies with the previous symbol's six (twelve) active bins it kept
 // in registers, and scatters the soft bits to their frequency-de-interleaved positions in a wave-private LDS row that leaves
-// as 16-byte stores.  Four independent wavefronts per workgroup; the size-generic LDS-Stockham kernel of ofdm_modes.hip
-// (1 TB/s, barrier-bound) remains for mode III, for the GUI views (fft_out) and as the cross-check of this one in the tests.
+// as 16-byte stores.  Mode III (256 = 4 x 8 x 8) does its radix-4 pass inside the lane too and the 64-point sub-transforms on half
+// of the lanes (fft256_wave).  Four independent wavefronts per workgroup; the size-generic LDS-Stockham kernel of ofdm_modes.hip
+// (1 TB/s, barrier-bound) remains for the GUI views (fft_out) and as the cross-check of this one in the tests.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
@@ -26,6 +27,36 @@ namespace dabgpu {
 template <int MODE> struct W512Geom;
 template <> struct W512Geom<2> { static constexpr int N = 512, CP = 126, PERIOD = 638, NSYM = 76, NC = 384, NULLP = 664; };
 template <> struct W512Geom<4> { static constexpr int N = 1024, CP = 252, PERIOD = 1276, NSYM = 76, NC = 768, NULLP = 1328; };
+template <> struct W512Geom<3> { static constexpr int N = 256, CP = 63, PERIOD = 319, NSYM = 153, NC = 192, NULLP = 345; };
+
+// mode III, 256 = 4 x 8 x 8: the radix-4 pass runs inside the lane (inputs lane + 64 j), the two radix-8 passes of the four 64-point
+// sub-transforms on 32 lanes (8 points each) around two LDS transposes in Stockham order.  x[j] = input lane + 64 j  ->  lanes 0..31:
+// a[k] = bin lane + 32 k
+__device__ __forceinline__ void fft256_wave(const f2 (&x)[4], f2 (&a)[8], f2* patch, const f2 (&w1)[3], const f2 (&w2)[7], int lane) {
+    f2 b0, b1, b2, b3;
+    dft4(x[0], x[1], x[2], x[3], b0, b1, b2, b3);
+    patch[lane] = b0;                                            // pass-1 output 4 p + k as [k][p]
+    patch[64 + lane] = cmul(b1, w1[0]);
+    patch[128 + lane] = cmul(b2, w1[1]);
+    patch[192 + lane] = cmul(b3, w1[2]);
+    wave_lds_fence();
+    const int q = (lane >> 3) & 3, p2 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[64 * q + p2 + 8 * j];
+    wave_lds_fence();
+    dft8(a);
+    if (lane < 32) {
+        f2* pb = patch + 256;                                    // pass-2 output q + 4 (8 p2 + k)
+        pb[q + 32 * p2] = a[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) pb[q + 32 * p2 + 4 * k] = cmul(a[k], w2[k - 1]);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = patch[256 + (lane & 31) + 32 * j];
+    wave_lds_fence();
+    dft8(a);
+}
 
 // the 512-point transform of one wavefront: a[j] = input lane + 64 j  ->  a[k] = bin (lane >> 3) + 8 (lane & 7) + 64 k
 __device__ __forceinline__ void fft512_wave(f2 (&a)[8], f2* patch, const f2 (&w2)[7], const f2 (&w3)[7], int lane) {
@@ -60,7 +91,8 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
     using G = W512Geom<MODE>;
     constexpr int N = G::N, CP = G::CP, PERIOD = G::PERIOD, NSYM = G::NSYM, NC = G::NC;
     constexpr int P = N / 64;                       // samples per lane
-    constexpr int Q = N / 512;                      // 512-point sub-transforms (mode IV: even / odd outputs of the radix-2 pass)
+    constexpr int Q = (N == 1024) ? 2 : 1;          // 512-point sub-transforms (mode IV: even / odd outputs of the radix-2 pass)
+    constexpr int STRIDE = N / 8;                   // bin distance between the registers of a lane after the last pass
     constexpr int SYM_BITS = 2 * NC, FRAME_BITS = (NSYM - 1) * SYM_BITS, FRAME_SAMPLES = NSYM * PERIOD + G::NULLP;
     constexpr int LEAVES = (CP + 63) / 64;          // correlation leaves per lane: the tree has 64 LEAVES leaves (128 / 256)
     constexpr int TAIL0 = N - CP;                   // body index of the sample that pairs with cyclic-prefix sample 0
@@ -95,9 +127,10 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
     const float f = freq_offset ? freq_offset[frame] : 0.0f;
 
     // twiddles resident in registers: pass r1 (mode IV) w_1024^{p}, p = lane + 64 j; then w_512^{lane k}, w_64^{(lane & 7) k}
+    // (mode III: pass 1 w_256^{lane k}, pass 2 w_64^{(lane & 7) k})
     f2 w0[8], w2[7], w3[7];
 #pragma unroll
-    for (int j = 0; j < 8; j++) w0[j] = (Q == 2) ? tw[2 * (lane + 64 * j)] : mk2(1.0f, 0.0f);
+    for (int j = 0; j < 8; j++) w0[j] = (Q == 2) ? tw[2 * (lane + 64 * j)] : ((MODE == 3 && j >= 1 && j < 4) ? tw[8 * lane * j] : mk2(1.0f, 0.0f));
 #pragma unroll
     for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
 
@@ -105,17 +138,19 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
     // 8 (lane & 7); carriers -NC/2 .. -1, 1 .. NC/2 are bins N - NC/2 .. N - 1 and 1 .. NC/2 = registers 5, 6, 7 and 0, 1, 2 (+ register 3
     // for bin NC/2 itself, which takes the place of the DC bin in the lane that holds both); carrier index c = bin - (N - NC/2) or
     // bin + NC/2 - 1
-    const int Ks = (lane >> 3) + 8 * (lane & 7);
+    // (mode III: lanes 0..31 hold bins lane + 32 k, the others none)
+    const int Ks = (MODE == 3) ? (lane & 31) : ((lane >> 3) + 8 * (lane & 7));
+    const bool has_bins = (MODE != 3) || lane < 32;
     int pos[Q][6];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int b0 = q + Q * Ks;                  // bin of register 0
         pos[q][0] = inv_map[(b0 == 0) ? (NC - 1) : (b0 + NC / 2 - 1)];
-        pos[q][1] = inv_map[b0 + Q * 64 + NC / 2 - 1];
-        pos[q][2] = inv_map[b0 + Q * 128 + NC / 2 - 1];
-        pos[q][3] = inv_map[b0 + Q * 320 - (N - NC / 2)];
-        pos[q][4] = inv_map[b0 + Q * 384 - (N - NC / 2)];
-        pos[q][5] = inv_map[b0 + Q * 448 - (N - NC / 2)];
+        pos[q][1] = inv_map[b0 + STRIDE + NC / 2 - 1];
+        pos[q][2] = inv_map[b0 + 2 * STRIDE + NC / 2 - 1];
+        pos[q][3] = inv_map[b0 + 5 * STRIDE - (N - NC / 2)];
+        pos[q][4] = inv_map[b0 + 6 * STRIDE - (N - NC / 2)];
+        pos[q][5] = inv_map[b0 + 7 * STRIDE - (N - NC / 2)];
     }
     f2 prev[Q][6];
 #pragma unroll
@@ -155,7 +190,8 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
             }
             float xr, xi;
             if constexpr (LEAVES == 4) { xr = (lr[0] + lr[2]) + (lr[1] + lr[3]); xi = (li[0] + li[2]) + (li[1] + li[3]); }
-            else { xr = lr[0] + lr[1]; xi = li[0] + li[1]; }
+            else if constexpr (LEAVES == 2) { xr = lr[0] + lr[1]; xi = li[0] + li[1]; }
+            else { xr = lr[0]; xi = li[0]; }
             xr = wave_tree_sum(xr, lane); xi = wave_tree_sum(xi, lane);
             if (lane == 0) cp_corr[(size_t)frame * NSYM + i] = mk2(xr, xi);
         }
@@ -165,16 +201,21 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             f2 a[8];
+            if constexpr (MODE == 3) {
+                const f2 w1[3] = {w0[1], w0[2], w0[3]};
+                fft256_wave(x, a, patch, w1, w3, lane);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if constexpr (Q == 1) a[j] = x[j];
-                else a[j] = (q == 0) ? (x[j] + x[j + 8]) : cmul(x[j] - x[j + 8], w0[j]);     // radix-2 pass, inside the lane
+                for (int j = 0; j < 8; j++) {
+                    if constexpr (Q == 1) a[j] = x[j];
+                    else a[j] = (q == 0) ? (x[j] + x[j + 8]) : cmul(x[j] - x[j + 8], w0[j]);     // radix-2 pass, inside the lane
+                }
+                fft512_wave(a, patch, w2, w3, lane);
             }
-            fft512_wave(a, patch, w2, w3, lane);
             f2 cur[6];
             cur[0] = (q == 0 && Ks == 0) ? a[3] : a[0];
             cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
-            if (emit) {
+            if (emit && has_bins) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
                     int bx, by;
@@ -200,12 +241,12 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
 
 using namespace dabgpu;
 
-// modes II and IV without the GUI views; frame = stream when d_desc != nullptr (stream bank rounds)
+// modes II, III and IV without the GUI views; frame = stream when d_desc != nullptr (stream bank rounds)
 int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                   int n_frames, int symbols_per_block, const dabgpu_frame_desc* d_desc, const void* d_block,
                                   size_t block_stride, hipStream_t s) {
     ModeGeom g;
-    if ((mode != 2 && mode != 4) || !mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_wave: mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    if ((mode != 2 && mode != 3 && mode != 4) || !mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_wave: mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     int st;
     // inverse of the frequency interleaver on the device, built on first use: carrier c carries soft bit inv[c] (get_DAB_mapper_ref)
     if (!c->d_mode_inv_map[mode]) {
@@ -231,7 +272,7 @@ int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int
         else if (src == 2) WAVE_GO(MODE, 2, true);               \
         else WAVE_GO(MODE, 3, true);                             \
     } while (0)
-    if (mode == 2) WAVE_MODE(2); else WAVE_MODE(4);
+    if (mode == 2) WAVE_MODE(2); else if (mode == 3) WAVE_MODE(3); else WAVE_MODE(4);
 #undef WAVE_MODE
 #undef WAVE_GO
     return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_wave_kernel launch");
