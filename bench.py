@@ -1,83 +1,101 @@
 #!/usr/bin/env python3
-"""bench.py -- Mode-I frames/s of the MI355X-native OFDM demodulation hot path.
+"""bench.py -- Mode-I frames/s of the MI355X-native DAB receive path (driver contract: one JSON line from rank 0).
 
-Workload (BASELINE.json configs[1]): a batch of 1024 frame-aligned Mode-I frames of synthetic IQ per GPU,
-resident in HBM as complex float32, pushed through the fused PLL + cyclic-prefix phase + 2048-pt FFT + DQPSK
-+ frequency de-interleave + soft-bit kernel and the per-frame phase/fine-frequency tail.  One "step" = one
-pass over the batch.  N>1: every rank owns an independent batch (independent ensembles, no collective in the
-data path; torch.distributed is used only for the timing barrier and the max over ranks) -> weak scaling.
+Workloads
+  demod (default; BASELINE.json configs[1], the configuration the metric is quoted on): a batch of 1024 frame-aligned Mode-I
+        frames of synthetic IQ per GPU, resident in HBM as complex float32, through the fused PLL + cyclic-prefix phase +
+        2048-pt FFT + DQPSK + frequency de-interleave + soft-bit kernel and the per-frame phase / fine-frequency tail.
+        One "step" = one pass over the batch.  At N = 1 the line also carries `extra.configs2` / `extra.configs3`
+        (demod + FIC Viterbi, and full FIC + MSC for 4096 concurrent ensembles) with their own roofline blocks.
+  full  (BASELINE.json configs[4], per GPU): 8192 ensembles per GPU (built on the device from <= 64 seeded multiplexes),
+        one step = demodulate one transmission frame of every ensemble into its frame-history ring + FIC Viterbi (4 FIB groups)
+        + MSC time de-interleave, Viterbi and descrambling of 18 sub-channels x 4 CIFs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--spb S] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+N > 1: every rank owns an independent block of frames / ensembles (dabgpu.shard.shard_range), no collective in the data path;
+torch.distributed (RCCL) carries only the timing barrier and the max over ranks -> "scaling": "weak".
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per launch (1,803,264 B/frame x frames)
-/ mean launch duration of ofdm_demod_kernel measured with HIP events on the launch stream; `cpu_baseline` is
-the oracle (a C port of the reference algorithm) timed on this box's host cores on a bounded sample.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload demod|full]
+`python bench.py --gpus N` started plainly (no RANK in the environment) launches N ranks itself through
+torch.distributed.run -- as a child process, before this process touches the GPU -- and exits with the child's status.
+
+`roofline` (dominant kernel ofdm_demod_kernel): achieved = algorithmic bytes per launch (1,803,264 B/frame x frames) /
+mean launch duration measured with HIP events INSIDE the timed loop (an event pair around every 8th demod launch on the launch
+stream); `cpu_baseline` = the oracle (C port of the reference algorithm) timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "dab-radio_amd")):
+for _p in (ROOT, os.path.join(ROOT, "dab-radio_amd"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import dabgpu  # noqa: E402
-from dabgpu import shard  # noqa: E402
 
 ALGO_BYTES_PER_FRAME = 196608 * 8 + 230400          # c32 IQ read + int8 soft bits written
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8 TB/s spec
 REALTIME_FRAMES_PER_S = 2.048e6 / 196608              # 10.4167
+# Viterbi kernels: VALU-issue bound.  peak trellis steps/s = SIMDs x clock x codewords per wavefront /
+# (VALU instructions per wavefront-step x cycles per instruction); instruction counts from the ISA of this build
+# (tools/isa_count.py), 4 cycles per packed-integer / cross-lane instruction (tools/ubench/pk16_rate.hip), 2.4 GHz, 1024 SIMDs.
+VIT_LANES_INSTR_PER_STEP = 185.0
+VIT_WAVE_INSTR_PER_STEP = 23.0
+VIT_CYCLES_PER_INSTR = 4.0
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 
 
-def synth_frames(n_frames, seed, device, mapper, prs, chunk=32):
-    """Random-payload Mode-I frames built on the device with torch (plumbing, untimed): QPSK per ETSI 14.5 on
-    de-interleaved positions, differential modulation from the PRS, IFFT, cyclic prefix, per-frame CFO.
-    Returns (iq [n,196608] complex64 in frame-buffer layout, bits [n,75,3072] uint8, freq [n] float32)."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    mp = torch.from_numpy(mapper.astype(np.int64)).to(device)
-    bins = torch.where(mp < 768, mp + (2048 - 768), mp - 768 + 1)            # carrier index -> FFT bin
-    prs_t = torch.from_numpy(prs).to(device)
-    a = 0.70710678
-    iq = torch.zeros((n_frames, 196608), dtype=torch.complex64, device=device)
-    bits = torch.empty((n_frames, 75, 3072), dtype=torch.uint8, device=device)
-    # carrier frequency offset per frame (+-5 kHz at 2.048 MS/s) so the PLL does real work
-    freq = ((torch.rand(n_frames, generator=g, device=device) * 2 - 1) * (5000.0 / 2.048e6)).float().contiguous()
-    n = torch.arange(196608, device=device, dtype=torch.float64)
-    for k0 in range(0, n_frames, chunk):
-        k1 = min(k0 + chunk, n_frames)
-        m = k1 - k0
-        b = torch.randint(0, 2, (m, 75, 3072), generator=g, device=device, dtype=torch.uint8)
-        bits[k0:k1] = b
-        z = torch.complex((1.0 - 2.0 * b[:, :, :1536].float()) * a, (1.0 - 2.0 * b[:, :, 1536:].float()) * a)
-        spec = torch.zeros((m, 76, 2048), dtype=torch.complex64, device=device)
-        spec[:, 0] = prs_t
-        cur = prs_t[bins].expand(m, -1).clone()
-        for s_ in range(75):                                  # differential modulation, symbol by symbol
-            cur = cur * z[:, s_]
-            spec[:, s_ + 1, bins] = cur
-        t = torch.fft.ifft(spec, dim=2) * 2048.0
-        body = iq[k0:k1, : 76 * 2552].view(m, 76, 2552)
-        body[:, :, 504:] = t
-        body[:, :, :504] = t[:, :, 2048 - 504:]
-        ph = (-2.0 * np.pi) * freq[k0:k1, None].double() * n[None, :]
-        iq[k0:k1] *= torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
-    iq *= (1.0 / 39.2)                                                          # unit-ish RMS like a normalised capture
-    return iq, bits, freq
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("demod", "full"), default="demod")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed steps before the W warm-up steps, until this much wall time has passed: MI355X settles its "
+                         "clock over tens of ms of sustained load (profiles/r01/ab_notes.md)")
+    ap.add_argument("--frames", type=int, default=1024, help="demod: frames per GPU per step (BASELINE configs[1]: 1024)")
+    ap.add_argument("--ensembles", type=int, default=8192, help="full: ensembles per GPU (BASELINE configs[4]: 65536 / 8)")
+    ap.add_argument("--distinct", type=int, default=64, help="full / extras: distinct seeded multiplexes the ensembles are built from")
+    ap.add_argument("--extra-ensembles", type=int, default=4096, help="demod, N = 1: ensembles of extra.configs2 / configs3")
+    ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / sharding plumbing only, on CPU with gloo (tests/test_bench_launcher.py); no kernels, value = null")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits 3 (exit-status propagation test)")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 400 if args.workload == "demod" else 10
+    if args.warmup is None:
+        args.warmup = 50 if args.workload == "demod" else 2
+    return args
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a rendezvous in the environment: start the N ranks as a child (never re-exec a process
+    that may have touched the GPU) and hand its exit status back."""
+    import socket
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(seconds_target=12.0):
     """oracle (C port of the reference algorithm) on the host cores; bounded sample; returns dict for the JSON line"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import concurrent.futures as cf
+    import numpy as np
     import oracle as O
     O.lib()
     rng = np.random.default_rng(0)
@@ -125,31 +143,178 @@ def cpu_baseline(seconds_target=12.0):
                       f"(FFTW absent -> oracle's own radix-4/8 FFT), {dt:.1f} s wall"}
 
 
+def hbm_roofline(kernel, k_ms, frames):
+    achieved = ALGO_BYTES_PER_FRAME * frames / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * frames}
+
+
+def viterbi_roofline(kernel, steps, k_ms, lanes):
+    """VALU-issue bound of the trellis recursion; `lanes`: lane-per-codeword mapping (64 codewords per wavefront) or one wavefront per codeword"""
+    per_wave = 64.0 if lanes else 1.0
+    instr = VIT_LANES_INSTR_PER_STEP if lanes else VIT_WAVE_INSTR_PER_STEP
+    peak = N_SIMD * CLOCK_HZ * per_wave / (instr * VIT_CYCLES_PER_INSTR) / 1e9
+    achieved = steps / (k_ms * 1e-3) / 1e9
+    return {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G trellis steps/s", "frac": achieved / peak,
+            "kernel_ms": k_ms, "trellis_steps_per_launch": steps,
+            "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU instructions per "
+                               f"wavefront-step x {VIT_CYCLES_PER_INSTR} cycles)"}
+
+
+class Pipeline:
+    """E ensembles, one transmission frame of IQ each, history ring of H frames, FIC + MSC outputs (configs[2]/[3]/[4])."""
+
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed):
+        import dabsynth
+        self.ctx, self.torch, self.E, self.H = ctx, torch, E, 5
+        prs, mapper, _ = dabgpu.host_tables()
+        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs)
+        self.iq_f = torch.view_as_real(self.iq)
+        self.n_sub = dabsynth.N_SUB
+        self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
+        self.corr = torch.empty((E, 76, 2), dtype=torch.float32, device=device)
+        self.fic_out = torch.zeros((E, 4, 96), dtype=torch.uint8, device=device)
+        self.fic_res = torch.zeros((E * 4, 16), dtype=torch.uint8, device=device)
+        self.msc_out = torch.zeros((E, 4, self.n_sub * dabsynth.SUB_BYTES), dtype=torch.uint8, device=device)
+        self.msc_res = torch.zeros((E * 4 * self.n_sub, 16), dtype=torch.uint8, device=device)
+        self.subs = self.mux.subchannels(dabgpu)
+        self.fic_steps = E * dabsynth.FIC_STEPS_PER_FRAME
+        self.msc_steps = E * dabsynth.MSC_STEPS_PER_FRAME
+        self.stride = self.H * 230400
+
+    def demod(self, slot):
+        self.ctx.ofdm_demod_frames(self.iq_f, self.hist[:, slot], cp_corr=self.corr, n_frames=self.E, bits_frame_stride=self.stride)
+
+    def fic(self, slot):
+        self.ctx.fic_decode_frames(self.hist[:, slot], self.E, self.fic_out, self.fic_res, frame_stride=self.stride)
+
+    def msc(self, slot):
+        self.ctx.msc_decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.msc_out,
+                                   4 * self.n_sub * 192, self.msc_res)
+
+    def step(self, k):
+        s = k % self.H
+        self.demod(s); self.fic(s); self.msc(s)
+
+    def fill(self):
+        for slot in range(self.H):                   # fill the history ring: the time de-interleaver needs 16 CIFs = 4 frames
+            self.demod(slot)
+        self.fic(0); self.msc(0)
+        self.torch.cuda.synchronize()
+
+    def timed(self, fn, reps):
+        torch = self.torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(reps):
+            fn(k % self.H)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def check(self, dabgpu):
+        import numpy as np
+        torch, E, nd = self.torch, self.E, self.mux.n
+        res_f = self.fic_res.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
+        crc_ok = int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
+        idx = torch.arange(E, device=self.fic_out.device) % nd
+        fib_eq = bool(torch.equal(self.fic_out, self.mux.fibs[idx]))
+        exp = self.mux.payload[idx].unsqueeze(1).expand(E, 4, self.n_sub, 192)
+        msc_eq = bool(torch.equal(self.msc_out.view(E, 4, self.n_sub, 192), exp))
+        return {"fib_crc_pass": crc_ok, "fib_crc_expected": E * 12, "fib_bytes_equal_transmitted": fib_eq,
+                "msc_bytes_equal_transmitted": msc_eq, "ensembles_checked": E, "distinct_multiplexes": nd}
+
+
+def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
+    """BASELINE configs[2] (demod + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7)
+    p.fill()
+    for k in range(3):
+        p.step(k)
+    torch.cuda.synchronize()
+    t_demod, t_fic, t_msc = p.timed(p.demod, reps), p.timed(p.fic, reps), p.timed(p.msc, reps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(reps):
+        p.demod(k % p.H); p.fic(k % p.H)
+    e1.record(); torch.cuda.synchronize()
+    t_c2 = e0.elapsed_time(e1) / reps
+    t0 = time.perf_counter()
+    for k in range(reps):
+        p.step(k)
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / reps * 1e3
+    chk = p.check(dabgpu)
+    lanes_fic = E >= 2000                      # DABGPU_VIT_MAP_AUTO's switch points (DESIGN.md 4.3b)
+    c2 = {"workload": f"BASELINE configs[2]: full OFDM demod + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
+          "ms_per_step": t_c2, "frames_per_s": E / t_c2 * 1e3, "x_realtime": E / t_c2 * 1e3 / REALTIME_FRAMES_PER_S,
+          "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic},
+          "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
+                       viterbi_roofline("vit_lanes_kernel (FIC)" if lanes_fic else "viterbi_kernel (FIC)", p.fic_steps, t_fic, lanes_fic)],
+          "check": {k: chk[k] for k in ("fib_crc_pass", "fib_crc_expected", "fib_bytes_equal_transmitted")}}
+    c3 = {"workload": f"BASELINE configs[3]: full FIC + MSC demod + Viterbi, {E} concurrent synthetic ensembles, 18 x 48 CU EEP 3-A", "ensembles": E,
+          "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,
+          "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi_incl_deinterleave": t_msc},
+          "algorithmic_hbm_GBps": 2.27e6 * E / (t_all * 1e-3) / 1e9,
+          "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
+                       viterbi_roofline("vit_prep_ring4_kernel + vit_lanes_kernel (MSC)", p.msc_steps, t_msc, True)],
+          "check": chk}
+    del p
+    torch.cuda.empty_cache()
+    return c2, c3
+
+
+def dry_run(args, rank, world):
+    """the multi-rank plumbing of main() without a GPU: rendezvous (gloo), shard ranges, barrier, max over ranks, one line from rank 0"""
+    import torch
+    import torch.distributed as dist
+    from dabgpu import shard
+    if rank == args.dry_run_fail_rank:
+        sys.exit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    units = args.frames if args.workload == "demod" else args.ensembles
+    first, n = shard.shard_range(units * world, rank, world)
+    shard.barrier(dist if world > 1 else None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    shard.barrier(dist if world > 1 else None)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    covered = shard.sum_over_ranks(n, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "dab_mode1_frames_per_sec", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run (no kernels)",
+                          "config": {"workload": args.workload, "units_per_rank": n, "units_covered": covered, "first_unit_rank0": first}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--prewarm-ms", type=float, default=400.0,
-                    help="untimed steps before the W warm-up steps, until this much wall time has passed: MI355X raises its "
-                         "clock over tens of ms of sustained load (0.59 -> 0.46 ms per launch, profiles/r01/ab_notes.md)")
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step (BASELINE configs[1]: 1024)")
-    ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-check", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np  # noqa: F401
+    import torch
+    import dabgpu
+    from dabgpu import shard
+    import dabsynth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N>1 must be launched through torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -157,46 +322,78 @@ def main():
 
     ctx = dabgpu.Context(local_rank)
     prs, mapper, _ = dabgpu.host_tables()
-    F = args.frames
-    # weak scaling: the ensemble set grows with the number of GPUs; rank r owns the contiguous block shard_range gives
-    first_unit, n_units = shard.shard_range(F * world, rank, world)
-    assert n_units == F
-    iq, tx_bits, freq = synth_frames(F, seed=1000 + first_unit, device=device, mapper=mapper, prs=prs)
-    # the receiver corrects with the negative of the applied shift... the PLL multiplies by e^{+j2pi f n}
-    d_freq = freq.clone()
-    d_bits = torch.empty((F, 230400), dtype=torch.int8, device=device)
-    d_corr = torch.empty((F, 76, 2), dtype=torch.float32, device=device)
-    d_total = torch.empty(F, dtype=torch.float32, device=device)
-    d_fine = torch.zeros(F, dtype=torch.float32, device=device)
-    iq_f = torch.view_as_real(iq)
-
-    def step():
-        ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
-        ctx.ofdm_phase_update(d_corr, F, total_phase=d_total, fine_freq=d_fine, beta=0.9)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    evs = []                                                  # (start, stop) event pairs around demod launches inside the timed loop
+
+    if args.workload == "demod":
+        F = args.frames
+        # weak scaling: the frame set grows with the number of GPUs; rank r owns the contiguous block shard_range gives
+        first_unit, n_units = shard.shard_range(F * world, rank, world)
+        assert n_units == F
+        iq, tx_bits, freq = dabsynth.random_frames(F, seed=1000 + first_unit, device=device, mapper=mapper, prs=prs)
+        d_freq = freq.clone()                                 # the PLL multiplies by e^{+j 2 pi f n}: the generator applied -f
+        d_bits = torch.empty((F, 230400), dtype=torch.int8, device=device)
+        d_corr = torch.empty((F, 76, 2), dtype=torch.float32, device=device)
+        d_total = torch.empty(F, dtype=torch.float32, device=device)
+        d_fine = torch.zeros(F, dtype=torch.float32, device=device)
+        iq_f = torch.view_as_real(iq)
+        units = F
+
+        def demod_launch():
+            ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
+
+        def step(k, timed=False):
+            if timed and k % 8 == 0:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); demod_launch(); b.record()
+                evs.append((a, b))
+            else:
+                demod_launch()
+            ctx.ofdm_phase_update(d_corr, F, total_phase=d_total, fine_freq=d_fine, beta=0.9)
+    else:
+        E = args.ensembles
+        first_unit, n_units = shard.shard_range(E * world, rank, world)
+        assert n_units == E
+        pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit)
+        pipe.fill()
+        units = E
+
+        def step(k, timed=False):
+            s = k % pipe.H
+            if timed and k % 2 == 0:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); pipe.demod(s); b.record()
+                evs.append((a, b))
+            else:
+                pipe.demod(s)
+            pipe.fic(s); pipe.msc(s)
+
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # clock ramp-up, untimed and not part of W
-        for _ in range(20):
-            step()
+    k = 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:      # clock settling, untimed and not part of W
+        for _ in range(20 if args.workload == "demod" else 1):
+            step(k); k += 1
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dist if world > 1 else None, device)
+    elapsed = shard.max_over_ranks(elapsed, dist, device)
+    ms_per_step = elapsed / args.steps * 1e3
+    k_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))      # mean demod launch duration inside the timed loop
 
     # ---- correctness of what was just timed (untimed) ----
     check = {}
-    if not args.no_check:
+    if args.workload == "demod" and not args.no_check:
         hard = (d_bits.view(F, 75, 3072) >= 0).to(torch.uint8)
         err = (hard != tx_bits)
         check["hard_bit_errors_vs_transmitted"] = int(err.sum().item())
@@ -206,53 +403,54 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import oracle as O
             mism = 0
-            for k in (0, F // 2, F - 1):
-                exp = O.demod_frame(iq[k].cpu().numpy(), float(freq[k].item()))
-                mism += int((exp["bits"] != d_bits[k].cpu().numpy()).sum())
+            for kk in (0, F // 2, F - 1):
+                exp = O.demod_frame(iq[kk].cpu().numpy(), float(freq[kk].item()))
+                mism += int((exp["bits"] != d_bits[kk].cpu().numpy()).sum())
             check["soft_bit_mismatches_vs_oracle_3_frames"] = mism
-
-    # ---- dominant kernel alone: HIP events on the launch stream (torch's current stream) around n_ev back-to-back
-    # launches, GPU already at its sustained clock (the timed region above has just run) ----
-    n_ev = max(20, min(args.steps, 200))
-    for _ in range(10):
-        ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(n_ev):
-        ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
-    ev1.record()
-    torch.cuda.synchronize()
-    k_ms = float(ev0.elapsed_time(ev1)) / n_ev
-    achieved = ALGO_BYTES_PER_FRAME * F / (k_ms * 1e-3) / 1e9
+    elif args.workload == "full" and not args.no_check:
+        check = pipe.check(dabgpu)
 
     if rank == 0:
-        value = world * F * args.steps / elapsed
+        assert k_ms <= ms_per_step * 1.001, f"demod launch {k_ms} ms cannot exceed the step {ms_per_step} ms it is part of"
+        value = world * units * args.steps / elapsed
+        if args.workload == "demod":
+            workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
+                        "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU")
+            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or 19,
+                      "sharding": "independent frames / ensembles per rank, no data-path collective"}
+        else:
+            workload = (f"BASELINE configs[4]: {units * world} synthetic ensembles ({units} per GPU, built on the device from "
+                        f"{min(args.distinct, units)} seeded multiplexes), full FIC+MSC: OFDM demod + FIC Viterbi + 18 x 48 CU EEP 3-A "
+                        "time de-interleave / Viterbi / descramble per transmission frame")
+            config = {"workload": workload, "ensembles_per_gpu": units, "frames_per_gpu_per_step": units,
+                      "sharding": "independent ensembles per rank, no data-path collective"}
         line = {
             "metric": "dab_mode1_frames_per_sec", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
-                                   "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU",
-                       "frames_per_gpu_per_step": F, "symbols_per_block": args.spb or 19,
-                       "sharding": "independent ensembles per rank, no data-path collective"},
+            "config": config,
             "x_realtime": value / REALTIME_FRAMES_PER_S,
-            "roofline": {"bound": "hbm", "kernel": "ofdm_demod_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * F},
+            "roofline": hbm_roofline("ofdm_demod_kernel", k_ms, units),
             "check": check,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+        line["roofline"]["timing"] = f"HIP events around {len(evs)} of the {args.steps} demod launches of the timed loop"
         # PMC-derived HBM traffic per launch, when a profiles/ summary of this round exists (see profiles/README.md)
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
                 tr = json.load(fh)
-            if tr.get("frames_per_launch") == F:
+            if tr.get("frames_per_launch") == units:
                 line["roofline"]["traffic"] = tr.get("bytes_per_launch")
                 line["roofline"]["traffic_source"] = tr.get("source")
         except Exception:
             pass
+        if world == 1 and args.workload == "demod" and not args.no_extras:
+            del iq, iq_f, tx_bits, d_bits
+            torch.cuda.empty_cache()
+            c2, c3 = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct)
+            line["extra"] = {"configs2": c2, "configs3": c3}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

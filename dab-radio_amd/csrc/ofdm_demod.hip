@@ -25,6 +25,12 @@
 #include "iq_decode.h"
 #include "ofdm_device.h"
 
+// development builds (tools/build_exp.sh + tools/kbench2.py; never set in the product build): timing-only ablations,
+//   2 = memory traffic only (loads, barriers, stores; no arithmetic)      4 = arithmetic only (one symbol loaded once)
+#ifndef DABGPU_EXP
+#define DABGPU_EXP 0
+#endif
+
 namespace dabgpu {
 
 // Input sample formats the loader can read straight from HBM (anything else goes through iq_convert_kernel first).
@@ -67,17 +73,6 @@ __device__ __forceinline__ int xcd_remap(int b, int G) {
 // from the caller's block (no assembly copy); split is even, the block side is only 8-byte aligned
 typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
 
-
-// workgroup barrier of the kernel.  With the LDS-DMA prefetch in flight the fence inside __syncthreads() would make the compiler
-// wait for the DMA (an LDS write it counts with vmcnt) at every barrier, i.e. a quarter into the symbol instead of at the
-// next one; the staged slots are wave-private, so the barrier only has to cover this wave's own ds_ writes: wait for them,
-// then s_barrier (the asm memory clobber keeps the compiler from moving LDS accesses across it).
-template <bool PREFETCH>
-__device__ __forceinline__ void block_barrier() {
-    if constexpr (PREFETCH) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else __syncthreads();
-}
-
 // stream banks: head of the frame from the (complex float) frame buffer, tail from the caller's block in its capture format SRC
 // (tail_base is pre-biased so that frame sample n sits at tail_base + n * bytes per sample; only naturally 2/4/8-byte aligned)
 template <int SRC>
@@ -104,19 +99,21 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
     }
 }
 
-template <bool PREFETCH>
-__device__ __forceinline__ f2* stage_area() {
-    if constexpr (PREFETCH) {
-        __shared__ __attribute__((aligned(16))) f2 stage_lds[NB_FFT];
-        return stage_lds;
-    } else {
-        return nullptr;
-    }
-}
+// LDS of one workgroup (float2 elements unless noted)
+constexpr int LDS_TW2 = 7 * 64;            // pass-2 twiddles [k][lane]
+constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7]
+constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2) + (LDS_TW2 + LDS_TW3) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
 // GetFrameFFT() / GetFrameDataVec()): their stores and per-carrier branches leave the symbol loop
-template <bool PREFETCH, int SRC, bool BANK, bool VIEWS = true>
+//
+// Software pipeline (round 2): a symbol's samples are dead once the PLL and the radix-4 pass have consumed them, so the NEXT
+// symbol's five 16-byte loads are issued right there, into the same registers, and have the three radix-8 passes, the demapper
+// and the end-of-symbol barrier to arrive (no second register set, no LDS staging).  To stay inside 128 VGPRs (4 workgroups
+// per CU) the pass-2 / pass-3 twiddles (28 registers) are read from two small LDS tables instead.  The vector-memory counter
+// of gfx9 is in order, therefore the previous symbol's soft-bit store is issued BEFORE the prefetch (from the middle of the
+// next symbol), never between a prefetch and its use.  0.438 -> 0.426 ms per 1024 frames (profiles/r02/ab_notes.md).
+template <int SRC, bool BANK, bool VIEWS = true>
 __global__ __launch_bounds__(256, 4)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
@@ -135,9 +132,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     f2* patch0 = bufA;
     int8_t* obuf = reinterpret_cast<int8_t*>(bufA + 4 * WAVE_PATCH);     // 3072 B
     f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 4 x 8 B
-    // PREFETCH: 2048 x 8 B, the next symbol's FFT body.  A separate LDS object on purpose: the compiler counts the DMA as a
-    // pending LDS write and would wait for it before ANY LDS read it cannot prove distinct from the staging area
-    f2* stage = stage_area<PREFETCH>();
+    f2* tw2l = red + 4;                                                  // 7 x 64 x 8 B
+    f2* tw3l = tw2l + LDS_TW2;                                           // 7 x 8 x 8 B
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -172,18 +168,22 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int k0 = 2 * (t & 1);
     const float ss0 = (float)k0 * f, ss1 = (float)(k0 + 1) * f;          // apply_pll.cpp:95-99
     const f2 step0 = mk2(ss0 + 0.25f, ss0), step1 = mk2(ss1 + 0.25f, ss1);
-    float gidx[5];                                                       // float(i4) of the five 16-byte slots
-#pragma unroll
-    for (int k = 0; k < 4; k++) gidx[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3);
-    gidx[4] = (float)((2 * (t - 4)) & ~3);
+    float gf[5];                                                         // float(i4) * f of the five 16-byte slots: the product
+#pragma unroll                                                           // of apply_pll.cpp:103 depends on (thread, slot) only
+    for (int k = 0; k < 4; k++) gf[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3) * f;
+    gf[4] = (float)((2 * (t - 4)) & ~3) * f;
 
-    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1), pass 2 w_512^{lane k},
-    // pass 3 w_64^{(lane&7) k}; resident in registers for the whole run of symbols
-    f2 w1a[3], w1b[3], w2[7], w3[7];
+    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1) stays in registers for the whole run of
+    // symbols; pass 2 w_512^{lane k} and pass 3 w_64^{(lane&7) k} sit in LDS as [k][lane] / [k][lane & 7] (conflict-free
+    // 8-byte reads; the same table entries the register version held, so the arithmetic is unchanged)
+    f2 w1a[3], w1b[3];
 #pragma unroll
     for (int k = 1; k < 4; k++) { w1a[k - 1] = tw[(2 * t) * k]; w1b[k - 1] = tw[(2 * t + 1) * k]; }
-#pragma unroll
-    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
+    for (int idx = t; idx < LDS_TW2; idx += 256) tw2l[idx] = tw[4 * (idx & 63) * ((idx >> 6) + 1)];
+    if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
+    __syncthreads();
+    const f2* const w2p = tw2l + lane;            // w2[k] = w2p[64 (k - 1)]
+    const f2* const w3p = tw3l + (lane & 7);      // w3[k] = w3p[8 (k - 1)]
 
     // LDS addresses (float2 element indices); every per-k term below is an instruction immediate
     f2* patch = patch0 + wave * WAVE_PATCH;
@@ -204,12 +204,13 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     pos[4] = inv_map[256 + Kb];
     pos[5] = inv_map[512 + Kb];
 
-    f2 prev[6];
+    f2 prev[6], keep[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
 
-    // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head
-    auto load_symbol = [&](int i, f4 (&v)[4], f4& h) {
+    // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head (threads 0..3 have no head
+    // sample: they load a valid address and never use it, so that the load stays unconditional inside the wave)
+    auto load_symbol = [&](int i, f4 (&v)[4], f4& h) __attribute__((always_inline)) {
         const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -217,54 +218,52 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             else v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
         }
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
-        h = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (dc && t >= 4) {
-            if constexpr (BANK) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * (t - 4));
-            else h = load_pair<SRC>(fbase, sym + 2 * (t - 4));
+        if (dc) {                                                        // uniform per workgroup
+            const int th = (t >= 4) ? t - 4 : 0;
+            if constexpr (BANK) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * th);
+            else h = load_pair<SRC>(fbase, sym + 2 * th);
         }
     };
-    // PREFETCH: the NEXT symbol's FFT body goes from HBM straight into LDS (global_load_lds_dwordx4: lane L's 16 bytes land
-    // at M0 + 16 L, no registers involved) while this symbol is transformed; every wave stages, reads back and re-stages only
-    // its own 4 x 1 KB slots, so the staging area needs no cross-wave synchronisation.  The 504-sample cyclic-prefix head
-    // (one 16-byte load per lane) is prefetched in registers.  The DMA is issued from inline asm on purpose: the compiler
-    // counts a DMA it knows about as a pending LDS write and waits for it (vmcnt(0)) before the next LDS read it cannot prove
-    // distinct, i.e. right after the first barrier; untracked, the only wait is the explicit one at the top of the next symbol
-    // (loads return in order, so the compiler's own vmcnt(n) waits can only become more conservative, never wrong).
-    f4 h_next = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    const unsigned stage_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(stage + 128 * wave));
-    auto stage_symbol = [&](int i) {
-        const uint8_t* sym = fbase + (size_t)i * NB_SYMBOL_PERIOD * 8;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint8_t* src = sym + (size_t)(NB_CP + 2 * t + 512 * k) * 8;
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + 512 * 8 * k));
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory");
+    // the 3072 soft bits of data symbol `row` + 1 sit de-interleaved in obuf: 192 lanes x 16-byte stores
+    auto store_row = [&](const int row) __attribute__((always_inline)) {
+        if (t < NB_SYM_BITS / 16) {
+            const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
+            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)row * NB_SYM_BITS);
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(dst + t));
         }
-        const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
-        h_next = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (dc && t >= 4) h_next = *reinterpret_cast<const f4*>(sym + (size_t)(2 * (t - 4)) * 8);
     };
-    f4 v[4], h;
-    if constexpr (PREFETCH) stage_symbol(out0);
 
-    for (int i = out0; i <= sym_end; i++) {
+    f4 v[4], h = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    load_symbol(out0, v, h);
+
+    // one symbol; pv = the six active bins of symbol i - 1 (in), cur = those of symbol i (out)
+    auto symbol = [&](const int i, const f2 (&pv)[6], f2 (&cur)[6]) __attribute__((always_inline)) {
         const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
-        if constexpr (PREFETCH) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's staged symbol (and head) arrived
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const f4*>(stage + 2 * t + 512 * k);
-            h = h_next;
-            if (i < sym_end) stage_symbol(i + 1);                        // (waits for the read-back before refilling the slots)
-        } else {
-            load_symbol(i, v, h);
-        }
         const bool do_corr = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+#if DABGPU_EXP & 2
+        {   // timing-only build: the memory traffic and the barriers of the kernel without its arithmetic
+            float s0 = h.x + h.y + h.z + h.w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s0 += v[k].x + v[k].y + v[k].z + v[k].w;
+            if (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS) store_row(i - 2);
+            __syncthreads();
+            if (i < sym_end) load_symbol(i + 1, v, h);
+            if (i > out0 && i < NB_FRAME_SYMBOLS) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) reinterpret_cast<float*>(obuf)[t * 3 + k] = s0;
+            }
+            __syncthreads();
+            if (i > out0 && i < NB_FRAME_SYMBOLS && i == sym_end) store_row(i - 1);
+            return;
+        }
+#endif
 
         // ---- PLL ----
         f2 a[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float base = dt0 + gidx[k] * f;                        // apply_pll.cpp:103
+            const float base = dt0 + gf[k];                              // apply_pll.cpp:103
             a[k]     = pll1(mk2(v[k].x, v[k].y), base, step0);
             a[4 + k] = pll1(mk2(v[k].z, v[k].w), base, step1);
         }
@@ -273,7 +272,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         if (do_corr) {                                                   // uniform per workgroup
             f2 p = mk2(0.0f, 0.0f);
             if (t >= 4) {
-                const float base = dt0 + gidx[4] * f;
+                const float base = dt0 + gf[4];
                 const f2 h0 = pll1(mk2(h.x, h.y), base, step0);
                 const f2 h1 = pll1(mk2(h.z, h.w), base, step1);
                 p = conj_mul(a[3], h0) + conj_mul(a[7], h1);
@@ -295,11 +294,19 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             dst[WAVE_PATCH]         = f4{b2.x, b2.y, c2.x, c2.y};
             dst[3 * WAVE_PATCH / 2] = f4{b3.x, b3.y, c3.x, c3.y};
         }
-        block_barrier<PREFETCH>();             // the only cross-wave exchange of the transform
+        // the previous symbol's soft bits leave from here, not from the end of that symbol: a store issued after the prefetch
+        // below would have to complete before the prefetched samples count as arrived (in-order vmcnt).  obuf is complete since
+        // the end-of-symbol barrier and is not written again before the barrier below.
+        if (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS) store_row(i - 2);
+        __syncthreads();                       // the only cross-wave exchange of the transform
         if (do_corr && t == 0) {
             const f2 r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
             cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
         }
+        // this symbol's samples are consumed: the next symbol's loads go into the same registers now
+#if !(DABGPU_EXP & 4)
+        if (i < sym_end) load_symbol(i + 1, v, h);
+#endif
 
         // ---- pass 2: radix 8 inside this wave's 512-point block ----
 #pragma unroll
@@ -307,7 +314,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         dft8(a);
         patch[ta_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2p[64 * (k - 1)]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
@@ -317,7 +324,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         dft8(a);
         patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3[k - 1]);
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3p[8 * (k - 1)]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
@@ -332,7 +339,6 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             for (int k = 0; k < 8; k++) dst[256 * k] = a[k];
         }
 
-        f2 cur[6];
         cur[0] = (Kb == 0) ? a[3] : a[0];
         cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
 
@@ -343,7 +349,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             float An[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const f2 d = conj_mul(prev[k], cur[k]);
+                const f2 d = conj_mul(pv[k], cur[k]);
                 if (dqpsk_out != nullptr) {                              // GetFrameDataVec() view, natural carrier order
                     const int cbase[6] = {767, 1023, 1279, 0, 256, 512};
                     const int c = (k == 0 && Kb == 0) ? 1535 : (cbase[k] + Kb);
@@ -357,8 +363,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             // compiler's expansion of n / A (v_div_scale x2, v_rcp, 2 + 4 fma, v_div_fmas, v_div_fixup) never scales where it
             // matters: the scaled cases (quotient below 2^-43) end as soft bit 0 either way.  The reciprocal refinement then
             // depends on A only and is shared by both quotients; outside the range (or NaN) the plain expressions run.
-            const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(An[0], An[1]), __builtin_fminf(An[2], An[3])), __builtin_fminf(An[4], An[5]));
-            const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(An[0], An[1]), __builtin_fmaxf(An[2], An[3])), __builtin_fmaxf(An[4], An[5]));
+            const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(An[0], An[1]), An[2]), __builtin_fminf(__builtin_fminf(An[3], An[4]), An[5]));
+            const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(An[0], An[1]), An[2]), __builtin_fmaxf(__builtin_fmaxf(An[3], An[4]), An[5]));
             if (amin >= 0x1p-60f && amax <= 0x1p60f) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
@@ -381,15 +387,13 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                 }
             }
         }
-        block_barrier<PREFETCH>();   // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
-        if (emit && t < NB_SYM_BITS / 16) {
-            const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
-            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)(i - 1) * NB_SYM_BITS);
-            typedef unsigned u4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(dst + t));
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) prev[k] = cur[k];
+        __syncthreads();             // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
+        if (emit && i == sym_end) store_row(i - 1);                      // (otherwise stored by the next symbol, ahead of its prefetch)
+    };
+    // two symbols per trip so that the bins kept for the next DQPSK change hands by name, not by 12 register moves
+    for (int i = out0; i <= sym_end; i += 2) {
+        symbol(i, prev, keep);
+        if (i + 1 <= sym_end) symbol(i + 1, keep, prev);
     }
 }
 
@@ -451,9 +455,6 @@ void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
 }  // namespace dabgpu
 
 // ---- launchers (called from dabgpu_abi.hip) ----
-static int g_dabgpu_variant = 0;
-extern "C" void dabgpu_debug_set_variant(int v) { g_dabgpu_variant = v; }   // development switch (tools/kbench.py)
-
 // src: 0 interleaved complex float, 1 raw_u8 / wav pcm8, 2 raw_s8, 3 raw_s16l / wav pcm16
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
@@ -465,25 +466,19 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
-    size_t lds = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2);
-    if (g_dabgpu_variant == 2) lds += 14 * 1024;      // development: 3 instead of 4 workgroups per CU (occupancy sensitivity)
-    if (g_dabgpu_variant == 3) lds += 42 * 1024;      // development: 2 workgroups per CU
+    const size_t lds = DEMOD_LDS_BYTES;
     const dim3 grid((unsigned)(n_frames * chunks));
-#define DABGPU_LAUNCH_V(PF, SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<PF, SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
+#define DABGPU_LAUNCH_V(SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
-#define DABGPU_LAUNCH(PF, SRC, BANK) do { if (views || (PF)) DABGPU_LAUNCH_V(PF, SRC, BANK, true); else DABGPU_LAUNCH_V(PF, SRC, BANK, false); } while (0)
+#define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
     switch (src) {
-    case SRC_C32:
-        if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_C32, true);
-        else if (g_dabgpu_variant == 1) DABGPU_LAUNCH(true, SRC_C32, false);
-        else DABGPU_LAUNCH(false, SRC_C32, false);
-        break;
-    case SRC_U8: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_U8, true); else DABGPU_LAUNCH(false, SRC_U8, false); break;
-    case SRC_S8: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_S8, true); else DABGPU_LAUNCH(false, SRC_S8, false); break;
-    case SRC_S16: if (d_desc != nullptr) DABGPU_LAUNCH(false, SRC_S16, true); else DABGPU_LAUNCH(false, SRC_S16, false); break;
+    case SRC_C32: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
+    case SRC_U8: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_U8, true); else DABGPU_LAUNCH(SRC_U8, false); break;
+    case SRC_S8: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S8, true); else DABGPU_LAUNCH(SRC_S8, false); break;
+    case SRC_S16: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S16, true); else DABGPU_LAUNCH(SRC_S16, false); break;
     default: return hipErrorInvalidValue;
     }
 #undef DABGPU_LAUNCH

@@ -1,0 +1,16 @@
+#!/bin/bash
+# development: build/exp/libdabgpu_<tag>.so = the product objects with ONE translation unit rebuilt with extra flags
+#   tools/build_exp.sh <source.hip> <tag>=<flags> [<tag>=<flags> ...]      e.g.  tools/build_exp.sh ofdm_demod.hip e4=-DDABGPU_EXP=4
+set -u
+cd "$(dirname "$0")/../dab-radio_amd/csrc"
+SRC=$1; shift
+OUT=../../build/exp; mkdir -p $OUT
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I../../include -I. -Wall -Wno-unused-function"
+OTHERS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
+for spec in "$@"; do
+  tag=${spec%%=*}; flags=${spec#*=}
+  ( hipcc $F $flags -c $SRC -o $OUT/${SRC%.hip}_$tag.o 2>$OUT/$tag.log && hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libdabgpu_$tag.so $OUT/${SRC%.hip}_$tag.o $OTHERS 2>>$OUT/$tag.log || { echo "FAILED $tag"; grep -A6 "error" $OUT/$tag.log | head -20; } ) &
+  while (( $(jobs -r | wc -l) >= 7 )); do wait -n; done
+done
+wait
+ls $OUT/*.so | wc -l
