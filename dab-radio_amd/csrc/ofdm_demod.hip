@@ -41,8 +41,8 @@ template <int SRC> struct src_bytes { static constexpr int value = (SRC == SRC_C
 
 // two consecutive IQ samples starting at sample index n (n even) of a frame -> (re0, im0, re1, im1)
 template <int SRC>
-__device__ __forceinline__ f4 load_pair(const uint8_t* __restrict__ frame_base, size_t n) {
-    const uint8_t* p = frame_base + n * src_bytes<SRC>::value;
+__device__ __forceinline__ f4 load_pair(const uint8_t* __restrict__ frame_base, unsigned n) {
+    const uint8_t* p = frame_base + (size_t)(n * (unsigned)src_bytes<SRC>::value);
     if constexpr (SRC == SRC_C32) {
         return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));   // streamed once: keep it out of the way in L2 (-2 %)
     } else if constexpr (SRC == SRC_S16) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
 
 // LDS of one workgroup (float2 elements unless noted)
 constexpr int LDS_TW2 = 7 * 64;            // pass-2 twiddles [k][lane]
-constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7]
+constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank instantiations only: their split loader needs the registers)
 constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2) + (LDS_TW2 + LDS_TW3) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
@@ -110,11 +110,11 @@ constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS +
 // Software pipeline (round 2): a symbol's samples are dead once the PLL and the radix-4 pass have consumed them, so the NEXT
 // symbol's five 16-byte loads are issued right there, into the same registers, and have the three radix-8 passes, the demapper
 // and the end-of-symbol barrier to arrive (no second register set, no LDS staging).  To stay inside 128 VGPRs (4 workgroups
-// per CU) the pass-2 / pass-3 twiddles (28 registers) are read from two small LDS tables instead.  The vector-memory counter
+// per CU) the pass-2 twiddles (14 registers) are read from a small LDS table instead.  The vector-memory counter
 // of gfx9 is in order, therefore the previous symbol's soft-bit store is issued BEFORE the prefetch (from the middle of the
 // next symbol), never between a prefetch and its use.  0.438 -> 0.426 ms per 1024 frames (profiles/r02/ab_notes.md).
 template <int SRC, bool BANK, bool VIEWS = true>
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256, VIEWS ? 3 : 4)      // (the display views need a few more registers: 3 workgroups per CU instead of spills)
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
@@ -173,14 +173,20 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     for (int k = 0; k < 4; k++) gf[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3) * f;
     gf[4] = (float)((2 * (t - 4)) & ~3) * f;
 
-    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1) stays in registers for the whole run of
-    // symbols; pass 2 w_512^{lane k} and pass 3 w_64^{(lane&7) k} sit in LDS as [k][lane] / [k][lane & 7] (conflict-free
-    // 8-byte reads; the same table entries the register version held, so the arithmetic is unchanged)
+    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1) and pass 3 w_64^{(lane&7) k} stay in
+    // registers for the whole run of symbols; pass 2 w_512^{lane k} sits in LDS as [k][lane] (conflict-free 8-byte reads; the
+    // same table entries the register version held, so the arithmetic is unchanged)
     f2 w1a[3], w1b[3];
 #pragma unroll
     for (int k = 1; k < 4; k++) { w1a[k - 1] = tw[(2 * t) * k]; w1b[k - 1] = tw[(2 * t + 1) * k]; }
     for (int idx = t; idx < LDS_TW2; idx += 256) tw2l[idx] = tw[4 * (idx & 63) * ((idx >> 6) + 1)];
-    if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
+    f2 w3[7];
+    if constexpr (BANK) {
+        if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
+    } else {
+#pragma unroll
+        for (int k = 1; k < 8; k++) w3[k - 1] = tw[32 * (lane & 7) * k];
+    }
     __syncthreads();
     const f2* const w2p = tw2l + lane;            // w2[k] = w2p[64 (k - 1)]
     const f2* const w3p = tw3l + (lane & 7);      // w3[k] = w3p[8 (k - 1)]
@@ -208,20 +214,21 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
     for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
 
+    const unsigned lane_off = 2u * (unsigned)t, head_off = 2u * (unsigned)((t >= 4) ? t - 4 : 0);    // sample offsets of this lane
     // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head (threads 0..3 have no head
     // sample: they load a valid address and never use it, so that the load stays unconditional inside the wave)
     auto load_symbol = [&](int i, f4 (&v)[4], f4& h) __attribute__((always_inline)) {
         const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if constexpr (BANK) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
-            else v[k] = load_pair<SRC>(fbase, sym + NB_CP + 2 * t + 512 * k);
-        }
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
-        if (dc) {                                                        // uniform per workgroup
-            const int th = (t >= 4) ? t - 4 : 0;
-            if constexpr (BANK) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * th);
-            else h = load_pair<SRC>(fbase, sym + 2 * th);
+        if constexpr (BANK) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
+            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0));   // uniform per workgroup
+        } else {
+            // uniform base per (symbol, slot) + one loop-invariant 32-bit lane offset
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = load_pair<SRC>(fbase + (sym + NB_CP + 512 * k) * src_bytes<SRC>::value, lane_off);
+            if (dc) h = load_pair<SRC>(fbase + sym * src_bytes<SRC>::value, head_off);
         }
     };
     // the 3072 soft bits of data symbol `row` + 1 sit de-interleaved in obuf: 192 lanes x 16-byte stores
@@ -324,7 +331,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         dft8(a);
         patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3p[8 * (k - 1)]);
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], BANK ? w3p[8 * (k - 1)] : w3[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
@@ -464,7 +471,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 {
     using namespace dabgpu;
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
-    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 19;
+    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 25;     // 3 x 1024 workgroups per 1024 frames = three full rounds of the chip
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = DEMOD_LDS_BYTES;
     const dim3 grid((unsigned)(n_frames * chunks));

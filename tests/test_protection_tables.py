@@ -1,0 +1,78 @@
+"""The PRODUCT's sub-channel protection tables (csrc/dabgpu_decode_abi.hip: its own copy of EN 300 401 tables 7/8/9,
+subchannel_protection_tables.h:21-139) against the golden plans generated from the reference's tables
+(tests/golden/reference_vectors.npz:subchannel_plans, generator tests/golden/make_golden.py): all 64 UEP rows and the EEP grid.
+CPU half: dabgpu_subchannel_plan is host-only.  GPU half: one logical frame of every profile is encoded by the oracle, pushed through
+the history ring and decoded by the kernels -- a typo in any row changes the puncturing schedule and garbles the bytes."""
+import numpy as np
+import pytest
+
+
+def _rows(golden):
+    for row in golden["subchannel_plans"]:
+        length, is_uep, idx, lvl, tb, k = [int(v) for v in row[:6]]
+        yield length, is_uep, idx, lvl, tb, [int(v) for v in row[6:6 + k]], [int(v) for v in row[10:10 + k]]
+
+
+def test_product_plans_equal_reference_plans_for_every_profile(golden):
+    import dabgpu
+    n_uep = n_eep = 0
+    for length, is_uep, idx, lvl, tb, pi, lx in _rows(golden):
+        g = dabgpu.SubChannel(0, length, is_uep, idx, lvl, tb)
+        ppi, plx, nb = dabgpu.subchannel_plan(g)
+        assert ppi == pi and plx == lx, (length, is_uep, idx, lvl, tb)
+        assert nb == 4 * sum(lx)
+        n_uep += is_uep
+        n_eep += 1 - is_uep
+    assert n_uep == 64 and n_eep >= 20
+
+
+def test_product_rejects_out_of_table_profiles():
+    """where the reference would index past its tables (subchannel_protection_tables.h:91-139 has no range check) the product says no"""
+    import dabgpu
+    for bad in (dabgpu.SubChannel(0, 48, 1, 64, 0, 0), dabgpu.SubChannel(0, 48, 1, -1, 0, 0), dabgpu.SubChannel(0, 48, 0, 0, 4, 0),
+                dabgpu.SubChannel(0, 48, 0, 0, -1, 0), dabgpu.SubChannel(0, 0, 0, 0, 2, 0)):
+        with pytest.raises(dabgpu.DabGpuError):
+            dabgpu.subchannel_plan(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mapping", [1, 2], ids=["wave", "lane"])
+def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    ctx.viterbi_set_mapping(mapping)
+    rng = np.random.default_rng(5)
+    H = 5
+    for length, is_uep, idx, lvl, tb, pi, lx in _rows(golden):
+        start = int(rng.integers(0, 864 - length + 1))
+        sc = oracle.subchannel(start, length, eep_level=lvl, eep_type=tb, is_uep=bool(is_uep), uep_index=idx)
+        g = dabgpu.SubChannel(start, length, is_uep, idx, lvl, tb)
+        nb = 4 * sum(lx)
+        n_ens = 3
+        hist = np.zeros((n_ens, H, oracle.NB_FRAME_BITS), np.int8)
+        payloads = []
+        for e in range(n_ens):
+            payload = rng.integers(0, 256, nb, dtype=np.uint8)
+            payloads.append(payload)
+            lf = oracle.msc_encode_logical(sc, payload)                       # 0/1 bits of one logical frame
+            soft = np.clip(np.rint((2.0 * lf - 1.0) * 60.0 + rng.normal(0.0, 22.0, lf.size)), -127, 127).astype(np.int8)
+            # every CIF repeats the same logical frame: the time interleaver is transparent in steady state
+            cif = rng.integers(-127, 128, oracle.NB_CIF_BITS, dtype=np.int8)
+            cif[start * 64:(start + length) * 64] = soft
+            hist[e, :, 9216:] = np.tile(cif, 4)
+            exp_bytes, exp_err = oracle.msc_decode_logical(sc, soft)
+            assert np.array_equal(exp_bytes, payload), "oracle cannot decode its own encoding?"
+        d_hist = torch.from_numpy(hist).cuda()
+        d_out = torch.zeros((n_ens, 4, nb), dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros((n_ens * 4, 16), dtype=torch.uint8, device="cuda")
+        ctx.msc_decode_frames(d_hist, n_ens, H * oracle.NB_FRAME_BITS, H, 0, [g], d_out, 4 * nb, d_res)
+        torch.cuda.synchronize()
+        out = d_out.cpu().numpy()
+        res = d_res.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(n_ens, 4)
+        for e in range(n_ens):
+            soft = hist[e, 0, 9216 + start * 64: 9216 + (start + length) * 64]
+            exp_bytes, exp_err = oracle.msc_decode_logical(sc, soft)
+            for c in range(4):
+                assert np.array_equal(out[e, c], payloads[e]), (length, is_uep, idx, lvl, tb, e, c)
+                assert int(res[e, c]["path_error"]) == exp_err and int(res[e, c]["n_out_bytes"]) == nb
