@@ -191,8 +191,36 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     for (float* p : c->d_mode_prs) if (p) (void)hipFree(p);
     for (float* p : c->d_mode_prs_time_ref) if (p) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
+    for (auto& sl : c->stage) {
+        if (sl.pending) (void)hipEventSynchronize(sl.ev);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.h) (void)hipHostFree(sl.h);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return DABGPU_OK;
+    std::lock_guard<std::mutex> g(c->stage_mu);
+    dabgpu_ctx::stage_slot& sl = c->stage[c->stage_next++ % 8];
+    int st;
+    if (sl.pending) {                                              // the DMA that last used this slot
+        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.ev), "hipEventSynchronize(stage)"))) return st;
+        sl.pending = false;
+    }
+    if (!sl.ev && (st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming), "hipEventCreate(stage)"))) return st;
+    if (sl.bytes < bytes) {
+        if (sl.h) { (void)hipHostFree(sl.h); sl.h = nullptr; sl.bytes = 0; }
+        const size_t want = bytes < (size_t)65536 ? (size_t)65536 : bytes;
+        if ((st = dabgpu_check_hip(hipHostMalloc(&sl.h, want, hipHostMallocDefault), "hipHostMalloc(stage)"))) return st;
+        sl.bytes = want;
+    }
+    memcpy(sl.h, h_src, bytes);
+    if ((st = dabgpu_check_hip(hipMemcpyAsync(d_dst, sl.h, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(stage)"))) return st;
+    if ((st = dabgpu_check_hip(hipEventRecord(sl.ev, s), "hipEventRecord(stage)"))) return st;
+    sl.pending = true;
+    return DABGPU_OK;
 }
 
 int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
@@ -273,6 +301,7 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t 
     if (n_frames == 0) return DABGPU_OK;
     int st;
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = n_frames * DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
     const size_t bits_bytes = n_frames * DABGPU_NB_FRAME_BITS;
     const size_t fft_bytes = n_frames * 77 * DABGPU_NB_FFT * 2 * sizeof(float);
@@ -302,6 +331,7 @@ int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float 
     if (!c || !h_iq || !h_bits || !h_freq_fine) { dabgpu_set_error("ofdm_demod_stream_frame_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     int st;
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = (size_t)DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
     const size_t fft_bytes = (size_t)77 * DABGPU_NB_FFT * 2 * sizeof(float);
     const size_t dq_bytes = (size_t)75 * DABGPU_NB_DATA_CARRIERS * 2 * sizeof(float);
@@ -367,6 +397,7 @@ int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabg
                                float* h_impulse, float* h_freq) {
     if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(c);
     int st;
     float *d_sym, *d_imp, *d_frq; dabgpu_sync_state* d_st;
     if ((st = dabgpu_scratch(c, 7, sizeof(float) * 2 * DABGPU_NB_FFT, (void**)&d_sym))) return st;

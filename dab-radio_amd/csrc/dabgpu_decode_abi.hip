@@ -202,9 +202,8 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     dabgpu_cw_desc* d_descs = nullptr;
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
-    st = dabgpu_check_hip(hipMemcpyAsync(d_descs, h_cw, n * sizeof(dabgpu_cw_desc), hipMemcpyHostToDevice, s), "hipMemcpyAsync(descs)");
-    if (st) return st;
-    // pageable host memory: the copy above has consumed h_cw when it returns, the caller may reuse it
+    if ((st = dabgpu_stage_h2d(c, d_descs, h_cw, n * sizeof(dabgpu_cw_desc), s))) return st;
+    // (through the pinned staging ring: h_cw is consumed when this returns, the caller may reuse it)
     bool uniform = true;                                  // one puncturing schedule for the whole batch?
     for (size_t i = 1; i < n && uniform; i++)
         uniform = h_cw[i].n_steps == h_cw[0].n_steps && !memcmp(h_cw[i].seg_pi, h_cw[0].seg_pi, sizeof(h_cw[0].seg_pi)) &&
@@ -306,7 +305,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
     if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
-    if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
+    if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
     // Which sub-channels go to the lane-per-codeword kernel?  The k longest can be left to viterbi_kernel (one wavefront per
@@ -346,7 +345,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if (n_lane > 0) {
         // flag the lane-mapped sub-channels in the plans the descriptor builder read: rebuild the descriptors with the flags
         for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
-        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), hipMemcpyHostToDevice, s), "hipMemcpyAsync(plans)"))) return st;
+        if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                            d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
         // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
@@ -365,7 +364,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
         uint64_t* d_lane_subs = nullptr;
         if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs))) return st;
-        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s), "hipMemcpyAsync(lane subs)"))) return st;
+        if ((st = dabgpu_stage_h2d(c, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
         for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
             const size_t ne = std::min(n_ens - e0, ens_per_slice);
             const uint32_t gps = (uint32_t)((ne * 4 + 63) / 64);
@@ -429,6 +428,7 @@ static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src,
 extern "C" int dabgpu_fic_decode_group_host_sync(dabgpu_ctx* c, const int8_t* h_bits, uint8_t* h_bytes, uint32_t* crc_ok_mask,
                                                  uint64_t* path_error, int tie_rule) {
     if (!c || !h_bits || !h_bytes) { dabgpu_set_error("fic_decode_group_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_HOST_LOCK(c);
     dabgpu_cw_desc D = {};
     D.n_steps = 774;
     D.seg_pi[0] = 16; D.seg_steps[0] = 32 * 21;
@@ -447,6 +447,7 @@ extern "C" int dabgpu_viterbi_decode_host_sync(dabgpu_ctx* c, const int8_t* h_sr
                                                const uint32_t* seg_steps, uint32_t start_state, uint32_t end_state, uint32_t flags,
                                                uint8_t* h_out, size_t n_out_bytes, uint64_t* path_error, int tie_rule) {
     if (!c || !h_src || !seg_pi || !seg_steps || !h_out) { dabgpu_set_error("viterbi_decode_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_HOST_LOCK(c);
     dabgpu_cw_desc D = {};
     uint32_t steps = 0; size_t need = 12;
     for (int k = 0; k < 4; k++) {
@@ -514,8 +515,9 @@ extern "C" void dabgpu_msc_stream_destroy(dabgpu_msc_stream* s) {
 extern "C" int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_bits) {
     if (!s || !h_bits) return DABGPU_ERR_INVALID_ARG;
     (void)hipSetDevice(s->ctx->device);
-    int st = dabgpu_check_hip(hipMemcpyAsync(s->d_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits,
-                                             hipMemcpyHostToDevice, s->ctx->stream), "hipMemcpyAsync(cif)");
+    DABGPU_HOST_LOCK(s->ctx);
+    // through the pinned staging ring: the caller's span is only valid during DecodeCIF (SURVEY 8b ownership)
+    int st = dabgpu_stage_h2d(s->ctx, s->d_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits, s->ctx->stream);
     if (st) return st;
     s->next_slot = (s->next_slot + 1) % 16;                    // cif_deinterleaver.cpp:28-33
     if (s->stored < 16) s->stored++;
@@ -524,6 +526,7 @@ extern "C" int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_
 
 extern "C" int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t* h_out) {
     if (!s || !h_out) return DABGPU_ERR_INVALID_ARG;
+    DABGPU_HOST_LOCK(s->ctx);
     if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // cif_deinterleaver.cpp:40-42
     (void)hipSetDevice(s->ctx->device);
     hipStream_t q = s->ctx->stream;
@@ -536,6 +539,7 @@ extern "C" int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t*
 
 extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_out, size_t* n_out, uint64_t* path_error, int tie_rule) {
     if (!s || !h_out || !n_out) return DABGPU_ERR_INVALID_ARG;
+    DABGPU_HOST_LOCK(s->ctx);
     *n_out = 0;
     if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // msc_decoder.cpp:60-63
     dabgpu_cw_desc D = s->proto;

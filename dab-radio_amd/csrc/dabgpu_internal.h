@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
+#include <mutex>
 #include <vector>
 
 #include "dabgpu.h"
@@ -25,7 +26,21 @@ struct dabgpu_ctx {
     float* d_mode_prs_time_ref[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
+    // Host-side entry points (*_host_sync, msc_stream_*, dabplus_process_frame_host_sync) share the context's stream and scratch
+    // slots: they serialise on this lock, so decoder objects living on different threads (BasicThreadPool workers,
+    // src/basic_radio/basic_radio.cpp:51-60) may share one context.  The batch entry points (device pointers + caller's stream)
+    // take no lock: one thread per context, or the caller's own exclusion.
+    std::recursive_mutex host_mu;
+    // pinned staging ring for small host -> device copies whose source does not outlive the call (descriptor tables, a caller's
+    // CIF): copy into a pinned slot, asynchronous DMA from there, an event marks the slot reusable
+    struct stage_slot { void* h = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    stage_slot stage[8];
+    unsigned stage_next = 0;
+    std::mutex stage_mu;
 };
+#define DABGPU_HOST_LOCK(ctx) std::lock_guard<std::recursive_mutex> dabgpu_host_lock_(ctx->host_mu)
+// asynchronous host -> device copy on `s` that has consumed h_src when it returns (h_src may be freed or overwritten at once)
+extern "C" int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 
 void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);

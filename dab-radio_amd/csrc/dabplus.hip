@@ -172,6 +172,12 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
     }
     DpState st = states[s];
     const int n = (int)frame_bytes[s];
+    // what this kernel cannot hold is reported, not skipped in silence: logical frames above 1536 bytes (the reference accepts any
+    // N >= 11, aac_frame_processor.cpp:129-137) -> counts[1] = -1; a super-frame slot smaller than 5 frames -> counts[1] = -2
+    if (n > DP_MAX_FRAME_BYTES || (n >= 11 && (size_t)(5 * n) > sf_out_stride)) {
+        if (lane == 0) { counts[4 * s] = 0; counts[4 * s + 1] = (n > DP_MAX_FRAME_BYTES) ? -1 : -2; counts[4 * s + 2] = 0; counts[4 * s + 3] = st.curr_dab_frame; }
+        return;
+    }
     uint8_t* acc = sf_acc + (size_t)s * DP_MAX_SF;
     const uint8_t* base = frames + stream_offsets[s];
     int n_sf = 0, n_wait_failed = 0, last_wait_crc = 0;
@@ -179,7 +185,7 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
 
     for (int f = 0; f < n_frames; f++) {
         const uint8_t* frame = base + (size_t)f * frame_stride;
-        if (n < 11 || n > DP_MAX_FRAME_BYTES) continue;                    // :129-137 (and this kernel's buffer size)
+        if (n < 11) continue;                                              // :129-137
         if (st.prev_n != n) { st.prev_n = n; st.curr_dab_frame = 0; st.wait_frame_start = 1; }       // :140-147
         if (st.desync_count >= 10) { st.desync_count = 0; st.synced = 0; }                           // :151-154
         if (st.synced) st.wait_frame_start = 0;                                                       // :158-160
@@ -425,6 +431,7 @@ int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank* b, const uint8_t
     }
     dabgpu_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(b->ctx);
     hipStream_t s = c->stream;
     int st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)

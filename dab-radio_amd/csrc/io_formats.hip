@@ -214,6 +214,7 @@ static int round_trip(dabgpu_ctx* c, const void* h_in, size_t in_bytes, void* h_
 
 int dabgpu_iq_convert_host_sync(dabgpu_ctx* c, const void* h_raw, int format, size_t n_samples, float* h_iq) {
     if (!c) { dabgpu_set_error("iq_convert_host_sync: null context"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_HOST_LOCK(c);
     const size_t sb = dabgpu_iq_format_sample_bytes(format);
     if (sb == 0) { dabgpu_set_error("iq_convert_host_sync: unknown format %d", format); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
@@ -225,6 +226,7 @@ int dabgpu_iq_convert_host_sync(dabgpu_ctx* c, const void* h_raw, int format, si
 
 int dabgpu_soft_bits_to_hard_bytes_host_sync(dabgpu_ctx* c, const int8_t* h_bits, size_t n_bytes, uint8_t* h_bytes) {
     if (!c) { dabgpu_set_error("soft_bits_to_hard_bytes_host_sync: null context"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_HOST_LOCK(c);
     if (n_bytes == 0) return DABGPU_OK;
     if (!h_bits || !h_bytes) { dabgpu_set_error("soft_bits_to_hard_bytes_host_sync: null buffer"); return DABGPU_ERR_INVALID_ARG; }
     return round_trip(c, h_bits, n_bytes * 8, h_bytes, n_bytes,
@@ -234,6 +236,7 @@ int dabgpu_soft_bits_to_hard_bytes_host_sync(dabgpu_ctx* c, const int8_t* h_bits
 
 int dabgpu_hard_bytes_to_soft_bits_host_sync(dabgpu_ctx* c, const uint8_t* h_bytes, size_t n_bytes, int8_t* h_bits) {
     if (!c) { dabgpu_set_error("hard_bytes_to_soft_bits_host_sync: null context"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_HOST_LOCK(c);
     if (n_bytes == 0) return DABGPU_OK;
     if (!h_bits || !h_bytes) { dabgpu_set_error("hard_bytes_to_soft_bits_host_sync: null buffer"); return DABGPU_ERR_INVALID_ARG; }
     return round_trip(c, h_bytes, n_bytes, h_bits, n_bytes * 8,

@@ -179,8 +179,10 @@ int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int
     if (!c->d_mode_mapper[mode]) {
         std::vector<int> m((size_t)g.n_carriers);
         if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
-        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_mapper[mode], m.size() * sizeof(int)), "hipMalloc(mode mapper)"))) return st;
-        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_mapper[mode], m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode mapper)"))) return st;
+        int* d_m = nullptr;
+        if ((st = dabgpu_check_hip(hipMalloc(&d_m, m.size() * sizeof(int)), "hipMalloc(mode mapper)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpy(d_m, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode mapper)"))) { (void)hipFree(d_m); return st; }
+        c->d_mode_mapper[mode] = d_m;
     }
     if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
     const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;
@@ -225,6 +227,7 @@ int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, si
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 22)) { dabgpu_set_error("ofdm_demod_frames_mode: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
     if ((uintptr_t)d_iq & 7) { dabgpu_set_error("ofdm_demod_frames_mode: d_iq must be 8-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    if ((uintptr_t)d_bits & 15) { dabgpu_set_error("ofdm_demod_frames_mode: d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
     (void)hipSetDevice(c->device);
     hipStream_t s = (hipStream_t)stream;
     int st;
@@ -244,6 +247,7 @@ int dabgpu_ofdm_demod_stream_frame_sync_mode(dabgpu_ctx* c, int mode, const floa
     if (mode == 1) return dabgpu_ofdm_demod_stream_frame_sync(c, h_iq, freq_coarse, h_freq_fine, beta, h_bits, h_total_phase, h_fft, nullptr);
     int st;
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = (size_t)g.frame_samples * 2 * sizeof(float);
     const size_t fft_bytes = (size_t)(g.n_sym + 1) * g.n_fft * 2 * sizeof(float);
     float *d_iq, *d_small, *d_corr, *d_fft = nullptr; int8_t* d_bits;
@@ -274,6 +278,7 @@ int dabgpu_ofdm_sync_host_sync_mode(dabgpu_ctx* c, int mode, const float* h_prs_
     if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_sync_host_sync_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     (void)hipSetDevice(c->device);
+    DABGPU_HOST_LOCK(c);
     int st;
     const size_t N = (size_t)g.n_fft;
     float *d_sym, *d_imp, *d_frq; dabgpu_sync_state* d_st;

@@ -253,8 +253,11 @@ int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int
         std::vector<int> m((size_t)g.n_carriers), inv((size_t)g.n_carriers);
         if ((st = dabgpu_get_carrier_mapper(mode, m.data()))) return st;
         for (int n = 0; n < g.n_carriers; n++) inv[(size_t)m[(size_t)n]] = n;
-        if ((st = dabgpu_check_hip(hipMalloc(&c->d_mode_inv_map[mode], inv.size() * sizeof(int)), "hipMalloc(mode inverse mapper)"))) return st;
-        if ((st = dabgpu_check_hip(hipMemcpy(c->d_mode_inv_map[mode], inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode inverse mapper)"))) return st;
+        // (into a local first: a failed copy must not leave a non-null pointer to uninitialised indices on the context)
+        int* d_inv = nullptr;
+        if ((st = dabgpu_check_hip(hipMalloc(&d_inv, inv.size() * sizeof(int)), "hipMalloc(mode inverse mapper)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpy(d_inv, inv.data(), inv.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy(mode inverse mapper)"))) { (void)hipFree(d_inv); return st; }
+        c->d_mode_inv_map[mode] = d_inv;
     }
     if (symbols_per_block <= 0 || symbols_per_block > g.n_sym - 1) symbols_per_block = 19;
     const int chunks = (g.n_sym - 1 + symbols_per_block - 1) / symbols_per_block;

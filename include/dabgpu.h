@@ -327,7 +327,7 @@ int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *
  *         samples per frame (symbols + NULL), soft bits per symbol, soft bits per frame}; host only */
 int dabgpu_get_ofdm_params(int transmission_mode, int *out9);
 /*   d_iq   [n_frames][samples per frame] complex float, layout as for mode I (symbols, PRS first, then the NULL symbol)
- *   d_bits [n_frames][soft bits per frame] int8;  d_cp_corr [n_frames][nb_frame_symbols] complex float, may be NULL
+ *   d_bits [n_frames][soft bits per frame] int8, 16-byte aligned;  d_cp_corr [n_frames][nb_frame_symbols] complex float, may be NULL
  *   d_fft  [n_frames][nb_frame_symbols + 1][nb_fft] complex float, may be NULL.  transmission_mode 1 is accepted too
  *   (cross-check of the two kernels). */
 int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx *ctx, int transmission_mode, const float *d_iq, size_t n_frames,
@@ -447,6 +447,10 @@ int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank *bank, void *stream);
  *   d_counts      [n_streams][4]: super frames attempted, logical frames dropped while waiting for a valid fire code,
  *                 received << 16 | calculated fire code of the last dropped frame, logical frames collected so far
  *   max_superframes >= ceil(n_frames / 5), superframe_stride_bytes >= 5 * frame bytes
+ * Limits, reported per stream instead of being skipped in silence: a stream whose logical frames exceed 1536 bytes (the reference
+ * takes any N >= 11, aac_frame_processor.cpp:129-137) is not processed and gets d_counts[s][1] = -1; a stream whose
+ * 5 * frame bytes exceed superframe_stride_bytes gets d_counts[s][1] = -2.  (dabgpu_dabplus_process_frame_host_sync returns
+ * DABGPU_ERR_UNSUPPORTED for the first case.)
  */
 int dabgpu_dabplus_bank_process(dabgpu_dabplus_bank *bank, const uint8_t *d_frames, const uint64_t *d_stream_offsets,
                                 size_t frame_stride_bytes, const uint32_t *d_frame_bytes, int n_frames, uint8_t *d_superframes,

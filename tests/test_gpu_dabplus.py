@@ -176,3 +176,27 @@ def test_behind_the_msc_viterbi_kernel(ctx, oracle):
         for k, aus in enumerate(got[si]):
             assert same(aus, truth[si][j0 + k]), (si, k)
     bank.close()
+
+
+def test_unsupported_frame_sizes_are_reported_per_stream(ctx):
+    """logical frames above 1536 bytes / a super-frame slot below 5 frames: flagged in d_counts[s][1], never skipped in silence
+    (include/dabgpu.h); a normal stream in the same launch is unaffected"""
+    import dabgpu
+    import torch
+    n = 3
+    bank = dabgpu.DabPlusBank(ctx, n)
+    bank.reset()
+    frame_bytes = torch.tensor([1600, 192, 400], dtype=torch.uint32, device="cuda")
+    stride = 2048
+    frames = torch.zeros((n, 5, stride), dtype=torch.uint8, device="cuda")
+    offsets = torch.tensor([0, 5 * stride, 10 * stride], dtype=torch.uint64, device="cuda")
+    sf_stride = 5 * 192                                              # enough for stream 1 only
+    sf = torch.zeros((n, 1, sf_stride), dtype=torch.uint8, device="cuda")
+    res = torch.zeros((n, 1, 96), dtype=torch.uint8, device="cuda")
+    counts = torch.full((n, 4), 77, dtype=torch.int32, device="cuda")
+    bank.process(frames, offsets, stride, frame_bytes, 5, sf, sf_stride, res, 1, counts)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy()
+    assert c[0, 0] == 0 and c[0, 1] == -1                            # 1600-byte frames: not supported by the bank kernel
+    assert c[2, 0] == 0 and c[2, 1] == -2                            # 5 x 400 bytes do not fit the 960-byte slot
+    assert c[1, 1] >= 0 and c[1, 0] + c[1, 1] >= 1                  # the 192-byte stream was processed (a super frame attempted or frames dropped)

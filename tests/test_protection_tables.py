@@ -44,7 +44,15 @@ def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
     ctx.viterbi_set_mapping(mapping)
     rng = np.random.default_rng(5)
     H = 5
+    n_done = 0
     for length, is_uep, idx, lvl, tb, pi, lx in _rows(golden):
+        kept = sum(4 * l * (8 + p) for p, l in zip(pi, lx)) + 12
+        if kept > length * 64:
+            # reference quirk kept as data (subchannel_protection_tables.h:54-55: the 128 kbit/s level-5 / level-4 rows list their
+            # sizes 84 / 64 CU exchanged): UEP index 34 needs more coded bits than its 64 CU hold -- nothing can be encoded for it
+            assert is_uep and idx == 34
+            continue
+        n_done += 1
         start = int(rng.integers(0, 864 - length + 1))
         sc = oracle.subchannel(start, length, eep_level=lvl, eep_type=tb, is_uep=bool(is_uep), uep_index=idx)
         g = dabgpu.SubChannel(start, length, is_uep, idx, lvl, tb)
@@ -76,3 +84,4 @@ def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
             for c in range(4):
                 assert np.array_equal(out[e, c], payloads[e]), (length, is_uep, idx, lvl, tb, e, c)
                 assert int(res[e, c]["path_error"]) == exp_err and int(res[e, c]["n_out_bytes"]) == nb
+    assert n_done == len(golden["subchannel_plans"]) - 1
