@@ -40,7 +40,7 @@ REALTIME_FRAMES_PER_S = 2.048e6 / 196608              # 10.4167
 # Viterbi kernels: VALU-issue bound.  peak trellis steps/s = SIMDs x clock x codewords per wavefront /
 # (VALU instructions per wavefront-step x cycles per instruction); instruction counts from the ISA of this build
 # (tools/isa_count.py), 4 cycles per packed-integer / cross-lane instruction (tools/ubench/pk16_rate.hip), 2.4 GHz, 1024 SIMDs.
-VIT_LANES_INSTR_PER_STEP = 185.0
+VIT_LANES_INSTR_PER_STEP = 181.0
 VIT_WAVE_INSTR_PER_STEP = 23.0
 VIT_CYCLES_PER_INSTR = 4.0
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--ensembles", type=int, default=8192, help="full: ensembles per GPU (BASELINE configs[4]: 65536 / 8)")
     ap.add_argument("--distinct", type=int, default=64, help="full / extras: distinct seeded multiplexes the ensembles are built from")
     ap.add_argument("--extra-ensembles", type=int, default=4096, help="demod, N = 1: ensembles of extra.configs2 / configs3")
+    ap.add_argument("--inflight", type=int, default=2, help="full: transmission frames in flight (one stream + context each)")
     ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -163,44 +164,82 @@ def viterbi_roofline(kernel, steps, k_ms, lanes):
 
 
 class Pipeline:
-    """E ensembles, one transmission frame of IQ each, history ring of H frames, FIC + MSC outputs (configs[2]/[3]/[4])."""
+    """E ensembles, one transmission frame of IQ each, frame-history ring of H slots, FIC + MSC outputs (configs[2]/[3]/[4]).
 
-    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed):
+    `inflight` frames are in flight at once, frame j on stream / context j mod inflight (a context owns its scratch, so concurrent
+    calls need one each): the next frame's HBM-bound demodulation and gather kernels fill the wavefront slots that the trellis kernel's
+    last, partial round leaves idle.  Dependencies kept with events: msc(j) reads the ring slots of frames j-4..j -> waits for
+    demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it."""
+
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1):
         import dabsynth
-        self.ctx, self.torch, self.E, self.H = ctx, torch, E, 5
+        self.torch, self.E, self.inflight = torch, E, inflight
+        self.H = 5 if inflight == 1 else 8
         prs, mapper, _ = dabgpu.host_tables()
         self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs)
         self.iq_f = torch.view_as_real(self.iq)
         self.n_sub = dabsynth.N_SUB
         self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
-        self.corr = torch.empty((E, 76, 2), dtype=torch.float32, device=device)
-        self.fic_out = torch.zeros((E, 4, 96), dtype=torch.uint8, device=device)
-        self.fic_res = torch.zeros((E * 4, 16), dtype=torch.uint8, device=device)
-        self.msc_out = torch.zeros((E, 4, self.n_sub * dabsynth.SUB_BYTES), dtype=torch.uint8, device=device)
-        self.msc_res = torch.zeros((E * 4 * self.n_sub, 16), dtype=torch.uint8, device=device)
+        self.ctxs = [ctx] + [dabgpu.Context(device.index) for _ in range(inflight - 1)]
+        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
+        mk = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=device) for _ in range(inflight)]     # noqa: E731
+        self.corr = mk((E, 76, 2), torch.float32)
+        self.fic_out, self.fic_res = mk((E, 4, 96), torch.uint8), mk((E * 4, 16), torch.uint8)
+        self.msc_out, self.msc_res = mk((E, 4, self.n_sub * dabsynth.SUB_BYTES), torch.uint8), mk((E * 4 * self.n_sub, 16), torch.uint8)
         self.subs = self.mux.subchannels(dabgpu)
         self.fic_steps = E * dabsynth.FIC_STEPS_PER_FRAME
         self.msc_steps = E * dabsynth.MSC_STEPS_PER_FRAME
         self.stride = self.H * 230400
+        self.j = 0                                  # next frame number
+        self.ev_demod, self.ev_msc = {}, {}
 
-    def demod(self, slot):
-        self.ctx.ofdm_demod_frames(self.iq_f, self.hist[:, slot], cp_corr=self.corr, n_frames=self.E, bits_frame_stride=self.stride)
+    # the three stages of frame-slot `slot` on lane k (context k, stream k)
+    def demod(self, slot, k=0):
+        self.ctxs[k].ofdm_demod_frames(self.iq_f, self.hist[:, slot], cp_corr=self.corr[k], n_frames=self.E, bits_frame_stride=self.stride,
+                                       stream=self.streams[k].cuda_stream)
 
-    def fic(self, slot):
-        self.ctx.fic_decode_frames(self.hist[:, slot], self.E, self.fic_out, self.fic_res, frame_stride=self.stride)
+    def fic(self, slot, k=0):
+        self.ctxs[k].fic_decode_frames(self.hist[:, slot], self.E, self.fic_out[k], self.fic_res[k], frame_stride=self.stride,
+                                       stream=self.streams[k].cuda_stream)
 
-    def msc(self, slot):
-        self.ctx.msc_decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.msc_out,
-                                   4 * self.n_sub * 192, self.msc_res)
+    def msc(self, slot, k=0):
+        self.ctxs[k].msc_decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.msc_out[k],
+                                       4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream)
 
-    def step(self, k):
-        s = k % self.H
-        self.demod(s); self.fic(s); self.msc(s)
+    def step(self, on_demod=None):
+        """one transmission frame of every ensemble: demod -> FIC -> MSC"""
+        torch, j, n = self.torch, self.j, self.inflight
+        k, slot, st = j % n, j % self.H, self.streams[j % n]
+        self.j += 1
+        if n == 1:
+            if on_demod:
+                on_demod(lambda: self.demod(slot))
+            else:
+                self.demod(slot)
+            self.fic(slot); self.msc(slot)
+            return
+        w = self.ev_msc.pop(j - self.H + 4, None)                    # the last reader of the slot this frame overwrites
+        if w is not None:
+            st.wait_event(w)
+        if on_demod:
+            on_demod(lambda: self.demod(slot, k))
+        else:
+            self.demod(slot, k)
+        ev = torch.cuda.Event(); ev.record(st)
+        self.ev_demod[j] = ev
+        self.fic(slot, k)
+        for d in range(1, n):                                        # frames j-1 .. j-n+1 were demodulated on the other streams
+            w = self.ev_demod.get(j - d)
+            if w is not None:
+                st.wait_event(w)
+        self.ev_demod.pop(j - n, None)
+        self.msc(slot, k)
+        ev = torch.cuda.Event(); ev.record(st)
+        self.ev_msc[j] = ev
 
     def fill(self):
-        for slot in range(self.H):                   # fill the history ring: the time de-interleaver needs 16 CIFs = 4 frames
-            self.demod(slot)
-        self.fic(0); self.msc(0)
+        for _ in range(self.H + self.inflight):      # fill the history ring: the time de-interleaver needs 16 CIFs = 4 frames
+            self.step()
         self.torch.cuda.synchronize()
 
     def timed(self, fn, reps):
@@ -216,24 +255,24 @@ class Pipeline:
     def check(self, dabgpu):
         import numpy as np
         torch, E, nd = self.torch, self.E, self.mux.n
-        res_f = self.fic_res.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
-        crc_ok = int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
-        idx = torch.arange(E, device=self.fic_out.device) % nd
-        fib_eq = bool(torch.equal(self.fic_out, self.mux.fibs[idx]))
+        out = {"fib_crc_pass": 0, "fib_crc_expected": E * 12 * self.inflight, "fib_bytes_equal_transmitted": True,
+               "msc_bytes_equal_transmitted": True, "ensembles_checked": E, "distinct_multiplexes": nd, "frames_in_flight": self.inflight}
+        idx = torch.arange(E, device=self.hist.device) % nd
         exp = self.mux.payload[idx].unsqueeze(1).expand(E, 4, self.n_sub, 192)
-        msc_eq = bool(torch.equal(self.msc_out.view(E, 4, self.n_sub, 192), exp))
-        return {"fib_crc_pass": crc_ok, "fib_crc_expected": E * 12, "fib_bytes_equal_transmitted": fib_eq,
-                "msc_bytes_equal_transmitted": msc_eq, "ensembles_checked": E, "distinct_multiplexes": nd}
+        for k in range(self.inflight):                               # the outputs of the last frame of every lane
+            res_f = self.fic_res[k].cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
+            out["fib_crc_pass"] += int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
+            out["fib_bytes_equal_transmitted"] &= bool(torch.equal(self.fic_out[k], self.mux.fibs[idx]))
+            out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k].view(E, 4, self.n_sub, 192), exp))
+        return out
 
 
 def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
     """BASELINE configs[2] (demod + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
-    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7)
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2)
     p.fill()
-    for k in range(3):
-        p.step(k)
     torch.cuda.synchronize()
-    t_demod, t_fic, t_msc = p.timed(p.demod, reps), p.timed(p.fic, reps), p.timed(p.msc, reps)
+    t_demod, t_fic, t_msc = p.timed(p.demod, reps), p.timed(p.fic, reps), p.timed(p.msc, reps)      # one stage at a time, stream 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for k in range(reps):
@@ -241,10 +280,16 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
     e1.record(); torch.cuda.synchronize()
     t_c2 = e0.elapsed_time(e1) / reps
     t0 = time.perf_counter()
-    for k in range(reps):
-        p.step(k)
+    for k in range(reps):                                     # one frame at a time on one stream
+        p.demod(k % p.H); p.fic(k % p.H); p.msc(k % p.H)
     torch.cuda.synchronize()
-    t_all = (time.perf_counter() - t0) / reps * 1e3
+    t_seq = (time.perf_counter() - t0) / reps * 1e3
+    p.fill()
+    t0 = time.perf_counter()
+    for k in range(2 * reps):                                 # two frames in flight (Pipeline.step)
+        p.step()
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / (2 * reps) * 1e3
     chk = p.check(dabgpu)
     lanes_fic = E >= 2000                      # DABGPU_VIT_MAP_AUTO's switch points
     c2 = {"workload": f"BASELINE configs[2]: full OFDM demod + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
@@ -255,6 +300,7 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
           "check": {k: chk[k] for k in ("fib_crc_pass", "fib_crc_expected", "fib_bytes_equal_transmitted")}}
     c3 = {"workload": f"BASELINE configs[3]: full FIC + MSC demod + Viterbi, {E} concurrent synthetic ensembles, 18 x 48 CU EEP 3-A", "ensembles": E,
           "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,
+          "frames_in_flight": 2, "ms_per_step_one_frame_at_a_time": t_seq, "frames_per_s_one_frame_at_a_time": E / t_seq * 1e3,
           "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi_incl_deinterleave": t_msc},
           "algorithmic_hbm_GBps": 2.27e6 * E / (t_all * 1e-3) / 1e9,
           "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
@@ -359,19 +405,18 @@ def main():
         E = args.ensembles
         first_unit, n_units = shard.shard_range(E * world, rank, world)
         assert n_units == E
-        pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit)
+        pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit, inflight=args.inflight)
         pipe.fill()
         units = E
 
+        def timed_demod(launch):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = pipe.streams[(pipe.j - 1) % pipe.inflight]
+            a.record(st); launch(); b.record(st)
+            evs.append((a, b))
+
         def step(k, timed=False):
-            s = k % pipe.H
-            if timed and k % 2 == 0:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); pipe.demod(s); b.record()
-                evs.append((a, b))
-            else:
-                pipe.demod(s)
-            pipe.fic(s); pipe.msc(s)
+            pipe.step(on_demod=timed_demod if (timed and k % 2 == 0) else None)
 
     t_pre = time.perf_counter()
     k = 0

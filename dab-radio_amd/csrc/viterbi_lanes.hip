@@ -81,13 +81,14 @@ __device__ __forceinline__ void vl_gather(const s2 (&D)[32], uint32_t& w0, uint3
         // bits pos = 32 w + 8 j + k, g = 8 w + k: bytes j = 0,1 are the two halves of one register, j = 2,3 of another
         const int base = ((g >> 3) << 5) | (g & 7);
         const int r_lo = vl_idx(vl_rotl6(base, S), QN), r_hi = vl_idx(vl_rotl6(base | 16, S), QN);
-        G[g] = __builtin_amdgcn_perm(as_u32(D[r_hi]), as_u32(D[r_lo]), 0x07050301u);
+        // selectors 8..11 of v_perm_b32 replicate the SIGN of bytes 1 / 3 / 5 / 7: every byte of G[g] is 0x00 or 0xFF
+        G[g] = __builtin_amdgcn_perm(as_u32(D[r_hi]), as_u32(D[r_lo]), 0x0B0A0908u);
     }
     uint32_t a0 = G[0], a1 = G[8];
 #pragma unroll
-    for (int k = 1; k < 8; k++) {                                    // bit k of every byte <- sign byte of G[k]
-        a0 = vl_bfi(0x80808080u, G[k], a0 >> 1);
-        a1 = vl_bfi(0x80808080u, G[8 + k], a1 >> 1);
+    for (int k = 1; k < 8; k++) {                                    // bit k of every byte <- G[k] (no shifts: the bytes are masks already)
+        a0 = vl_bfi(0x01010101u << k, G[k], a0);
+        a1 = vl_bfi(0x01010101u << k, G[8 + k], a1);
     }
     w0 = a0; w1 = a1;
 }

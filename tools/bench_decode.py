@@ -202,6 +202,50 @@ def main():
     torch.cuda.synchronize()
     t_all2 = (time.perf_counter() - t0) / args.steps * 1e3
 
+    # frames in flight on two streams (two contexts: each owns its scratch): even frames on one, odd frames on the other, history ring of
+    # H2 = 8 slots so that the demodulator of frame j + 1 never writes a slot the MSC decoder of frame j still reads (it reads
+    # frames j - 4 .. j).  The next frame's HBM-bound demod / gather kernels fill the wavefront slots the trellis kernel's last,
+    # partial round leaves idle.  Dependencies: msc(j) needs the ring slots written by demod(j - 4 .. j) -> wait for demod(j - 1).
+    H2 = 8
+    hist2 = torch.zeros((E, H2, 230400), dtype=torch.int8, device=dev)
+    ctxs = [ctx, dabgpu.Context(0)]
+    ctxs[1].viterbi_set_mapping(args.mapping)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    fic_out2 = [fic_out, torch.zeros_like(fic_out)]
+    fic_res2 = [fic_res, torch.zeros_like(fic_res)]
+    msc_out2 = [msc_out, torch.zeros_like(msc_out)]
+    msc_res2 = [msc_res, torch.zeros_like(msc_res)]
+    corr2 = [corr, torch.empty_like(corr)]
+
+    def frame_on(j, ev_prev_demod):
+        k = j & 1
+        c, st = ctxs[k], streams[k]
+        slot = j % H2
+        with torch.cuda.stream(st):
+            c.ofdm_demod_frames(iq_f, hist2[:, slot], cp_corr=corr2[k], n_frames=E, bits_frame_stride=H2 * 230400, stream=st.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            c.fic_decode_frames(hist2[:, slot], E, fic_out2[k], fic_res2[k], frame_stride=H2 * 230400, tie_rule=args.tie_rule, stream=st.cuda_stream)
+            if ev_prev_demod is not None:
+                st.wait_event(ev_prev_demod)
+            c.msc_decode_frames(hist2, E, H2 * 230400, H2, slot, subs, msc_out2[k], 4 * n_sub * 192, msc_res2[k], tie_rule=args.tie_rule,
+                                stream=st.cuda_stream)
+        return ev
+
+    torch.cuda.synchronize()
+    ev = None
+    for j in range(H2):                       # fill the longer ring
+        ev = frame_on(j, ev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev = None
+    n_pp = 2 * args.steps
+    for j in range(n_pp):
+        ev = frame_on(H2 + j, ev)
+    torch.cuda.synchronize()
+    t_pp = (time.perf_counter() - t0) / n_pp * 1e3
+    pp_ok = bool(torch.equal(msc_out2[1].view(E, 4, n_sub, 192), payload.unsqueeze(1).expand(E, 4, n_sub, 192))) and bool(torch.equal(fic_out2[1], fibs))
+
     res_f = fic_res.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
     crc_ok = int(sum(bin(int(m)).count("1") for m in res_f["crc_ok_mask"].reshape(-1)))
     fib_eq = bool(torch.equal(fic_out, fibs))
@@ -214,6 +258,7 @@ def main():
         "config4_full": {"ms_per_frame_step_sum_of_kernels": t_demod + t_fic + t_msc, "ms_per_frame_step_wall": t_all,
                          "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / (2.048e6 / 196608),
                          "ms_per_frame_step_wall_fic_on_second_stream": t_all2, "frames_per_s_fic_on_second_stream": E / t_all2 * 1e3,
+                         "ms_per_frame_step_two_frames_in_flight": t_pp, "frames_per_s_two_frames_in_flight": E / t_pp * 1e3, "two_frames_in_flight_outputs_ok": pp_ok,
                          "msc_trellis_steps_per_s": E * msc_steps / t_msc * 1e3},
         "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi": t_msc},
         "check": {"fib_crc_pass": crc_ok, "fib_crc_expected": E * 12, "fib_bytes_equal_transmitted": fib_eq,
