@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
+    "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
 IQ_FORMATS = ["raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l", "raw_s32b", "raw_u32l", "raw_u32b",
@@ -208,6 +209,12 @@ def lib():
                                                     C.c_void_p, C.c_int, C.c_void_p]
         L.dabgpu_ofdm_phase_update_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p,
                                                     C.c_void_p]
+        L.dabgpu_ingest_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.dabgpu_ingest_destroy.argtypes = [C.c_void_p]
+        L.dabgpu_ingest_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.dabgpu_ingest_submit.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.dabgpu_ingest_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dabgpu_ingest_consumed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -474,6 +481,46 @@ class StreamBank:
         out = np.zeros(self.n, dtype=np.dtype(STREAM_STATUS_DTYPE))
         check(lib().dabgpu_stream_bank_status(self._h, _ptr(out), Context._stream(stream)), "dabgpu_stream_bank_status")
         return out
+
+
+class IngestPipe:
+    """dabgpu_ingest: ring of pinned host buffers + device twins + a copy stream (include/dabgpu.h)"""
+
+    def __init__(self, ctx, buffer_bytes, depth=2):
+        self._ctx = ctx
+        self.bytes = buffer_bytes
+        self._h = C.c_void_p()
+        check(lib().dabgpu_ingest_create(ctx._h, buffer_bytes, depth, C.byref(self._h)), "dabgpu_ingest_create")
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_ingest_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def acquire(self):
+        """-> numpy uint8 view of the next pinned buffer"""
+        import numpy as np
+        p = C.c_void_p()
+        check(lib().dabgpu_ingest_acquire(self._h, C.byref(p)), "dabgpu_ingest_acquire")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.bytes,))
+
+    def submit(self, n_bytes):
+        """starts the copy of the acquired buffer -> device pointer (int) of its twin"""
+        d = C.c_void_p()
+        check(lib().dabgpu_ingest_submit(self._h, n_bytes, C.byref(d)), "dabgpu_ingest_submit")
+        return d.value
+
+    def wait(self, d_buffer, stream=None):
+        check(lib().dabgpu_ingest_wait(self._h, C.c_void_p(d_buffer), Context._stream(stream)), "dabgpu_ingest_wait")
+
+    def consumed(self, d_buffer, stream=None):
+        check(lib().dabgpu_ingest_consumed(self._h, C.c_void_p(d_buffer), Context._stream(stream)), "dabgpu_ingest_consumed")
 
 
 class DabPlusBank:

@@ -526,6 +526,25 @@ int dabgpu_hard_bytes_to_soft_bits(dabgpu_ctx *ctx, const uint8_t *d_bytes, size
 int dabgpu_soft_bits_to_hard_bytes_host_sync(dabgpu_ctx *ctx, const int8_t *h_bits, size_t n_bytes, uint8_t *h_bytes);
 int dabgpu_hard_bytes_to_soft_bits_host_sync(dabgpu_ctx *ctx, const uint8_t *h_bytes, size_t n_bytes, int8_t *h_bits);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Ingest pipe: the host -> device hand-over of capture bytes.  Replaces the reader thread -> OFDM_Demod::Process hand-over
+ * of examples/app_helpers/app_ofdm_blocks.h:45-58 and the memcpy of OFDM_Demod::ReadSymbols (src/ofdm/ofdm_demodulator.cpp:550-577).
+ * A ring of `depth` PINNED host buffers with device twins and a copy stream of its own:
+ *     dabgpu_ingest_acquire(pipe, &h)            fill h (e.g. fread straight into it; capture format, 2 B per sample for raw_u8)
+ *     dabgpu_ingest_submit(pipe, bytes, &d)      asynchronous copy on the pipe's copy stream; d = device twin
+ *     dabgpu_ingest_wait(pipe, d, s)             stream s waits for the copy into d (right before the kernels that read it: a batch may be copied ahead)
+ *     ... enqueue kernels reading d on s (dabgpu_ofdm_demod_frames_raw, dabgpu_stream_bank_process_raw, ...)
+ *     dabgpu_ingest_consumed(pipe, d, s)         d may be overwritten once those kernels have run
+ * With depth >= 2 the copy of batch k + 1 overlaps the demodulation of batch k; acquire blocks only while the ring is full.
+ * One pipe = one producer thread. */
+typedef struct dabgpu_ingest dabgpu_ingest;
+int dabgpu_ingest_create(dabgpu_ctx *ctx, size_t buffer_bytes, int depth, dabgpu_ingest **out);
+void dabgpu_ingest_destroy(dabgpu_ingest *pipe);
+int dabgpu_ingest_acquire(dabgpu_ingest *pipe, void **h_buffer);
+int dabgpu_ingest_submit(dabgpu_ingest *pipe, size_t bytes, void **d_buffer);
+int dabgpu_ingest_wait(dabgpu_ingest *pipe, const void *d_buffer, void *compute_stream);
+int dabgpu_ingest_consumed(dabgpu_ingest *pipe, const void *d_buffer, void *compute_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,10 @@
 // produces is written to files that tests/test_gpu_cpp_mirror.py compares byte for byte with the CPU oracle.
 //
 //   mirror_harness <iq.c32> <out_dir> <block_size> [<start_cu> <length_cu> <eep_level> <eep_type_b>]...
+// DABGPU_HARNESS_BENCH=1: nothing is written; the harness times the whole run (frames/s against the 10.42 frames/s of a live
+// signal) and every DecodeFIBGroup / DecodeCIF call (one synchronous launch + two copies each) and prints one JSON line.
+#include <algorithm>
+#include <chrono>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +24,10 @@
 #include "dab/msc/msc_decoder.h"
 #include "ofdm/ofdm_helpers.h"
 
+static bool g_bench = false;
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void append(const std::string& path, const void* p, size_t n) {
+    if (g_bench) return;
     std::ofstream f(path, std::ios::binary | std::ios::app);
     f.write(reinterpret_cast<const char*>(p), (std::streamsize)n);
 }
@@ -32,6 +39,8 @@ int main(int argc, char** argv) {
     std::ifstream in(argv[1], std::ios::binary);
     if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
 
+    g_bench = std::getenv("DABGPU_HARNESS_BENCH") != nullptr;
+    std::vector<double> lat_fib, lat_cif;
     const DAB_Parameters dab = get_dab_parameters(1);
     const char* mode_env = std::getenv("DABGPU_HARNESS_MODE");
     const int tx_mode = mode_env ? std::atoi(mode_env) : 1;
@@ -75,12 +84,14 @@ int main(int argc, char** argv) {
         auto msc_bits = bits.subspan((size_t)dab.nb_fic_bits, (size_t)dab.nb_msc_bits);
         for (int c = 0; c < dab.nb_cifs; c++) {                                         // basic_fic_runner.cpp:44-48
             auto grp = fic_bits.subspan((size_t)c * dab.nb_fib_cif_bits, (size_t)dab.nb_fib_cif_bits);
+            const double t_fib = now_us();
             fic.DecodeFIBGroup(grp, (size_t)c);
+            lat_fib.push_back(now_us() - t_fib);
             const uint32_t m = fic.GetLastCrcMask();
             const uint64_t e = fic.GetLastPathError();
             append(out + "/fic_status.bin", &m, 4);
             append(out + "/fic_status.bin", &e, 8);
-            if (c == 0) {                                                               // DAB_Viterbi_Decoder used directly, fic_decoder.cpp:74-87
+            if (c == 0 && !g_bench) {                                                   // DAB_Viterbi_Decoder used directly, fic_decoder.cpp:74-87
                 uint8_t raw[96];
                 vit.reset();
                 size_t used = vit.update(grp, GetPunctureCode(16), 128 * 21);
@@ -95,12 +106,14 @@ int main(int argc, char** argv) {
         for (int c = 0; c < dab.nb_cifs; c++) {                                         // basic_dab_plus_channel.cpp:47-51
             auto cif = msc_bits.subspan((size_t)c * dab.nb_cif_bits, (size_t)dab.nb_cif_bits);
             for (size_t s = 0; s < msc.size(); s++) {
+                const double t_cif = now_us();
                 auto bytes = msc[s]->DecodeCIF(cif);
+                lat_cif.push_back(now_us() - t_cif);
                 const uint32_t nb = (uint32_t)bytes.size();
                 append(out + "/msc_" + std::to_string(s) + ".bin", &nb, 4);
                 append(out + "/msc_" + std::to_string(s) + ".bin", bytes.data(), bytes.size());
             }
-            if (deint) {
+            if (deint && !g_bench) {
                 const size_t nbits = (size_t)subs[0].length * 64;
                 std::vector<viterbi_bit_t> lf(nbits);
                 deint->Consume(cif.subspan((size_t)subs[0].start_address * 64, nbits));
@@ -111,12 +124,30 @@ int main(int argc, char** argv) {
         }
     });
 
+    if (g_bench) demod->EnableDebugBuffers(false);
     std::vector<std::complex<float>> buf(block);
+    const double t_run = now_us();
     while (in) {
         in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(block * sizeof(std::complex<float>)));
         const size_t got = (size_t)in.gcount() / sizeof(std::complex<float>);
         if (got == 0) break;
         demod->Process(tcb::span<const std::complex<float>>(buf.data(), got));
+    }
+    if (g_bench) {
+        const double sec = (now_us() - t_run) * 1e-6;
+        auto stats = [](std::vector<double>& v, double& med, double& p99, double& mx) {
+            med = p99 = mx = 0;
+            if (v.empty()) return;
+            std::sort(v.begin(), v.end());
+            med = v[v.size() / 2]; p99 = v[(size_t)((double)(v.size() - 1) * 0.99)]; mx = v.back();
+        };
+        double fm, fp, fx, cm, cp, cx;
+        stats(lat_fib, fm, fp, fx); stats(lat_cif, cm, cp, cx);
+        std::printf("{\"frames\": %d, \"seconds\": %.4f, \"frames_per_s\": %.2f, \"x_realtime\": %.2f, \"sub_channels\": %zu, "
+                    "\"decode_fib_group_us\": {\"median\": %.1f, \"p99\": %.1f, \"max\": %.1f, \"calls\": %zu}, "
+                    "\"decode_cif_us\": {\"median\": %.1f, \"p99\": %.1f, \"max\": %.1f, \"calls\": %zu}}\n",
+                    n_frames, sec, n_frames / sec, n_frames / sec / (2.048e6 / 196608.0), msc.size(), fm, fp, fx, lat_fib.size(), cm, cp, cx, lat_cif.size());
+        return 0;
     }
     std::printf("frames=%d read=%d desync=%d state=%d signal_avg=%.9g\n", n_frames, demod->GetTotalFramesRead(),
                 demod->GetTotalFramesDesync(), (int)demod->GetState(), demod->GetSignalAverage());
