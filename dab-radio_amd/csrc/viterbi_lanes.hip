@@ -267,22 +267,20 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
     unsigned char* out = reinterpret_cast<unsigned char*>(Dd.d_out);
     // The walk is done on pos = rotr6(state, QN - 3) (vl_gather).  Chunks of 24 steps: n_steps = 8 m + 6 and the last step ends in
     // layout L_0, so every chunk starts in layout L_0 at bit 7 of a byte -- phases and byte boundaries are compile-time.
-    // Decision words do not depend on the survivor: 24 steps are fetched ahead of the 24 being walked.
+    // One chunk of decision words (24 steps = 12 sixteen-byte loads per lane) is fetched, then walked.  The earlier version fetched
+    // the next chunk while walking this one; its second set of 48 registers spilled under the 128-VGPR budget of the forward pass,
+    // and the walk of all resident wavefronts is bound by HBM throughput, not by the latency of one wavefront's loads.
     uint32_t pos = ((es >> 3) | (es << 3)) & 63u;                  // rotr6(es, 3): layout L_0 after the last step
     constexpr int CB = 24;
-    uint32_t cx[CB], cy[CB], nx[CB], ny[CB];
-    // words of steps th - u, u = 0..23, th odd: pair (th - 2 v) >> 1 holds step th - 2 v - 1 in .x .y and step th - 2 v in .z .w
-    auto fetch = [&](int th, uint32_t (&ax)[CB], uint32_t (&ay)[CB]) {
+    uint32_t cx[CB], cy[CB];
+    for (int th = T - 1; th >= 6; th -= CB) {
+        // words of steps th - u, u = 0..23, th odd: pair (th - 2 v) >> 1 holds step th - 2 v - 1 in .x .y and step th - 2 v in .z .w
 #pragma unroll
         for (int v = 0; v < CB / 2; v++) {
             const int pr = (th >> 1) - v;
             const u4v q4 = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256) + lane);
-            ax[2 * v] = q4.z; ay[2 * v] = q4.w; ax[2 * v + 1] = q4.x; ay[2 * v + 1] = q4.y;
+            cx[2 * v] = q4.z; cy[2 * v] = q4.w; cx[2 * v + 1] = q4.x; cy[2 * v + 1] = q4.y;
         }
-    };
-    fetch(T - 1, cx, cy);
-    for (int th = T - 1; th >= 6; th -= CB) {
-        fetch(th - CB, nx, ny);
 #pragma unroll
         for (int ub = 0; ub < CB; ub += 8) {
             if (th - ub >= 6) {                                            // wave-uniform; steps come in whole bytes
@@ -300,8 +298,6 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
                 if (live) out[k] = (unsigned char)(acc ^ pb);
             }
         }
-#pragma unroll
-        for (int u = 0; u < CB; u++) { cx[u] = nx[u]; cy[u] = ny[u]; }
     }
 
     // ---- optional FIB CRC16 (fic_decoder.cpp:19-31,103-116) over the lane's own bytes + result record ----

@@ -37,6 +37,7 @@ def counter_average(path, counter, kernel="ofdm_demod_kernel"):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
     out = os.path.join(root, f"summary_{tag}")
     os.makedirs(out, exist_ok=True)
     stats = find(os.path.join(root, "prof"), "*kernel_stats.csv")
@@ -57,7 +58,7 @@ def main():
         traffic["fetch_bytes_corrected_x2"] = traffic["fetch_kb_avg"] * 1024 * 2
         traffic["write_bytes"] = traffic["write_kb_avg"] * 1024
         traffic["bytes_per_launch"] = traffic["fetch_bytes_corrected_x2"] + traffic["write_bytes"]
-        traffic["source"] = (f"profiles/r01/pmc_fetch_size_{tag}.csv + pmc_write_size_{tag}.csv (separate rocprofv3 --pmc passes; "
+        traffic["source"] = (f"profiles/{rnd}/pmc_fetch_size_{tag}.csv + pmc_write_size_{tag}.csv (separate rocprofv3 --pmc passes; "
                              "FETCH_SIZE x2 per MI355X_MICROARCH.md HBM section; KB units)")
     with open(os.path.join(out, "hbm_traffic.json"), "w") as g:
         json.dump(traffic, g, indent=1)
