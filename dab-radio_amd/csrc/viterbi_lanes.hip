@@ -177,8 +177,11 @@ __device__ __forceinline__ void vl_renorm(s2 (&N)[32], uint32_t& total) {
 // up to 1024 groups get a SIMD each.  Single-wavefront workgroups are placed one by one and a few per cent of them double up on
 // a SIMD -- and one doubled SIMD (1.4 ms instead of 0.9) sets the time of the whole launch (tools/ubench/hwid_probe.hip).
 // With at most one group per CU, or more groups than SIMDs, single-wavefront workgroups are ~5 % faster (no CU-level sharing).
-template <int TIE, int VL_WAVES>
-__global__ __launch_bounds__(64 * VL_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// OCC = wavefronts per SIMD the register budget is set for: 4 (114 VGPRs, no scratch) or 5 (96 VGPRs, 22 spills): with 4097..5120
+// groups five per SIMD finish in ONE round instead of a full round + a tail of lone wavefronts (4096 ensembles of the canonical multiplex
+// = 4608 groups: 5.10 -> 4.92 ms)
+template <int TIE, int VL_WAVES, int OCC = 4>
+__global__ __launch_bounds__(64 * VL_WAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups, const dabgpu_cw_desc* __restrict__ descs,
                       const uint32_t* __restrict__ sym, uint32_t* __restrict__ dec, dabgpu_cw_result* __restrict__ results,
                       const dabgpu_vit_tables* __restrict__ tables)
@@ -581,7 +584,12 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
 #define VL_GO(TIE, W) hipLaunchKernelGGL((vit_lanes_kernel<TIE, W>), dim3((unsigned)((n_groups + (W) - 1) / (W))), dim3(64 * (W)), 0, stream, \
                                          d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables)
     const bool four = n_groups > (size_t)n_cu && n_groups <= (size_t)4 * n_cu;
-    if (tie_rule) { if (four) VL_GO(1, 4); else VL_GO(1, 1); }
+    const bool five_per_simd = n_groups > (size_t)16 * n_cu && n_groups <= (size_t)20 * n_cu;        // 4 SIMDs per CU
+    if (five_per_simd) {
+        if (tie_rule) hipLaunchKernelGGL((vit_lanes_kernel<1, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables);
+        else hipLaunchKernelGGL((vit_lanes_kernel<0, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables);
+    }
+    else if (tie_rule) { if (four) VL_GO(1, 4); else VL_GO(1, 1); }
     else { if (four) VL_GO(0, 4); else VL_GO(0, 1); }
 #undef VL_GO
     return hipGetLastError();
