@@ -20,7 +20,7 @@ torch.distributed.run -- as a child process, before this process touches the GPU
 
 `roofline` (dominant kernel ofdm_demod_kernel): achieved = algorithmic bytes per launch (1,803,264 B/frame x frames) /
 mean launch duration measured with HIP events INSIDE the timed loop (an event pair around every 8th demod launch on the launch
-stream); `cpu_baseline` = the oracle (C port of the reference algorithm) timed on this box's host cores on a bounded sample.
+stream; around every launch when K <= 100); `cpu_baseline` = the oracle (C port of the reference algorithm) timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -375,6 +375,7 @@ def main():
         torch.cuda.synchronize()
 
     evs = []                                                  # (start, stop) event pairs around demod launches inside the timed loop
+    ev_every = 8 if args.steps > 100 else 1                   # every 8th launch of a long run, every launch of a short one
 
     if args.workload == "demod":
         F = args.frames
@@ -394,7 +395,7 @@ def main():
             ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
 
         def step(k, timed=False):
-            if timed and k % 8 == 0:
+            if timed and k % ev_every == 0:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); demod_launch(); b.record()
                 evs.append((a, b))
@@ -456,7 +457,7 @@ def main():
         check = pipe.check(dabgpu)
 
     if rank == 0:
-        assert k_ms <= ms_per_step * 1.001, f"demod launch {k_ms} ms cannot exceed the step {ms_per_step} ms it is part of"
+        assert k_ms <= ms_per_step * 1.02, f"demod launch {k_ms} ms cannot exceed the step {ms_per_step} ms it is part of (2 % event jitter allowed)"
         value = world * units * args.steps / elapsed
         if args.workload == "demod":
             workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
