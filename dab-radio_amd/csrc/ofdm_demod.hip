@@ -102,7 +102,7 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
 // LDS of one workgroup (float2 elements unless noted)
 constexpr int LDS_TW2 = 7 * 64;            // pass-2 twiddles [k][lane]
 constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank instantiations only: their split loader needs the registers)
-constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 4 * sizeof(f2) + (LDS_TW2 + LDS_TW3) * sizeof(f2);
+constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW2 + LDS_TW3) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
 // GetFrameFFT() / GetFrameDataVec()): their stores and per-carrier branches leave the symbol loop
@@ -131,8 +131,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     f2* bufA = reinterpret_cast<f2*>(smem);                              // 4 x 576 x 8 B
     f2* patch0 = bufA;
     int8_t* obuf = reinterpret_cast<int8_t*>(bufA + 4 * WAVE_PATCH);     // 3072 B
-    f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 4 x 8 B
-    f2* tw2l = red + 4;                                                  // 7 x 64 x 8 B
+    f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 2 x 4 x 8 B
+    f2* tw2l = red + 8;                                                  // 7 x 64 x 8 B
     f2* tw3l = tw2l + LDS_TW2;                                           // 7 x 8 x 8 B
 
     const int t = threadIdx.x;
@@ -286,7 +286,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             }
             p.x = wave_tree_sum(p.x, lane);
             p.y = wave_tree_sum(p.y, lane);
-            if (lane == 0) red[wave] = p;
+            if (lane == 0) red[4 * (i & 1) + wave] = p;      // (two sets: the next symbol's sums may be written before thread 0 has read these)
         }
         // ---- pass 1: radix 4 on positions p + 512 j (p = 2t, 2t+1); outputs stay in place ----
         {
@@ -295,6 +295,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
             b1 = cmul(b1, w1a[0]); b2 = cmul(b2, w1a[1]); b3 = cmul(b3, w1a[2]);
             c1 = cmul(c1, w1b[0]); c2 = cmul(c2, w1b[1]); c3 = cmul(c3, w1b[2]);
+            // every wave is past its use of bufA / its transpose patch / obuf for the previous symbol.  This barrier sits HERE and not
+            // at the end of the symbol: the PLL and the radix-4 arithmetic above need no LDS, so a wave that finished the previous
+            // symbol early runs them while the slower waves catch up -- one skew-absorbing barrier per symbol instead of two
+            __syncthreads();
             f4* dst = reinterpret_cast<f4*>(bufA + 2 * t);
             dst[0]                  = f4{b0.x, b0.y, c0.x, c0.y};        // block j of 512 positions starts at j * WAVE_PATCH
             dst[WAVE_PATCH / 2]     = f4{b1.x, b1.y, c1.x, c1.y};
@@ -307,7 +311,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         if (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS) store_row(i - 2);
         __syncthreads();                       // the only cross-wave exchange of the transform
         if (do_corr && t == 0) {
-            const f2 r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+            const f2* rr = red + 4 * (i & 1);
+            const f2 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
             cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
         }
         // this symbol's samples are consumed: the next symbol's loads go into the same registers now
@@ -394,8 +399,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                 }
             }
         }
-        __syncthreads();             // obuf complete; also every wave is past its bufA reads before the next pass-1 writes
-        if (emit && i == sym_end) store_row(i - 1);                      // (otherwise stored by the next symbol, ahead of its prefetch)
+        if (emit && i == sym_end) { __syncthreads(); store_row(i - 1); }  // (otherwise stored by the next symbol, ahead of its prefetch)
     };
     // two symbols per trip so that the bins kept for the next DQPSK change hands by name, not by 12 register moves
     for (int i = out0; i <= sym_end; i += 2) {
