@@ -22,11 +22,10 @@ dev = torch.device("cuda", 0)
 stride = 196608 + a.pad
 if a.data == "ofdm":
     import dabgpu
-    src = open(os.path.join(ROOT, "bench.py")).read().split("def cpu_baseline")[0]
-    ns = {"__file__": os.path.join(ROOT, "bench.py")}
-    exec(compile(src, "bench_head", "exec"), ns)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dabsynth
     prs, mapper, _ = dabgpu.host_tables()
-    iqc, _, freq = ns["synth_frames"](F, 1000, dev, mapper, prs)
+    iqc, _, freq = dabsynth.random_frames(F, 1000, dev, mapper, prs)
     iq0 = torch.view_as_real(iqc).contiguous()
 elif a.data == "zeros":
     iq0 = torch.zeros((F, 196608, 2), dtype=torch.float32, device=dev)
