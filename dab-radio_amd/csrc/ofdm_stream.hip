@@ -137,14 +137,10 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
         }
         if (t == 0) { S.pending = PEND_NONE; B.sync_active[s] = 0; }
         __syncthreads();
-    } else if (S.pending == PEND_DEMOD) {
-        __syncthreads();
-        if (t == 0) {                                                      // :563-576
-            S.total_frames_read++; S.n_out++; S.frame_length = 0; S.state = ST_READING_NULL_PRS;
-            S.pending = PEND_NONE; B.desc[s].slot = -1;
-        }
-        __syncthreads();
     }
+    // (a demodulation request never stays pending: the frame's bookkeeping is done where the request is made, see ReadSymbols below)
+    if (t == 0) B.desc[s].slot = -1;
+    __syncthreads();
 
     // ---- UpdateSignalAverage over the whole block, once per process() (:934-950); windows from stream_l1_kernel ----
     if (!S.avg_done) {
@@ -273,7 +269,11 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
                     d.split = have + (have & 1);
                     d.tail_off = pos0 + (have & 1);
                     B.desc[s] = d;
-                    S.pending = PEND_DEMOD;
+                    // The demodulation of this frame runs in THIS round (the round's kernel order is advance, copy, demod, phase, sync),
+                    // so the state machine does the frame's bookkeeping now (:563-576) and reads on into the next NULL + PRS window: one
+                    // round per frame instead of two.  The reference's order is kept -- the fine-frequency update of frame k - 1 (phase
+                    // kernel) precedes the synchronisation of frame k (sync kernel) inside the round.
+                    S.total_frames_read++; S.n_out++; S.frame_length = 0; S.state = ST_READING_NULL_PRS;
                 }
             }
             __syncthreads();
@@ -497,8 +497,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     }
     const float *d_prs = nullptr, *d_prs_time_ref = nullptr;               // PRS spectrum / coarse-sync reference of the bank's mode
     if ((st = dabgpu_mode_sync_tables(c, G.mode, &d_prs, &d_prs_time_ref))) return st;
-    // rounds every locked stream needs: (sync, demod) per frame that can complete inside this block, plus one to drain
-    const int blind_rounds = 2 * (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
+    // rounds every locked stream needs: one per frame that can complete inside this block (the demodulation of frame k - 1 and the
+    // synchronisation of frame k share a round), plus one for the partial frame at either end and one to drain
+    const int blind_rounds = (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 2;
     int h_not_done = 1;
     for (int round = 0; h_not_done != 0; round++) {
         CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
@@ -508,8 +509,6 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, static_cast<const uint8_t*>(d_iq),
                            stream_stride_samples);
         CK(hipGetLastError());
-        CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
-                              nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active, G.mode, s));
         if (G.mode == 1) {
             CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
                                         n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
@@ -519,6 +518,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         }
         CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
                                     (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, G.n_sym, G.n_fft, s));
+        // (after the phase kernel: the synchroniser of frame k sees the fine frequency the phase of frame k - 1 left, as in the reference)
+        CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
+                              nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active, G.mode, s));
         if (round + 1 >= blind_rounds) {
             CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
             CK(hipStreamSynchronize(s));
