@@ -498,8 +498,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     const float *d_prs = nullptr, *d_prs_time_ref = nullptr;               // PRS spectrum / coarse-sync reference of the bank's mode
     if ((st = dabgpu_mode_sync_tables(c, G.mode, &d_prs, &d_prs_time_ref))) return st;
     // rounds every locked stream needs: one per frame that can complete inside this block (the demodulation of frame k - 1 and the
-    // synchronisation of frame k share a round), plus one for the partial frame at either end and one to drain
-    const int blind_rounds = (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 2;
+    // synchronisation of frame k share a round) plus one for the partial frame at the end; a stream that needs more (re-acquisition)
+    // is caught by the counter read back after these
+    const int blind_rounds = (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
     int h_not_done = 1;
     for (int round = 0; h_not_done != 0; round++) {
         CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
