@@ -27,9 +27,17 @@
 
 // development builds (tools/build_exp.sh + tools/kbench2.py; never set in the product build): timing-only ablations,
 //   2 = memory traffic only (loads, barriers, stores; no arithmetic)      4 = arithmetic only (one symbol loaded once)
+//   8 = phase clock: every wave accumulates core-clock cycles per phase of the symbol loop and writes them (with the elapsed
+//       constant-rate clock) to the buffer passed as d_fft; results stay valid (tools/kphase.py)
 #ifndef DABGPU_EXP
 #define DABGPU_EXP 0
 #endif
+// wave priority by phase of the symbol loop, one hex digit per point (F = leave as it is): start of symbol, before the
+// correlation, after barrier 1, after barrier 2, after the last radix-8 pass, end of the demapper
+#ifndef DABGPU_PRIO
+#define DABGPU_PRIO 0x0F3FFF
+#endif
+#define PRIO_AT(k) do { constexpr int prio_ = (DABGPU_PRIO >> (4 * (k))) & 0xF; if (prio_ != 0xF) __builtin_amdgcn_s_setprio(prio_); } while (0)
 
 namespace dabgpu {
 
@@ -39,21 +47,30 @@ namespace dabgpu {
 enum { SRC_C32 = 0, SRC_U8 = 1, SRC_S8 = 2, SRC_S16 = 3 };
 template <int SRC> struct src_bytes { static constexpr int value = (SRC == SRC_C32) ? 8 : (SRC == SRC_S16) ? 4 : 2; };
 
-// two consecutive IQ samples starting at sample index n (n even) of a frame -> (re0, im0, re1, im1)
+// two consecutive IQ samples of a frame -> (re0, im0, re1, im1), read through a buffer descriptor of the frame:
+// voffset = this lane's loop-invariant byte offset, soffset = the uniform byte
+// offset of (symbol, slot) -- all per-symbol address arithmetic is scalar, none is left on the vector ALU, which is the unit this
+// kernel is bound by (profiles/r02/ab_notes.md).  Loads past the frame return zero.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr int BUF_NT = 2;                  // cache-policy operand: non-temporal
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 template <int SRC>
-__device__ __forceinline__ f4 load_pair(const uint8_t* __restrict__ frame_base, unsigned n) {
-    const uint8_t* p = frame_base + (size_t)(n * (unsigned)src_bytes<SRC>::value);
+__device__ __forceinline__ f4 load_pair_buf(__amdgpu_buffer_rsrc_t rs, unsigned lane_bytes, unsigned uniform_bytes) {
     if constexpr (SRC == SRC_C32) {
-        return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));   // streamed once: keep it out of the way in L2 (-2 %)
+        const u4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_bytes, (int)uniform_bytes, BUF_NT);   // streamed once (-2 %)
+        return f4{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
     } else if constexpr (SRC == SRC_S16) {
         raw_words<2> r;
-        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        const u2v q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_bytes, (int)uniform_bytes, 0);
         r.w[0] = q.x; r.w[1] = q.y;
         return f4{decode<K_S16, 2, false>(r, 0), decode<K_S16, 2, false>(r, 1), decode<K_S16, 2, false>(r, 2), decode<K_S16, 2, false>(r, 3)};
     } else {
         constexpr comp_kind K = (SRC == SRC_U8) ? K_U8 : K_S8;
         raw_words<1> r;
-        r.w[0] = *reinterpret_cast<const uint32_t*>(p);
+        r.w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)lane_bytes, (int)uniform_bytes, 0);
         return f4{decode<K, 1, false>(r, 0), decode<K, 1, false>(r, 1), decode<K, 1, false>(r, 2), decode<K, 1, false>(r, 3)};
     }
 }
@@ -100,9 +117,9 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
 }
 
 // LDS of one workgroup (float2 elements unless noted)
-constexpr int LDS_TW2 = 7 * 64;            // pass-2 twiddles [k][lane]
+constexpr int LDS_TW1 = 6 * 256;           // pass-1 twiddles [thread][6]: a private 48-byte slot per thread (registers parked in LDS)
 constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank instantiations only: their split loader needs the registers)
-constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW2 + LDS_TW3) * sizeof(f2);
+constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW1 + LDS_TW3) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
 // GetFrameFFT() / GetFrameDataVec()): their stores and per-carrier branches leave the symbol loop
@@ -114,7 +131,11 @@ constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS +
 // of gfx9 is in order, therefore the previous symbol's soft-bit store is issued BEFORE the prefetch (from the middle of the
 // next symbol), never between a prefetch and its use.  0.438 -> 0.426 ms per 1024 frames (profiles/r02/ab_notes.md).
 template <int SRC, bool BANK, bool VIEWS = true>
+#if DABGPU_EXP & 16
+__global__ __launch_bounds__(256, 5)
+#else
 __global__ __launch_bounds__(256, VIEWS ? 3 : 4)      // (the display views need a few more registers: 3 workgroups per CU instead of spills)
+#endif
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
@@ -132,8 +153,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     f2* patch0 = bufA;
     int8_t* obuf = reinterpret_cast<int8_t*>(bufA + 4 * WAVE_PATCH);     // 3072 B
     f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 2 x 4 x 8 B
-    f2* tw2l = red + 8;                                                  // 7 x 64 x 8 B
-    f2* tw3l = tw2l + LDS_TW2;                                           // 7 x 8 x 8 B
+    f2* tw1l = red + 8;                                                  // 256 x 6 x 8 B
+    f2* tw3l = tw1l + LDS_TW1;                                           // 7 x 8 x 8 B
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -173,22 +194,27 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     for (int k = 0; k < 4; k++) gf[k] = (float)((NB_CP + 2 * t + 512 * k) & ~3) * f;
     gf[4] = (float)((2 * (t - 4)) & ~3) * f;
 
-    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048): pass 1 w_2048^{p k} (p = 2t, 2t+1) and pass 3 w_64^{(lane&7) k} stay in
-    // registers for the whole run of symbols; pass 2 w_512^{lane k} sits in LDS as [k][lane] (conflict-free 8-byte reads; the
-    // same table entries the register version held, so the arithmetic is unchanged)
-    f2 w1a[3], w1b[3];
+    // twiddles tw[m] = (cos, -sin)(2 pi m / 2048).  Pass 2 w_512^{lane k} and pass 3 w_64^{(lane&7) k} stay in registers for the
+    // whole run of symbols: they are used between two LDS round trips of the transform, where a table read would add a third.
+    // The six pass-1 twiddles w_2048^{p k} (p = 2t, 2t+1; k = 1..3) are parked in a private LDS slot of the thread and read back
+    // at the start of every symbol: the PLL in front of their use hides the latency.  Same table entries either way.
+#if !(DABGPU_EXP & 16)
 #pragma unroll
-    for (int k = 1; k < 4; k++) { w1a[k - 1] = tw[(2 * t) * k]; w1b[k - 1] = tw[(2 * t + 1) * k]; }
-    for (int idx = t; idx < LDS_TW2; idx += 256) tw2l[idx] = tw[4 * (idx & 63) * ((idx >> 6) + 1)];
+    for (int k = 1; k < 4; k++) { tw1l[6 * t + 2 * (k - 1)] = tw[(2 * t) * k]; tw1l[6 * t + 2 * (k - 1) + 1] = tw[(2 * t + 1) * k]; }
+#endif
+    f2 w2[7];
+#pragma unroll
+    for (int k = 1; k < 8; k++) w2[k - 1] = tw[4 * lane * k];
     f2 w3[7];
-    if constexpr (BANK) {
+    constexpr bool W3_LDS = BANK || (DABGPU_EXP & 16);
+    if constexpr (W3_LDS) {
         if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
     } else {
 #pragma unroll
         for (int k = 1; k < 8; k++) w3[k - 1] = tw[32 * (lane & 7) * k];
     }
     __syncthreads();
-    const f2* const w2p = tw2l + lane;            // w2[k] = w2p[64 (k - 1)]
+    const f4* const w1p = reinterpret_cast<const f4*>(tw1l + 6 * t);      // (w1a[k], w1b[k]) = w1p[k - 1]
     const f2* const w3p = tw3l + (lane & 7);      // w3[k] = w3p[8 (k - 1)]
 
     // LDS addresses (float2 element indices); every per-k term below is an instruction immediate
@@ -214,7 +240,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
     for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
 
-    const unsigned lane_off = 2u * (unsigned)t, head_off = 2u * (unsigned)((t >= 4) ? t - 4 : 0);    // sample offsets of this lane
+    constexpr unsigned SB = BANK ? 8u : (unsigned)src_bytes<SRC>::value;                              // bytes per sample of the frame
+    const unsigned lane_off = 2u * SB * (unsigned)t, head_off = 2u * SB * (unsigned)((t >= 4) ? t - 4 : 0);   // byte offsets of this lane
+    const __amdgpu_buffer_rsrc_t iq_rs = frame_rsrc(fbase, NB_FRAME_SAMPLES * SB);
+    const __amdgpu_buffer_rsrc_t bits_rs = frame_rsrc(bits + out_frame * bits_frame_stride, (NB_FRAME_SYMBOLS - 1) * NB_SYM_BITS);
     // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head (threads 0..3 have no head
     // sample: they load a valid address and never use it, so that the load stays unconditional inside the wave)
     auto load_symbol = [&](int i, f4 (&v)[4], f4& h) __attribute__((always_inline)) {
@@ -225,24 +254,33 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
             if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0));   // uniform per workgroup
         } else {
-            // uniform base per (symbol, slot) + one loop-invariant 32-bit lane offset
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = load_pair<SRC>(fbase + (sym + NB_CP + 512 * k) * src_bytes<SRC>::value, lane_off);
-            if (dc) h = load_pair<SRC>(fbase + sym * src_bytes<SRC>::value, head_off);
+            for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(iq_rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * SB);
+            if (dc) h = load_pair_buf<SRC>(iq_rs, head_off, (unsigned)sym * SB);
         }
     };
-    // the 3072 soft bits of data symbol `row` + 1 sit de-interleaved in obuf: 192 lanes x 16-byte stores
-    auto store_row = [&](const int row) __attribute__((always_inline)) {
-        if (t < NB_SYM_BITS / 16) {
-            const uint4 o = reinterpret_cast<const uint4*>(obuf)[t];
-            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * bits_frame_stride + (size_t)row * NB_SYM_BITS);
-            typedef unsigned u4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u4v{o.x, o.y, o.z, o.w}, reinterpret_cast<u4v*>(dst + t));
-        }
+    // the 3072 soft bits of data symbol `row` + 1 sit de-interleaved in obuf: 192 lanes x 16-byte stores (LDS read and HBM store are
+    // separate steps so that the read can be issued ahead of the radix-4 exchange writes and the store behind them)
+    auto row_read = [&]() __attribute__((always_inline)) -> u4v {
+        const uint4 o = reinterpret_cast<const uint4*>(obuf)[(t < NB_SYM_BITS / 16) ? t : 0];
+        return u4v{o.x, o.y, o.z, o.w};
     };
+    auto row_write = [&](const int row, const u4v o) __attribute__((always_inline)) {
+        if (t < NB_SYM_BITS / 16) __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, 16 * t, row * NB_SYM_BITS, BUF_NT);
+    };
+    auto store_row = [&](const int row) __attribute__((always_inline)) { row_write(row, row_read()); };
 
     f4 v[4], h = f4{0.0f, 0.0f, 0.0f, 0.0f};
     load_symbol(out0, v, h);
+#if DABGPU_EXP & 8
+    unsigned long long ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}, ph_last, ph_t0, ph_r0;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_r0), "=s"(ph_t0) :: "memory");
+    ph_last = ph_t0;
+#define PHASE_STAMP(k) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                            ph_acc[k] += now_ - ph_last; ph_last = now_; } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
 
     // one symbol; pv = the six active bins of symbol i - 1 (in), cur = those of symbol i (out)
     auto symbol = [&](const int i, const f2 (&pv)[6], f2 (&cur)[6]) __attribute__((always_inline)) {
@@ -267,6 +305,12 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #endif
 
         // ---- PLL ----
+        PRIO_AT(0);
+#if DABGPU_EXP & 16
+        const f4 w1_1 = f4{0.6f, 0.8f, 0.8f, 0.6f}, w1_2 = w1_1, w1_3 = w1_1;       // timing only
+#else
+        const f4 w1_1 = w1p[0], w1_2 = w1p[1], w1_3 = w1p[2];
+#endif
         f2 a[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -276,6 +320,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         }
 
         // ---- cyclic prefix correlation: tail (slot k=3) x conj(head), fixed 256-leaf tree ----
+        PRIO_AT(1);
         if (do_corr) {                                                   // uniform per workgroup
             f2 p = mk2(0.0f, 0.0f);
             if (t >= 4) {
@@ -284,32 +329,45 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                 const f2 h1 = pll1(mk2(h.z, h.w), base, step1);
                 p = conj_mul(a[3], h0) + conj_mul(a[7], h1);
             }
-            p.x = wave_tree_sum(p.x, lane);
-            p.y = wave_tree_sum(p.y, lane);
-            if (lane == 0) red[4 * (i & 1) + wave] = p;      // (two sets: the next symbol's sums may be written before thread 0 has read these)
+            const float ps = wave_tree_sum_pair(p.x, p.y);   // lane 0: sum of p.x, lane 32: sum of p.y
+            // (two sets: the next symbol's sums may be written before thread 0 has read these)
+            if ((lane & 31) == 0) reinterpret_cast<float*>(red + 4 * (i & 1) + wave)[lane >> 5] = ps;
         }
         // ---- pass 1: radix 4 on positions p + 512 j (p = 2t, 2t+1); outputs stay in place ----
         {
             f2 b0, b1, b2, b3, c0, c1, c2, c3;
             dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
             dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
-            b1 = cmul(b1, w1a[0]); b2 = cmul(b2, w1a[1]); b3 = cmul(b3, w1a[2]);
-            c1 = cmul(c1, w1b[0]); c2 = cmul(c2, w1b[1]); c3 = cmul(c3, w1b[2]);
+            b1 = cmul(b1, mk2(w1_1.x, w1_1.y)); b2 = cmul(b2, mk2(w1_2.x, w1_2.y)); b3 = cmul(b3, mk2(w1_3.x, w1_3.y));
+            c1 = cmul(c1, mk2(w1_1.z, w1_1.w)); c2 = cmul(c2, mk2(w1_2.z, w1_2.w)); c3 = cmul(c3, mk2(w1_3.z, w1_3.w));
+            PHASE_STAMP(0);                    // PLL + correlation + radix 4
+            // (the empty statement orders the arithmetic above against the barrier below: the compiler is otherwise free to sink
+            // the PLL behind it, which puts the skew wait back in front of the longest arithmetic phase)
+            asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b1.x), "+v"(b1.y), "+v"(b2.x), "+v"(b2.y), "+v"(b3.x), "+v"(b3.y),
+                              "+v"(c0.x), "+v"(c0.y), "+v"(c1.x), "+v"(c1.y), "+v"(c2.x), "+v"(c2.y), "+v"(c3.x), "+v"(c3.y));
             // every wave is past its use of bufA / its transpose patch / obuf for the previous symbol.  This barrier sits HERE and not
             // at the end of the symbol: the PLL and the radix-4 arithmetic above need no LDS, so a wave that finished the previous
             // symbol early runs them while the slower waves catch up -- one skew-absorbing barrier per symbol instead of two
             __syncthreads();
+            PHASE_STAMP(1);                    // skew barrier
+            PRIO_AT(2);
+            // the previous symbol's soft bits leave from here, not from the end of that symbol: a store issued after the prefetch
+            // below would have to complete before the prefetched samples count as arrived (in-order vmcnt).  obuf is complete since
+            // the barrier above and is not written again before the barrier below; its read goes ahead of the exchange writes so
+            // that the HBM store does not wait for them
+            const bool row_due = (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS);
+            u4v row = u4v{0u, 0u, 0u, 0u};
+            if (row_due) row = row_read();
             f4* dst = reinterpret_cast<f4*>(bufA + 2 * t);
             dst[0]                  = f4{b0.x, b0.y, c0.x, c0.y};        // block j of 512 positions starts at j * WAVE_PATCH
             dst[WAVE_PATCH / 2]     = f4{b1.x, b1.y, c1.x, c1.y};
             dst[WAVE_PATCH]         = f4{b2.x, b2.y, c2.x, c2.y};
             dst[3 * WAVE_PATCH / 2] = f4{b3.x, b3.y, c3.x, c3.y};
+            if (row_due) row_write(i - 2, row);
         }
-        // the previous symbol's soft bits leave from here, not from the end of that symbol: a store issued after the prefetch
-        // below would have to complete before the prefetched samples count as arrived (in-order vmcnt).  obuf is complete since
-        // the end-of-symbol barrier and is not written again before the barrier below.
-        if (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS) store_row(i - 2);
         __syncthreads();                       // the only cross-wave exchange of the transform
+        PHASE_STAMP(2);                        // exchange writes + previous row store + barrier
+        PRIO_AT(3);
         if (do_corr && t == 0) {
             const f2* rr = red + 4 * (i & 1);
             const f2 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
@@ -324,9 +382,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = bufA[rd2 + 64 * j];
         dft8(a);
+        PHASE_STAMP(3);                        // prefetch issue + pass-2 reads + radix 8
         patch[ta_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2p[64 * (k - 1)]);
+        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
@@ -334,9 +393,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 
         // ---- pass 3: radix 8 inside 64-point blocks ----
         dft8(a);
+        PHASE_STAMP(4);                        // transpose A + radix 8
         patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], BANK ? w3p[8 * (k - 1)] : w3[k - 1]);
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], W3_LDS ? w3p[8 * (k - 1)] : w3[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
@@ -344,6 +404,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 
         // ---- pass 4: radix 8; thread ends with bins Kb + 256 k ----
         dft8(a);
+        PHASE_STAMP(5);                        // transpose B + radix 8
+        PRIO_AT(4);
 
         if (fft_out != nullptr) {
             f2* dst = fft_out + ((size_t)frame * (NB_FRAME_SYMBOLS + 1) + i) * NB_FFT + Kb;
@@ -400,12 +462,28 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             }
         }
         if (emit && i == sym_end) { __syncthreads(); store_row(i - 1); }  // (otherwise stored by the next symbol, ahead of its prefetch)
+        PHASE_STAMP(6);                        // demapper
+        PRIO_AT(5);
     };
     // two symbols per trip so that the bins kept for the next DQPSK change hands by name, not by 12 register moves
     for (int i = out0; i <= sym_end; i += 2) {
         symbol(i, prev, keep);
         if (i + 1 <= sym_end) symbol(i + 1, keep, prev);
     }
+#if DABGPU_EXP & 8
+    {
+        unsigned long long ph_r1, ph_t1;
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_r1), "=s"(ph_t1) :: "memory");
+        if (lane == 0 && fft_out_ != nullptr) {
+            float* dbg = reinterpret_cast<float*>(fft_out_) + ((size_t)unit * 4 + wave) * 12;
+#pragma unroll
+            for (int k = 0; k < 7; k++) dbg[k] = (float)ph_acc[k];
+            dbg[7] = (float)(ph_t1 - ph_t0); dbg[8] = (float)(ph_r1 - ph_r0); dbg[9] = (float)(sym_end - out0 + 1);
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            dbg[10] = (float)hwid; dbg[11] = (float)(ph_r0 & 0xFFFFFF);
+        }
+    }
+#endif
 }
 
 // ---- deterministic atan2 (same operation sequence as the oracle's dab_atan2f) ----
@@ -483,7 +561,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
+#if DABGPU_EXP & 8
+    const bool views = false;                  // d_fft is the phase-clock buffer of the soft-bits-only instantiation
+#else
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
+#endif
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
     switch (src) {
     case SRC_C32: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
