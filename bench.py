@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=64, help="full / extras: distinct seeded multiplexes the ensembles are built from")
     ap.add_argument("--extra-ensembles", type=int, default=4096, help="demod, N = 1: ensembles of extra.configs2 / configs3")
     ap.add_argument("--inflight", type=int, default=2, help="full: transmission frames in flight (one stream + context each)")
+    ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed",
+                    help="full / extras: order of the MSC soft bits in the frame-history ring (classed = DABGPU_BITS_MSC_CLASSED)")
     ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -171,9 +173,12 @@ class Pipeline:
     last, partial round leaves idle.  Dependencies kept with events: msc(j) reads the ring slots of frames j-4..j -> waits for
     demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it."""
 
-    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1):
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1):
         import dabsynth
         self.torch, self.E, self.inflight = torch, E, inflight
+        # layout of the MSC soft bits in the history ring: 1 = time-interleaver class order (DABGPU_BITS_MSC_CLASSED: the demodulator
+        # writes it for free and the decoder's gather then reads ~1.3 instead of 4.75 history bytes per soft bit), 0 = On_OFDM_Frame()
+        self.layout, self.fmt_f32 = layout, dabgpu.IQ_FORMATS.index("raw_f32l")
         self.H = 5 if inflight == 1 else 8
         prs, mapper, _ = dabgpu.host_tables()
         self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs)
@@ -195,8 +200,8 @@ class Pipeline:
 
     # the three stages of frame-slot `slot` on lane k (context k, stream k)
     def demod(self, slot, k=0):
-        self.ctxs[k].ofdm_demod_frames(self.iq_f, self.hist[:, slot], cp_corr=self.corr[k], n_frames=self.E, bits_frame_stride=self.stride,
-                                       stream=self.streams[k].cuda_stream)
+        self.ctxs[k].ofdm_demod_frames_history(self.iq_f, self.fmt_f32, self.E, self.hist[:, slot], cp_corr=self.corr[k],
+                                               bits_frame_stride=self.stride, bits_layout=self.layout, stream=self.streams[k].cuda_stream)
 
     def fic(self, slot, k=0):
         self.ctxs[k].fic_decode_frames(self.hist[:, slot], self.E, self.fic_out[k], self.fic_res[k], frame_stride=self.stride,
@@ -204,7 +209,7 @@ class Pipeline:
 
     def msc(self, slot, k=0):
         self.ctxs[k].msc_decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.msc_out[k],
-                                       4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream)
+                                       4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
 
     def step(self, on_demod=None):
         """one transmission frame of every ensemble: demod -> FIC -> MSC"""
@@ -267,9 +272,9 @@ class Pipeline:
         return out
 
 
-def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
+def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1):
     """BASELINE configs[2] (demod + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
-    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2)
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2, layout=layout)
     p.fill()
     torch.cuda.synchronize()
     t_demod, t_fic, t_msc = p.timed(p.demod, reps), p.timed(p.fic, reps), p.timed(p.msc, reps)      # one stage at a time, stream 0
@@ -300,11 +305,12 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6):
           "check": {k: chk[k] for k in ("fib_crc_pass", "fib_crc_expected", "fib_bytes_equal_transmitted")}}
     c3 = {"workload": f"BASELINE configs[3]: full FIC + MSC demod + Viterbi, {E} concurrent synthetic ensembles, 18 x 48 CU EEP 3-A", "ensembles": E,
           "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,
-          "frames_in_flight": 2, "ms_per_step_one_frame_at_a_time": t_seq, "frames_per_s_one_frame_at_a_time": E / t_seq * 1e3,
+          "frames_in_flight": 2, "history_layout": "time-interleaver class order" if layout else "natural",
+          "ms_per_step_one_frame_at_a_time": t_seq, "frames_per_s_one_frame_at_a_time": E / t_seq * 1e3,
           "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi_incl_deinterleave": t_msc},
           "algorithmic_hbm_GBps": 2.27e6 * E / (t_all * 1e-3) / 1e9,
           "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
-                       viterbi_roofline("vit_prep_ring4_kernel + vit_lanes_kernel (MSC)", p.msc_steps, t_msc, True)],
+                       viterbi_roofline(("vit_prep_ring4c_kernel" if layout else "vit_prep_ring4_kernel") + " + vit_lanes_kernel (MSC)", p.msc_steps, t_msc, True)],
           "check": chk}
     del p
     torch.cuda.empty_cache()
@@ -406,7 +412,8 @@ def main():
         E = args.ensembles
         first_unit, n_units = shard.shard_range(E * world, rank, world)
         assert n_units == E
-        pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit, inflight=args.inflight)
+        pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit, inflight=args.inflight,
+                        layout=int(args.hist_layout == "classed"))
         pipe.fill()
         units = E
 
@@ -493,7 +500,7 @@ def main():
         if world == 1 and args.workload == "demod" and not args.no_extras:
             del iq, iq_f, tx_bits, d_bits
             torch.cuda.empty_cache()
-            c2, c3 = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct)
+            c2, c3 = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"))
             line["extra"] = {"configs2": c2, "configs3": c3}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

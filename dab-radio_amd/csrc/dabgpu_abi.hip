@@ -230,7 +230,11 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 
 // ---- OFDM ----
 static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_frames, const float* d_freq, int8_t* d_bits,
-                         float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
+                         float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream,
+                         int bits_layout = DABGPU_BITS_NATURAL) {
+    if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
+        dabgpu_set_error("ofdm_demod_frames: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG;
+    }
     if (!c || !d_iq || !d_bits) { dabgpu_set_error("ofdm_demod_frames: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_demod_frames: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
@@ -245,7 +249,8 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
-                                                     (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0, s), "ofdm_demod_kernel launch");
+                                                     (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0,
+                                                     bits_layout == DABGPU_BITS_MSC_CLASSED, s), "ofdm_demod_kernel launch");
 }
 
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
@@ -273,6 +278,20 @@ int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, s
     if (st) return st;
     if ((st = dabgpu_iq_convert(c, d_raw, format, n_frames * DABGPU_NB_FRAME_SAMPLES, d_iq, stream))) return st;
     return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
+}
+
+int dabgpu_ofdm_demod_frames_history(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                                     float* d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout, void* stream) {
+    int src = -1;
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: src = 0; break;
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: src = 1; break;
+    case DABGPU_IQ_RAW_S8: src = 2; break;
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: src = 3; break;
+    default: break;
+    }
+    if (src < 0) { dabgpu_set_error("ofdm_demod_frames_history: format %d has no fused loader (float32, u8, s8, s16 little endian do)", format); return DABGPU_ERR_INVALID_ARG; }
+    return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, nullptr, nullptr, symbols_per_block, bits_frame_stride, stream, bits_layout);
 }
 
 int dabgpu_ofdm_phase_update_mode(dabgpu_ctx* c, int mode, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,

@@ -154,7 +154,7 @@ static size_t lanes_max_rows() {
 }
 
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
-                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, bool ring4, dabgpu_codeword_result* d_results,
+                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, int ring4, dabgpu_codeword_result* d_results,
                              hipStream_t s, int slot_off = 0) {
     int st = ensure_vit_tables(c);
     if (st) return st;
@@ -162,7 +162,7 @@ static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const
     if ((st = dabgpu_scratch(c, 18 + slot_off, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
     if ((st = dabgpu_scratch(c, 19 + slot_off, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, ring4 ? 1 : 0, c->d_vit_tables, device_waves(c) / 32, s), "vit_lanes_kernel launch");
+                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, device_waves(c) / 32, s), "vit_lanes_kernel launch");
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
@@ -219,7 +219,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, 0, d_results + cw0, s))) return st;
         }
         return DABGPU_OK;
     }
@@ -249,7 +249,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17 + FIC_SLOTS, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, false, d_results + cw0, s, FIC_SLOTS))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, 0, d_results + cw0, s, FIC_SLOTS))) return st;
         }
         return DABGPU_OK;
     }
@@ -269,8 +269,13 @@ extern "C" int dabgpu_fic_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_
 
 static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
                           int newest_frame_slot, const int32_t* d_slots, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
-                          size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
+                          size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream,
+                          int bits_layout = DABGPU_BITS_NATURAL) {
     if (!c || !d_hist || !h_sub || !d_out || !d_results) { dabgpu_set_error("msc_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
+        dabgpu_set_error("msc_decode_frames: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG;
+    }
+    const int classed = bits_layout == DABGPU_BITS_MSC_CLASSED;
     if (n_ens == 0 || n_sub == 0) return DABGPU_OK;
     if (hist_frames < 5 || newest_frame_slot < 0 || newest_frame_slot >= hist_frames || n_sub < 0) {
         dabgpu_set_error("msc_decode_frames: history_frames must be >= 5 (16 CIFs of delay + the 4 new ones) and 0 <= newest < history_frames");
@@ -307,7 +312,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
     if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                       d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
+                                                       d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
     // Which sub-channels go to the lane-per-codeword kernel?  The k longest can be left to viterbi_kernel (one wavefront per
     // codeword) and the rest given to vit_lanes_kernel in the same call; AUTO only compares the two pure choices k = 0 and
     // k = n_sub with the cost model of use_lane_mapping() -- a partial viterbi_kernel launch is a single lockstep round of
@@ -347,7 +352,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
         if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                           d_out, out_ens_stride, (int)off, d_slots, s), "msc_build_descs launch"))) return st;
+                                                           d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
         // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
         // stays inside the scratch bound
         size_t rows_per_gq = 0;
@@ -373,8 +378,9 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
-            // the staged gather reads the ring rows in aligned 16-byte chunks
-            const bool ring4 = ((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0);
+            // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / 4-byte aligned windows (class order)
+            const int ring4 = classed ? ((((uintptr_t)d_hist % 4 == 0) && (ens_stride % 4 == 0)) ? 2 : 0)
+                                      : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
             if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(lane_max_steps),
                                         tie_rule, ring4, d_results + cw0, s))) return st;
         }
@@ -388,6 +394,14 @@ extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, siz
                                         size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
     return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, nullptr, h_sub, n_sub, d_out, out_ens_stride,
                           d_results, tie_rule, stream);
+}
+
+extern "C" int dabgpu_msc_decode_frames_layout(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                               int newest_frame_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                                               size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, int bits_layout,
+                                               void* stream) {
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, nullptr, h_sub, n_sub, d_out, out_ens_stride,
+                          d_results, tie_rule, stream, bits_layout);
 }
 
 extern "C" int dabgpu_msc_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,

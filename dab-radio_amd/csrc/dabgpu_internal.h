@@ -59,7 +59,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
-                                               hipStream_t stream);
+                                               int classed, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
                                                float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
                                                hipStream_t stream);
@@ -122,7 +122,7 @@ extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
-                                              hipStream_t stream);
+                                              int classed, hipStream_t stream);
 
 // ---- sync ----
 extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream);

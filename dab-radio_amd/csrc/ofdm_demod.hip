@@ -118,7 +118,7 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
 
 // LDS of one workgroup (float2 elements unless noted)
 constexpr int LDS_TW1 = 6 * 256;           // pass-1 twiddles [thread][6]: a private 48-byte slot per thread (registers parked in LDS)
-constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank instantiations only: their split loader needs the registers)
+constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank and class-order instantiations only: they need the registers)
 constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW1 + LDS_TW3) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
@@ -130,7 +130,13 @@ constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS +
 // per CU) the pass-2 twiddles (14 registers) are read from a small LDS table instead.  The vector-memory counter
 // of gfx9 is in order, therefore the previous symbol's soft-bit store is issued BEFORE the prefetch (from the middle of the
 // next symbol), never between a prefetch and its use.  0.438 -> 0.426 ms per 1024 frames (profiles/r02/ab_notes.md).
-template <int SRC, bool BANK, bool VIEWS = true>
+//
+// CLASSED = true (soft bits only, frame batches only): the MSC symbols leave in time-interleaver class order -- inside every CIF row
+// of 55296 soft bits, bit i is stored at (i mod 16) * 3456 + i / 16 -- so that the channel decoder's gather, which needs for one
+// output CIF the bits of class c from the CIF that is 15 - bitrev4(c) CIFs old (cif_deinterleaver.cpp:57-68), reads each history row
+// in contiguous pieces instead of one byte in sixteen.  The permutation rides on the frequency de-interleave scatter (a second
+// set of LDS positions) and on the row store's addresses: no extra pass, no extra instructions.  The FIC symbols stay as they are.
+template <int SRC, bool BANK, bool VIEWS = true, bool CLASSED = false>
 #if DABGPU_EXP & 16
 __global__ __launch_bounds__(256, 5)
 #else
@@ -206,7 +212,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
     for (int k = 1; k < 8; k++) w2[k - 1] = tw[4 * lane * k];
     f2 w3[7];
-    constexpr bool W3_LDS = BANK || (DABGPU_EXP & 16);
+    constexpr bool W3_LDS = BANK || CLASSED || (DABGPU_EXP & 16);     // (class order keeps a second set of scatter positions instead)
     if constexpr (W3_LDS) {
         if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
     } else {
@@ -235,6 +241,9 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     pos[3] = inv_map[Kb];
     pos[4] = inv_map[256 + Kb];
     pos[5] = inv_map[512 + Kb];
+    int posc[6];                                  // the same positions in class order: (b mod 16) * 192 + b / 16; the imaginary half sits 96 further
+#pragma unroll
+    for (int k = 0; k < 6; k++) posc[k] = CLASSED ? ((pos[k] & 15) * 192 + (pos[k] >> 4)) : 0;
 
     f2 prev[6], keep[6];
 #pragma unroll
@@ -265,8 +274,16 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         const uint4 o = reinterpret_cast<const uint4*>(obuf)[(t < NB_SYM_BITS / 16) ? t : 0];
         return u4v{o.x, o.y, o.z, o.w};
     };
+    const int row_voff_c = (t / 12) * (NB_CIF_BITS / 16) + 16 * (t % 12);      // CLASSED: class t / 12, bytes 16 (t mod 12) .. + 15 of this symbol's 192
     auto row_write = [&](const int row, const u4v o) __attribute__((always_inline)) {
-        if (t < NB_SYM_BITS / 16) __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, 16 * t, row * NB_SYM_BITS, BUF_NT);
+        if (t < NB_SYM_BITS / 16) {
+            if (CLASSED && row >= NB_FIC_SYMBOLS) {                               // (uniform) symbol s of CIF q: 192 bytes per class
+                const int q = (row - NB_FIC_SYMBOLS) / NB_CIF_SYMBOLS, sy = (row - NB_FIC_SYMBOLS) % NB_CIF_SYMBOLS;
+                __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, row_voff_c, NB_FIC_SYMBOLS * NB_SYM_BITS + q * NB_CIF_BITS + sy * (NB_SYM_BITS / 16), BUF_NT);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, 16 * t, row * NB_SYM_BITS, BUF_NT);
+            }
+        }
     };
     auto store_row = [&](const int row) __attribute__((always_inline)) { row_write(row, row_read()); };
 
@@ -439,6 +456,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             // depends on A only and is shared by both quotients; outside the range (or NaN) the plain expressions run.
             const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(An[0], An[1]), An[2]), __builtin_fminf(__builtin_fminf(An[3], An[4]), An[5]));
             const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(An[0], An[1]), An[2]), __builtin_fmaxf(__builtin_fmaxf(An[3], An[4]), An[5]));
+            int bx[6], by[6];
             if (amin >= 0x1p-60f && amax <= 0x1p60f) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
@@ -450,15 +468,22 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                     qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
                     qx = __builtin_fmaf(__builtin_fmaf(-A, qx, nx), r, qx);
                     qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
-                    obuf[pos[k]] = (int8_t)to_vbit(qx);
-                    obuf[pos[k] + 1536] = (int8_t)to_vbit(qy);
+                    bx[k] = to_vbit(qx);
+                    by[k] = to_vbit(qy);
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
-                    obuf[pos[k]] = (int8_t)to_vbit(dq[k].x / An[k]);
-                    obuf[pos[k] + 1536] = (int8_t)to_vbit(-(dq[k].y / An[k]));
+                    bx[k] = to_vbit(dq[k].x / An[k]);
+                    by[k] = to_vbit(-(dq[k].y / An[k]));
                 }
+            }
+            if (CLASSED && i - 1 >= NB_FIC_SYMBOLS) {                             // (uniform) MSC symbol in class order
+#pragma unroll
+                for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + 96] = (int8_t)by[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) { obuf[pos[k]] = (int8_t)bx[k]; obuf[pos[k] + 1536] = (int8_t)by[k]; }
             }
         }
         if (emit && i == sym_end) { __syncthreads(); store_row(i - 1); }  // (otherwise stored by the next symbol, ahead of its prefetch)
@@ -549,9 +574,10 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
-                                               hipStream_t stream)
+                                               int classed, hipStream_t stream)
 {
     using namespace dabgpu;
+    if (classed && (d_desc != nullptr || d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits of frame batches only
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 25;     // 3 x 1024 workgroups per 1024 frames = three full rounds of the chip
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
@@ -567,13 +593,17 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
 #endif
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
+#define DABGPU_LAUNCH_C(SRC) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, false, false, true>), grid, dim3(256), lds, stream, \
+                       d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \
+                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
     switch (src) {
-    case SRC_C32: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
-    case SRC_U8: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_U8, true); else DABGPU_LAUNCH(SRC_U8, false); break;
-    case SRC_S8: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S8, true); else DABGPU_LAUNCH(SRC_S8, false); break;
-    case SRC_S16: if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S16, true); else DABGPU_LAUNCH(SRC_S16, false); break;
+    case SRC_C32: if (classed) DABGPU_LAUNCH_C(SRC_C32); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
+    case SRC_U8: if (classed) DABGPU_LAUNCH_C(SRC_U8); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_U8, true); else DABGPU_LAUNCH(SRC_U8, false); break;
+    case SRC_S8: if (classed) DABGPU_LAUNCH_C(SRC_S8); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S8, true); else DABGPU_LAUNCH(SRC_S8, false); break;
+    case SRC_S16: if (classed) DABGPU_LAUNCH_C(SRC_S16); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_S16, true); else DABGPU_LAUNCH(SRC_S16, false); break;
     default: return hipErrorInvalidValue;
     }
+#undef DABGPU_LAUNCH_C
 #undef DABGPU_LAUNCH
 #undef DABGPU_LAUNCH_V
     return hipGetLastError();

@@ -20,6 +20,9 @@ constexpr int NB_FRAME_SAMPLES = 196608;
 constexpr int NB_SYM_BITS = 3072;
 constexpr int NB_FRAME_BITS = 230400;
 constexpr int NB_FRAME_SYMBOLS = 76;
+constexpr int NB_FIC_SYMBOLS = 3;        // data symbols 1..3 carry the FIC (9216 soft bits), 4..75 the four CIFs of 18 symbols each
+constexpr int NB_CIF_SYMBOLS = 18;
+constexpr int NB_CIF_BITS = 55296;
 constexpr int WAVE_PATCH = 576;          // float2 elements per wave transpose patch (8 rows x 72, padded)
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

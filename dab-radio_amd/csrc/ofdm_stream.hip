@@ -512,7 +512,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         CK(hipGetLastError());
         if (G.mode == 1) {
             CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
-                                        n, 0, 0, b->view.desc, d_iq, stream_stride_samples, s));
+                                        n, 0, 0, b->view.desc, d_iq, stream_stride_samples, 0, s));
         } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
                                                        b->view.desc, d_iq, stream_stride_samples, s))) {
             return st;

@@ -265,11 +265,13 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 if (slot < 0) slot += (int)D.n_slots;
                 const int fr = slot / (int)D.cifs_per_frame, ci = slot - fr * (int)D.cifs_per_frame;
                 off = (unsigned long long)fr * D.frame_stride + (unsigned long long)ci * D.cif_stride;
+                if (D.flags & DABGPU_CW_CLASSED) off += (unsigned long long)lane * (D.cif_stride >> 4);    // class order: + class segment
             }
             age_off[lane] = off;
         }
         __syncthreads();
         const int8_t* src_base = reinterpret_cast<const int8_t*>(D.d_src);
+        const unsigned ish = (D.n_slots != 0 && (D.flags & DABGPU_CW_CLASSED)) ? 4u : 0u;                  // ... + i / 16 inside the segment
 
         // ---- de-puncturing as a running index (dab_viterbi_decoder.cpp:131-181): lane L owns mother symbols 64 q + L of every
         // 48-step block, i.e. step offset so = (64 q + L) / 4, code bit r = L % 4.  Inside a puncturing segment the kept / dropped
@@ -307,7 +309,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 const int step = t0 + 16 * q + (lane >> 2);
                 int y = 0;
                 if (step < n_steps && ((fkeep >> q) & 1)) {
-                    y = src_base[age_off[fidx[q] & 15] + (unsigned long long)(unsigned)fidx[q]];
+                    y = src_base[age_off[fidx[q] & 15] + (unsigned long long)((unsigned)fidx[q] >> ish)];
                     y = max(y, -127);          // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                 }
                 // pack the 4 symbols of a step into one dword in every lane of the quad
@@ -424,7 +426,7 @@ __global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits
 // straight out of the history of demodulated frames (msc_decoder.cpp:46-75 + cif_deinterleaver.cpp:36-71)
 __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride,
                                        int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub,
-                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots)
+                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots, int classed)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_ens = (size_t)4 * n_sub;
@@ -437,7 +439,9 @@ __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist
         newest_frame_slot = slots[e];
         if (newest_frame_slot < 0) { descs[i] = D; return; }
     }
-    D.d_src = (uint64_t)(uintptr_t)(hist + e * ens_stride + 9216 + (size_t)P.start_address * 64);
+    // natural order: the sub-channel's first soft bit; class order: its first byte of class 0 (64 soft bits per CU = 4 per class)
+    D.d_src = (uint64_t)(uintptr_t)(hist + e * ens_stride + 9216 + (size_t)P.start_address * (classed ? 4 : 64));
+    if (classed) D.flags |= DABGPU_CW_CLASSED;
     D.d_out = (uint64_t)(uintptr_t)(out + e * out_ens_stride + (size_t)c * cif_out_bytes + P.out_offset);
     D.n_steps = P.n_steps;
     for (int k = 0; k < 4; k++) { D.seg_pi[k] = P.seg_pi[k]; D.seg_steps[k] = P.seg_steps[k]; }
@@ -485,11 +489,11 @@ extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
-                                              hipStream_t stream)
+                                              int classed, hipStream_t stream)
 {
     const size_t n = n_ens * 4 * (size_t)n_sub;
     hipLaunchKernelGGL(dabgpu::msc_build_descs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub, d_out,
-                       out_ens_stride, cif_out_bytes, d_slots);
+                       out_ens_stride, cif_out_bytes, d_slots, classed);
     return hipGetLastError();
 }

@@ -23,6 +23,16 @@ NB_FRAME_BITS = 230400
 NB_FIC_BITS = 9216
 NB_FIB_GROUP_BITS = 2304
 NB_CIF_BITS = 55296
+BITS_NATURAL, BITS_MSC_CLASSED = 0, 1     # dabgpu_ofdm_demod_frames_history / dabgpu_msc_decode_frames_layout
+
+
+def classed_to_natural_index():
+    """index array P with natural_frame_bits == classed_frame_bits[P]: FIC unchanged, inside each CIF row bit i sits at
+    (i mod 16) * 3456 + i // 16 (DABGPU_BITS_MSC_CLASSED)"""
+    import numpy as np
+    i = np.arange(NB_CIF_BITS)
+    row = (i % 16) * (NB_CIF_BITS // 16) + i // 16
+    return np.concatenate([np.arange(NB_FIC_BITS)] + [NB_FIC_BITS + q * NB_CIF_BITS + row for q in range(4)])
 
 # every symbol include/dabgpu.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
@@ -46,6 +56,7 @@ ABI_SYMBOLS = [
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
+    "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
@@ -149,6 +160,10 @@ def lib():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        L.dabgpu_ofdm_demod_frames_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+        L.dabgpu_msc_decode_frames_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
@@ -307,6 +322,14 @@ class Context:
                                                  _ptr(cp_corr), _ptr(fft), _ptr(dqpsk), symbols_per_block, bits_frame_stride,
                                                  self._stream(stream)), "dabgpu_ofdm_demod_frames_raw")
 
+    def ofdm_demod_frames_history(self, raw, fmt, n_frames, bits, freq_offset=None, cp_corr=None, symbols_per_block=0,
+                                  bits_frame_stride=0, bits_layout=BITS_NATURAL, stream=None):
+        """Soft bits straight into the decoder's frame-history ring; bits_layout = BITS_MSC_CLASSED stores the MSC part in
+        time-interleaver class order (read it with msc_decode_frames(..., bits_layout=BITS_MSC_CLASSED))."""
+        check(lib().dabgpu_ofdm_demod_frames_history(self._h, _ptr(raw), int(fmt), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
+                                                     symbols_per_block, bits_frame_stride, int(bits_layout), self._stream(stream)),
+              "dabgpu_ofdm_demod_frames_history")
+
     def ofdm_demod_frames_mode(self, mode, iq, n_frames, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0, stream=None):
         """frame-aligned frames of transmission mode 1..4 through the size-generic kernel"""
         check(lib().dabgpu_ofdm_demod_frames_mode(self._h, int(mode), _ptr(iq), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
@@ -393,9 +416,14 @@ class Context:
               "dabgpu_msc_decode_ring")
 
     def msc_decode_frames(self, history, n_ensembles, ensemble_stride, history_frames, newest_frame_slot, subchannels,
-                          out, out_ensemble_stride, results, tie_rule=0, stream=None):
+                          out, out_ensemble_stride, results, tie_rule=0, stream=None, bits_layout=BITS_NATURAL):
         n = len(subchannels)
         arr = (SubChannel * n)(*subchannels)
+        if bits_layout != BITS_NATURAL:
+            check(lib().dabgpu_msc_decode_frames_layout(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames,
+                                                        newest_frame_slot, arr, n, _ptr(out), out_ensemble_stride, _ptr(results),
+                                                        tie_rule, int(bits_layout), self._stream(stream)), "dabgpu_msc_decode_frames_layout")
+            return
         check(lib().dabgpu_msc_decode_frames(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames,
                                              newest_frame_slot, arr, n, _ptr(out), out_ensemble_stride, _ptr(results),
                                              tie_rule, self._stream(stream)), "dabgpu_msc_decode_frames")

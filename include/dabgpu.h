@@ -114,6 +114,24 @@ int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx *ctx, const void *d_raw, int format,
                                  size_t bits_frame_stride, void *stream);
 
 /*
+ * Demodulation straight into the frame-history ring the channel decoder reads (dabgpu_msc_decode_frames), with a choice of
+ * how the MSC soft bits are laid out there.  Formats with a fused loader only (float32, u8, s8, s16 little endian, and the wav
+ * payloads of those); soft bits and the cyclic-prefix correlation only.
+ *   DABGPU_BITS_NATURAL      the layout of On_OFDM_Frame() (ofdm_demodulator.cpp:635): identical to dabgpu_ofdm_demod_frames_raw
+ *   DABGPU_BITS_MSC_CLASSED  FIC (soft bits 0..9215) as above; inside each of the four CIF rows of 55296 soft bits, bit i is
+ *                            stored at (i mod 16) * 3456 + i / 16.  CIF_Deinterleaver takes the bits of class i mod 16 from the
+ *                            CIF that is 15 - bitrev4(i mod 16) CIFs old (src/dab/msc/cif_deinterleaver.cpp:57-68); in this order
+ *                            each of those reads is contiguous, which cuts the history traffic of the decoder's gather from
+ *                            19/4 of the decoded bits to 1 (the permutation itself costs nothing: it rides on the frequency
+ *                            de-interleave the kernel performs anyway).  Only the *_layout decoders below read it.
+ */
+#define DABGPU_BITS_NATURAL 0
+#define DABGPU_BITS_MSC_CLASSED 1
+int dabgpu_ofdm_demod_frames_history(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, const float *d_freq_offset,
+                                     int8_t *d_bits, float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride,
+                                     int bits_layout, void *stream);
+
+/*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]
  * (sequential, i = 0..75), and optionally fine <- fmod(fine - beta*err, wrap).
  * Replaces OFDM_Demod::CoordinatorThread's phase section (ofdm_demodulator.cpp:606-618) +
@@ -209,6 +227,9 @@ typedef struct {
     uint32_t flags;            /* DABGPU_CW_RAW: emit the decoder output without the energy-dispersal XOR */
 } dabgpu_codeword;
 #define DABGPU_CW_RAW 1u
+#define DABGPU_CW_CLASSED 4u   /* ring codewords only: every ring row holds its cif_stride soft bits in time-interleaver class order;
+                                  input bit i of a slot lives at d_src + slot offset + (i mod 16) * (cif_stride / 16) + i / 16, and
+                                  d_src points at the sub-channel's first byte of class 0 (slot 0) */
 
 typedef struct {
     uint64_t path_error;       /* DAB_Viterbi_Decoder::chainback() return value (dab_viterbi_decoder.cpp:124-129) */
@@ -281,6 +302,12 @@ int dabgpu_msc_decode_frames(dabgpu_ctx *ctx, const int8_t *d_bits_history, size
                              int history_frames, int newest_frame_slot, const dabgpu_subchannel *h_subchannels,
                              int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
                              dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
+/* The same reading a history whose MSC part was written in `bits_layout` (dabgpu_ofdm_demod_frames_history) */
+int dabgpu_msc_decode_frames_layout(dabgpu_ctx *ctx, const int8_t *d_bits_history, size_t n_ensembles, size_t ensemble_stride,
+                                    int history_frames, int newest_frame_slot, const dabgpu_subchannel *h_subchannels,
+                                    int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
+                                    dabgpu_codeword_result *d_results, int tie_rule, int bits_layout, void *stream);
 
 /* Ring forms: ensemble e decodes the frame in slot d_newest_slot[e] of its own frame-history ring d_hist + e*ensemble_stride
  * (each ensemble at its own ring position, as dabgpu_stream_bank_process_ring leaves them); a negative slot skips the ensemble

@@ -1,0 +1,122 @@
+"""-m gpu: the time-interleaver class order of the MSC soft bits (DABGPU_BITS_MSC_CLASSED, include/dabgpu.h) is a pure re-arrangement:
+the demodulator's class-order output is the natural output permuted (every capture format with a fused loader), and the channel decoder
+gives identical bytes, CRC-less results and path errors from either order, for both device mappings, a forced hybrid, both tie rules,
+ragged ensemble counts and batches large enough for several gather workgroups per group.  (Parity with the oracle of the class-order
+path itself: tests/test_gpu_viterbi.py::test_msc_frames_with_history_ring[classed-*].)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import dabgpu
+    c = dabgpu.Context(0)
+    yield c
+    c.close()
+
+
+def test_index_helper_is_the_documented_permutation():
+    import dabgpu
+    P = dabgpu.classed_to_natural_index()
+    assert P.shape == (230400,) and np.array_equal(np.sort(P), np.arange(230400)) and np.array_equal(P[:9216], np.arange(9216))
+    for q in (0, 3):
+        for i in (0, 1, 15, 16, 17, 3455 * 16 + 15, 55295):
+            assert P[9216 + q * 55296 + i] == 9216 + q * 55296 + (i % 16) * 3456 + i // 16
+
+
+@pytest.mark.parametrize("fmt_name", ["raw_f32l", "raw_u8", "raw_s8", "raw_s16l"])
+@pytest.mark.parametrize("stride_extra", [0, 4 * 230400])
+def test_demodulator_class_order_is_the_natural_output_permuted(ctx, fmt_name, stride_extra):
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(5)
+    n = 7
+    fmt = dabgpu.IQ_FORMATS.index(fmt_name)
+    if fmt_name == "raw_f32l":
+        raw = torch.from_numpy(rng.standard_normal((n, 196608, 2)).astype(np.float32)).cuda()
+    elif fmt_name == "raw_s16l":
+        raw = torch.from_numpy(rng.integers(-30000, 30000, (n, 196608, 2), dtype=np.int16)).cuda()
+    elif fmt_name == "raw_s8":
+        raw = torch.from_numpy(rng.integers(-128, 128, (n, 196608, 2), dtype=np.int8)).cuda()
+    else:
+        raw = torch.from_numpy(rng.integers(0, 256, (n, 196608, 2), dtype=np.uint8)).cuda()
+    freq = torch.from_numpy(((rng.random(n) * 2 - 1) * 2.0e-3).astype(np.float32)).cuda()
+    stride = 230400 + stride_extra
+    outs, corrs = [], []
+    for layout in (dabgpu.BITS_NATURAL, dabgpu.BITS_MSC_CLASSED):
+        for spb in (0, 7, 75):
+            bits = torch.full((n, stride), 99, dtype=torch.int8, device="cuda")
+            corr = torch.zeros((n, 76, 2), dtype=torch.float32, device="cuda")
+            ctx.ofdm_demod_frames_history(raw, fmt, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb,
+                                          bits_frame_stride=stride if stride_extra else 0, bits_layout=layout)
+            torch.cuda.synchronize()
+            b = bits.cpu().numpy()
+            assert stride_extra == 0 or (b[:, 230400:] == 99).all(), "nothing is written past a frame's 230400 soft bits"
+            outs.append(b[:, :230400]); corrs.append(corr.cpu().numpy())
+    ref = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
+    ctx.ofdm_demod_frames_raw(raw, fmt, n, ref, freq_offset=freq)
+    torch.cuda.synchronize()
+    ref = ref.cpu().numpy()
+    assert len(np.unique(ref)) > 100
+    P = dabgpu.classed_to_natural_index()
+    for k in range(3):
+        assert np.array_equal(outs[k], ref), "natural layout == dabgpu_ofdm_demod_frames_raw"
+        assert np.array_equal(outs[3 + k][:, P], ref), "class order == the natural output permuted"
+        assert np.array_equal(corrs[k].view(np.uint32), corrs[0].view(np.uint32)) and np.array_equal(corrs[3 + k].view(np.uint32), corrs[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("tie_rule", [0, 1])
+@pytest.mark.parametrize("n_ens", [5, 37, 130])
+def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens):
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(100 + n_ens + tie_rule)
+    subs = [dabgpu.SubChannel(0, 48, False, 0, 2, 0), dabgpu.SubChannel(48, 8, False, 0, 1, 0), dabgpu.SubChannel(60, 27, False, 0, 0, 1),
+            dabgpu.SubChannel(100, 35, True, 4, 0, 0), dabgpu.SubChannel(700, 164, False, 0, 3, 0), dabgpu.SubChannel(300, 4, False, 0, 3, 0),
+            dabgpu.SubChannel(310, 8, False, 0, 3, 0), dabgpu.SubChannel(400, 96, False, 0, 1, 0)]
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    H = 6
+    nat = rng.integers(-128, 128, (n_ens, H, 230400), dtype=np.int8)
+    nat[1] = 0
+    nat[2] = 127
+    to_classed = np.argsort(dabgpu.classed_to_natural_index())
+    hists = {0: torch.from_numpy(nat).cuda(), 1: torch.from_numpy(np.ascontiguousarray(nat[:, :, to_classed])).cuda()}
+    got = {}
+    for m in (1, 2, 0):                                   # WAVE, LANE, AUTO with a forced hybrid (3 longest sub-channels by WAVE)
+        ctx.viterbi_set_mapping(m)
+        if m == 0:
+            os.environ["DABGPU_VIT_HYBRID_K"] = "3"
+        try:
+            for layout in (0, 1):
+                for slot in (0, 4):
+                    d_out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda")
+                    d_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+                    ctx.msc_decode_frames(hists[layout], n_ens, H * 230400, H, slot, subs, d_out, 4 * cif_out, d_res, tie_rule=tie_rule,
+                                          bits_layout=layout)
+                    torch.cuda.synchronize()
+                    got[(m, layout, slot)] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+        finally:
+            os.environ.pop("DABGPU_VIT_HYBRID_K", None)
+    ctx.viterbi_set_mapping(0)
+    for slot in (0, 4):
+        base = got[(1, 0, slot)]
+        assert base[0].any()
+        for m in (1, 2, 0):
+            for layout in (0, 1):
+                assert np.array_equal(got[(m, layout, slot)][0], base[0]), (m, layout, slot)
+                assert np.array_equal(got[(m, layout, slot)][1], base[1]), (m, layout, slot)
+
+
+def test_bad_layout_and_unsupported_format_are_refused(ctx):
+    import dabgpu
+    import torch
+    raw = torch.zeros((1, 196608, 2), dtype=torch.float32, device="cuda")
+    bits = torch.zeros((1, 230400), dtype=torch.int8, device="cuda")
+    with pytest.raises(dabgpu.DabGpuError):
+        ctx.ofdm_demod_frames_history(raw, dabgpu.IQ_FORMATS.index("raw_f32l"), 1, bits, bits_layout=7)
+    with pytest.raises(dabgpu.DabGpuError):
+        ctx.ofdm_demod_frames_history(raw, dabgpu.IQ_FORMATS.index("raw_s16b"), 1, bits, bits_layout=1)

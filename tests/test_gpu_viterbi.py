@@ -138,12 +138,15 @@ def test_edge_inputs(ctx, oracle, mapping):
         ctx.viterbi_decode_batch([bad], d_res)
 
 
+@pytest.mark.parametrize("layout", [0, 1], ids=["natural", "classed"])
 @pytest.mark.parametrize("tie_rule", [0, 1])
-def test_msc_frames_with_history_ring(ctx, oracle, tie_rule, mapping):
+def test_msc_frames_with_history_ring(ctx, oracle, tie_rule, mapping, layout):
     """3 ensembles x mixed multiplex (EEP-A, EEP-B, 2-A special, UEP) through 7 frames (28 CIFs): the kernel's
-    de-interleave-by-index over the frame-history ring must equal CIF_Deinterleaver + MSC_Decoder of the oracle"""
+    de-interleave-by-index over the frame-history ring must equal CIF_Deinterleaver + MSC_Decoder of the oracle --
+    with the history in On_OFDM_Frame() order and in time-interleaver class order (DABGPU_BITS_MSC_CLASSED)"""
     import dabgpu
     import torch
+    to_classed = np.argsort(dabgpu.classed_to_natural_index())      # classed_frame = natural_frame[to_classed]
     rng = np.random.default_rng(31 + tie_rule)
     subs = [oracle.subchannel(0, 48, eep_level=2, eep_type=0), oracle.subchannel(48, 8, eep_level=1, eep_type=0),
             oracle.subchannel(60, 27, eep_level=0, eep_type=1), oracle.subchannel(100, 35, is_uep=True, uep_index=4),
@@ -173,8 +176,11 @@ def test_msc_frames_with_history_ring(ctx, oracle, tie_rule, mapping):
         slot = f % H
         frame = np.zeros((n_ens, oracle.NB_FRAME_BITS), np.int8)
         frame[:, 9216:] = cifs[:, 4 * f:4 * f + 4].reshape(n_ens, -1)
+        if layout:
+            frame = np.ascontiguousarray(frame[:, to_classed])
         hist[:, slot].copy_(torch.from_numpy(frame).cuda())
-        ctx.msc_decode_frames(hist, n_ens, H * oracle.NB_FRAME_BITS, H, slot, gsubs, d_out, 4 * cif_out, d_res, tie_rule=tie_rule)
+        ctx.msc_decode_frames(hist, n_ens, H * oracle.NB_FRAME_BITS, H, slot, gsubs, d_out, 4 * cif_out, d_res, tie_rule=tie_rule,
+                              bits_layout=layout)
         torch.cuda.synchronize()
         out, res = d_out.cpu().numpy(), results_np(d_res).reshape(n_ens, 4, len(subs))
         for e in range(n_ens):

@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--ensembles", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--tie-rule", type=int, default=0)
+    ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed",
+                    help="order of the MSC soft bits in the frame-history ring (classed = DABGPU_BITS_MSC_CLASSED)")
     ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword (DABGPU_VIT_MAP_*)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -139,6 +141,7 @@ def main():
     iq_f = torch.view_as_real(iq)
 
     hist = torch.zeros((E, H, 230400), dtype=torch.int8, device=dev)
+    LAYOUT, F32 = int(args.hist_layout == "classed"), dabgpu.IQ_FORMATS.index("raw_f32l")
     corr = torch.empty((E, 76, 2), dtype=torch.float32, device=dev)
     fic_out = torch.zeros((E, 4, 96), dtype=torch.uint8, device=dev)
     fic_res = torch.zeros((E * 4, 16), dtype=torch.uint8, device=dev)
@@ -147,13 +150,13 @@ def main():
     subs = [dabgpu.SubChannel(48 * s, 48, 0, 0, 2, 0) for s in range(n_sub)]
 
     def demod(slot):
-        ctx.ofdm_demod_frames(iq_f, hist[:, slot], cp_corr=corr, n_frames=E, bits_frame_stride=H * 230400)
+        ctx.ofdm_demod_frames_history(iq_f, F32, E, hist[:, slot], cp_corr=corr, bits_frame_stride=H * 230400, bits_layout=LAYOUT)
 
     def fic(slot):
         ctx.fic_decode_frames(hist[:, slot], E, fic_out, fic_res, frame_stride=H * 230400, tie_rule=args.tie_rule)
 
     def msc(slot):
-        ctx.msc_decode_frames(hist, E, H * 230400, H, slot, subs, msc_out, 4 * n_sub * 192, msc_res, tie_rule=args.tie_rule)
+        ctx.msc_decode_frames(hist, E, H * 230400, H, slot, subs, msc_out, 4 * n_sub * 192, msc_res, tie_rule=args.tie_rule, bits_layout=LAYOUT)
 
     for slot in range(H):                   # fill the history ring (and warm up)
         demod(slot)
@@ -222,14 +225,15 @@ def main():
         c, st = ctxs[k], streams[k]
         slot = j % H2
         with torch.cuda.stream(st):
-            c.ofdm_demod_frames(iq_f, hist2[:, slot], cp_corr=corr2[k], n_frames=E, bits_frame_stride=H2 * 230400, stream=st.cuda_stream)
+            c.ofdm_demod_frames_history(iq_f, F32, E, hist2[:, slot], cp_corr=corr2[k], bits_frame_stride=H2 * 230400, bits_layout=LAYOUT,
+                                        stream=st.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(st)
             c.fic_decode_frames(hist2[:, slot], E, fic_out2[k], fic_res2[k], frame_stride=H2 * 230400, tie_rule=args.tie_rule, stream=st.cuda_stream)
             if ev_prev_demod is not None:
                 st.wait_event(ev_prev_demod)
             c.msc_decode_frames(hist2, E, H2 * 230400, H2, slot, subs, msc_out2[k], 4 * n_sub * 192, msc_res2[k], tie_rule=args.tie_rule,
-                                stream=st.cuda_stream)
+                                stream=st.cuda_stream, bits_layout=LAYOUT)
         return ev
 
     torch.cuda.synchronize()
