@@ -456,7 +456,13 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             // depends on A only and is shared by both quotients; outside the range (or NaN) the plain expressions run.
             const float amin = __builtin_fminf(__builtin_fminf(__builtin_fminf(An[0], An[1]), An[2]), __builtin_fminf(__builtin_fminf(An[3], An[4]), An[5]));
             const float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(An[0], An[1]), An[2]), __builtin_fmaxf(__builtin_fmaxf(An[3], An[4]), An[5]));
-            int bx[6], by[6];
+            // natural order: every byte goes to LDS as soon as it exists; class order keeps the twelve until the (uniform) choice of
+            // the position set, so that the choice is one branch and not twelve selects
+            int bx[CLASSED ? 6 : 1], by[CLASSED ? 6 : 1];
+            auto put = [&](const int k, const int vx, const int vy) __attribute__((always_inline)) {
+                if constexpr (CLASSED) { bx[k] = vx; by[k] = vy; }
+                else { obuf[pos[k]] = (int8_t)vx; obuf[pos[k] + 1536] = (int8_t)vy; }
+            };
             if (amin >= 0x1p-60f && amax <= 0x1p60f) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) {
@@ -468,22 +474,20 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                     qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
                     qx = __builtin_fmaf(__builtin_fmaf(-A, qx, nx), r, qx);
                     qy = __builtin_fmaf(__builtin_fmaf(-A, qy, ny), r, qy);
-                    bx[k] = to_vbit(qx);
-                    by[k] = to_vbit(qy);
+                    put(k, to_vbit(qx), to_vbit(qy));
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    bx[k] = to_vbit(dq[k].x / An[k]);
-                    by[k] = to_vbit(-(dq[k].y / An[k]));
-                }
+                for (int k = 0; k < 6; k++) put(k, to_vbit(dq[k].x / An[k]), to_vbit(-(dq[k].y / An[k])));
             }
-            if (CLASSED && i - 1 >= NB_FIC_SYMBOLS) {                             // (uniform) MSC symbol in class order
+            if constexpr (CLASSED) {
+                if (i - 1 >= NB_FIC_SYMBOLS) {                                    // (uniform) MSC symbol in class order
 #pragma unroll
-                for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + 96] = (int8_t)by[k]; }
-            } else {
+                    for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + 96] = (int8_t)by[k]; }
+                } else {
 #pragma unroll
-                for (int k = 0; k < 6; k++) { obuf[pos[k]] = (int8_t)bx[k]; obuf[pos[k] + 1536] = (int8_t)by[k]; }
+                    for (int k = 0; k < 6; k++) { obuf[pos[k]] = (int8_t)bx[k]; obuf[pos[k] + 1536] = (int8_t)by[k]; }
+                }
             }
         }
         if (emit && i == sym_end) { __syncthreads(); store_row(i - 1); }  // (otherwise stored by the next symbol, ahead of its prefetch)
@@ -579,7 +583,9 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     using namespace dabgpu;
     if (classed && (d_desc != nullptr || d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits of frame batches only
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
-    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 25;     // 3 x 1024 workgroups per 1024 frames = three full rounds of the chip
+    // default: a whole frame per workgroup once the batch fills the chip (256 CUs x 4 workgroups) -- no halo symbol, one round per
+    // 1024 frames; smaller batches are cut into three chunks per frame (one extra FFT per chunk) to spread over the CUs
+    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = (n_frames >= 1024) ? 75 : 25;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = DEMOD_LDS_BYTES;
     const dim3 grid((unsigned)(n_frames * chunks));

@@ -63,6 +63,29 @@ def main():
     with open(os.path.join(out, "hbm_traffic.json"), "w") as g:
         json.dump(traffic, g, indent=1)
     print(json.dumps(traffic))
+    # channel decoder (tools/bench_decode.py --ensembles 1024, both history layouts): HBM bytes per launch of its kernels
+    dec = {"ensembles": 1024, "note": "FETCH_SIZE x 2 + WRITE_SIZE (KB units) per launch, separate rocprofv3 --pmc passes of "
+                                      "tools/bench_decode.py --ensembles 1024 --steps 2 --hist-layout <layout>"}
+    for layout in ("classed", "natural"):
+        per = {}
+        for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            path = find(os.path.join(root, f"pmc_dec_{name}_{layout}"), "*counter_collection.csv")
+            if not path:
+                continue
+            for kern in ("vit_prep_ring4c_kernel", "vit_prep_ring4_kernel", "vit_lanes_kernel<0, 1, 4>", "vit_lanes_kernel<0, 1, 5>", "vit_lanes_kernel<0, 4, 4>",
+                         "ofdm_demod_kernel"):
+                avg, n, _ = counter_average(path, counter, kern)
+                if avg is not None:
+                    per.setdefault(kern, {})[f"{name}_kb_avg"] = avg
+                    per[kern][f"{name}_launches"] = n
+        for kern, d in per.items():
+            if "fetch_kb_avg" in d and "write_kb_avg" in d:
+                d["hbm_bytes_per_launch"] = d["fetch_kb_avg"] * 2048 + d["write_kb_avg"] * 1024
+        if per:
+            dec[layout] = per
+    if len(dec) > 2:
+        with open(os.path.join(out, f"hbm_traffic_decode_{tag}.json"), "w") as g:
+            json.dump(dec, g, indent=1)
 
 
 if __name__ == "__main__":

@@ -21,10 +21,15 @@ python3 tools/bench_mirror.py > $OUT/bench_mirror_$TAG.json 2> $OUT/bench_mirror
 python3 tools/bench_stream.py --streams 1024 --block-frames 4 > $OUT/bench_stream_1024x4_$TAG.json 2> $OUT/bench_stream_1024x4_$TAG.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_dec -o trace -- python3 tools/bench_decode.py --ensembles 4096 --steps 4 > $OUT/prof_dec.log 2>&1
 cp $(find $OUT/prof_dec -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_decode4096_$TAG.csv; rm -rf $OUT/prof_dec
+for L in classed natural; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_dec_fetch_$L -o pmc -- python3 tools/bench_decode.py --ensembles 1024 --steps 2 --hist-layout $L > $OUT/pmc_dec.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_dec_write_$L -o pmc -- python3 tools/bench_decode.py --ensembles 1024 --steps 2 --hist-layout $L > $OUT/pmc_dec.log 2>&1
+done
+python3 tools/bench_decode.py --ensembles 4096 --steps 6 --hist-layout natural > $OUT/bench_decode_4096_natural_$TAG.json 2> $OUT/bench_decode_4096_natural_$TAG.err
 python3 tools/bench_io.py > $OUT/bench_io_$TAG.json 2> $OUT/bench_io_$TAG.err
 python3 tools/bench_stream.py > $OUT/bench_stream_$TAG.json 2> $OUT/bench_stream_$TAG.err
 python3 tools/bench_dabplus.py > $OUT/bench_dabplus_$TAG.json 2> $OUT/bench_dabplus_$TAG.err
 # keep the merge-back small: reduce on the box, then drop the raw dumps
 python3 tools/collect_profiles.py $OUT $TAG $ROUND > $OUT/collect_$TAG.log 2>&1
-rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/prof $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_dec_*
 du -sh $OUT
