@@ -469,7 +469,7 @@ def main():
         if args.workload == "demod":
             workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
                         "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU")
-            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or 25,
+            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or (75 if units >= 1024 else 25),
                       "sharding": "independent frames / ensembles per rank, no data-path collective"}
         else:
             workload = (f"BASELINE configs[4]: {units * world} synthetic ensembles ({units} per GPU, built on the device from "
