@@ -509,22 +509,28 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
 
 // ---- input gather, MSC form, history in time-interleaver class order (DABGPU_CW_CLASSED) ----
 // In class order the bits an output CIF takes from one history row are contiguous: class c of output CIF q lives in row
-// q - age(c) + 15 at [c * cif_stride / 16 + i / 16].  A workgroup handles 256 trellis steps of a QUARTER group (4 ensembles x 4 CIFs
-// = 16 lanes): per ensemble 64 pieces (4 output CIFs x 16 classes) of <= 65 needed bytes are staged in LDS through 80-byte
-// windows (five 16-byte loads each, 4-byte aligned), then thread = (step, ensemble) picks the <= 4 soft bits of its four lanes from LDS and writes
-// 16 bytes of the [step][lane] symbol array: the four threads of a step fill one 64-byte sector.
-// A workgroup walks all tiles of its quarter group: group and ring descriptors are read once, and the next tile's loads are in
-// flight while the current one is picked (two window buffers).
-// History traffic: ~1.3 bytes per decoded soft bit instead of 19/4 (whole rows) of vit_prep_ring4_kernel.
-// grid (4 n_groups), 256 threads
-constexpr int VC_STEPS = 256, VC_ENS = 4;                               // (128 / 192 / 512 steps per tile measured 1.40 / 1.71 / 1.10 ms against 1.00)
-constexpr int VC_CP = (VC_STEPS / 4 + 4 + 15) / 16, VC_WIN = 16 * VC_CP;  // <= STEPS / 4 + 1 needed bytes per piece + 3 of alignment, in 16-byte chunks
-constexpr int VC_CHUNKS = 64 * VC_CP, VC_H = (VC_CHUNKS + 255) / 256;
+// q - age(c) + 15 at [c * cif_stride / 16 + i / 16].  A workgroup owns a QUARTER group (4 ensembles x 4 CIFs = 16 lanes) and walks its
+// trellis steps in tiles; the 4 x 64 byte streams it reads (ensemble x output CIF x class, all advancing together because every stream
+// is indexed by i / 16) are fetched ONE 64-BYTE MEMORY LINE AT A TIME into per-stream LDS rings of VC_RING lines: a tile loads only the
+// lines the previous tiles have not brought in yet -- every history byte crosses HBM -> LDS once (the first version staged
+// 80-byte windows per tile and fetched ~3.5 x what it used: profiles/r02/hbm_traffic_decode_v3.json).  The next tile's lines are in
+// flight while thread (step, ensemble) picks the <= 4 soft bits of its four lanes from LDS; the four threads of a step fill one
+// 64-byte sector of the [step][lane] symbol array.  Group and ring descriptors are read once per workgroup (scalar loads).
+// grid (4 n_groups), 256 threads: thread = (stream tid / 4 of an ensemble, 16-byte chunk tid % 4 of a line) when loading
+#ifndef VC_STEPS_
+#define VC_STEPS_ 256
+#endif
+constexpr int VC_STEPS = VC_STEPS_, VC_ENS = 4;
+constexpr int VC_NEED = (VC_STEPS / 4 + 1 + 63 + 63) / 64;                // lines a tile can touch: <= STEPS / 4 + 1 bytes at any line phase
+constexpr int VC_RING = VC_NEED <= 2 ? 2 : 4;                             // lines per LDS ring (power of two)
+constexpr int VC_NEW = (VC_STEPS / 4 + 63) / 64 + 1;                      // new lines a tile can need (the first tile: VC_NEED, loaded in rounds)
+constexpr int VC_PITCH = VC_RING * 64 + 16;                               // bytes between the rings of two classes: 36 (68) dwords apart,
+                                                                          // so the 16 classes a wave's byte reads touch fall on different banks
 __global__ __launch_bounds__(256)
 void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
                             uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char win[2][VC_ENS][4][16][VC_WIN];   // [buffer][ensemble][output CIF][class][window]
+    __shared__ __attribute__((aligned(16))) unsigned char ring[VC_ENS][4][16][VC_PITCH];     // [ensemble][output CIF][class][ring of lines]
     __shared__ uint16_t pi_tab[25 * 8];
     const int tid = threadIdx.x;
     const dabgpu_vit_group Gd = groups[blockIdx.x >> 2];
@@ -548,8 +554,6 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
     };
     int n_in = 12;                                                         // input soft bits the decoder consumes (EEP: the sub-channel size;
     for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);   // UEP: less, the rest is padding)
-    // bytes of one class segment the loads may touch: rounded up to whole dwords, which is still inside the sub-channel's 4 bytes per CU
-    const int n_j = (((n_in + 15) >> 4) + 3) & ~3;
 
     // the four ensembles of this quarter group (uniform descriptors: scalar loads, once per workgroup)
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
@@ -566,77 +570,84 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
         newest[e] = Dd.newest_slot;                                        // lane 4 ens is CIF 0: its newest slot is 4 nf
         if (e == 0 || on[e]) { n_slots = Dd.n_slots; frame_stride = Dd.frame_stride; cif_stride = Dd.cif_stride; }   // one ring geometry per group
     }
-    // chunk q = tid (and 256 + tid for tid < 64) of the 64 pieces x 5 sixteen-byte chunks of an ensemble: loop-invariant parts
-    int c_off[VC_H], c_m[VC_H], c_rel[VC_H];                                        // class offset in the row, chunk in the window, co - age
+    // memory lines: the class segments start at multiples of 64 bytes inside a row (cif_stride / 16 = 3456 = 54 x 64), the
+    // sub-channel phi bytes into a line (4 bytes per capacity unit); line L of a stream = its bytes [64 L - phi, 64 L - phi + 64)
+    const int phi = (int)((uintptr_t)src[0] & 63);
+    // this thread's stream when loading: piece = (output CIF, class) = tid / 4, chunk tid % 4 of the line
+    const int piece = tid >> 2, chunk = tid & 3, l_c16 = piece & 15;
+    const int l_rel = (piece >> 4) - (15 - (int)(__brev((unsigned)l_c16) >> 28));       // output CIF - age
+    size_t l_off[VC_ENS];                                                  // byte offset of the stream's line 0, chunk `chunk`, per ensemble
 #pragma unroll
-    for (int h = 0; h < VC_H; h++) {
-        const int q = tid + 256 * h, piece = q / VC_CP, c16 = piece & 15;
-        c_m[h] = q - VC_CP * piece;
-        c_off[h] = c16 * (int)(cif_stride >> 4);
-        c_rel[h] = (piece >> 4) - (15 - (int)(__brev((unsigned)c16) >> 28));
+    for (int e = 0; e < VC_ENS; e++) {
+        int slot = (int)newest[e] + l_rel;
+        if (slot < 0) slot += (int)n_slots;
+        if (slot >= (int)n_slots) slot -= (int)n_slots;
+        l_off[e] = (size_t)(slot >> 2) * frame_stride + (size_t)(slot & 3) * cif_stride + (size_t)l_c16 * (cif_stride >> 4) + (size_t)(16 * chunk) - (size_t)phi;
     }
+    unsigned char* const l_lds = &ring[0][piece >> 4][l_c16][16 * chunk];  // + e * (4 * 16 * PITCH) + (line & (RING - 1)) * 64
 
-    int jb = 0;
-    auto tile_range = [&](int t0, int& jb_, int& j_end_) {                 // (uniform) input range of the 256 steps from t0
+    auto tile_lines = [&](int t0, int& la, int& lb) {                      // (uniform) memory lines [la, lb] the 256 steps from t0 read
         int dummy;
         const int i_lo = (t0 < T) ? locate(t0, dummy) : n_in;
-        int i_hi = i_lo;
+        int i_hi = i_lo + 1;
         if (t0 < T) { const int tl = min(t0 + VC_STEPS, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
-        jb_ = (i_lo >> 4) & ~3;                                            // first byte of the windows inside a class segment, 4-byte aligned
-        j_end_ = min((i_hi + 15) >> 4, n_j);
+        const int last = (((n_in - 1) >> 4) + phi) >> 6;                   // nothing past the last line that holds input of this codeword
+        lb = min((((max(i_hi, i_lo + 1) - 1) >> 4) + phi) >> 6, last);
+        la = min(((i_lo >> 4) + phi) >> 6, lb);
     };
-    u4v v[VC_ENS][VC_H];
-    auto fetch = [&](int t0) {
-        int jbf, j_end;
-        tile_range(t0, jbf, j_end);
+    u4v v[VC_NEW][VC_ENS];
+    auto fetch = [&](int line0, int n) {                                   // lines line0 .. line0 + n - 1 (n <= VC_NEW) -> registers
 #pragma unroll
-        for (int e = 0; e < VC_ENS; e++) {
+        for (int k = 0; k < VC_NEW; k++) {
 #pragma unroll
-            for (int h = 0; h < VC_H; h++) {
-                v[e][h] = u4v{0u, 0u, 0u, 0u};
-                const int o = jbf + 16 * c_m[h];
-                if (on[e] && tid + 256 * h < VC_CHUNKS && o < j_end) {
-                    int slot = (int)newest[e] + c_rel[h];
-                    if (slot < 0) slot += (int)n_slots;
-                    if (slot >= (int)n_slots) slot -= (int)n_slots;
-                    const gptr p = src[e] + ((size_t)(slot >> 2) * frame_stride + (size_t)(slot & 3) * cif_stride + (size_t)(c_off[h] + o));
-                    typedef uint32_t u32a4 __attribute__((aligned(4)));
-                    const __attribute__((address_space(1))) u32a4* pw = (const __attribute__((address_space(1))) u32a4*)p;
-                    if (o + 16 <= n_j) {                                   // (the last window of a segment is cut at the sub-channel's end)
-                        typedef u4v u4a4 __attribute__((aligned(4)));
-                        v[e][h] = *(const __attribute__((address_space(1))) u4a4*)p;
-                    } else {
-                        v[e][h].x = pw[0];
-                        if (o + 8 <= n_j) v[e][h].y = pw[1];
-                        if (o + 12 <= n_j) v[e][h].z = pw[2];
-                    }
-                }
+            for (int e = 0; e < VC_ENS; e++) {
+                v[k][e] = u4v{0u, 0u, 0u, 0u};
+                if (k < n && on[e]) v[k][e] = *(const __attribute__((address_space(1))) u4v*)(src[e] + (l_off[e] + (size_t)(64 * (line0 + k))));
+            }
+        }
+    };
+    auto stash = [&](int line0, int n) {                                   // registers -> LDS rings
+#pragma unroll
+        for (int k = 0; k < VC_NEW; k++) {
+            if (k < n) {
+#pragma unroll
+                for (int e = 0; e < VC_ENS; e++)
+                    *reinterpret_cast<u4v*>(l_lds + e * (4 * 16 * VC_PITCH) + ((line0 + k) & (VC_RING - 1)) * 64) = v[k][e];
             }
         }
     };
 
     const int n_tiles = ((int)Gd.alloc_steps + VC_STEPS - 1) / VC_STEPS;
-    fetch(0);
+    // the line range of every tile, once, one thread per tile (a sub-channel has at most 864 CU = 55296 input bits: < 49,300 steps)
+    constexpr int VC_MAX_TILES = (49408 + VC_STEPS - 1) / VC_STEPS;
+    __shared__ int tl_a[VC_MAX_TILES], tl_b[VC_MAX_TILES];
+    if (tid < n_tiles) { int a_, b_; tile_lines(tid * VC_STEPS, a_, b_); tl_a[tid] = a_; tl_b[tid] = b_; }
+    __syncthreads();
+    int la = tl_a[0], lb, loaded;                                          // loaded = highest line in (or on its way to) the rings
+    loaded = la - 1;
+    int pend0 = 0, pendn = 0;                                              // lines in registers, not yet in LDS
     for (int st = 0; st < n_tiles; st++) {
-        const int t0 = st * VC_STEPS, buf = st & 1;
-        // the windows of this tile: registers -> LDS (the buffer was last read two tiles ago, before the previous barrier)
-#pragma unroll
-        for (int e = 0; e < VC_ENS; e++) {
-#pragma unroll
-            for (int h = 0; h < VC_H; h++) {
-                const int q = tid + 256 * h, piece = q / VC_CP;
-                if (q < VC_CHUNKS) *reinterpret_cast<u4v*>(&win[buf][e][piece >> 4][piece & 15][16 * c_m[h]]) = v[e][h];
-            }
+        const int t0 = st * VC_STEPS;
+        la = tl_a[st]; lb = tl_b[st];
+        // lines of this tile that are neither in LDS nor in registers (the first tile, or a tile that needs more new lines than
+        // one fetch holds): load them now, in rounds
+        if (pendn) { stash(pend0, pendn); pendn = 0; }
+        while (loaded < lb) {
+            const int n = min(lb - loaded, VC_NEW);
+            fetch(loaded + 1, n);
+            stash(loaded + 1, n);
+            loaded += n;
         }
-        int j_end_unused;
-        tile_range(t0, jb, j_end_unused);
         __syncthreads();
-        if (st + 1 < n_tiles) fetch(t0 + VC_STEPS);                        // in flight while this tile is picked
+        if (st + 1 < n_tiles) {                                            // the next tile's new lines: in flight while this tile is picked
+            const int n = min(tl_b[st + 1] - loaded, VC_NEW);
+            if (n > 0) { fetch(loaded + 1, n); pend0 = loaded + 1; pendn = n; loaded += n; }
+        }
 
         // ---- pick: thread = (step, ensemble) for 64 steps at a time; byte of bit i for (ensemble e, output CIF co) sits at
-        // win[e][co][i & 15][(i >> 4) - jb].  The four threads of a step write 64 contiguous bytes of the [step][lane] symbol array ----
+        // ring[e][co][i & 15][((i >> 4) + phi) & (64 RING - 1)] ----
         const int e = tid & 3;
-        const unsigned char* wb = &win[buf][0][0][0][0] + e * (4 * 16 * VC_WIN);
+        const unsigned char* wb = &ring[0][0][0][0] + e * (4 * 16 * VC_PITCH);
 #pragma unroll
         for (int it = 0; it < VC_STEPS / 64; it++) {
             const int t = t0 + 64 * it + (tid >> 2);
@@ -648,10 +659,10 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
                 for (int r = 0; r < 4; r++) {
                     if (r < cnt) {
                         const int i = idx0 + r;
-                        const unsigned char* pb = wb + ((i & 15) * VC_WIN + (i >> 4) - jb);
+                        const unsigned char* pb = wb + ((i & 15) * VC_PITCH + (((i >> 4) + phi) & (VC_RING * 64 - 1)));
 #pragma unroll
                         for (int co = 0; co < 4; co++) {
-                            int yv = (int)(signed char)pb[co * 16 * VC_WIN];
+                            int yv = (int)(signed char)pb[co * 16 * VC_PITCH];
                             yv = max(yv, -127);                            // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                             w[co] |= ((uint32_t)yv & 0xFFu) << (8 * r);
                         }
@@ -660,6 +671,7 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
                 *reinterpret_cast<u4v*>(sym + Gd.sym_off + (size_t)t * 64 + 16 * qg + 4 * e) = u4v{w[0], w[1], w[2], w[3]};
             }
         }
+        __syncthreads();                                                   // the rings are rewritten by the next tile's stash
     }
 }
 

@@ -111,6 +111,33 @@ def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens)
                 assert np.array_equal(got[(m, layout, slot)][1], base[1]), (m, layout, slot)
 
 
+@pytest.mark.parametrize("level,type_b", [(3, 0), (0, 0), (3, 1)])
+def test_one_sub_channel_filling_the_cif(ctx, level, type_b):
+    """864 CU in one sub-channel (up to 44,000 trellis steps: more than a hundred gather tiles per group, the last memory line of the
+    last class segment of every row in use): class order == natural order through the lane mapping, == the wave mapping"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(9 + level)
+    subs = [dabgpu.SubChannel(0, 864, False, 0, level, type_b)]
+    nb = dabgpu.subchannel_plan(subs[0])[2]
+    n_ens, H = 3, 5
+    nat = rng.integers(-128, 128, (n_ens, H, 230400), dtype=np.int8)
+    to_classed = np.argsort(dabgpu.classed_to_natural_index())
+    hists = {0: torch.from_numpy(nat).cuda(), 1: torch.from_numpy(np.ascontiguousarray(nat[:, :, to_classed])).cuda()}
+    got = {}
+    for m in (1, 2):
+        ctx.viterbi_set_mapping(m)
+        for layout in (0, 1):
+            d_out = torch.zeros((n_ens, 4, nb), dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_ens * 4, 16), dtype=torch.uint8, device="cuda")
+            ctx.msc_decode_frames(hists[layout], n_ens, H * 230400, H, 3, subs, d_out, 4 * nb, d_res, bits_layout=layout)
+            torch.cuda.synchronize()
+            got[(m, layout)] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+    ctx.viterbi_set_mapping(0)
+    for key in ((1, 1), (2, 0), (2, 1)):
+        assert np.array_equal(got[key][0], got[(1, 0)][0]) and np.array_equal(got[key][1], got[(1, 0)][1]), key
+
+
 def test_bad_layout_and_unsupported_format_are_refused(ctx):
     import dabgpu
     import torch
