@@ -67,7 +67,7 @@ struct BankView {
     int* copy_cnt;                   // [n] ... samples (0 = none)
     float* win;                      // [n][win_cap] L1 windows of the current block
     long long win_cap;
-    int* not_done;                   // [1]
+    int* not_done;                   // [2] one counter per lane
 };
 
 constexpr int COPY_WGS = 16;         // workgroups per stream of the bulk copy
@@ -95,15 +95,15 @@ __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __r
 
 template <int SRC>
 __global__ __launch_bounds__(256)
-void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
-                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode)
+void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
+                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode, int* __restrict__ not_done)
 {
     __shared__ StreamState S;
     __shared__ float win[256];
     __shared__ int sh_i[2];
     __shared__ long long sh_w;
-    const int s = blockIdx.x, t = threadIdx.x;
-    if (s >= n_streams) return;
+    const int s = s0 + blockIdx.x, t = threadIdx.x;       // streams s0 .. s0 + n_streams - 1 (a lane of the bank, see bank_process_impl)
+    if (s >= s0 + n_streams) return;
     if (t == 0) S = B.st[s];
     __syncthreads();
     const uint8_t* block = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
@@ -286,7 +286,7 @@ void stream_advance_kernel(BankView B, int n_streams, const uint8_t* __restrict_
     }
     if (t == 0) {
         B.st[s] = S;
-        if (S.pos < n_samples || S.pending != PEND_NONE) atomicAdd(B.not_done, 1);
+        if (S.pos < n_samples || S.pending != PEND_NONE) atomicAdd(not_done, 1);
     }
 }
 
@@ -323,8 +323,8 @@ void stream_l1_kernel(BankView B, const uint8_t* __restrict__ iq, size_t stream_
 // the round's bulk copy block -> frame buffer (the unfinished frame at the end of a block), COPY_WGS workgroups per stream
 template <int SRC>
 __global__ __launch_bounds__(256)
-void stream_copy_kernel(BankView B, const uint8_t* __restrict__ iq, size_t stream_stride) {
-    const int s = blockIdx.y;
+void stream_copy_kernel(BankView B, int s0, const uint8_t* __restrict__ iq, size_t stream_stride) {
+    const int s = s0 + blockIdx.y;
     const int cnt = B.copy_cnt[s];
     if (cnt == 0) return;
     const uint8_t* src = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
@@ -366,6 +366,8 @@ struct dabgpu_stream_bank {
     float* d_raw_scratch = nullptr;    // converted block of dabgpu_stream_bank_process_raw (grow-only)
     size_t raw_scratch_bytes = 0;
     std::vector<void*> allocs;
+    hipStream_t side = nullptr;        // second lane of a call (mode I banks of >= 256 streams): half of the streams run their rounds here
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" {
@@ -382,6 +384,9 @@ void dabgpu_stream_bank_destroy(dabgpu_stream_bank* b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipDeviceSynchronize();
     for (void* p : b->allocs) (void)hipFree(p);
+    if (b->side) (void)hipStreamDestroy(b->side);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     delete b;
 }
 
@@ -398,7 +403,7 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.ring, 0, b->n * (size_t)b->view.g.null_period * sizeof(f2), s));
     CK(hipMemsetAsync(b->view.corr, 0, b->n * (size_t)b->view.g.n_corr * sizeof(f2), s));
-    CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
+    CK(hipMemsetAsync(b->view.not_done, 0, 2 * sizeof(int), s));
 #undef CK
     return DABGPU_OK;
 }
@@ -438,9 +443,12 @@ int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, co
     alloc((void**)&b->view.copy_src, n_streams * sizeof(long long));
     alloc((void**)&b->view.copy_dst, n_streams * sizeof(int));
     alloc((void**)&b->view.copy_cnt, n_streams * sizeof(int));
-    alloc((void**)&b->view.not_done, sizeof(int));
+    alloc((void**)&b->view.not_done, 2 * sizeof(int));
     alloc((void**)&b->d_corr_out, n_streams * (size_t)G.n_sym * 2 * sizeof(float));
     alloc((void**)&b->d_status, n_streams * sizeof(dabgpu_stream_status));
+    if (!st) st = dabgpu_check_hip(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking), "hipStreamCreate(stream bank)");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming), "hipEventCreate");
     if (!st) st = dabgpu_stream_bank_reset(b, c->stream);
     if (!st) st = dabgpu_check_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     if (st) { dabgpu_stream_bank_destroy(b); return st; }
@@ -501,32 +509,55 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     // synchronisation of frame k share a round) plus one for the partial frame at the end; a stream that needs more (re-acquisition)
     // is caught by the counter read back after these
     const int blind_rounds = (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
-    int h_not_done = 1;
-    for (int round = 0; h_not_done != 0; round++) {
-        CK(hipMemsetAsync(b->view.not_done, 0, sizeof(int), s));
-        hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)n), dim3(256), 0, s, b->view, n, static_cast<const uint8_t*>(d_iq),
-                           stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0, ring_mode);
-        CK(hipGetLastError());
-        hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, static_cast<const uint8_t*>(d_iq),
-                           stream_stride_samples);
-        CK(hipGetLastError());
-        if (G.mode == 1) {
-            CK(dabgpu_launch_ofdm_demod(b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, nullptr, c->d_tw, c->d_inv_map,
-                                        n, 0, 0, b->view.desc, d_iq, stream_stride_samples, 0, s));
-        } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
-                                                       b->view.desc, d_iq, stream_stride_samples, s))) {
-            return st;
+    // Two lanes: the rounds of a stream are a serial chain (advance -> copy -> demodulate frame k - 1 -> phase -> synchronise frame k
+    // -> advance ...) of one bandwidth-sized kernel and four latency-bound small ones, but streams are independent -- a mode I bank
+    // of >= 256 streams runs the two halves of its streams on two HIP streams, so that one half's small kernels run beside the other
+    // half's demodulation.  Same kernels, same per-stream order, same results.
+    const int n_lanes = (G.mode == 1 && n >= 256) ? 2 : 1;
+    hipStream_t lane_stream[2] = {s, b->side};
+    const int lane_lo[3] = {0, (n_lanes == 2) ? n / 2 : n, n};
+    if (n_lanes == 2) {
+        CK(hipEventRecord(b->ev_fork, s));
+        CK(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+    }
+    const size_t sb = src_sample_bytes<SRC>::value;
+    int h_not_done[2] = {1, 0};
+    for (int round = 0; h_not_done[0] + h_not_done[1] != 0; round++) {
+        for (int l = 0; l < n_lanes; l++) {
+            hipStream_t ls = lane_stream[l];
+            const int s0 = lane_lo[l], cnt = lane_lo[l + 1] - lane_lo[l];
+            const uint8_t* iq_l = static_cast<const uint8_t*>(d_iq) + (size_t)s0 * stream_stride_samples * sb;
+            CK(hipMemsetAsync(b->view.not_done + l, 0, sizeof(int), ls));
+            hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)cnt), dim3(256), 0, ls, b->view, s0, cnt, static_cast<const uint8_t*>(d_iq),
+                               stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0, ring_mode,
+                               b->view.not_done + l);
+            CK(hipGetLastError());
+            hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)cnt), dim3(256), 0, ls, b->view, s0, static_cast<const uint8_t*>(d_iq),
+                               stream_stride_samples);
+            CK(hipGetLastError());
+            float* corr_l = b->d_corr_out + (size_t)s0 * G.n_sym * 2;
+            if (G.mode == 1) {
+                CK(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
+                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, 0, ls));
+            } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
+                                                           b->view.desc, d_iq, stream_stride_samples, ls))) {
+                return st;
+            }
+            CK(dabgpu_launch_ofdm_phase(corr_l, cnt, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[s0].freq_fine,
+                                        (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc + s0, G.n_sym, G.n_fft, ls));
+            // (after the phase kernel: the synchroniser of frame k sees the fine frequency the phase of frame k - 1 left, as in the reference)
+            CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + (size_t)s0 * NB_CORR + NB_NULL_PERIOD), NB_CORR, cnt, &b->cfg.sync,
+                                  b->view.sync + s0, nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active + s0, G.mode, ls));
         }
-        CK(dabgpu_launch_ofdm_phase(b->d_corr_out, n, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[0].freq_fine,
-                                    (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc, G.n_sym, G.n_fft, s));
-        // (after the phase kernel: the synchroniser of frame k sees the fine frequency the phase of frame k - 1 left, as in the reference)
-        CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + NB_NULL_PERIOD), NB_CORR, n, &b->cfg.sync, b->view.sync,
-                              nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active, G.mode, s));
         if (round + 1 >= blind_rounds) {
-            CK(hipMemcpyAsync(&h_not_done, b->view.not_done, sizeof(int), hipMemcpyDeviceToHost, s));
-            CK(hipStreamSynchronize(s));
+            for (int l = 0; l < n_lanes; l++) CK(hipMemcpyAsync(&h_not_done[l], b->view.not_done + l, sizeof(int), hipMemcpyDeviceToHost, lane_stream[l]));
+            for (int l = 0; l < n_lanes; l++) CK(hipStreamSynchronize(lane_stream[l]));
         }
         if (round > (1 << 22)) { dabgpu_set_error("stream_bank_process: no progress"); return DABGPU_ERR_HIP; }
+    }
+    if (n_lanes == 2) {
+        CK(hipEventRecord(b->ev_join, b->side));
+        CK(hipStreamWaitEvent(s, b->ev_join, 0));
     }
     if (d_n_frames) {
         hipLaunchKernelGGL(stream_report_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, b->view, n, d_n_frames,
