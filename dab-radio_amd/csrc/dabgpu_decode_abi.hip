@@ -180,6 +180,10 @@ static int validate_codeword(const dabgpu_codeword& d, size_t i) {
         dabgpu_set_error("codeword %zu: n_steps=%u does not equal sum(seg_steps)+6 with whole output bytes, or null address", i, d.n_steps);
         return DABGPU_ERR_INVALID_ARG;
     }
+    if ((d.flags & DABGPU_CW_CLASSED) && d.n_slots != 0 && (d.cif_stride == 0 || (d.cif_stride & 15))) {
+        dabgpu_set_error("codeword %zu: DABGPU_CW_CLASSED needs cif_stride = soft bits per ring row, a multiple of 16 (got %u)", i, d.cif_stride);
+        return DABGPU_ERR_INVALID_ARG;
+    }
     if (d.n_slots != 0 && (d.n_slots < 16 || d.cifs_per_frame == 0 || d.newest_slot >= d.n_slots)) {
         dabgpu_set_error("codeword %zu: bad CIF ring geometry (n_slots=%u newest=%u cifs_per_frame=%u)", i, d.n_slots, d.newest_slot, d.cifs_per_frame);
         return DABGPU_ERR_INVALID_ARG;

@@ -138,6 +138,54 @@ def test_one_sub_channel_filling_the_cif(ctx, level, type_b):
         assert np.array_equal(got[key][0], got[(1, 0)][0]) and np.array_equal(got[key][1], got[(1, 0)][1]), key
 
 
+@pytest.mark.parametrize("mapping", [1, 2], ids=["wave", "lane"])
+def test_generic_batch_with_a_classed_ring_of_any_geometry(ctx, mapping):
+    """DABGPU_CW_CLASSED through dabgpu_viterbi_decode_batch: 70 codewords of one schedule, each with its own 16-slot ring of one
+    sub-channel per row (cifs_per_frame = 1, cif_stride = the sub-channel's soft bits) -- the general readers (wave-mapped decoder,
+    byte gather of the lane mapping) must give the same bytes and path errors from the class-ordered rows as from the natural ones"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(21)
+    n_cw = 70                                             # EEP 3-A on 24 CU: the (PI, L) plan comes from the library
+    sub = dabgpu.SubChannel(0, 24, False, 0, 2, 0)
+    pi, lx, nb = dabgpu.subchannel_plan(sub)
+    n_in = 24 * 64
+    rows = rng.integers(-128, 128, (n_cw, 16, n_in), dtype=np.int8)
+    i = np.arange(n_in)
+    perm = np.empty(n_in, np.int64)
+    perm[(i % 16) * (n_in // 16) + i // 16] = i            # classed_row = natural_row[perm]
+    outs = {}
+    ctx.viterbi_set_mapping(mapping)
+    try:
+        for layout in (0, 1):
+            d_ring = torch.from_numpy(np.ascontiguousarray(rows[:, :, perm]) if layout else rows).cuda()
+            d_out = torch.zeros((n_cw, nb), dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_cw, 16), dtype=torch.uint8, device="cuda")
+            cws = []
+            for k in range(n_cw):
+                cw = dabgpu.Codeword()
+                cw.d_src, cw.d_out = d_ring[k].data_ptr(), d_out[k].data_ptr()
+                cw.n_steps = 32 * sum(lx) + 6
+                for q in range(len(lx)):
+                    cw.seg_pi[q], cw.seg_steps[q] = (pi[q] if lx[q] else 0), 32 * lx[q]
+                cw.n_slots, cw.newest_slot, cw.cifs_per_frame, cw.frame_stride, cw.cif_stride = 16, (k * 5) % 16, 1, n_in, n_in
+                cw.flags = 4 if layout else 0                                   # DABGPU_CW_CLASSED
+                cws.append(cw)
+            ctx.viterbi_decode_batch(cws, d_res, tie_rule=0)
+            torch.cuda.synchronize()
+            outs[layout] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+    finally:
+        ctx.viterbi_set_mapping(0)
+    assert outs[0][0].any()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    bad = dabgpu.Codeword()
+    bad.d_src = bad.d_out = 4096
+    bad.n_steps, bad.seg_pi[0], bad.seg_steps[0] = 38, 8, 32
+    bad.n_slots, bad.cifs_per_frame, bad.frame_stride, bad.cif_stride, bad.flags = 16, 1, 100, 100, 4
+    with pytest.raises(dabgpu.DabGpuError):
+        ctx.viterbi_decode_batch([bad], torch.zeros((1, 16), dtype=torch.uint8, device="cuda"))
+
+
 def test_bad_layout_and_unsupported_format_are_refused(ctx):
     import dabgpu
     import torch
