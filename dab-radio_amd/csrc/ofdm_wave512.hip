@@ -192,8 +192,8 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
             if constexpr (LEAVES == 4) { xr = (lr[0] + lr[2]) + (lr[1] + lr[3]); xi = (li[0] + li[2]) + (li[1] + li[3]); }
             else if constexpr (LEAVES == 2) { xr = lr[0] + lr[1]; xi = li[0] + li[1]; }
             else { xr = lr[0]; xi = li[0]; }
-            xr = wave_tree_sum(xr, lane); xi = wave_tree_sum(xi, lane);
-            if (lane == 0) cp_corr[(size_t)frame * NSYM + i] = mk2(xr, xi);
+            const float xs = wave_tree_sum_pair(xr, xi);                 // lane 0: the sum of xr, lane 32: the sum of xi (same additions)
+            if ((lane & 31) == 0) reinterpret_cast<float*>(cp_corr + (size_t)frame * NSYM + i)[lane >> 5] = xs;
         }
 
         // ---- transform(s) + DQPSK + soft bits ----
