@@ -408,12 +408,20 @@ extern "C" int dabgpu_msc_decode_frames_layout(dabgpu_ctx* c, const int8_t* d_hi
                           d_results, tie_rule, stream, bits_layout);
 }
 
+extern "C" int dabgpu_msc_decode_ring_layout(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                             const int32_t* d_newest_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
+                                             size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, int bits_layout,
+                                             void* stream) {
+    if (!d_newest_slot) { dabgpu_set_error("msc_decode_ring: null slot array"); return DABGPU_ERR_INVALID_ARG; }
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, 0, d_newest_slot, h_sub, n_sub, d_out, out_ens_stride, d_results,
+                          tie_rule, stream, bits_layout);
+}
+
 extern "C" int dabgpu_msc_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
                                       const int32_t* d_newest_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
                                       size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream) {
-    if (!d_newest_slot) { dabgpu_set_error("msc_decode_ring: null slot array"); return DABGPU_ERR_INVALID_ARG; }
-    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, 0, d_newest_slot, h_sub, n_sub, d_out, out_ens_stride, d_results,
-                          tie_rule, stream);
+    return dabgpu_msc_decode_ring_layout(c, d_hist, n_ens, ens_stride, hist_frames, d_newest_slot, h_sub, n_sub, d_out, out_ens_stride,
+                                         d_results, tie_rule, DABGPU_BITS_NATURAL, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -131,7 +131,7 @@ constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS +
 // of gfx9 is in order, therefore the previous symbol's soft-bit store is issued BEFORE the prefetch (from the middle of the
 // next symbol), never between a prefetch and its use.  0.438 -> 0.426 ms per 1024 frames (profiles/r02/ab_notes.md).
 //
-// CLASSED = true (soft bits only, frame batches only): the MSC symbols leave in time-interleaver class order -- inside every CIF row
+// CLASSED = true (soft bits only): the MSC symbols leave in time-interleaver class order -- inside every CIF row
 // of 55296 soft bits, bit i is stored at (i mod 16) * 3456 + i / 16 -- so that the channel decoder's gather, which needs for one
 // output CIF the bits of class c from the CIF that is 15 - bitrev4(c) CIFs old (cif_deinterleaver.cpp:57-68), reads each history row
 // in contiguous pieces instead of one byte in sixteen.  The permutation rides on the frequency de-interleave scatter (a second
@@ -140,7 +140,8 @@ template <int SRC, bool BANK, bool VIEWS = true, bool CLASSED = false>
 #if DABGPU_EXP & 16
 __global__ __launch_bounds__(256, 5)
 #else
-__global__ __launch_bounds__(256, VIEWS ? 3 : 4)      // (the display views need a few more registers: 3 workgroups per CU instead of spills)
+__global__ __launch_bounds__(256, (VIEWS || (BANK && CLASSED)) ? 3 : 4)      // (the display views, and the stream-bank loader with the
+                                                                            // second position set, need a few more registers: 3 workgroups per CU instead of spills)
 #endif
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
@@ -581,7 +582,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                int classed, hipStream_t stream)
 {
     using namespace dabgpu;
-    if (classed && (d_desc != nullptr || d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits of frame batches only
+    if (classed && (d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits only
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     // default: a whole frame per workgroup once the batch fills the chip (256 CUs x 4 workgroups) -- no halo symbol, one round per
     // 1024 frames; smaller batches are cut into three chunks per frame (one extra FFT per chunk) to spread over the CUs
@@ -599,9 +600,10 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
 #endif
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
-#define DABGPU_LAUNCH_C(SRC) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, false, false, true>), grid, dim3(256), lds, stream, \
+#define DABGPU_LAUNCH_CB(SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, false, true>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \
                        reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
+#define DABGPU_LAUNCH_C(SRC) do { if (d_desc != nullptr) DABGPU_LAUNCH_CB(SRC, true); else DABGPU_LAUNCH_CB(SRC, false); } while (0)
     switch (src) {
     case SRC_C32: if (classed) DABGPU_LAUNCH_C(SRC_C32); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
     case SRC_U8: if (classed) DABGPU_LAUNCH_C(SRC_U8); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_U8, true); else DABGPU_LAUNCH(SRC_U8, false); break;
@@ -610,6 +612,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     default: return hipErrorInvalidValue;
     }
 #undef DABGPU_LAUNCH_C
+#undef DABGPU_LAUNCH_CB
 #undef DABGPU_LAUNCH
 #undef DABGPU_LAUNCH_V
     return hipGetLastError();

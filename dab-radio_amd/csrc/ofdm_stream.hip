@@ -462,7 +462,8 @@ int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, co
 // (frames demodulated so far) mod ring length, d_n_frames receives the slot written in this call or -1
 template <int SRC>
 static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t stream_stride_samples, size_t n_samples,
-                             int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream, int ring_mode = 0) {
+                             int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream, int ring_mode = 0,
+                             int classed = 0) {
     if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
     const BankGeom& G = b->view.g;
@@ -538,7 +539,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
             float* corr_l = b->d_corr_out + (size_t)s0 * G.n_sym * 2;
             if (G.mode == 1) {
                 CK(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
-                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, 0, ls));
+                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls));
             } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
                                                            b->view.desc, d_iq, stream_stride_samples, ls))) {
                 return st;
@@ -620,23 +621,37 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int
 }
 
 // frames go straight into per-stream frame-history rings (the layout dabgpu_fic_decode_ring / dabgpu_msc_decode_ring read)
-int dabgpu_stream_bank_process_ring(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
-                                    int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, void* stream) {
+int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                           int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, int bits_layout, void* stream) {
     if (!b || !d_raw || !d_hist || !d_newest_slot) { dabgpu_set_error("stream_bank_process_ring: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (hist_frames < 5) { dabgpu_set_error("stream_bank_process_ring: the ring needs at least 5 frames"); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
+        dabgpu_set_error("stream_bank_process_ring: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG;
+    }
+    const int classed = bits_layout == DABGPU_BITS_MSC_CLASSED;
+    if (classed && b->view.g.mode != 1) {
+        dabgpu_set_error("stream_bank_process_ring: class order is defined for transmission mode I (the DAB layer above the soft bits is mode I only)");
+        return DABGPU_ERR_UNSUPPORTED;
+    }
     switch (format) {
     case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32:
-        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
     case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8:
-        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
     case DABGPU_IQ_RAW_S8:
-        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
     case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16:
-        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1);
+        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
     default:
         dabgpu_set_error("stream_bank_process_ring: format %d is not read directly (use raw_f32l, raw_u8, raw_s8 or raw_s16l)", format);
         return DABGPU_ERR_UNSUPPORTED;
     }
+}
+
+int dabgpu_stream_bank_process_ring(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                    int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, void* stream) {
+    return dabgpu_stream_bank_process_ring_layout(b, d_raw, format, stream_stride_samples, n_samples, d_hist, hist_frames, d_newest_slot,
+                                                  DABGPU_BITS_NATURAL, stream);
 }
 
 int dabgpu_stream_bank_status(dabgpu_stream_bank* b, dabgpu_stream_status* h_status, void* stream) {

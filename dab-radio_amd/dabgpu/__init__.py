@@ -56,7 +56,8 @@ ABI_SYMBOLS = [
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
-    "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout",
+    "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout", "dabgpu_stream_bank_process_ring_layout",
+    "dabgpu_msc_decode_ring_layout",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
@@ -202,6 +203,10 @@ def lib():
                                                      C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
                                                       C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_process_ring_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
+                                                             C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_msc_decode_ring_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dabgpu_fic_decode_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p]
         L.dabgpu_msc_decode_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -408,9 +413,14 @@ class Context:
                                            _ptr(results), tie_rule, self._stream(stream)), "dabgpu_fic_decode_ring")
 
     def msc_decode_ring(self, history, n_ensembles, ensemble_stride, history_frames, newest_slot, subchannels, out, out_ensemble_stride,
-                        results, tie_rule=0, stream=None):
+                        results, tie_rule=0, stream=None, bits_layout=BITS_NATURAL):
         n = len(subchannels)
         arr = (SubChannel * n)(*subchannels)
+        if bits_layout != BITS_NATURAL:
+            check(lib().dabgpu_msc_decode_ring_layout(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, _ptr(newest_slot),
+                                                      arr, n, _ptr(out), out_ensemble_stride, _ptr(results), tie_rule, int(bits_layout),
+                                                      self._stream(stream)), "dabgpu_msc_decode_ring_layout")
+            return
         check(lib().dabgpu_msc_decode_ring(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, _ptr(newest_slot), arr, n,
                                            _ptr(out), out_ensemble_stride, _ptr(results), tie_rule, self._stream(stream)),
               "dabgpu_msc_decode_ring")
@@ -500,7 +510,12 @@ class StreamBank:
         check(lib().dabgpu_stream_bank_process_raw(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(bits), max_frames,
                                                    _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process_raw")
 
-    def process_ring(self, raw, fmt, stream_stride_samples, n_samples, hist, hist_frames, newest_slot, stream=None):
+    def process_ring(self, raw, fmt, stream_stride_samples, n_samples, hist, hist_frames, newest_slot, stream=None, bits_layout=BITS_NATURAL):
+        if bits_layout != BITS_NATURAL:
+            check(lib().dabgpu_stream_bank_process_ring_layout(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(hist),
+                                                               hist_frames, _ptr(newest_slot), int(bits_layout), Context._stream(stream)),
+                  "dabgpu_stream_bank_process_ring_layout")
+            return
         check(lib().dabgpu_stream_bank_process_ring(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(hist), hist_frames,
                                                     _ptr(newest_slot), Context._stream(stream)), "dabgpu_stream_bank_process_ring")
 

@@ -319,6 +319,12 @@ int dabgpu_msc_decode_ring(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensem
                            const int32_t *d_newest_slot, const dabgpu_subchannel *subchannels, int n_subchannels, uint8_t *d_out,
                            size_t out_ensemble_stride, dabgpu_codeword_result *d_results, int tie_rule, void *stream);
 
+/* msc_decode_ring for rings whose MSC part is in `bits_layout` (dabgpu_stream_bank_process_ring_layout) */
+int dabgpu_msc_decode_ring_layout(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride, int history_frames,
+                                  const int32_t *d_newest_slot, const dabgpu_subchannel *subchannels, int n_subchannels, uint8_t *d_out,
+                                  size_t out_ensemble_stride, dabgpu_codeword_result *d_results, int tie_rule, int bits_layout,
+                                  void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Single-stream, host-buffer, synchronous forms used by the C++ mirror classes (one codeword per call).
  */
@@ -434,6 +440,11 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank *bank, const void *d_raw, 
  * directly (raw_f32l, raw_u8, raw_s8, raw_s16l, wav PCM8/PCM16/float32). */
 int dabgpu_stream_bank_process_ring(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
                                     size_t n_samples, int8_t *d_hist, int hist_frames, int32_t *d_newest_slot, void *stream);
+/* the same with the MSC part of every frame stored in `bits_layout` (DABGPU_BITS_NATURAL / DABGPU_BITS_MSC_CLASSED, see
+ * dabgpu_ofdm_demod_frames_history; mode I banks) -- read the rings with dabgpu_fic_decode_ring + dabgpu_msc_decode_ring_layout */
+int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
+                                           size_t n_samples, int8_t *d_hist, int hist_frames, int32_t *d_newest_slot,
+                                           int bits_layout, void *stream);
 /* snapshot of every stream's getters (GetState, GetSignalAverage, Get*FrequencyOffset, ...) into host memory; synchronous */
 int dabgpu_stream_bank_status(dabgpu_stream_bank *bank, dabgpu_stream_status *h_status, void *stream);
 

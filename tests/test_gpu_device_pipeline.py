@@ -9,7 +9,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_streams_to_access_units_on_the_device(oracle):
+@pytest.mark.parametrize("layout", [0, 1], ids=["natural", "classed"])
+def test_streams_to_access_units_on_the_device(oracle, layout):
+    """layout = 1: the rings hold the MSC soft bits in time-interleaver class order (dabgpu_stream_bank_process_ring_layout /
+    dabgpu_msc_decode_ring_layout): same FIBs, sub-channel bytes and access units; the ring content is the natural frame permuted"""
     import dabgpu
     import dabplus_model as M
     import stream_model as SM
@@ -52,6 +55,7 @@ def test_streams_to_access_units_on_the_device(oracle):
     d_off = (torch.arange(E, dtype=torch.int64, device="cuda") * (4 * nbytes))
     d_nb = torch.full((E,), nbytes, dtype=torch.int32, device="cuda")
 
+    to_natural = dabgpu.classed_to_natural_index()
     models = [SM.StreamModel(oracle) for _ in range(E)]
     iq = [oracle.iq_convert(raw[e], 0).view(np.complex64) for e in range(E)]
     deint = [oracle.Deinterleaver(sub.length * 8) for _ in range(E)]
@@ -60,9 +64,9 @@ def test_streams_to_access_units_on_the_device(oracle):
     checked = dict(frames=0, fibs=0, msc=0, superframes=0)
     for k in range(0, n, block):
         m = min(block, n - k)
-        bank.process_ring(d_raw[:, 2 * k:].data_ptr(), 0, n, m, d_hist, H, d_slot)
+        bank.process_ring(d_raw[:, 2 * k:].data_ptr(), 0, n, m, d_hist, H, d_slot, bits_layout=layout)
         ctx.fic_decode_ring(d_hist, E, H * dabgpu.NB_FRAME_BITS, d_slot, d_fib, d_fres)
-        ctx.msc_decode_ring(d_hist, E, H * dabgpu.NB_FRAME_BITS, H, d_slot, [gsub], d_msc, 4 * nbytes, d_mres)
+        ctx.msc_decode_ring(d_hist, E, H * dabgpu.NB_FRAME_BITS, H, d_slot, [gsub], d_msc, 4 * nbytes, d_mres, bits_layout=layout)
         torch.cuda.synchronize()
         slot = d_slot.cpu().numpy()
         st = bank.status()
@@ -85,7 +89,7 @@ def test_streams_to_access_units_on_the_device(oracle):
                 continue
             bits = new[0]["bits"]
             assert slot[e] == (models[e].frames_read - 1) % H
-            assert np.array_equal(hist[e, slot[e]], bits), (k, e)
+            assert np.array_equal(hist[e, slot[e]][to_natural] if layout else hist[e, slot[e]], bits), (k, e)
             checked["frames"] += 1
             for g in range(4):
                 eb, em, ee = oracle.fic_decode_group(bits[g * 2304:(g + 1) * 2304], 0)
