@@ -366,7 +366,7 @@ struct dabgpu_stream_bank {
     float* d_raw_scratch = nullptr;    // converted block of dabgpu_stream_bank_process_raw (grow-only)
     size_t raw_scratch_bytes = 0;
     std::vector<void*> allocs;
-    hipStream_t side = nullptr;        // second lane of a call (mode I banks of >= 256 streams): half of the streams run their rounds here
+    hipStream_t side = nullptr;        // second lane of a call (mode I banks of >= 1024 streams): half of the streams run their rounds here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -512,9 +512,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     const int blind_rounds = (int)((n_samples + NB_FRAME_SAMPLES - 1) / NB_FRAME_SAMPLES) + 1;
     // Two lanes: the rounds of a stream are a serial chain (advance -> copy -> demodulate frame k - 1 -> phase -> synchronise frame k
     // -> advance ...) of one bandwidth-sized kernel and four latency-bound small ones, but streams are independent -- a mode I bank
-    // of >= 256 streams runs the two halves of its streams on two HIP streams, so that one half's small kernels run beside the other
+    // of >= 1024 streams runs the two halves of its streams on two HIP streams, so that one half's small kernels run beside the other
     // half's demodulation.  Same kernels, same per-stream order, same results.
-    const int n_lanes = (G.mode == 1 && n >= 256) ? 2 : 1;
+    const int n_lanes = (G.mode == 1 && n >= 1024) ? 2 : 1;      // (each half must still fill the chip: 256 streams lost 10-30 % in two lanes)
     hipStream_t lane_stream[2] = {s, b->side};
     const int lane_lo[3] = {0, (n_lanes == 2) ? n / 2 : n, n};
     if (n_lanes == 2) {

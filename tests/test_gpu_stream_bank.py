@@ -270,3 +270,44 @@ def test_clean_streams_starting_anywhere_count_the_desyncs_the_model_counts(orac
     assert sum(m.frames_desync for m in models) >= 1, "expected at least one start position with a false first NULL"
     assert all(m.frames_read >= 1 for m in models), "every receiver locks within three frames"
     bank.close()
+
+
+def test_bank_of_1024_streams_in_two_lanes_equals_the_small_bank(oracle):
+    """from 1024 streams on a mode I bank runs the two halves of its streams on two HIP streams: 1024 receivers fed four distinct
+    captures (each 256 times, interleaved so that every capture is in both halves) must give, stream by stream, the frames and the
+    status of a 4-stream bank fed the same blocks -- bits, frame counts and every status field after every call"""
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    base = [make_stream(oracle, 11, 3, 1.8e-3, 1234, 3.0), make_stream(oracle, 12, 3, -7.3e-3, 77, 6.0),
+            make_stream(oracle, 13, 3, 2.0e-4, 2551, 1.0, dropout=(215000, 235000)), noise_with_dips(14, streams_len=650000)]
+    n = min(s.size for s in base)
+    n -= n % 2
+    q = [np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 127.0 + 127.5), 0, 255).astype(np.uint8)
+         for s in base]                                                      # raw_u8 captures: 2 bytes per sample
+    small = np.stack(q)                                                      # [4][n][2]
+    N = 1024
+    d_small = torch.from_numpy(small).cuda()
+    d_big = d_small.repeat(N // 4, 1, 1).contiguous()                        # stream s = capture s mod 4
+    fmt = dabgpu.IQ_FORMATS.index("raw_u8")
+    block, max_frames = 300000, 3
+    banks = {4: dabgpu.StreamBank(ctx, 4), N: dabgpu.StreamBank(ctx, N)}
+    bits = {4: torch.zeros((4, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda"),
+            N: torch.zeros((N, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda")}
+    nf = {4: torch.zeros(4, dtype=torch.int32, device="cuda"), N: torch.zeros(N, dtype=torch.int32, device="cuda")}
+    frames = 0
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        for E, d in ((4, d_small), (N, d_big)):
+            bits[E].zero_()
+            banks[E].process_raw(d[:, k:].data_ptr(), fmt, n, m, bits[E], max_frames, nf[E])
+        torch.cuda.synchronize()
+        n4, nN = nf[4].cpu().numpy(), nf[N].cpu().numpy()
+        assert np.array_equal(nN, np.tile(n4, N // 4)), k
+        assert torch.equal(bits[N].view(N // 4, 4, -1), bits[4].view(1, 4, -1).expand(N // 4, -1, -1)), k
+        s4, sN = banks[4].status(), banks[N].status()
+        for name in s4.dtype.names:
+            assert np.array_equal(sN[name].view(np.uint32) if sN[name].dtype == np.float32 else sN[name],
+                                  np.tile(s4[name].view(np.uint32) if s4[name].dtype == np.float32 else s4[name], N // 4)), (k, name)
+        frames += int(n4.sum())
+    assert frames >= 5
