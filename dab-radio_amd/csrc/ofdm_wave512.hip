@@ -22,6 +22,12 @@
 #include "iq_sample.h"
 #include "ofdm_device.h"
 
+// minimum waves per SIMD asked of the compiler for mode IV: 1 = no cap (140 VGPRs, three waves per SIMD, 0.45 ms per 2048 frames);
+// 4 caps at 128 registers, spills 10 and measured 0.51 ms (the register-table version before: 176 VGPRs, two waves, 0.48 ms)
+#ifndef W512_M4_WAVES
+#define W512_M4_WAVES 1
+#endif
+
 namespace dabgpu {
 
 template <int MODE> struct W512Geom;
@@ -59,21 +65,33 @@ __device__ __forceinline__ void fft256_wave(const f2 (&x)[4], f2 (&a)[8], f2* pa
 }
 
 // the 512-point transform of one wavefront: a[j] = input lane + 64 j  ->  a[k] = bin (lane >> 3) + 8 (lane & 7) + 64 k
-__device__ __forceinline__ void fft512_wave(f2 (&a)[8], f2* patch, const f2 (&w2)[7], const f2 (&w3)[7], int lane) {
+// LW: the twiddles come from the workgroup's LDS tables (w2p[64 (k - 1)], w3p[8 (k - 1)]; mode IV, whose sixteen samples per lane
+// leave no registers for them) instead of registers -- the same table entries
+template <bool LW>
+__device__ __forceinline__ void fft512_wave(f2 (&a)[8], f2* patch, const f2 (&w2)[7], const f2 (&w3)[7], const f2* w2p, const f2* w3p, int lane) {
     const int la = lane & 7, lb = lane >> 3;
     const int ta_w = lane, ta_r = la + 72 * lb, tb_w = la + 72 * lb, tb_r = 9 * la + 72 * lb;
     dft8(a);
+    f2 t2[7], t3[7];
+    if constexpr (LW) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) t2[k] = w2p[64 * k];
+    }
     patch[ta_w] = a[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+    for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], LW ? t2[k - 1] : w2[k - 1]);
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
     wave_lds_fence();
     dft8(a);
+    if constexpr (LW) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) t3[k] = w3p[8 * k];
+    }
     patch[tb_w] = a[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], w3[k - 1]);
+    for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], LW ? t3[k - 1] : w3[k - 1]);
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
@@ -82,7 +100,7 @@ __device__ __forceinline__ void fft512_wave(f2 (&a)[8], f2* patch, const f2 (&w2
 }
 
 template <int MODE, int SRC, bool BANK>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, MODE == 4 ? W512_M4_WAVES : 1)
 void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset, int8_t* __restrict__ bits,
                             f2* __restrict__ cp_corr, const f2* __restrict__ tw, const int* __restrict__ inv_map, int n_frames,
                             int sym_per_chunk, int chunks_per_frame, const dabgpu_frame_desc* __restrict__ desc,
@@ -102,6 +120,16 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     f2* patch = patches[wave];
     int8_t* obuf = obufs[wave];
+    // mode IV keeps its three twiddle sets in LDS tables of the workgroup (filled here, by all four waves, before any of them can
+    // leave: the only workgroup barrier of the kernel)
+    constexpr bool LW = (MODE == 4);
+    __shared__ f2 tw_lds[LW ? (8 * 64 + 7 * 64 + 7 * 8) : 1];
+    if constexpr (LW) {
+        for (int e = (int)threadIdx.x; e < 8 * 64; e += 256) tw_lds[e] = tw[2 * ((e & 63) + 64 * (e >> 6))];                 // w0 [j][lane]
+        for (int e = (int)threadIdx.x; e < 7 * 64; e += 256) tw_lds[8 * 64 + e] = tw[4 * (e & 63) * ((e >> 6) + 1)];           // w2 [k - 1][lane]
+        for (int e = (int)threadIdx.x; e < 7 * 8; e += 256) tw_lds[15 * 64 + e] = tw[32 * (e & 7) * ((e >> 3) + 1)];           // w3 [k - 1][lane & 7]
+        __syncthreads();
+    }
 
     const int unit = (int)blockIdx.x * 4 + wave;
     const int frame = unit / chunks_per_frame, chunk = unit % chunks_per_frame;
@@ -128,11 +156,23 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
 
     // twiddles resident in registers: pass r1 (mode IV) w_1024^{p}, p = lane + 64 j; then w_512^{lane k}, w_64^{(lane & 7) k}
     // (mode III: pass 1 w_256^{lane k}, pass 2 w_64^{(lane & 7) k})
+    // (mode IV: sixteen samples per lane and twelve kept bins leave no registers for 44 twiddle registers -- 176 VGPRs, two waves per
+    // SIMD; its three sets sit in LDS tables of the workgroup instead: 8.4 KB, read just before use)
     f2 w0[8], w2[7], w3[7];
+    if constexpr (LW) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) w0[j] = (Q == 2) ? tw[2 * (lane + 64 * j)] : ((MODE == 3 && j >= 1 && j < 4) ? tw[8 * lane * j] : mk2(1.0f, 0.0f));
+        for (int j = 0; j < 8; j++) w0[j] = mk2(1.0f, 0.0f);
 #pragma unroll
-    for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
+        for (int k = 0; k < 7; k++) { w2[k] = mk2(1.0f, 0.0f); w3[k] = mk2(1.0f, 0.0f); }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) w0[j] = (Q == 2) ? tw[2 * (lane + 64 * j)] : ((MODE == 3 && j >= 1 && j < 4) ? tw[8 * lane * j] : mk2(1.0f, 0.0f));
+#pragma unroll
+        for (int k = 1; k < 8; k++) { w2[k - 1] = tw[4 * lane * k]; w3[k - 1] = tw[32 * (lane & 7) * k]; }
+    }
+    const f2* const w0p = tw_lds + lane;
+    const f2* const w2p = tw_lds + (LW ? 8 * 64 : 0) + lane;
+    const f2* const w3p = tw_lds + (LW ? 15 * 64 : 0) + (lane & 7);
 
     // soft-bit positions of the lane's active bins.  Sub-transform q leaves bin q + Q (Ks + 64 k) in register k, Ks = (lane >> 3) +
     // 8 (lane & 7); carriers -NC/2 .. -1, 1 .. NC/2 are bins N - NC/2 .. N - 1 and 1 .. NC/2 = registers 5, 6, 7 and 0, 1, 2 (+ register 3
@@ -208,9 +248,9 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     if constexpr (Q == 1) a[j] = x[j];
-                    else a[j] = (q == 0) ? (x[j] + x[j + 8]) : cmul(x[j] - x[j + 8], w0[j]);     // radix-2 pass, inside the lane
+                    else a[j] = (q == 0) ? (x[j] + x[j + 8]) : cmul(x[j] - x[j + 8], LW ? w0p[64 * j] : w0[j]);     // radix-2 pass, inside the lane
                 }
-                fft512_wave(a, patch, w2, w3, lane);
+                fft512_wave<LW>(a, patch, w2, w3, w2p, w3p, lane);
             }
             f2 cur[6];
             cur[0] = (q == 0 && Ks == 0) ? a[3] : a[0];
