@@ -314,9 +314,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
     if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
-    if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
-    if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                       d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
+    // (the plans are staged and the descriptors built once the mapping of every sub-channel is known, below)
     // Which sub-channels go to the lane-per-codeword kernel?  The k longest can be left to viterbi_kernel (one wavefront per
     // codeword) and the rest given to vit_lanes_kernel in the same call; AUTO only compares the two pure choices k = 0 and
     // k = n_sub with the cost model of use_lane_mapping() -- a partial viterbi_kernel launch is a single lockstep round of
@@ -351,12 +349,12 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         }
     }
     const int n_lane = n_sub - k_wave;
+    // flag the lane-mapped sub-channels in the plans the descriptor builder reads, then stage the plans and build the descriptors
+    for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
+    if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
+    if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
+                                                       d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
     if (n_lane > 0) {
-        // flag the lane-mapped sub-channels in the plans the descriptor builder read: rebuild the descriptors with the flags
-        for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
-        if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
-        if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                           d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
         // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
         // stays inside the scratch bound
         size_t rows_per_gq = 0;
