@@ -397,8 +397,30 @@ def main():
         iq_f = torch.view_as_real(iq)
         units = F
 
+        fmt_f32 = dabgpu.IQ_FORMATS.index("raw_f32l")
+        spb_timing = None
+        if args.spb == 0 and F >= 1024 and not args.dry_run:
+            # symbols per workgroup: a whole frame (75: one round of workgroups on a full chip, phase tail inside the kernel) or three
+            # runs per frame (25, the library default) -- which is faster depends on whether the box holds F workgroups at once, so
+            # both are timed (untimed region) and the faster one is used for the run
+            spb_timing = {}
+            for rep in range(3):                                       # interleaved, the last pass counts: both see the same clock state
+                for cand in (25, 75):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20):
+                        ctx.ofdm_demod_phase_frames(iq_f, fmt_f32, F, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=cand,
+                                                    beta=0.9, total_phase=d_total, fine_freq=d_fine)
+                    e1.record(); torch.cuda.synchronize()
+                    spb_timing[cand] = e0.elapsed_time(e1) / 20
+            args.spb = min(spb_timing, key=spb_timing.get)
+            d_fine.zero_()
+
         def demod_launch():
-            ctx.ofdm_demod_frames(iq_f, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb, n_frames=F)
+            # demodulation + the phase tail of the fine-frequency loop (ofdm_phase_update) as one call: one launch when a workgroup walks
+            # a whole frame (the default from 1024 frames), else the tail follows as its own small launch inside the call
+            ctx.ofdm_demod_phase_frames(iq_f, fmt_f32, F, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb,
+                                        beta=0.9, total_phase=d_total, fine_freq=d_fine)
 
         def step(k, timed=False):
             if timed and k % ev_every == 0:
@@ -407,7 +429,6 @@ def main():
                 evs.append((a, b))
             else:
                 demod_launch()
-            ctx.ofdm_phase_update(d_corr, F, total_phase=d_total, fine_freq=d_fine, beta=0.9)
     else:
         E = args.ensembles
         first_unit, n_units = shard.shard_range(E * world, rank, world)
@@ -469,8 +490,10 @@ def main():
         if args.workload == "demod":
             workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
                         "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU")
-            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or (75 if units >= 1024 else 25),
+            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or 25,
                       "sharding": "independent frames / ensembles per rank, no data-path collective"}
+            if spb_timing:
+                config["symbols_per_block_timed_ms"] = {str(k): v for k, v in spb_timing.items()}
         else:
             workload = (f"BASELINE configs[4]: {units * world} synthetic ensembles ({units} per GPU, built on the device from "
                         f"{min(args.distinct, units)} seeded multiplexes), full FIC+MSC: OFDM demod + FIC Viterbi + 18 x 48 CU EEP 3-A "

@@ -231,7 +231,7 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 // ---- OFDM ----
 static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_frames, const float* d_freq, int8_t* d_bits,
                          float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream,
-                         int bits_layout = DABGPU_BITS_NATURAL) {
+                         int bits_layout = DABGPU_BITS_NATURAL, float* d_total_phase = nullptr, float* d_fine_freq = nullptr, float beta = 0.0f) {
     if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
         dabgpu_set_error("ofdm_demod_frames: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG;
     }
@@ -250,7 +250,8 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
     }
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
                                                      (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0,
-                                                     bits_layout == DABGPU_BITS_MSC_CLASSED, s), "ofdm_demod_kernel launch");
+                                                     bits_layout == DABGPU_BITS_MSC_CLASSED, s, d_total_phase, d_fine_freq, beta),
+                            "ofdm_demod_kernel launch");
 }
 
 int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
@@ -278,6 +279,25 @@ int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, s
     if (st) return st;
     if ((st = dabgpu_iq_convert(c, d_raw, format, n_frames * DABGPU_NB_FRAME_SAMPLES, d_iq, stream))) return st;
     return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
+}
+
+static int fused_loader_of(int format) {
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: return 0;
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: return 1;
+    case DABGPU_IQ_RAW_S8: return 2;
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: return 3;
+    default: return -1;
+    }
+}
+
+int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
+                                   float* d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
+                                   float fine_freq_update_beta, float* d_total_phase, float* d_fine_freq, void* stream) {
+    const int src = fused_loader_of(format);
+    if (src < 0) { dabgpu_set_error("ofdm_demod_phase_frames: format %d has no fused loader (float32, u8, s8, s16 little endian do)", format); return DABGPU_ERR_INVALID_ARG; }
+    return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, nullptr, nullptr, symbols_per_block, bits_frame_stride, stream, bits_layout,
+                          d_total_phase, d_fine_freq, fine_freq_update_beta);
 }
 
 int dabgpu_ofdm_demod_frames_history(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,

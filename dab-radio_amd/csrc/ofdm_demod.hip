@@ -116,10 +116,14 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
     }
 }
 
+// optional fused tail of the kernel = ofdm_phase_kernel of the frame (total_phase / fine_freq may each be null)
+struct demod_phase_tail { float* total_phase; float* fine_freq; float beta; };
+
 // LDS of one workgroup (float2 elements unless noted)
 constexpr int LDS_TW1 = 6 * 256;           // pass-1 twiddles [thread][6]: a private 48-byte slot per thread (registers parked in LDS)
 constexpr int LDS_TW3 = 7 * 8;             // pass-3 twiddles [k][lane & 7] (stream-bank and class-order instantiations only: they need the registers)
-constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW1 + LDS_TW3) * sizeof(f2);
+constexpr int LDS_PHASE = 80 + 40;         // fused phase tail: the frame's 76 correlations (f2) + their 76 angles (float)
+constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS + 8 * sizeof(f2) + (LDS_TW1 + LDS_TW3 + LDS_PHASE) * sizeof(f2);
 
 // VIEWS = false: the instantiation for callers that want soft bits only (fft_out / dqpsk_out are GUI views of the reference's
 // GetFrameFFT() / GetFrameDataVec()): their stores and per-carrier branches leave the symbol loop
@@ -147,7 +151,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
-                       const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride)
+                       const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride, demod_phase_tail pt)
 {
     f2* const fft_out = VIEWS ? fft_out_ : nullptr;
     f2* const dqpsk_out = VIEWS ? dqpsk_out_ : nullptr;
@@ -162,6 +166,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     f2* red = reinterpret_cast<f2*>(obuf + NB_SYM_BITS);                 // 2 x 4 x 8 B
     f2* tw1l = red + 8;                                                  // 256 x 6 x 8 B
     f2* tw3l = tw1l + LDS_TW1;                                           // 7 x 8 x 8 B
+    f2* ph_corr = tw3l + LDS_TW3;                                        // 80 x 8 B + 80 x 4 B (fused phase tail)
+    // fused phase tail (the launcher asks for it only when this workgroup walks the whole frame): ofdm_phase_kernel's work at the
+    // end of the run -- the per-symbol angles in parallel, their sum in symbol order, the fine-frequency update
+    const bool phase_tail = !VIEWS && !BANK && (pt.total_phase != nullptr || pt.fine_freq != nullptr);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -389,7 +397,9 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         if (do_corr && t == 0) {
             const f2* rr = red + 4 * (i & 1);
             const f2 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
-            cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = (r0 + r1) + (r2 + r3);
+            const f2 rsum = (r0 + r1) + (r2 + r3);
+            cp_corr[(size_t)frame * NB_FRAME_SYMBOLS + i] = rsum;
+            if (phase_tail) ph_corr[i] = rsum;
         }
         // this symbol's samples are consumed: the next symbol's loads go into the same registers now
 #if !(DABGPU_EXP & 4)
@@ -500,6 +510,18 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         symbol(i, prev, keep);
         if (i + 1 <= sym_end) symbol(i + 1, keep, prev);
     }
+    if (phase_tail) {
+        float* ang = reinterpret_cast<float*>(ph_corr + 80);
+        __syncthreads();
+        if (t < NB_FRAME_SYMBOLS) { const f2 c = ph_corr[t]; ang[t] = atan2_det(c.y, c.x); }
+        __syncthreads();
+        if (t == 0) {
+            float total = 0.0f;
+            for (int k = 0; k < NB_FRAME_SYMBOLS; k++) total += ang[k];                 // the reference's sequential sum (:606-618)
+            if (pt.total_phase) pt.total_phase[frame] = total;
+            if (pt.fine_freq) pt.fine_freq[frame] = fine_freq_update(pt.fine_freq[frame], total, pt.beta, NB_FRAME_SYMBOLS, NB_FFT);
+        }
+    }
 #if DABGPU_EXP & 8
     {
         unsigned long long ph_r1, ph_t1;
@@ -514,28 +536,6 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         }
     }
 #endif
-}
-
-// ---- deterministic atan2 (same operation sequence as the oracle's dab_atan2f) ----
-__device__ __forceinline__ float atan2_det(float y, float x) {
-    const float PI_F = 3.14159274101257324f, PIO2_F = 1.57079637050628662f, PIO4_F = 0.785398185253143311f;
-    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    const float mx = (ax > ay) ? ax : ay;
-    const float mn = (ax > ay) ? ay : ax;
-    if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;
-    float base = 0.0f;
-    if (a > 0.4142135679721832f) { base = PIO4_F; a = (a - 1.0f) / (a + 1.0f); }
-    const float z = a * a;
-    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
-    p = fma_(p, z, 1.99777106478e-1f);
-    p = fma_(p, z, -3.33329491539e-1f);
-    float r = fma_(p * z, a, a);
-    r = base + r;
-    if (ay > ax) r = PIO2_F - r;
-    if (x < 0.0f) r = PI_F - r;
-    if (y < 0.0f) r = -r;
-    return r;
 }
 
 // one thread per frame: sequential sum of the 76 per-symbol phase errors, then the fine-frequency IIR
@@ -558,17 +558,7 @@ void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
     float total = 0.0f;
     for (int i = 0; i < n_sym; i++) total += ph[i];
     if (total_phase) total_phase[fr] = total;
-    if (fine_freq) {
-        const float TWO_PI = 3.14159274101257324f * 2.0f;
-        const float avg = total / (float)n_sym;
-        const float spacing = 1.0f / (float)n_fft;
-        const float err = spacing * avg / TWO_PI;
-        const float delta = -beta * err;
-        const float wrap = 0.5f * spacing * 1.01f;
-        float fine = fine_freq[(size_t)fr * fine_freq_stride] + delta;
-        fine = fmodf(fine, wrap);
-        fine_freq[(size_t)fr * fine_freq_stride] = fine;
-    }
+    if (fine_freq) fine_freq[(size_t)fr * fine_freq_stride] = fine_freq_update(fine_freq[(size_t)fr * fine_freq_stride], total, beta, n_sym, n_fft);
 }
 
 }  // namespace dabgpu
@@ -579,21 +569,26 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
-                                               int classed, hipStream_t stream)
+                                               int classed, hipStream_t stream, float* d_total_phase, float* d_fine_freq, float beta)
 {
     using namespace dabgpu;
     if (classed && (d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits only
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
-    // default: a whole frame per workgroup once the batch fills the chip (256 CUs x 4 workgroups) -- no halo symbol, one round per
-    // 1024 frames; smaller batches are cut into three chunks per frame (one extra FFT per chunk) to spread over the CUs
-    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = (n_frames >= 1024) ? 75 : 25;
+    // default: three runs per frame (one extra FFT per run).  A whole frame per workgroup (75) is 1 % faster when 1024 frames are
+    // exactly one round of a 256-CU chip (and lets the phase tail run inside the kernel) but 25 % slower on a box where those 1024
+    // workgroups did not all fit at once (0.536 against 0.427 ms): callers that care time both (bench.py does) and pass it
+    if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 25;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = DEMOD_LDS_BYTES;
+    const bool views_ = (d_fft != nullptr) || (d_dqpsk != nullptr);
+    // the phase tail runs inside the kernel when one workgroup walks the whole frame; otherwise as its own launch below
+    const bool fuse = (d_total_phase != nullptr || d_fine_freq != nullptr) && chunks == 1 && d_desc == nullptr && !views_;
+    const demod_phase_tail pt = {fuse ? d_total_phase : nullptr, fuse ? d_fine_freq : nullptr, beta};
     const dim3 grid((unsigned)(n_frames * chunks));
 #define DABGPU_LAUNCH_V(SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt)
 #if DABGPU_EXP & 8
     const bool views = false;                  // d_fft is the phase-clock buffer of the soft-bits-only instantiation
 #else
@@ -602,7 +597,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
 #define DABGPU_LAUNCH_CB(SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, false, true>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \
-                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride)
+                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt)
 #define DABGPU_LAUNCH_C(SRC) do { if (d_desc != nullptr) DABGPU_LAUNCH_CB(SRC, true); else DABGPU_LAUNCH_CB(SRC, false); } while (0)
     switch (src) {
     case SRC_C32: if (classed) DABGPU_LAUNCH_C(SRC_C32); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
@@ -615,7 +610,13 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 #undef DABGPU_LAUNCH_CB
 #undef DABGPU_LAUNCH
 #undef DABGPU_LAUNCH_V
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !fuse && (d_total_phase != nullptr || d_fine_freq != nullptr) && d_desc == nullptr) {
+        hipLaunchKernelGGL(ofdm_phase_kernel, dim3((unsigned)n_frames), dim3(64), 0, stream, reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta,
+                           d_total_phase, d_fine_freq, 1, static_cast<const dabgpu_frame_desc*>(nullptr), NB_FRAME_SYMBOLS, NB_FFT);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,

@@ -143,6 +143,39 @@ __device__ __forceinline__ void soft_bit_pair(f2 d, int& bx, int& by) {
     }
 }
 
+// ---- deterministic atan2 (same operation sequence as the oracle's dab_atan2f) ----
+__device__ __forceinline__ float atan2_det(float y, float x) {
+    const float PI_F = 3.14159274101257324f, PIO2_F = 1.57079637050628662f, PIO4_F = 0.785398185253143311f;
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = (ax > ay) ? ax : ay;
+    const float mn = (ax > ay) ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float base = 0.0f;
+    if (a > 0.4142135679721832f) { base = PIO4_F; a = (a - 1.0f) / (a + 1.0f); }
+    const float z = a * a;
+    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fma_(p, z, 1.99777106478e-1f);
+    p = fma_(p, z, -3.33329491539e-1f);
+    float r = fma_(p * z, a, a);
+    r = base + r;
+    if (ay > ax) r = PIO2_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+// fine-frequency loop of one frame from its summed cyclic-prefix phase (ofdm_demodulator.cpp:779-824, :829-840)
+__device__ __forceinline__ float fine_freq_update(float fine, float total, float beta, int n_sym, int n_fft) {
+    const float TWO_PI = 3.14159274101257324f * 2.0f;
+    const float avg = total / (float)n_sym;
+    const float spacing = 1.0f / (float)n_fft;
+    const float err = spacing * avg / TWO_PI;
+    const float delta = -beta * err;
+    const float wrap = 0.5f * spacing * 1.01f;
+    return fmodf(fine + delta, wrap);
+}
+
 // value of `v` held by lane (lane ^ XORMASK), XORMASK in {32,16,8,4,2,1}, without touching the LDS crossbar:
 // v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row_ror:8 / bank-masked row shifts / quad_perm
 template <int XORMASK>

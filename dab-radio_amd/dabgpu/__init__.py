@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
     "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout", "dabgpu_stream_bank_process_ring_layout",
-    "dabgpu_msc_decode_ring_layout",
+    "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
@@ -163,6 +163,8 @@ def lib():
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.dabgpu_ofdm_demod_frames_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                        C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+        L.dabgpu_ofdm_demod_phase_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_msc_decode_frames_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
                                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
@@ -334,6 +336,13 @@ class Context:
         check(lib().dabgpu_ofdm_demod_frames_history(self._h, _ptr(raw), int(fmt), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
                                                      symbols_per_block, bits_frame_stride, int(bits_layout), self._stream(stream)),
               "dabgpu_ofdm_demod_frames_history")
+
+    def ofdm_demod_phase_frames(self, raw, fmt, n_frames, bits, freq_offset=None, cp_corr=None, symbols_per_block=0, bits_frame_stride=0,
+                                bits_layout=BITS_NATURAL, beta=0.0, total_phase=None, fine_freq=None, stream=None):
+        """demodulation + phase tail (ofdm_phase_update) as one call; one launch when a workgroup walks a whole frame"""
+        check(lib().dabgpu_ofdm_demod_phase_frames(self._h, _ptr(raw), int(fmt), n_frames, _ptr(freq_offset), _ptr(bits), _ptr(cp_corr),
+                                                   symbols_per_block, bits_frame_stride, int(bits_layout), float(beta), _ptr(total_phase),
+                                                   _ptr(fine_freq), self._stream(stream)), "dabgpu_ofdm_demod_phase_frames")
 
     def ofdm_demod_frames_mode(self, mode, iq, n_frames, bits, freq_offset=None, cp_corr=None, fft=None, symbols_per_block=0, stream=None):
         """frame-aligned frames of transmission mode 1..4 through the size-generic kernel"""

@@ -132,6 +132,17 @@ int dabgpu_ofdm_demod_frames_history(dabgpu_ctx *ctx, const void *d_raw, int for
                                      int bits_layout, void *stream);
 
 /*
+ * dabgpu_ofdm_demod_frames_history followed by dabgpu_ofdm_phase_update(d_cp_corr, ...) as one call -- and as ONE launch whenever a
+ * workgroup walks a whole frame (symbols_per_block = 75, which is the default for batches of >= 1024 frames): the phase tail
+ * (per-symbol atan2, sequential sum, fine-frequency update: ofdm_demodulator.cpp:606-618, :779-840) then runs at the end of the
+ * demodulation kernel, on the correlations it has just produced.  Otherwise the tail follows as its own launch.  Results are
+ * identical to the two separate calls.  d_total_phase / d_fine_freq as in dabgpu_ofdm_phase_update (either may be NULL).
+ */
+int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, const float *d_freq_offset,
+                                   int8_t *d_bits, float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
+                                   float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
+
+/*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]
  * (sequential, i = 0..75), and optionally fine <- fmod(fine - beta*err, wrap).
  * Replaces OFDM_Demod::CoordinatorThread's phase section (ofdm_demodulator.cpp:606-618) +

@@ -179,3 +179,47 @@ def test_full_size_batch_properties(ctx, oracle):
     per_variant = {key: zlib.crc32(gb[k].tobytes()) for key, k in first.items()}
     assert zlib.crc32(np.array([zlib.crc32(gb[k].tobytes()) for k in range(len(order))], dtype=np.uint32).tobytes()) == \
         zlib.crc32(np.array([per_variant[key] for key in order], dtype=np.uint32).tobytes())
+
+
+@pytest.mark.parametrize("fmt_name", ["raw_f32l", "raw_u8"])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_fused_phase_tail_equals_the_two_calls(ctx, fmt_name, layout):
+    """dabgpu_ofdm_demod_phase_frames == dabgpu_ofdm_demod_frames_history + dabgpu_ofdm_phase_update, bit for bit (soft bits,
+    correlations, summed phase, updated fine frequency), both when the tail runs inside the demodulation kernel (a workgroup per
+    frame: symbols_per_block 75) and when it follows as its own launch (25, 7), with either output null"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(77)
+    n = 9
+    fmt = dabgpu.IQ_FORMATS.index(fmt_name)
+    if fmt_name == "raw_f32l":
+        raw = torch.from_numpy(rng.standard_normal((n, 196608, 2)).astype(np.float32)).cuda()
+    else:
+        raw = torch.from_numpy(rng.integers(0, 256, (n, 196608, 2), dtype=np.uint8)).cuda()
+    freq = torch.from_numpy(((rng.random(n) * 2 - 1) * 2.0e-3).astype(np.float32)).cuda()
+    fine0 = torch.from_numpy(((rng.random(n) * 2 - 1) * 1.0e-4).astype(np.float32)).cuda()
+    ref_bits = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
+    ref_corr = torch.zeros((n, 76, 2), dtype=torch.float32, device="cuda")
+    ref_total = torch.zeros(n, dtype=torch.float32, device="cuda")
+    ref_fine = fine0.clone()
+    ctx.ofdm_demod_frames_history(raw, fmt, n, ref_bits, freq_offset=freq, cp_corr=ref_corr, bits_layout=layout)
+    ctx.ofdm_phase_update(ref_corr, n, total_phase=ref_total, fine_freq=ref_fine, beta=0.9)
+    torch.cuda.synchronize()
+    assert len(torch.unique(ref_total)) == n and not torch.equal(ref_fine, fine0)
+    for spb in (75, 25, 7):
+        for want_total, want_fine in ((True, True), (True, False), (False, True)):
+            bits = torch.zeros_like(ref_bits); corr = torch.zeros_like(ref_corr)
+            total = torch.zeros_like(ref_total); fine = fine0.clone()
+            ctx.ofdm_demod_phase_frames(raw, fmt, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb, bits_layout=layout,
+                                        beta=0.9, total_phase=total if want_total else None, fine_freq=fine if want_fine else None)
+            torch.cuda.synchronize()
+            assert torch.equal(bits, ref_bits) and torch.equal(corr.view(torch.int32), ref_corr.view(torch.int32)), (spb, want_total, want_fine)
+            if want_total:
+                assert torch.equal(total.view(torch.int32), ref_total.view(torch.int32)), spb
+            if want_fine:
+                assert torch.equal(fine.view(torch.int32), ref_fine.view(torch.int32)), spb
+    # without a correlation buffer of the caller's (context scratch) the tail still runs
+    total = torch.zeros_like(ref_total)
+    ctx.ofdm_demod_phase_frames(raw, fmt, n, torch.zeros_like(ref_bits), freq_offset=freq, symbols_per_block=75, bits_layout=layout, total_phase=total)
+    torch.cuda.synchronize()
+    assert torch.equal(total.view(torch.int32), ref_total.view(torch.int32))
