@@ -575,8 +575,9 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     if (classed && (d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits only
     if (bits_frame_stride == 0) bits_frame_stride = NB_FRAME_BITS;
     // default: three runs per frame (one extra FFT per run).  A whole frame per workgroup (75) is 1 % faster when 1024 frames are
-    // exactly one round of a 256-CU chip (and lets the phase tail run inside the kernel) but 25 % slower on a box where those 1024
-    // workgroups did not all fit at once (0.536 against 0.427 ms): callers that care time both (bench.py does) and pass it
+    // exactly one round of a 256-CU chip (and lets the phase tail run inside the kernel) but 25 % slower on boxes whose CUs do not
+    // all run at one speed (workgroup lifetimes 0.33 .. 0.53 ms in one static round: 0.536 against 0.427 ms): callers that care
+    // time both (bench.py does) and pass it
     if (sym_per_chunk <= 0 || sym_per_chunk > 75) sym_per_chunk = 25;
     const int chunks = (75 + sym_per_chunk - 1) / sym_per_chunk;
     const size_t lds = DEMOD_LDS_BYTES;
