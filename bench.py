@@ -400,12 +400,12 @@ def main():
         fmt_f32 = dabgpu.IQ_FORMATS.index("raw_f32l")
         spb_timing = None
         if args.spb == 0 and F >= 1024 and not args.dry_run:
-            # symbols per workgroup: a whole frame (75: one round of workgroups on a full chip, phase tail inside the kernel) or three
-            # runs per frame (25, the library default) -- which is faster depends on whether the box holds F workgroups at once, so
-            # both are timed (untimed region) and the faster one is used for the run
+            # symbols per workgroup: a whole frame (75: one round of workgroups on a full chip, phase tail inside the kernel), two or
+            # three runs per frame (38, 25 = the library default) -- which is fastest depends on the box, so they are
+            # timed here (untimed region) and the fastest is used for the run
             spb_timing = {}
             for rep in range(3):                                       # interleaved, the last pass counts: both see the same clock state
-                for cand in (25, 75):
+                for cand in (25, 38, 75):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(20):
