@@ -10,6 +10,9 @@ mkdir -p $OUT
 BENCH_ARGS="--no-cpu-baseline --no-check --no-extras"
 ROUND=${2:-r02}
 python3 bench.py > $OUT/bench_n1_$TAG.json 2> $OUT/bench_n1_$TAG.err
+# the profiled runs use the workgroup size the bench run chose on this box (its set-up timing would add launches of the other sizes)
+SPB=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench_n1_$TAG.json').read().strip().splitlines()[-1])['config']['symbols_per_block'])" 2>/dev/null || echo 25)
+BENCH_ARGS="$BENCH_ARGS --spb $SPB"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 bench.py --steps 20 --warmup 3 $BENCH_ARGS > $OUT/prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 bench.py --steps 3 --warmup 1 $BENCH_ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 bench.py --steps 3 --warmup 1 $BENCH_ARGS > $OUT/pmc_write.log 2>&1
