@@ -15,6 +15,7 @@
 // (1 TB/s, barrier-bound) remains for the GUI views (fft_out) and as the cross-check of this one in the tests.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "dabgpu.h"
@@ -277,6 +278,167 @@ void ofdm_demod_wave_kernel(const f2* __restrict__ iq, const float* __restrict__
     }
 }
 
+
+// ---- mode III, two symbols per wavefront ----
+// 256 = 4 x 8 x 8 leaves bins on 32 lanes only: in ofdm_demod_wave_kernel<3> the two radix-8 passes, their twiddle products and the
+// demapper run with half of the lanes idle.  Here a wavefront walks its run of symbols in PAIRS: the PLL and the in-lane radix-4
+// pass take both symbols on all 64 lanes (4 samples per lane and symbol), then lanes 0..31 carry the 64-point sub-transforms and
+// the demapper of symbol i, lanes 32..63 those of symbol i + 1.  DQPSK needs the bins of the symbol before: lanes 32..63 take
+// symbol i's from the lower half of this pair, lanes 0..31 symbol i - 1's from the upper half of the previous pair -- one
+// v_permlane32_swap + select per kept float.  Operation for operation the arithmetic of fft256_wave / the generic path (same
+// tables, same butterflies, same trees), so the results are bit-identical; an odd last symbol runs with the upper half masked.
+template <int SRC, bool BANK>
+__global__ __launch_bounds__(256)
+void ofdm_demod_wave3_kernel(const f2* __restrict__ iq, const float* __restrict__ freq_offset, int8_t* __restrict__ bits,
+                             f2* __restrict__ cp_corr, const f2* __restrict__ tw, const int* __restrict__ inv_map, int n_frames,
+                             int sym_per_chunk, int chunks_per_frame, const dabgpu_frame_desc* __restrict__ desc,
+                             const uint8_t* __restrict__ block, size_t block_stride)
+{
+    using G = W512Geom<3>;
+    constexpr int N = G::N, CP = G::CP, PERIOD = G::PERIOD, NSYM = G::NSYM, NC = G::NC;
+    constexpr int SYM_BITS = 2 * NC, FRAME_BITS = (NSYM - 1) * SYM_BITS, FRAME_SAMPLES = NSYM * PERIOD + G::NULLP;
+    constexpr int TAIL0 = N - CP;                   // body index of the sample that pairs with cyclic-prefix sample 0
+    constexpr int STRIDE = N / 8;
+
+    __shared__ __attribute__((aligned(16))) f2 patches[4][4 * 256];        // per wave: pass-1 outputs of both symbols, pass-2 outputs of both
+    __shared__ __attribute__((aligned(16))) int8_t obufs[4][2][SYM_BITS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    f2* patch = patches[wave];
+    const int h = lane >> 5, l5 = lane & 31;         // half (symbol of the pair) and lane inside the half
+    int8_t* obuf = obufs[wave][h];
+
+    const int unit = (int)blockIdx.x * 4 + wave;
+    const int frame = unit / chunks_per_frame, chunk = unit % chunks_per_frame;
+    if (frame >= n_frames) return;
+    const f2* fbase = iq + (size_t)frame * FRAME_SAMPLES;
+    size_t out_frame = (size_t)frame;
+    int split = FRAME_SAMPLES;
+    long long tail_off = 0;
+    const uint8_t* tail = nullptr;
+    if constexpr (BANK) {
+        const dabgpu_frame_desc d = desc[frame];
+        if (d.slot < 0) return;
+        out_frame = (size_t)d.slot; split = d.split; tail_off = d.tail_off;
+        tail = block + (size_t)frame * block_stride * src_sample_bytes<SRC>::value;
+    }
+    auto fetch = [&](int j) -> f2 {                 // sample j of the frame
+        if constexpr (BANK) return (j < split) ? fbase[j] : sample_at<SRC>(tail, tail_off + (j - split));
+        else return fbase[j];
+    };
+    const int out0 = chunk * sym_per_chunk;
+    const int out1 = min(out0 + sym_per_chunk, NSYM - 1);
+    const float f = freq_offset ? freq_offset[frame] : 0.0f;
+
+    f2 w1[3], w3[7];                                 // pass 1 w_256^{lane k}, pass 2 w_64^{(lane & 7) k}
+#pragma unroll
+    for (int k = 1; k < 4; k++) w1[k - 1] = tw[8 * lane * k];
+#pragma unroll
+    for (int k = 1; k < 8; k++) w3[k - 1] = tw[32 * (lane & 7) * k];
+
+    const int Ks = l5;                               // register k of lane (h, l5) ends with bin l5 + 32 k of symbol i + h
+    int pos[6];
+    pos[0] = inv_map[(Ks == 0) ? (NC - 1) : (Ks + NC / 2 - 1)];
+    pos[1] = inv_map[Ks + STRIDE + NC / 2 - 1];
+    pos[2] = inv_map[Ks + 2 * STRIDE + NC / 2 - 1];
+    pos[3] = inv_map[Ks + 5 * STRIDE - (N - NC / 2)];
+    pos[4] = inv_map[Ks + 6 * STRIDE - (N - NC / 2)];
+    pos[5] = inv_map[Ks + 7 * STRIDE - (N - NC / 2)];
+    f2 last[6];                                      // the kept bins this lane produced in the previous pair
+#pragma unroll
+    for (int k = 0; k < 6; k++) last[k] = mk2(0.0f, 0.0f);
+
+    constexpr int SH = TAIL0 & 63, RB = TAIL0 >> 6;  // the partner of prefix sample n is body sample TAIL0 + n
+    const int csrc = (lane + SH) & 63;
+    const bool cwrap = lane + SH >= 64;
+
+    for (int i = out0; i <= out1; i += 2) {
+        const bool second = (i + 1 <= out1);         // (uniform) the pair has its second symbol
+        const int sym[2] = {i, second ? i + 1 : i};  // an odd last symbol is loaded twice, its copy is never used
+        // ---- both symbols on all lanes: PLL, correlation leaf, radix 4 ----
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int si = sym[u];
+            const float dt0 = (float)(si * PERIOD) * f;                    // ofdm_demodulator.cpp:675-676
+            const int s0 = si * PERIOD;
+            f2 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int n = CP + lane + 64 * j; x[j] = pll_any(fetch(s0 + n), n, PERIOD, f, dt0); }
+            const bool do_corr = (u == 0 || second) && (si < out1 || si == NSYM - 1);       // (uniform)
+            if (do_corr) {
+                const float ax = __shfl(x[RB].x, csrc), ay = __shfl(x[RB].y, csrc);
+                float bx = 0.0f, by = 0.0f;
+                if (RB + 1 < 4) { bx = __shfl(x[(RB + 1 < 4) ? (RB + 1) : 0].x, csrc); by = __shfl(x[(RB + 1 < 4) ? (RB + 1) : 0].y, csrc); }
+                const f2 tl = cwrap ? mk2(bx, by) : mk2(ax, ay);
+                float lr = 0.0f, li = 0.0f;
+                if (lane < CP) {
+                    const f2 hd = pll_any(fetch(s0 + lane), lane, PERIOD, f, dt0);
+                    const f2 p = conj_mul(tl, hd);
+                    lr = p.x; li = p.y;
+                }
+                const float xs = wave_tree_sum_pair(lr, li);
+                if ((lane & 31) == 0) reinterpret_cast<float*>(cp_corr + (size_t)frame * NSYM + si)[lane >> 5] = xs;
+            }
+            f2 b0, b1, b2, b3;
+            dft4(x[0], x[1], x[2], x[3], b0, b1, b2, b3);
+            f2* pa = patch + 256 * u;                                      // pass-1 output 4 p + k of symbol u as [k][p]
+            pa[lane] = b0;
+            pa[64 + lane] = cmul(b1, w1[0]);
+            pa[128 + lane] = cmul(b2, w1[1]);
+            pa[192 + lane] = cmul(b3, w1[2]);
+        }
+        wave_lds_fence();
+        // ---- each half its symbol: two radix-8 passes of the four 64-point sub-transforms ----
+        f2 a[8];
+        const int q = (l5 >> 3) & 3, p2 = l5 & 7;
+        {
+            const f2* pa = patch + 256 * h;
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = pa[64 * q + p2 + 8 * j];
+        }
+        wave_lds_fence();
+        dft8(a);
+        {
+            f2* pb = patch + 512 + 256 * h;                                // pass-2 output q + 4 (8 p2 + k)
+            pb[q + 32 * p2] = a[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) pb[q + 32 * p2 + 4 * k] = cmul(a[k], w3[k - 1]);
+        }
+        wave_lds_fence();
+        {
+            const f2* pb = patch + 512 + 256 * h;
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = pb[l5 + 32 * j];
+        }
+        wave_lds_fence();
+        dft8(a);
+        f2 cur[6];
+        cur[0] = (Ks == 0) ? a[3] : a[0];
+        cur[1] = a[1]; cur[2] = a[2]; cur[3] = a[5]; cur[4] = a[6]; cur[5] = a[7];
+        // ---- DQPSK against the symbol before: lower half <- upper half of the previous pair, upper half <- lower half of this pair ----
+        const bool emit = h ? second : (i > out0);                          // symbol i + h produces row i + h - 1
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(last[k].x), __float_as_uint(cur[k].x), false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(last[k].y), __float_as_uint(cur[k].y), false, false);
+            // swap(a = last, b = cur): a' = [a.lo | b.lo], b' = [a.hi | b.hi] -> lower lanes want a.hi = b'.lo, upper lanes b.lo = a'.hi
+            const f2 pv = mk2(__uint_as_float(h ? sx[0] : sx[1]), __uint_as_float(h ? sy[0] : sy[1]));
+            if (emit) {
+                int bx, by;
+                soft_bit_pair(conj_mul(pv, cur[k]), bx, by);
+                obuf[pos[k]] = (int8_t)bx;
+                obuf[pos[k] + NC] = (int8_t)by;
+            }
+            last[k] = cur[k];
+        }
+        wave_lds_fence();
+        if (emit && l5 < SYM_BITS / 16) {
+            uint4* dst = reinterpret_cast<uint4*>(bits + out_frame * FRAME_BITS + (size_t)(i + h - 1) * SYM_BITS);
+            dst[l5] = reinterpret_cast<const uint4*>(obuf)[l5];
+        }
+        wave_lds_fence();
+    }
+}
+
 }  // namespace dabgpu
 
 using namespace dabgpu;
@@ -315,7 +477,19 @@ int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int
         else if (src == 2) WAVE_GO(MODE, 2, true);               \
         else WAVE_GO(MODE, 3, true);                             \
     } while (0)
-    if (mode == 2) WAVE_MODE(2); else if (mode == 3) WAVE_MODE(3); else WAVE_MODE(4);
+#define WAVE3_GO(SRC, BANK)                                                                                                          \
+    hipLaunchKernelGGL((ofdm_demod_wave3_kernel<SRC, BANK>), grid, dim3(256), 0, s, reinterpret_cast<const f2*>(d_iq), d_freq, d_bits,    \
+                       reinterpret_cast<f2*>(d_cp_corr), reinterpret_cast<const f2*>(c->d_tw), c->d_mode_inv_map[mode], n_frames,     \
+                       symbols_per_block, chunks, d_desc, static_cast<const uint8_t*>(d_block), block_stride)
+    if (mode == 2) WAVE_MODE(2);
+    else if (mode == 4) WAVE_MODE(4);
+    else if (getenv("DABGPU_MODE3_SINGLE")) WAVE_MODE(3);          // development: one symbol per wavefront (the cross-check of the tests)
+    else if (!d_desc) WAVE3_GO(0, false);
+    else if (src == 0) WAVE3_GO(0, true);
+    else if (src == 1) WAVE3_GO(1, true);
+    else if (src == 2) WAVE3_GO(2, true);
+    else WAVE3_GO(3, true);
+#undef WAVE3_GO
 #undef WAVE_MODE
 #undef WAVE_GO
     return dabgpu_check_hip(hipGetLastError(), "ofdm_demod_wave_kernel launch");

@@ -183,3 +183,30 @@ def test_cpp_mirror_stream_in_other_modes(oracle, tmp_path, mode):
     # estimates keep jittering on this noisy stream (same behaviour in the oracle: parity is the criterion there)
     if mode != 2:
         assert good >= 1, "once locked, the hard bits are the transmitted bits"
+
+
+@pytest.mark.parametrize("spb", [0, 1, 2, 6, 7, 152])
+def test_mode_3_pairs_of_symbols_equal_one_symbol_per_wavefront(ctx, spb):
+    """mode III demodulates two symbols per wavefront (csrc/ofdm_wave512.hip ofdm_demod_wave3_kernel); DABGPU_MODE3_SINGLE=1 selects
+    the one-symbol-per-wavefront path it replaced: soft bits and correlations must be identical for even and odd runs of symbols
+    (runs of 1, 2, 6, 7, 19 and the whole frame of 152 data symbols)"""
+    import os
+    import torch
+    rng = np.random.default_rng(33 + spb)
+    n, fs = 5, 153 * 319 + 345
+    iq = torch.from_numpy(rng.standard_normal((n, fs, 2)).astype(np.float32)).cuda()
+    freq = torch.from_numpy(((rng.random(n) * 2 - 1) * 3.0e-3).astype(np.float32)).cuda()
+    out = {}
+    for single in (False, True):
+        if single:
+            os.environ["DABGPU_MODE3_SINGLE"] = "1"
+        try:
+            bits = torch.zeros((n, 152 * 384), dtype=torch.int8, device="cuda")
+            corr = torch.zeros((n, 153, 2), dtype=torch.float32, device="cuda")
+            ctx.ofdm_demod_frames_mode(3, iq, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb)
+            torch.cuda.synchronize()
+            out[single] = (bits.cpu().numpy(), corr.cpu().numpy().view(np.uint32))
+        finally:
+            os.environ.pop("DABGPU_MODE3_SINGLE", None)
+    assert len(np.unique(out[False][0])) > 100
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
