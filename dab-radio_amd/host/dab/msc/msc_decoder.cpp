@@ -7,7 +7,7 @@
 #include "dabgpu.h"
 #include "../dabgpu_shared_context.h"
 
-MSC_Decoder::MSC_Decoder(const Subchannel subchannel) : m_subchannel(subchannel), m_stream(nullptr) {
+MSC_Decoder::MSC_Decoder(const Subchannel subchannel) : m_subchannel(subchannel), m_stream(nullptr), m_ctx(dabgpu_private_context()) {
     dabgpu_subchannel sc;
     sc.start_address = subchannel.start_address;
     sc.length = subchannel.length;
@@ -15,13 +15,20 @@ MSC_Decoder::MSC_Decoder(const Subchannel subchannel) : m_subchannel(subchannel)
     sc.uep_prot_index = subchannel.uep_prot_index;
     sc.eep_prot_level = subchannel.eep_prot_level;
     sc.eep_type = (subchannel.eep_type == EEP_Type::TYPE_B) ? 1 : 0;
-    const int st = dabgpu_msc_stream_create(dabgpu_shared_context(), &sc, &m_stream);
+    const int st = dabgpu_msc_stream_create(m_ctx, &sc, &m_stream);
+    if (st != DABGPU_OK) {
+        dabgpu_destroy(m_ctx);
+        m_ctx = nullptr;
+    }
     if (st != DABGPU_OK)
         throw std::runtime_error(std::string("MSC_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
     m_decoded_bytes.resize((size_t)subchannel.length * 8);                              // :30
 }
 
-MSC_Decoder::~MSC_Decoder() { dabgpu_msc_stream_destroy(m_stream); }
+MSC_Decoder::~MSC_Decoder() {
+    dabgpu_msc_stream_destroy(m_stream);
+    dabgpu_destroy(m_ctx);
+}
 
 tcb::span<uint8_t> MSC_Decoder::DecodeCIF(tcb::span<const viterbi_bit_t> buf) {
     const size_t start_bit = (size_t)m_subchannel.start_address * 64, n_bits = (size_t)m_subchannel.length * 64;

@@ -23,6 +23,7 @@ public:
 private:
     const Subchannel m_subchannel;
     dabgpu_msc_stream* m_stream;
+    struct dabgpu_ctx* m_ctx;          // this decoder's own device context (stream + scratch): decoders of different threads run side by side
     std::vector<uint8_t> m_decoded_bytes;
     uint64_t m_last_error = 0;
 };

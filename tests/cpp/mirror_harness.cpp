@@ -4,6 +4,8 @@
 // produces is written to files that tests/test_gpu_cpp_mirror.py compares byte for byte with the CPU oracle.
 //
 //   mirror_harness <iq.c32> <out_dir> <block_size> [<start_cu> <length_cu> <eep_level> <eep_type_b>]...
+// DABGPU_HARNESS_THREADS=n: the sub-channels of a CIF are decoded by n threads (s = t, t + n, ...), the way basic_radio's thread pool
+// runs one task per sub-channel (src/basic_radio/basic_radio.cpp:51-62); outputs are identical, written in sub-channel order.
 // DABGPU_HARNESS_BENCH=1: nothing is written; the harness times the whole run (frames/s against the 10.42 frames/s of a live
 // signal) and every DecodeFIBGroup / DecodeCIF call (one synchronous launch + two copies each) and prints one JSON line.
 #include <algorithm>
@@ -14,6 +16,7 @@
 #include <fstream>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dab/algorithms/dab_viterbi_decoder.h"
@@ -40,6 +43,8 @@ int main(int argc, char** argv) {
     if (!in) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
 
     g_bench = std::getenv("DABGPU_HARNESS_BENCH") != nullptr;
+    const char* thr_env = std::getenv("DABGPU_HARNESS_THREADS");
+    const int n_threads = thr_env ? std::atoi(thr_env) : 1;
     std::vector<double> lat_fib, lat_cif;
     const DAB_Parameters dab = get_dab_parameters(1);
     const char* mode_env = std::getenv("DABGPU_HARNESS_MODE");
@@ -105,13 +110,27 @@ int main(int argc, char** argv) {
         }
         for (int c = 0; c < dab.nb_cifs; c++) {                                         // basic_dab_plus_channel.cpp:47-51
             auto cif = msc_bits.subspan((size_t)c * dab.nb_cif_bits, (size_t)dab.nb_cif_bits);
+            std::vector<tcb::span<uint8_t>> got(msc.size());
+            std::vector<double> took(msc.size(), 0.0);
+            auto work = [&](size_t first, size_t step) {
+                for (size_t s = first; s < msc.size(); s += step) {
+                    const double t_cif = now_us();
+                    got[s] = msc[s]->DecodeCIF(cif);
+                    took[s] = now_us() - t_cif;
+                }
+            };
+            if (n_threads <= 1) {
+                work(0, 1);
+            } else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < n_threads; t++) pool.emplace_back(work, (size_t)t, (size_t)n_threads);
+                for (auto& th : pool) th.join();
+            }
             for (size_t s = 0; s < msc.size(); s++) {
-                const double t_cif = now_us();
-                auto bytes = msc[s]->DecodeCIF(cif);
-                lat_cif.push_back(now_us() - t_cif);
-                const uint32_t nb = (uint32_t)bytes.size();
+                lat_cif.push_back(took[s]);
+                const uint32_t nb = (uint32_t)got[s].size();
                 append(out + "/msc_" + std::to_string(s) + ".bin", &nb, 4);
-                append(out + "/msc_" + std::to_string(s) + ".bin", bytes.data(), bytes.size());
+                append(out + "/msc_" + std::to_string(s) + ".bin", got[s].data(), got[s].size());
             }
             if (deint && !g_bench) {
                 const size_t nbits = (size_t)subs[0].length * 64;
@@ -143,10 +162,10 @@ int main(int argc, char** argv) {
         };
         double fm, fp, fx, cm, cp, cx;
         stats(lat_fib, fm, fp, fx); stats(lat_cif, cm, cp, cx);
-        std::printf("{\"frames\": %d, \"seconds\": %.4f, \"frames_per_s\": %.2f, \"x_realtime\": %.2f, \"sub_channels\": %zu, "
+        std::printf("{\"frames\": %d, \"seconds\": %.4f, \"frames_per_s\": %.2f, \"x_realtime\": %.2f, \"sub_channels\": %zu, \"decode_threads\": %d, "
                     "\"decode_fib_group_us\": {\"median\": %.1f, \"p99\": %.1f, \"max\": %.1f, \"calls\": %zu}, "
                     "\"decode_cif_us\": {\"median\": %.1f, \"p99\": %.1f, \"max\": %.1f, \"calls\": %zu}}\n",
-                    n_frames, sec, n_frames / sec, n_frames / sec / (2.048e6 / 196608.0), msc.size(), fm, fp, fx, lat_fib.size(), cm, cp, cx, lat_cif.size());
+                    n_frames, sec, n_frames / sec, n_frames / sec / (2.048e6 / 196608.0), msc.size(), n_threads, fm, fp, fx, lat_fib.size(), cm, cp, cx, lat_cif.size());
         return 0;
     }
     std::printf("frames=%d read=%d desync=%d state=%d signal_avg=%.9g\n", n_frames, demod->GetTotalFramesRead(),

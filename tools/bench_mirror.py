@@ -14,6 +14,7 @@ import numpy as np, torch, dabgpu, dabsynth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=40)
+ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
 ap.add_argument("--subchannels", type=int, default=18)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -32,13 +33,17 @@ with tempfile.TemporaryDirectory() as d:
     args = [harness, path, d, "65536"]
     for s in range(a.subchannels):
         args += [str(48 * s), "48", "2", "0"]
-    env = dict(os.environ, DABGPU_HARNESS_BENCH="1")
-    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
-if res.returncode != 0:
-    print(res.stderr[-2000:], file=sys.stderr)
-    sys.exit(res.returncode)
-line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-out = json.loads(line)
-out["what"] = "OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame, all synchronous, one stream" % a.subchannels
+    runs = []
+    for threads in (1, a.threads):
+        env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(threads))
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+        res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
+        if res.returncode != 0:
+            print(res.stderr[-2000:], file=sys.stderr)
+            sys.exit(res.returncode)
+        runs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]))
+out = runs[0]
+out["what"] = "OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame, all synchronous, one caller thread" % a.subchannels
+out["with_decode_threads"] = dict(runs[1], what="the same with the sub-channels of a CIF decoded by %d threads, one task per sub-channel as "
+                                  "basic_radio's thread pool runs them (each MSC_Decoder owns a device context)" % a.threads)
 print(json.dumps(out))
