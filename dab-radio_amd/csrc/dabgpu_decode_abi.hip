@@ -243,6 +243,8 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     if (st) return st;
     st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
+    // FIB groups are contiguous runs of 2304 soft bits; with 16-byte aligned frames the staged gather applies (mode 3)
+    const int fic_direct = (((uintptr_t)d_bits % 16 == 0) && (frame_stride % 16 == 0)) ? 3 : 0;
     if (use_lane_mapping(c, n, (n + 63) / 64, (double)n * 774.0, (double)((n + 63) / 64) * 774.0, 774.0, false)) {
         // one schedule for every FIB group: groups of 64 consecutive codewords, processed in bounded slices
         const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
@@ -253,7 +255,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17 + FIC_SLOTS, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, 0, d_results + cw0, s, FIC_SLOTS))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, fic_direct, d_results + cw0, s, FIC_SLOTS))) return st;
         }
         return DABGPU_OK;
     }

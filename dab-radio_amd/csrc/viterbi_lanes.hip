@@ -400,6 +400,96 @@ void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_c
     }
 }
 
+// ---- input gather, direct form (FIC): every codeword of the group is a contiguous run of soft bits at a 16-byte aligned address ----
+// The tile's byte range (<= 272 bytes, the same for all 64 codewords: one puncturing schedule) of every codeword is staged in LDS
+// with 16-byte loads -- 1088 chunks, all in flight at once -- and thread (step, wave) picks its <= 4 soft bits per codeword there; the
+// byte-granular loads of vit_prep_kernel cost one address-coalescer slot per byte (64 byte-load instructions per thread and tile).
+// grid (n_groups, ceil(alloc_steps / 64)), 256 threads
+constexpr int VD_CHUNKS = 17, VD_PITCH = VD_CHUNKS * 16 + 16;
+__global__ __launch_bounds__(256)
+void vit_prep_direct_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
+                            uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+{
+    __shared__ uint32_t tile[VL_TILE][65];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[64][VD_PITCH];
+    __shared__ uint16_t pi_tab[25 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const dabgpu_vit_group Gd = groups[blockIdx.x];
+    const int t0 = blockIdx.y * VL_TILE;
+    if (t0 >= (int)Gd.alloc_steps) return;
+    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
+    __syncthreads();
+    const int T = (int)Gd.n_steps;
+    auto locate = [&](int t, int& cnt) {                                   // dab_viterbi_decoder.cpp:131-181
+        int sstart = 0, in0 = 0, pi = 8, k = 0;
+        for (; k < 4; k++) {
+            const int len = (int)Gd.seg_steps[k];
+            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
+            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
+            sstart += len;
+        }
+        const int sis = t - sstart;
+        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
+        cnt = e & 0xFF;
+        return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
+    };
+    int n_in = 12;
+    for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);
+    int dummy;
+    const int i_lo = ((t0 < T) ? locate(t0, dummy) : n_in) & ~15;          // (uniform) first byte of the tile, 16-byte aligned
+    int i_hi = i_lo;
+    if (t0 < T) { const int tl = min(t0 + VL_TILE, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
+    // stage: chunk q = tid + 256 h of the 64 x 17 sixteen-byte chunks
+    typedef const __attribute__((address_space(1))) unsigned char* gptr;
+    u4v v[5];
+#pragma unroll
+    for (int h = 0; h < 5; h++) {
+        const int q = tid + 256 * h, c = q / VD_CHUNKS, ch = q - c * VD_CHUNKS;
+        v[h] = u4v{0u, 0u, 0u, 0u};
+        if (c < (int)Gd.count && c < 64) {
+            const dabgpu_cw_desc* Dd = descs + ((size_t)Gd.first + (size_t)Gd.stride * (size_t)c);
+            const int o = i_lo + 16 * ch;
+            if (Dd->n_steps != 0 && o < i_hi) {
+                const gptr p = (gptr)(uintptr_t)Dd->d_src + o;
+                if (o + 16 <= n_in) v[h] = *(const __attribute__((address_space(1))) u4v*)p;
+                else {                                                     // the last chunk of the codeword: whole dwords only (n_in is a multiple of 4)
+                    const __attribute__((address_space(1))) uint32_t* pw = (const __attribute__((address_space(1))) uint32_t*)p;
+                    v[h].x = pw[0];
+                    if (o + 8 <= n_in) v[h].y = pw[1];
+                    if (o + 12 <= n_in) v[h].z = pw[2];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 5; h++) {
+        const int q = tid + 256 * h, c = q / VD_CHUNKS, ch = q - c * VD_CHUNKS;
+        if (c < 64) *reinterpret_cast<u4v*>(&rows[c][16 * ch]) = v[h];
+    }
+    __syncthreads();
+    // pick: lane = step of the tile, wave wv takes codewords wv, wv + 4, ...
+    const int t = t0 + lane;
+    int cnt = 0, idx0 = 0;
+    if (t < T) idx0 = locate(t, cnt);
+    for (int c = wv; c < 64; c += 4) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (r < cnt) {
+                int yv = (int)(signed char)rows[c][idx0 + r - i_lo];
+                yv = max(yv, -127);                                        // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
+                packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
+            }
+        }
+        tile[lane][c] = packed;
+    }
+    __syncthreads();
+    uint32_t* dst = sym + Gd.sym_off;
+    for (int s = wv; s < VL_TILE; s += 4) {
+        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+    }
+}
+
 // ---- input gather, MSC form: lane 4 k + c of a group = CIF c of ensemble k (16 ensembles), all read through a frame-history
 // ring with 4 CIFs per frame.  Output CIFs c = 0..3 with ages 0..15 touch the 19 ring slots 4 nf - 15 .. 4 nf + 3; per ensemble
 // the tile's byte range of those 19 rows is staged in LDS with 16-byte loads (the byte-granular gather of vit_prep_kernel
@@ -747,7 +837,9 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
 {
     using namespace dabgpu;
     const unsigned tiles = (max_alloc_steps + VL_TILE - 1) / VL_TILE;
-    if (ring4 == 2)      // ring of 4 CIFs per frame in class order
+    if (ring4 == 3)      // direct, contiguous, 16-byte aligned codewords (FIC)
+        hipLaunchKernelGGL(vit_prep_direct_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+    else if (ring4 == 2)      // ring of 4 CIFs per frame in class order
         hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
     else if (ring4)
         hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
