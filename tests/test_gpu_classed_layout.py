@@ -69,9 +69,18 @@ def test_demodulator_class_order_is_the_natural_output_permuted(ctx, fmt_name, s
         assert np.array_equal(corrs[k].view(np.uint32), corrs[0].view(np.uint32)) and np.array_equal(corrs[3 + k].view(np.uint32), corrs[0].view(np.uint32))
 
 
+@pytest.fixture(params=[0, 2], ids=["one_launch", "sliced"])
+def scratch_mb(request):
+    """DABGPU_VIT_SCRATCH_MB = 2 forces the lane mapping to run the batch as several launches over slices of the ensembles"""
+    if request.param:
+        os.environ["DABGPU_VIT_SCRATCH_MB"] = str(request.param)
+    yield request.param
+    os.environ.pop("DABGPU_VIT_SCRATCH_MB", None)
+
+
 @pytest.mark.parametrize("tie_rule", [0, 1])
 @pytest.mark.parametrize("n_ens", [5, 37, 130])
-def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens):
+def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens, scratch_mb):
     import dabgpu
     import torch
     rng = np.random.default_rng(100 + n_ens + tie_rule)
