@@ -382,8 +382,10 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
-            // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / 4-byte aligned windows (class order)
-            const int ring4 = classed ? ((((uintptr_t)d_hist % 4 == 0) && (ens_stride % 4 == 0)) ? 2 : 0)
+            // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / aligned 64-byte lines (class order)
+            // (class order: whole 64-byte memory lines are loaded -- with the history and every ensemble 64-byte aligned no line reaches
+            // past the end of a row, 230400 = 3600 x 64)
+            const int ring4 = classed ? ((((uintptr_t)d_hist % 64 == 0) && (ens_stride % 64 == 0)) ? 2 : 0)
                                       : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
             if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(lane_max_steps),
                                         tie_rule, ring4, d_results + cw0, s))) return st;
