@@ -195,6 +195,39 @@ def test_generic_batch_with_a_classed_ring_of_any_geometry(ctx, mapping):
         ctx.viterbi_decode_batch([bad], torch.zeros((1, 16), dtype=torch.uint8, device="cuda"))
 
 
+def test_history_that_is_not_64_byte_aligned_takes_the_general_gather(ctx):
+    """the line-streaming gather loads whole 64-byte memory lines and therefore asks for a 64-byte aligned history; a history 16 bytes
+    off (and an ensemble stride that is no multiple of 64) must still decode, through the general gather, to the same bytes"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(5)
+    subs = [dabgpu.SubChannel(0, 48, False, 0, 2, 0), dabgpu.SubChannel(100, 35, True, 4, 0, 0), dabgpu.SubChannel(700, 164, False, 0, 3, 0)]
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    n_ens, H = 70, 5
+    nat = rng.integers(-128, 128, (n_ens, H, 230400), dtype=np.int8)
+    to_classed = np.argsort(dabgpu.classed_to_natural_index())
+    cls = np.ascontiguousarray(nat[:, :, to_classed])
+    stride = H * 230400 + 16                                              # 16 mod 64
+    buf = torch.zeros(n_ens * stride + 64, dtype=torch.int8, device="cuda")
+    off = (16 - buf.data_ptr() % 64) % 64                                 # data pointer = 16 mod 64
+    view = buf[off:off + n_ens * stride].view(n_ens, stride)
+    view[:, :H * 230400].copy_(torch.from_numpy(cls.reshape(n_ens, -1)).cuda())
+    assert view.data_ptr() % 64 == 16
+    aligned = torch.from_numpy(cls).cuda()
+    got = []
+    ctx.viterbi_set_mapping(2)
+    try:
+        for hist, st in ((aligned, H * 230400), (view, stride)):
+            d_out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+            ctx.msc_decode_frames(hist, n_ens, st, H, 2, subs, d_out, 4 * cif_out, d_res, bits_layout=1)
+            torch.cuda.synchronize()
+            got.append((d_out.cpu().numpy(), d_res.cpu().numpy()))
+    finally:
+        ctx.viterbi_set_mapping(0)
+    assert got[0][0].any() and np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
 def test_bad_layout_and_unsupported_format_are_refused(ctx):
     import dabgpu
     import torch
