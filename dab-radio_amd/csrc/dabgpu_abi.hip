@@ -25,6 +25,11 @@ int dabgpu_check_hip(hipError_t e, const char* what) {
     return DABGPU_ERR_HIP;
 }
 
+int dabgpu_bind_device(const dabgpu_ctx* c) {
+    if (!c) { dabgpu_set_error("null context"); return DABGPU_ERR_INVALID_ARG; }
+    return dabgpu_check_hip(hipSetDevice(c->device), "hipSetDevice");
+}
+
 extern "C" {
 
 const char* dabgpu_strerror(int status) {
@@ -202,29 +207,40 @@ void dabgpu_destroy(dabgpu_ctx* c) {
 
 int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
     if (bytes == 0) return DABGPU_OK;
-    std::lock_guard<std::mutex> g(c->stage_mu);
-    dabgpu_ctx::stage_slot& sl = c->stage[c->stage_next++ % 8];
     int st;
-    if (sl.pending) {                                              // the DMA that last used this slot
-        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.ev), "hipEventSynchronize(stage)"))) return st;
-        sl.pending = false;
+    // The ring is for small, short-lived sources (plans, lane tables, one CIF, one descriptor).  A large table (the descriptor
+    // array of dabgpu_viterbi_decode_batch: tens of MB) goes through the runtime's own pageable path, which has consumed h_src
+    // when it returns: no second host copy, and no pinned slot grows to the largest table ever seen.
+    constexpr size_t STAGE_MAX = (size_t)1 << 20;
+    if (bytes > STAGE_MAX) return dabgpu_check_hip(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(pageable)");
+    dabgpu_ctx::stage_slot* sl;
+    {
+        std::lock_guard<std::mutex> g(c->stage_mu);
+        sl = &c->stage[c->stage_next++ % 8];
     }
-    if (!sl.ev && (st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming), "hipEventCreate(stage)"))) return st;
-    if (sl.bytes < bytes) {
-        if (sl.h) { (void)hipHostFree(sl.h); sl.h = nullptr; sl.bytes = 0; }
-        const size_t want = bytes < (size_t)65536 ? (size_t)65536 : bytes;
-        if ((st = dabgpu_check_hip(hipHostMalloc(&sl.h, want, hipHostMallocDefault), "hipHostMalloc(stage)"))) return st;
-        sl.bytes = want;
+    // per-slot lock: a thread that has to wait for its slot's last DMA holds up only the callers that wrap around to the same slot
+    std::lock_guard<std::mutex> g(sl->mu);
+    if (sl->pending) {
+        if ((st = dabgpu_check_hip(hipEventSynchronize(sl->ev), "hipEventSynchronize(stage)"))) return st;
+        sl->pending = false;
     }
-    memcpy(sl.h, h_src, bytes);
-    if ((st = dabgpu_check_hip(hipMemcpyAsync(d_dst, sl.h, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(stage)"))) return st;
-    if ((st = dabgpu_check_hip(hipEventRecord(sl.ev, s), "hipEventRecord(stage)"))) return st;
-    sl.pending = true;
+    if (!sl->ev && (st = dabgpu_check_hip(hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming), "hipEventCreate(stage)"))) return st;
+    if (sl->bytes < bytes) {
+        if (sl->h) { (void)hipHostFree(sl->h); sl->h = nullptr; sl->bytes = 0; }
+        const size_t want = bytes < (size_t)65536 ? (size_t)65536 : STAGE_MAX;
+        if ((st = dabgpu_check_hip(hipHostMalloc(&sl->h, want, hipHostMallocDefault), "hipHostMalloc(stage)"))) return st;
+        sl->bytes = want;
+    }
+    memcpy(sl->h, h_src, bytes);
+    if ((st = dabgpu_check_hip(hipMemcpyAsync(d_dst, sl->h, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(stage)"))) return st;
+    if ((st = dabgpu_check_hip(hipEventRecord(sl->ev, s), "hipEventRecord(stage)"))) return st;
+    sl->pending = true;
     return DABGPU_OK;
 }
 
 int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
     if (!c) return DABGPU_ERR_INVALID_ARG;
+    DABGPU_BIND(c);
     return dabgpu_check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
 }
 
@@ -242,6 +258,7 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         dabgpu_set_error("ofdm_demod_frames: bits_frame_stride must be 0 or a multiple of 16 >= 230400"); return DABGPU_ERR_INVALID_ARG;
     }
     if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_demod_frames: d_iq and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;      // NULL = the HIP default (null) stream
     float* corr = d_cp_corr;
     if (!corr) {     // the kernel always produces the correlation; park it in context scratch when unwanted
@@ -259,16 +276,20 @@ int dabgpu_ofdm_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_frames, 
     return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
 }
 
+// capture formats the demodulator's loader dequantises itself (iq_decode.h): 0 = complex float, 1 = u8, 2 = s8, 3 = s16 little endian
+static int fused_loader_of(int format) {
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: return 0;
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: return 1;
+    case DABGPU_IQ_RAW_S8: return 2;
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: return 3;
+    default: return -1;
+    }
+}
+
 int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
                                  float* d_cp_corr, float* d_fft, float* d_dqpsk, int symbols_per_block, size_t bits_frame_stride, void* stream) {
-    int src = -1;
-    switch (format) {
-    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: src = 0; break;
-    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: src = 1; break;
-    case DABGPU_IQ_RAW_S8: src = 2; break;
-    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: src = 3; break;
-    default: break;
-    }
+    const int src = fused_loader_of(format);
     if (src >= 0) return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
     // formats without a fused loader: convert into context scratch on the same stream, then demodulate
     if (!c) { dabgpu_set_error("ofdm_demod_frames_raw: null context"); return DABGPU_ERR_INVALID_ARG; }
@@ -279,16 +300,6 @@ int dabgpu_ofdm_demod_frames_raw(dabgpu_ctx* c, const void* d_raw, int format, s
     if (st) return st;
     if ((st = dabgpu_iq_convert(c, d_raw, format, n_frames * DABGPU_NB_FRAME_SAMPLES, d_iq, stream))) return st;
     return ofdm_demod_any(c, d_iq, 0, n_frames, d_freq, d_bits, d_cp_corr, d_fft, d_dqpsk, symbols_per_block, bits_frame_stride, stream);
-}
-
-static int fused_loader_of(int format) {
-    switch (format) {
-    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: return 0;
-    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: return 1;
-    case DABGPU_IQ_RAW_S8: return 2;
-    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: return 3;
-    default: return -1;
-    }
 }
 
 int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
@@ -302,14 +313,7 @@ int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx* c, const void* d_raw, int format,
 
 int dabgpu_ofdm_demod_frames_history(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, const float* d_freq, int8_t* d_bits,
                                      float* d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout, void* stream) {
-    int src = -1;
-    switch (format) {
-    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: src = 0; break;
-    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: src = 1; break;
-    case DABGPU_IQ_RAW_S8: src = 2; break;
-    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: src = 3; break;
-    default: break;
-    }
+    const int src = fused_loader_of(format);
     if (src < 0) { dabgpu_set_error("ofdm_demod_frames_history: format %d has no fused loader (float32, u8, s8, s16 little endian do)", format); return DABGPU_ERR_INVALID_ARG; }
     return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, nullptr, nullptr, symbols_per_block, bits_frame_stride, stream, bits_layout);
 }
@@ -320,6 +324,7 @@ int dabgpu_ofdm_phase_update_mode(dabgpu_ctx* c, int mode, const float* d_cp_cor
     if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update_mode: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
     if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
     if (n_frames == 0) return DABGPU_OK;
+    DABGPU_BIND(c);
     return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, geom[0], geom[3],
                                                      (hipStream_t)stream), "ofdm_phase_kernel launch");
 }
@@ -328,6 +333,7 @@ int dabgpu_ofdm_phase_update(dabgpu_ctx* c, const float* d_cp_corr, size_t n_fra
                              float* d_fine_freq, void* stream) {
     if (!c || !d_cp_corr) { dabgpu_set_error("ofdm_phase_update: null ctx/corr"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     return dabgpu_check_hip(dabgpu_launch_ofdm_phase(d_cp_corr, (int)n_frames, beta, d_total_phase, d_fine_freq, 1, nullptr, DABGPU_NB_FRAME_SYMBOLS,
                                                      DABGPU_NB_FFT, s),
@@ -339,7 +345,7 @@ int dabgpu_ofdm_demod_frames_host_sync(dabgpu_ctx* c, const float* h_iq, size_t 
     if (!c || !h_iq || !h_bits) { dabgpu_set_error("ofdm_demod_frames_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     int st;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = n_frames * DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
     const size_t bits_bytes = n_frames * DABGPU_NB_FRAME_BITS;
@@ -369,7 +375,7 @@ int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float 
                                         int8_t* h_bits, float* h_total_phase, float* h_fft, float* h_dqpsk) {
     if (!c || !h_iq || !h_bits || !h_freq_fine) { dabgpu_set_error("ofdm_demod_stream_frame_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     int st;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = (size_t)DABGPU_NB_FRAME_SAMPLES * 2 * sizeof(float);
     const size_t fft_bytes = (size_t)77 * DABGPU_NB_FFT * 2 * sizeof(float);
@@ -416,6 +422,7 @@ int dabgpu_ofdm_sync(dabgpu_ctx* c, const float* d_prs_syms, size_t n_streams, s
     if (!c || !d_prs_syms || !cfg || !d_states) { dabgpu_set_error("ofdm_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_streams == 0) return DABGPU_OK;
     if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(c);
     return dabgpu_check_hip(dabgpu_launch_sync(d_prs_syms, stride_samples, (int)n_streams, cfg, d_states, d_impulse, d_freq,
                                                c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, 1, (hipStream_t)stream), "ofdm_sync_kernel launch");
 }
@@ -425,6 +432,7 @@ int dabgpu_ofdm_sync_mode(dabgpu_ctx* c, int mode, const float* d_prs_syms, size
     if (!c || !d_prs_syms || !cfg || !d_states) { dabgpu_set_error("ofdm_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_streams == 0) return DABGPU_OK;
     if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync_mode: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(c);
     const float *d_prs, *d_ref;
     int st = dabgpu_mode_sync_tables(c, mode, &d_prs, &d_ref);
     if (st) return st;
@@ -435,7 +443,7 @@ int dabgpu_ofdm_sync_mode(dabgpu_ctx* c, int mode, const float* d_prs_syms, size
 int dabgpu_ofdm_sync_host_sync(dabgpu_ctx* c, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* h_state,
                                float* h_impulse, float* h_freq) {
     if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(c);
     int st;
     float *d_sym, *d_imp, *d_frq; dabgpu_sync_state* d_st;
@@ -468,7 +476,7 @@ int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const 
         std::vector<float> prs(2 * (size_t)geom[3]);
         int st = dabgpu_get_prs_fft_ref(mode, prs.data());
         if (st) return st;
-        (void)hipSetDevice(c->device);
+        DABGPU_BIND(c);
         float *dp = nullptr, *dr = nullptr;
         if ((st = dabgpu_check_hip(hipMalloc(&dp, bytes), "hipMalloc(mode prs)"))) return st;
         if ((st = dabgpu_check_hip(hipMalloc(&dr, bytes), "hipMalloc(mode prs ref)"))) { (void)hipFree(dp); return st; }

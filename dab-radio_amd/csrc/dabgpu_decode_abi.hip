@@ -144,8 +144,8 @@ static bool use_lane_mapping(dabgpu_ctx* c, size_t n_cw, size_t n_groups, double
     return t_lane < t_wave;
 }
 
-// lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (768 bytes per row:
-// 6 GiB by default, DABGPU_VIT_SCRATCH_MB in the environment overrides), larger batches run as several launches over
+// lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (<= 768 bytes per decision
+// row: 6 GiB by default, DABGPU_VIT_SCRATCH_MB in the environment overrides), larger batches run as several launches over
 // consecutive groups
 static size_t lanes_max_rows() {
     size_t mb = 6144;
@@ -153,16 +153,37 @@ static size_t lanes_max_rows() {
     return std::max<size_t>(mb * 1024 * 1024 / 768, 1);
 }
 
+// sym_rows / dec_rows: rows of 64 dwords (kept soft bits, 4 per lane and row) and of 128 dwords (decisions, one row per step)
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
-                             size_t total_rows, uint32_t max_alloc_steps, int tie_rule, int ring4, dabgpu_codeword_result* d_results,
-                             hipStream_t s, int slot_off = 0) {
+                             size_t sym_rows, size_t dec_rows, uint32_t max_in_rows, int tie_rule, int ring4, const uint2* d_sched,
+                             dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
+    int st;
+    uint32_t *d_sym = nullptr, *d_dec = nullptr;
+    if ((st = dabgpu_scratch(c, 18 + slot_off, sym_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
+    if ((st = dabgpu_scratch(c, 19 + slot_off, dec_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+    return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_in_rows, d_descs, d_sym, d_dec, d_results,
+                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, device_waves(c) / 32, s), "vit_lanes_kernel launch");
+}
+
+// one puncturing schedule for a whole batch (FIC, uniform codeword batches): groups of 64 consecutive codewords, in bounded slices
+static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t n_steps, const uint32_t* seg_pi,
+                             const uint32_t* seg_steps, int tie_rule, int ring4, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off) {
     int st = ensure_vit_tables(c);
     if (st) return st;
-    uint32_t *d_sym = nullptr, *d_dec = nullptr;
-    if ((st = dabgpu_scratch(c, 18 + slot_off, total_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
-    if ((st = dabgpu_scratch(c, 19 + slot_off, total_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
-    return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_alloc_steps, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, device_waves(c) / 32, s), "vit_lanes_kernel launch");
+    const uint32_t dec_rows = dabgpu_vit_alloc_steps(n_steps), in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps));
+    uint2* d_sched = nullptr;
+    if ((st = dabgpu_scratch(c, 25 + slot_off, (size_t)dec_rows * sizeof(uint2), (void**)&d_sched))) return st;
+    if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_uniform(d_sched, dec_rows, seg_pi, seg_steps, c->d_vit_tables, s), "vit_sched launch"))) return st;
+    const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / dec_rows);
+    for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
+        const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
+        dabgpu_vit_group* d_groups = nullptr;
+        if ((st = dabgpu_scratch(c, 17 + slot_off, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+        if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, n_steps, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
+        if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * in_rows, n_groups * dec_rows, in_rows, tie_rule, ring4,
+                                    d_sched, d_results + cw0, s, slot_off))) return st;
+    }
+    return DABGPU_OK;
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
@@ -201,7 +222,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
         if (st) return st;
         max_steps = std::max(max_steps, h_cw[i].n_steps);
     }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     dabgpu_cw_desc* d_descs = nullptr;
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
@@ -215,18 +236,8 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     for (size_t i = 0; i < n && uniform; i++)             // the lane mapping keeps ring offsets in 32 bits
         uniform = h_cw[i].n_slots == 0 || (uint64_t)(h_cw[i].n_slots / h_cw[i].cifs_per_frame + 1) * h_cw[i].frame_stride +
                                           (uint64_t)h_cw[i].cifs_per_frame * h_cw[i].cif_stride < ((uint64_t)1 << 32);
-    if (uniform && use_lane_mapping(c, n, (n + 63) / 64, (double)n * max_steps, (double)((n + 63) / 64) * max_steps, (double)max_steps, false)) {
-        const uint32_t rows = dabgpu_vit_alloc_steps(max_steps);
-        const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / rows);
-        for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
-            const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
-            dabgpu_vit_group* d_groups = nullptr;
-            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
-            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, 0, d_results + cw0, s))) return st;
-        }
-        return DABGPU_OK;
-    }
+    if (uniform && use_lane_mapping(c, n, (n + 63) / 64, (double)n * max_steps, (double)((n + 63) / 64) * max_steps, (double)max_steps, false))
+        return run_lanes_uniform(c, d_descs, n, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, tie_rule, 0, d_results, s, 0);
     return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
 }
 
@@ -235,7 +246,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     if (!c || !d_bits || !d_fib_bytes || !d_results) { dabgpu_set_error("fic_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_frames == 0) return DABGPU_OK;
     if (frame_stride < DABGPU_NB_FIC_BITS) { dabgpu_set_error("fic_decode_frames: frame_stride %zu < 9216", frame_stride); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = n_frames * 4;
     dabgpu_cw_desc* d_descs = nullptr;
@@ -246,18 +257,9 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     // FIB groups are contiguous runs of 2304 soft bits; with 16-byte aligned frames the staged gather applies (mode 3)
     const int fic_direct = (((uintptr_t)d_bits % 16 == 0) && (frame_stride % 16 == 0)) ? 3 : 0;
     if (use_lane_mapping(c, n, (n + 63) / 64, (double)n * 774.0, (double)((n + 63) / 64) * 774.0, 774.0, false)) {
-        // one schedule for every FIB group: groups of 64 consecutive codewords, processed in bounded slices
+        // one schedule for every FIB group
         const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
-        const uint32_t rows = dabgpu_vit_alloc_steps(774);
-        const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / rows);
-        for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
-            const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
-            dabgpu_vit_group* d_groups = nullptr;
-            if ((st = dabgpu_scratch(c, 17 + FIC_SLOTS, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
-            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, 774, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * rows, rows, tie_rule, fic_direct, d_results + cw0, s, FIC_SLOTS))) return st;
-        }
-        return DABGPU_OK;
+        return run_lanes_uniform(c, d_descs, n, 774, seg_pi, seg_steps, tie_rule, fic_direct, d_results, s, FIC_SLOTS);
     }
     return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s, FIC_SLOTS);
 }
@@ -308,7 +310,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         max_out = std::max(max_out, (uint32_t)nb);
     }
     if (out_ens_stride < (size_t)4 * off) { dabgpu_set_error("msc_decode_frames: out_ensemble_stride %zu < 4 x %u", out_ens_stride, off); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = n_ens * 4 * (size_t)n_sub;
     dabgpu_cw_desc* d_descs = nullptr;
@@ -359,36 +361,47 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if (n_lane > 0) {
         // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
         // stays inside the scratch bound
-        size_t rows_per_gq = 0;
-        uint32_t lane_max_steps = 0;
-        std::vector<uint64_t> lane_subs((size_t)2 * n_lane);
+        if ((st = ensure_vit_tables(c))) return st;
+        size_t dec_rows_per_gq = 0, sym_rows_per_gq = 0;
+        uint32_t lane_max_steps = 0, lane_max_in_rows = 0;
+        std::vector<uint64_t> lane_subs((size_t)3 * n_lane);             // sub-channel, decision rows before it, symbol rows before it
         for (int j = 0; j < n_lane; j++) {
             const int sidx = order[(size_t)(k_wave + j)];
-            lane_subs[(size_t)2 * j] = (uint64_t)sidx;
-            lane_subs[(size_t)2 * j + 1] = rows_per_gq;
-            rows_per_gq += dabgpu_vit_alloc_steps(plans[(size_t)sidx].n_steps);
-            lane_max_steps = std::max(lane_max_steps, plans[(size_t)sidx].n_steps);
+            const dabgpu_msc_plan& P = plans[(size_t)sidx];
+            const uint32_t in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(P.seg_pi, P.seg_steps));
+            lane_subs[(size_t)3 * j] = (uint64_t)sidx;
+            lane_subs[(size_t)3 * j + 1] = dec_rows_per_gq;
+            lane_subs[(size_t)3 * j + 2] = sym_rows_per_gq;
+            dec_rows_per_gq += dabgpu_vit_alloc_steps(P.n_steps);
+            sym_rows_per_gq += in_rows;
+            lane_max_steps = std::max(lane_max_steps, P.n_steps);
+            lane_max_in_rows = std::max(lane_max_in_rows, in_rows);
         }
-        const size_t max_gq = std::max<size_t>(1, lanes_max_rows() / rows_per_gq);
+        const size_t max_gq = std::max<size_t>(1, lanes_max_rows() / dec_rows_per_gq);
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
         uint64_t* d_lane_subs = nullptr;
         if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs))) return st;
         if ((st = dabgpu_stage_h2d(c, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
+        // the schedule table of every lane-mapped sub-channel, once per call
+        const uint32_t sched_stride = dabgpu_vit_alloc_steps(lane_max_steps);
+        uint2* d_sched = nullptr;
+        if ((st = dabgpu_scratch(c, 25, (size_t)n_lane * sched_stride * sizeof(uint2), (void**)&d_sched))) return st;
+        if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_msc(d_sched, sched_stride, d_plans, d_lane_subs, n_lane, c->d_vit_tables, s), "vit_sched launch"))) return st;
         for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
             const size_t ne = std::min(n_ens - e0, ens_per_slice);
             const uint32_t gps = (uint32_t)((ne * 4 + 63) / 64);
             const size_t n_groups = (size_t)n_lane * gps;
             dabgpu_vit_group* d_groups = nullptr;
             if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
-            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, s), "vit_groups launch"))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, sched_stride, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
             // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / aligned 64-byte lines (class order)
             // (class order: whole 64-byte memory lines are loaded -- with the history and every ensemble 64-byte aligned no line reaches
             // past the end of a row, 230400 = 3600 x 64)
             const int ring4 = classed ? ((((uintptr_t)d_hist % 64 == 0) && (ens_stride % 64 == 0)) ? 2 : 0)
                                       : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, rows_per_gq * gps, dabgpu_vit_alloc_steps(lane_max_steps),
-                                        tie_rule, ring4, d_results + cw0, s))) return st;
+            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, sym_rows_per_gq * gps, dec_rows_per_gq * gps, lane_max_in_rows,
+                                        tie_rule, ring4, d_sched, d_results + cw0, s))) return st;
         }
         if (k_wave == 0) return DABGPU_OK;
     }
@@ -431,7 +444,7 @@ extern "C" int dabgpu_msc_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_
 // ------------------------------------------------------------------------------------------------
 static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src, size_t n_src, uint8_t* h_out, size_t n_out,
                            dabgpu_codeword_result* h_res, int tie_rule) {
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     int st;
     int8_t* d_src = nullptr; uint8_t* d_out; dabgpu_codeword_result* d_res; dabgpu_cw_desc* d_desc;
     if (h_src && (st = dabgpu_scratch(c, 14, n_src, (void**)&d_src))) return st;
@@ -513,7 +526,7 @@ extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* 
     *out = nullptr;
     int pi[4], lx[4], nb = 0;
     if (dabgpu_subchannel_plan(sc, pi, lx, &nb) < 0) { dabgpu_set_error("msc_stream_create: invalid protection profile"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     dabgpu_msc_stream* s = new dabgpu_msc_stream();
     s->ctx = c; s->sc = *sc; s->n_bits = sc->length * 64; s->n_out_bytes = nb; s->next_slot = 0; s->stored = 0;
     s->d_ring = nullptr; s->d_logical = nullptr;
@@ -542,7 +555,7 @@ extern "C" void dabgpu_msc_stream_destroy(dabgpu_msc_stream* s) {
 
 extern "C" int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_bits) {
     if (!s || !h_bits) return DABGPU_ERR_INVALID_ARG;
-    (void)hipSetDevice(s->ctx->device);
+    DABGPU_BIND(s->ctx);
     DABGPU_HOST_LOCK(s->ctx);
     // through the pinned staging ring: the caller's span is only valid during DecodeCIF (SURVEY 8b ownership)
     int st = dabgpu_stage_h2d(s->ctx, s->d_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits, s->ctx->stream);
@@ -556,7 +569,7 @@ extern "C" int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t*
     if (!s || !h_out) return DABGPU_ERR_INVALID_ARG;
     DABGPU_HOST_LOCK(s->ctx);
     if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // cif_deinterleaver.cpp:40-42
-    (void)hipSetDevice(s->ctx->device);
+    DABGPU_BIND(s->ctx);
     hipStream_t q = s->ctx->stream;
     int st = dabgpu_check_hip(dabgpu_launch_cif_deinterleave(s->d_ring, s->n_bits, 16, (s->next_slot + 15) % 16, s->d_logical, q),
                               "cif_deinterleave launch");

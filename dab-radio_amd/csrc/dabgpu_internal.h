@@ -33,7 +33,7 @@ struct dabgpu_ctx {
     std::recursive_mutex host_mu;
     // pinned staging ring for small host -> device copies whose source does not outlive the call (descriptor tables, a caller's
     // CIF): copy into a pinned slot, asynchronous DMA from there, an event marks the slot reusable
-    struct stage_slot { void* h = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    struct stage_slot { void* h = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool pending = false; std::mutex mu; };
     stage_slot stage[8];
     unsigned stage_next = 0;
     std::mutex stage_mu;
@@ -44,6 +44,10 @@ extern "C" int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, s
 
 void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);
+// Every entry point that launches, allocates or copies first makes the context's device current on the calling thread (a worker
+// thread of a one-process multi-GPU host starts on device 0) -- checked: a failed hipSetDevice is the call's status.
+int dabgpu_bind_device(const dabgpu_ctx* c);
+#define DABGPU_BIND(ctx) do { const int dabgpu_bind_st_ = dabgpu_bind_device(ctx); if (dabgpu_bind_st_) return dabgpu_bind_st_; } while (0)
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 // device PRS spectrum / coarse-sync time reference of a transmission mode (mode I: the context's own tables)
 int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const float** d_prs_time_ref);
@@ -88,32 +92,49 @@ struct dabgpu_msc_plan {            // device-side sub-channel plan (one per sub
     uint32_t lane_mapped;           // this call decodes the sub-channel with the lane-per-codeword kernel: viterbi_kernel skips it
 };
 #define DABGPU_CW_LANE_MAPPED 0x80000000u      // internal flag bit of dabgpu_codeword.flags (set by msc_build_descs_kernel)
-struct dabgpu_vit_tables {          // constant tables of the Viterbi kernel, built on the host at context creation
+struct dabgpu_vit_tables {          // constant tables of the Viterbi kernels, built on the host at context creation
     uint16_t pi_tab[25 * 8];        // [PI][group]: kept count | running prefix << 8 (puncture_codes.h:42-67)
     unsigned char prbs[512];        // energy-dispersal bytes, period 511 (additive_scrambler.h:16-35)
 };
-// lane-per-codeword decoder (viterbi_lanes.hip): a GROUP = up to 64 codewords with one puncturing schedule
+// lane-per-codeword decoder (viterbi_lanes.hip): a GROUP = up to 64 codewords with one puncturing schedule.
+// Symbol area of a group: the codewords' KEPT soft bits only, transposed -- row j, lane L = input bytes 4 j .. 4 j + 3 of lane L's
+// codeword (after the time de-interleaver, -128 clamped to -127).  The trellis kernel de-punctures with wave-uniform selectors.
 struct dabgpu_vit_group {
     uint32_t first, stride, count;  // lane L decodes descs[first + L * stride], L < count
     uint32_t n_steps;               // trellis steps incl. tail
-    uint32_t alloc_steps;           // rows of the group's symbol / decision areas (dabgpu_vit_alloc_steps)
+    uint32_t alloc_steps;           // rows of the group's decision area (dabgpu_vit_alloc_steps)
     uint32_t seg_pi[4];
     uint32_t seg_steps[4];
-    uint32_t pad_;
-    uint64_t sym_off;               // dwords into the symbol scratch   [alloc_steps][64]
+    uint32_t in_rows;               // rows of the group's symbol area (dabgpu_vit_in_rows)
+    uint64_t sched_off;             // entries into the schedule tables: (symbol row, v_perm_b32 selector) per trellis step
+    uint64_t sym_off;               // dwords into the symbol scratch   [in_rows][64]
     uint64_t dec_off;               // dwords into the decision scratch [alloc_steps][64][2]
 };
-// the forward pass prefetches one 6-step block past the end; the gather kernel works in tiles of 64 steps
+// decisions are stored two steps per row pair; the chain-back reads whole 24-step chunks
 static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_steps) { return (n_steps + 6u + 63u) & ~63u; }
+// soft bits a codeword consumes (dab_viterbi_decoder.cpp:131-181): 8 + PI per 8 steps, 12 for the tail
+static inline __host__ __device__ uint32_t dabgpu_vit_in_bytes(const uint32_t* seg_pi, const uint32_t* seg_steps) {
+    uint32_t n = 12;
+    for (int k = 0; k < 4; k++) n += (seg_steps[k] >> 3) * (8u + seg_pi[k]);
+    return n;
+}
+// symbol rows: 4 kept soft bits per row, + the row the last step's two-row window reaches into + one the prefetch may touch
+static inline __host__ __device__ uint32_t dabgpu_vit_in_rows(uint32_t n_in) { return (n_in + 3u) / 4u + 2u; }
 extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
                                                        const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const struct dabgpu_msc_plan* d_plans,
                                                    const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
-                                                   uint32_t groups_per_sub, hipStream_t stream);
-extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
+                                                   uint32_t groups_per_sub, uint32_t sched_stride, hipStream_t stream);
+// schedule tables (one per puncturing schedule of the call): sched_stride entries each, >= n_steps + 12
+extern "C" hipError_t dabgpu_launch_vit_sched_uniform(uint2* d_sched, uint32_t sched_stride, const uint32_t* seg_pi, const uint32_t* seg_steps,
+                                                      const struct dabgpu_vit_tables* d_tables, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched_stride, const struct dabgpu_msc_plan* d_plans,
+                                                  const uint64_t* d_lane_subs, int n_lane_sub, const struct dabgpu_vit_tables* d_tables,
+                                                  hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4,
-                                                  const struct dabgpu_vit_tables* d_tables, int n_cu, hipStream_t stream);
+                                                  const struct dabgpu_vit_tables* d_tables, const uint2* d_sched, int n_cu, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,

@@ -356,7 +356,7 @@ void dabgpu_dabplus_bank_destroy(dabgpu_dabplus_bank* b) {
 
 int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank* b, void* stream) {
     if (!b) { dabgpu_set_error("dabplus_bank_reset: null bank"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(b->ctx->device);
+    DABGPU_BIND(b->ctx);
     // AAC_Frame_Processor's constructor state (:121-125): WAIT_FRAME_START, nothing collected, unsynchronised
     std::vector<DpState> init(b->n, DpState{1, 0, 0, 0, 0});
     int st = dabgpu_check_hip(hipMemcpyAsync(b->d_states, init.data(), b->n * sizeof(DpState), hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync");
@@ -366,7 +366,7 @@ int dabgpu_dabplus_bank_reset(dabgpu_dabplus_bank* b, void* stream) {
 
 int dabgpu_dabplus_bank_create(dabgpu_ctx* c, size_t n_streams, dabgpu_dabplus_bank** out) {
     if (!c || !out || n_streams == 0 || n_streams > (size_t)(1 << 22)) { dabgpu_set_error("dabplus_bank_create: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     dabgpu_dabplus_bank* b = new (std::nothrow) dabgpu_dabplus_bank();
     if (!b) return DABGPU_ERR_HIP;
     b->ctx = c; b->n = n_streams;
@@ -410,7 +410,7 @@ int dabgpu_dabplus_bank_process_masked(dabgpu_dabplus_bank* b, const uint8_t* d_
     if (max_superframes < (n_frames + 4) / 5 || superframe_stride_bytes == 0) {
         dabgpu_set_error("dabplus_bank_process: max_superframes must be at least ceil(n_frames / 5)"); return DABGPU_ERR_INVALID_ARG;
     }
-    (void)hipSetDevice(b->ctx->device);
+    DABGPU_BIND(b->ctx);
     hipLaunchKernelGGL(dabplus_kernel, dim3((unsigned)b->n), dim3(64), 0, (hipStream_t)stream, b->d_states, d_frames,
                        reinterpret_cast<const unsigned long long*>(d_stream_offsets), frame_stride_bytes, d_frame_bytes, n_frames, b->d_acc,
                        d_superframes, superframe_stride_bytes, d_results, max_superframes, d_counts, (int)b->n, d_active, streams_per_flag);
@@ -430,7 +430,7 @@ int dabgpu_dabplus_process_frame_host_sync(dabgpu_dabplus_bank* b, const uint8_t
         return DABGPU_ERR_UNSUPPORTED;
     }
     dabgpu_ctx* c = b->ctx;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(b->ctx);
     hipStream_t s = c->stream;
     int st;

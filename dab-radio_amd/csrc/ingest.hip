@@ -27,7 +27,7 @@ extern "C" {
 
 int dabgpu_ingest_create(dabgpu_ctx* c, size_t buffer_bytes, int depth, dabgpu_ingest** out) {
     if (!c || !out || buffer_bytes == 0 || depth < 1 || depth > 16) { dabgpu_set_error("ingest_create: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     dabgpu_ingest* g = new dabgpu_ingest();
     g->ctx = c; g->bytes = buffer_bytes; g->depth = depth;
     g->slots.resize((size_t)depth);
@@ -62,7 +62,7 @@ void dabgpu_ingest_destroy(dabgpu_ingest* g) {
 // next pinned buffer to fill; blocks only while the copy that last read this buffer is still in flight (the ring is full)
 int dabgpu_ingest_acquire(dabgpu_ingest* g, void** h_buffer) {
     if (!g || !h_buffer) { dabgpu_set_error("ingest_acquire: null argument"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(g->ctx->device);
+    DABGPU_BIND(g->ctx);
     g->cur = (g->cur + 1) % g->depth;
     auto& s = g->slots[(size_t)g->cur];
     if (s.h2d_pending) {
@@ -83,7 +83,7 @@ static dabgpu_ingest::slot* slot_of(dabgpu_ingest* g, const void* d_buffer) {
 // that last read the twin.  *d_buffer = the twin; no stream waits for the copy until dabgpu_ingest_wait says so
 int dabgpu_ingest_submit(dabgpu_ingest* g, size_t bytes, void** d_buffer) {
     if (!g || !d_buffer || g->cur < 0 || bytes > g->bytes) { dabgpu_set_error("ingest_submit: invalid argument (acquire first; bytes <= buffer size)"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(g->ctx->device);
+    DABGPU_BIND(g->ctx);
     auto& s = g->slots[(size_t)g->cur];
     int st;
     if (s.consumed_pending) {
@@ -102,7 +102,7 @@ int dabgpu_ingest_submit(dabgpu_ingest* g, size_t bytes, void** d_buffer) {
 int dabgpu_ingest_wait(dabgpu_ingest* g, const void* d_buffer, void* compute_stream) {
     dabgpu_ingest::slot* s = g ? slot_of(g, d_buffer) : nullptr;
     if (!s) { dabgpu_set_error("ingest_wait: not a buffer of this pipe"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(g->ctx->device);
+    DABGPU_BIND(g->ctx);
     return dabgpu_check_hip(hipStreamWaitEvent((hipStream_t)compute_stream, s->h2d, 0), "hipStreamWaitEvent(ingest h2d)");
 }
 
@@ -110,7 +110,7 @@ int dabgpu_ingest_wait(dabgpu_ingest* g, const void* d_buffer, void* compute_str
 int dabgpu_ingest_consumed(dabgpu_ingest* g, const void* d_buffer, void* compute_stream) {
     dabgpu_ingest::slot* s = g ? slot_of(g, d_buffer) : nullptr;
     if (!s) { dabgpu_set_error("ingest_consumed: not a buffer of this pipe"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(g->ctx->device);
+    DABGPU_BIND(g->ctx);
     int st = dabgpu_check_hip(hipEventRecord(s->consumed, (hipStream_t)compute_stream), "hipEventRecord(ingest consumed)");
     if (st) return st;
     s->consumed_pending = true;

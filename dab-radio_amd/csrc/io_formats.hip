@@ -151,7 +151,7 @@ int dabgpu_iq_convert(dabgpu_ctx* c, const void* d_raw, int format, size_t n_sam
     if (n_samples == 0) return DABGPU_OK;
     if (!d_raw || !d_iq) { dabgpu_set_error("iq_convert: null buffer"); return DABGPU_ERR_INVALID_ARG; }
     if (((uintptr_t)d_raw | (uintptr_t)d_iq) & 15u) { dabgpu_set_error("iq_convert: buffers must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = 2 * n_samples;
     const fmt_info f = FMT_TABLE[format];
@@ -177,7 +177,7 @@ int dabgpu_soft_bits_to_hard_bytes(dabgpu_ctx* c, const int8_t* d_bits, size_t n
     if (n_bytes == 0) return DABGPU_OK;
     if (!d_bits || !d_bytes) { dabgpu_set_error("soft_bits_to_hard_bytes: null buffer"); return DABGPU_ERR_INVALID_ARG; }
     if (((uintptr_t)d_bits & 15u) || ((uintptr_t)d_bytes & 3u)) { dabgpu_set_error("soft_bits_to_hard_bytes: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     const size_t n_blocks = ((n_bytes + 3) / 4 + 255) / 256;
     hipLaunchKernelGGL(soft_to_hard_kernel, dim3((unsigned)n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_bits, d_bytes, n_bytes);
     return dabgpu_check_hip(hipGetLastError(), "soft_to_hard_kernel launch");
@@ -188,7 +188,7 @@ int dabgpu_hard_bytes_to_soft_bits(dabgpu_ctx* c, const uint8_t* d_bytes, size_t
     if (n_bytes == 0) return DABGPU_OK;
     if (!d_bits || !d_bytes) { dabgpu_set_error("hard_bytes_to_soft_bits: null buffer"); return DABGPU_ERR_INVALID_ARG; }
     if ((uintptr_t)d_bits & 15u) { dabgpu_set_error("hard_bytes_to_soft_bits: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     const size_t n_blocks = ((n_bytes + 1) / 2 + 255) / 256;
     hipLaunchKernelGGL(hard_to_soft_kernel, dim3((unsigned)n_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_bytes, d_bits, n_bytes);
     return dabgpu_check_hip(hipGetLastError(), "hard_to_soft_kernel launch");
@@ -199,7 +199,7 @@ int dabgpu_hard_bytes_to_soft_bits(dabgpu_ctx* c, const uint8_t* d_bytes, size_t
 static int round_trip(dabgpu_ctx* c, const void* h_in, size_t in_bytes, void* h_out, size_t out_bytes,
                       int (*run)(dabgpu_ctx*, const void*, void*, size_t, int, hipStream_t), size_t n, int arg) {
     int st;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     void *d_in, *d_out;
     if ((st = dabgpu_scratch(c, 20, in_bytes + 16, &d_in))) return st;
     if ((st = dabgpu_scratch(c, 21, out_bytes + 16, &d_out))) return st;

@@ -228,7 +228,7 @@ int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, si
     if (n_frames > (size_t)(1 << 22)) { dabgpu_set_error("ofdm_demod_frames_mode: n_frames too large"); return DABGPU_ERR_INVALID_ARG; }
     if ((uintptr_t)d_iq & 7) { dabgpu_set_error("ofdm_demod_frames_mode: d_iq must be 8-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
     if ((uintptr_t)d_bits & 15) { dabgpu_set_error("ofdm_demod_frames_mode: d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     int st;
     float* corr = d_cp_corr;
@@ -246,7 +246,7 @@ int dabgpu_ofdm_demod_stream_frame_sync_mode(dabgpu_ctx* c, int mode, const floa
     if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_demod_stream_frame_sync_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
     if (mode == 1) return dabgpu_ofdm_demod_stream_frame_sync(c, h_iq, freq_coarse, h_freq_fine, beta, h_bits, h_total_phase, h_fft, nullptr);
     int st;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(c);
     const size_t iq_bytes = (size_t)g.frame_samples * 2 * sizeof(float);
     const size_t fft_bytes = (size_t)(g.n_sym + 1) * g.n_fft * 2 * sizeof(float);
@@ -277,7 +277,7 @@ int dabgpu_ofdm_sync_host_sync_mode(dabgpu_ctx* c, int mode, const float* h_prs_
     ModeGeom g;
     if (!c || !h_prs_sym || !cfg || !h_state) { dabgpu_set_error("ofdm_sync_host_sync_mode: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (!mode_geometry(mode, g)) { dabgpu_set_error("ofdm_sync_host_sync_mode: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     DABGPU_HOST_LOCK(c);
     int st;
     const size_t N = (size_t)g.n_fft;

@@ -392,7 +392,7 @@ void dabgpu_stream_bank_destroy(dabgpu_stream_bank* b) {
 
 int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     if (!b) { dabgpu_set_error("stream_bank_reset: null bank"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(b->ctx->device);
+    DABGPU_BIND(b->ctx);
     hipStream_t s = (hipStream_t)stream;
     int st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
@@ -419,7 +419,7 @@ int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, co
     dabgpu_stream_cfg k;
     if (cfg) k = *cfg; else dabgpu_stream_cfg_default(&k);
     if (k.signal_l1_nb_samples <= 0 || k.signal_l1_nb_decimate <= 0) { dabgpu_set_error("stream_bank_create: invalid L1 window"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     dabgpu_stream_bank* b = new (std::nothrow) dabgpu_stream_bank();
     if (!b) return DABGPU_ERR_HIP;
     b->ctx = c; b->n = n_streams; b->cfg = k;
@@ -480,7 +480,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     }
     if (((uintptr_t)d_iq & (src_sample_bytes<SRC>::value - 1)) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("stream_bank_process: misaligned buffer"); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_ctx* c = b->ctx;
-    (void)hipSetDevice(c->device);
+    DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)b->n;
     int st;
@@ -599,7 +599,7 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int
     if (((stream_stride_samples * sb) & 15) != 0 && b->n > 1) {
         dabgpu_set_error("stream_bank_process_raw: the byte stride between streams must be a multiple of 16"); return DABGPU_ERR_INVALID_ARG;
     }
-    (void)hipSetDevice(b->ctx->device);
+    DABGPU_BIND(b->ctx);
     hipStream_t s = (hipStream_t)stream;
     const size_t padded = (n_samples + 1) & ~(size_t)1;                    // keeps every stream's converted block 16-byte aligned
     const size_t need = b->n * padded * 2 * sizeof(float);
@@ -656,7 +656,7 @@ int dabgpu_stream_bank_process_ring(dabgpu_stream_bank* b, const void* d_raw, in
 
 int dabgpu_stream_bank_status(dabgpu_stream_bank* b, dabgpu_stream_status* h_status, void* stream) {
     if (!b || !h_status) { dabgpu_set_error("stream_bank_status: null argument"); return DABGPU_ERR_INVALID_ARG; }
-    (void)hipSetDevice(b->ctx->device);
+    DABGPU_BIND(b->ctx);
     hipStream_t s = (hipStream_t)stream;
     const int n = (int)b->n;
     int st;

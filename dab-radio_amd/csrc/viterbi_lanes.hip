@@ -19,9 +19,11 @@
 //                       2 dwords per step and lane, streamed to HBM two steps at a time ([step / 2][lane][4], 1 KB per store)
 //   chain-back        = per lane, reading the lane's own decision words back (coalesced across the wavefront),
 //                       MSB-first bytes, energy-dispersal XOR, FIB CRC16 -- same outputs as viterbi.hip
-//   input             = vit_prep_kernel gathers the soft bits of a group through the time de-interleaver and the
-//                       puncturing tables into [step][lane] dwords (4 mother-code symbols, 0 = punctured), so the
-//                       forward pass streams 256 B per step
+//   input             = vit_prep_*_kernel transpose the KEPT soft bits of a group (through the time de-interleaver) into
+//                       [row][lane] dwords, 4 consecutive input bytes of the lane's codeword per row; the puncturing
+//                       schedule is wave-uniform, so the forward pass de-punctures with scalar bookkeeping: the SALU tracks
+//                       the input position of every step and hands the VALU one v_perm_b32 selector that picks the step's
+//                       <= 4 kept bytes out of a two-row window and zeroes the punctured ones (dab_viterbi_decoder.cpp:131-181)
 // Arithmetic and tie rules are those of viterbi.hip / oracle/dab_oracle_decode.c (bit-exact, incl. path_error).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -173,6 +175,33 @@ __device__ __forceinline__ void vl_renorm(s2 (&N)[32], uint32_t& total) {
     }
 }
 
+// ---- wave-uniform de-puncturing schedule (dab_viterbi_decoder.cpp:131-181) ----
+// Inside a segment the kept / dropped pattern repeats every 8 steps (one 32-bit puncturing vector): step u of a period keeps
+// cnt(u) of its 4 mother bits, always the first cnt (PI vectors only ever drop the tail of a 4-bit group), starting at input
+// byte k = (bytes of the periods before) + prefix(u).  vit_sched_kernel writes, once per call and schedule, one (row, selector)
+// pair per trellis step: row = k / 4 = the symbol row that holds the step's first kept byte, selector = the v_perm_b32 control
+// that builds (y0, y1, y2, y3) from rows (row + 1 : row) -- byte r = input byte k + r for r < cnt, constant 0x00 (selector 0x0C)
+// for the punctured ones.  The trellis kernels read the pairs with scalar loads, a block of steps ahead.
+__device__ __forceinline__ uint2 vl_sched_entry(int t, const uint32_t* seg_pi, const uint32_t* seg_steps, uint32_t in_rows,
+                                                const dabgpu_vit_tables* __restrict__ tables) {
+    int sstart = 0, in0 = 0, pi = 8, k = 0;
+    for (; k < 4; k++) {
+        const int len = (int)seg_steps[k];
+        if (t < sstart + len) { pi = (int)seg_pi[k]; break; }
+        in0 += (len >> 3) * (8 + (int)seg_pi[k]);
+        sstart += len;
+    }
+    // k == 4: the 6 tail steps, PI_X == PI_8 restricted to 6 groups (and the steps a prefetch reads past the end: their row is clamped)
+    const int sis = t - sstart;
+    const uint16_t e = tables->pi_tab[pi * 8 + (sis & 7)];
+    const uint32_t cnt = e & 0xFFu, kk = (uint32_t)(in0 + (sis >> 3) * (8 + pi)) + (uint32_t)(e >> 8);
+    const uint32_t keep = cnt >= 4u ? 0xFFFFFFFFu : ((1u << (8u * cnt)) - 1u);
+    uint2 r;
+    r.x = min(kk >> 2, in_rows - 2u);
+    r.y = ((0x03020100u + (kk & 3u) * 0x01010101u) & keep) | (0x0C0C0C0Cu & ~keep);
+    return r;
+}
+
 // Workgroups of FOUR wavefronts = four groups: the hardware puts the wavefronts of a workgroup on the four SIMDs of one CU, so
 // up to 1024 groups get a SIMD each.  Single-wavefront workgroups are placed one by one and a few per cent of them double up on
 // a SIMD -- and one doubled SIMD (1.4 ms instead of 0.9) sets the time of the whole launch (tools/ubench/hwid_probe.hip).
@@ -184,7 +213,7 @@ template <int TIE, int VL_WAVES, int OCC = 4>
 __global__ __launch_bounds__(64 * VL_WAVES) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups, const dabgpu_cw_desc* __restrict__ descs,
                       const uint32_t* __restrict__ sym, uint32_t* __restrict__ dec, dabgpu_cw_result* __restrict__ results,
-                      const dabgpu_vit_tables* __restrict__ tables)
+                      const dabgpu_vit_tables* __restrict__ tables, const uint2* __restrict__ sched)
 {
     __shared__ unsigned char prbs[512];
     const int lane = threadIdx.x & 63;
@@ -200,7 +229,7 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
     const dabgpu_cw_desc Dd = descs[cw];
     const bool live = valid && Dd.n_steps != 0;              // n_steps == 0: skipped work item of a ring decode
 
-    const uint32_t* grp_sym = sym + Gd.sym_off;              // [step][64]          (wave-uniform bases: scalar address + lane offset)
+    const uint32_t* grp_sym = sym + Gd.sym_off;              // [row][64]           (wave-uniform bases: scalar address + lane offset)
     uint32_t* grp_dec = dec + Gd.dec_off;                    // [step / 2][64][4]
 
     // ---- forward pass.  The LAST step runs in phase 5, so the metrics end in layout L_0.  n_steps = 8 m + 6 is even: the first,
@@ -219,6 +248,8 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
         }
     }
     uint32_t total = 0;
+    const uint2* sch = sched + Gd.sched_off;                 // (row, selector) per trellis step: scalar loads
+    const uint32_t lane4 = 4u * (uint32_t)lane, lane16 = 16u * (uint32_t)lane;
     // two trellis steps t, t + 1 (t even) in phases Q, Q + 1: M -> N -> M
 #define VL_PAIR(Q, TT, YA, YB)                                                                        \
     {                                                                                                 \
@@ -227,32 +258,45 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
         vl_renorm(N, total);                                                                          \
         vl_step<(Q) + 1, TIE>(N, M, YB, wv.z, wv.w);                                                  \
         vl_renorm(M, total);                                                                          \
-        __builtin_nontemporal_store(u4v{wv.x, wv.y, wv.z, wv.w}, reinterpret_cast<u4v*>(grp_dec + (size_t)((TT) >> 1) * 256) + lane); \
+        __builtin_nontemporal_store(u4v{wv.x, wv.y, wv.z, wv.w},                                      \
+                                    reinterpret_cast<u4v*>(reinterpret_cast<char*>(grp_dec + (size_t)((TT) >> 1) * 256) + lane16)); \
+    }
+    // the packed symbols of step TT: two rows of the group's symbol area (scalar base + lane offset) and the selector
+#define VL_ROWS(LO, HI, SEL, TT)                                                                      \
+    {                                                                                                 \
+        const uint2 e_ = sch[TT];                                                                     \
+        const char* rp_ = reinterpret_cast<const char*>(grp_sym + (size_t)e_.x * 64);                 \
+        LO = *reinterpret_cast<const uint32_t*>(rp_ + lane4);                                         \
+        HI = *reinterpret_cast<const uint32_t*>(rp_ + 256 + lane4);                                   \
+        SEL = e_.y;                                                                                   \
     }
     int t = 0;
     if (q0 == 2) {
-        const uint32_t ya = (grp_sym + (size_t)t * 64)[lane], yb = (grp_sym + (size_t)(t + 1) * 64)[lane];
-        VL_PAIR(2, t, ya, yb)
+        uint32_t a0, a1, b0, b1, sa, sb;
+        VL_ROWS(a0, a1, sa, t) VL_ROWS(b0, b1, sb, t + 1)
+        VL_PAIR(2, t, __builtin_amdgcn_perm(a1, a0, sa), __builtin_amdgcn_perm(b1, b0, sb))
         t += 2;
     }
     if (q0 != 0) {
-        const uint32_t ya = (grp_sym + (size_t)t * 64)[lane], yb = (grp_sym + (size_t)(t + 1) * 64)[lane];
-        VL_PAIR(4, t, ya, yb)
+        uint32_t a0, a1, b0, b1, sa, sb;
+        VL_ROWS(a0, a1, sa, t) VL_ROWS(b0, b1, sb, t + 1)
+        VL_PAIR(4, t, __builtin_amdgcn_perm(a1, a0, sa), __builtin_amdgcn_perm(b1, b0, sb))
         t += 2;
     }
-    uint32_t ynext[6];
+    uint32_t nlo[6], nhi[6], nsel[6];
 #pragma unroll
-    for (int q = 0; q < 6; q++) ynext[q] = (grp_sym + (size_t)(t + q) * 64)[lane];
+    for (int q = 0; q < 6; q++) VL_ROWS(nlo[q], nhi[q], nsel[q], t + q)
     for (; t < T; t += 6) {
         uint32_t y[6];
 #pragma unroll
-        for (int q = 0; q < 6; q++) y[q] = ynext[q];
+        for (int q = 0; q < 6; q++) y[q] = __builtin_amdgcn_perm(nhi[q], nlo[q], nsel[q]);
 #pragma unroll
-        for (int q = 0; q < 6; q++) ynext[q] = (grp_sym + (size_t)(t + 6 + q) * 64)[lane];     // the buffer is padded by one block
+        for (int q = 0; q < 6; q++) VL_ROWS(nlo[q], nhi[q], nsel[q], t + 6 + q)               // one block ahead (the table runs a block past the end)
         VL_PAIR(0, t, y[0], y[1])
         VL_PAIR(2, t + 2, y[2], y[3])
         VL_PAIR(4, t + 4, y[4], y[5])
     }
+#undef VL_ROWS
 #undef VL_PAIR
 
     // ---- end metric (layout L_0: register es >> 1, half es & 1) ----
@@ -281,7 +325,7 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
 #pragma unroll
         for (int v = 0; v < CB / 2; v++) {
             const int pr = (th >> 1) - v;
-            const u4v q4 = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256) + lane);
+            const u4v q4 = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(grp_dec + (size_t)(pr < 0 ? 0 : pr) * 256) + lane16));
             cx[2 * v] = q4.z; cy[2 * v] = q4.w; cx[2 * v + 1] = q4.x; cy[2 * v + 1] = q4.y;
         }
 #pragma unroll
@@ -331,39 +375,30 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
     }
 }
 
-// ---- input gather: soft bits of a group -> [step][lane] dwords ----
-// grid (n_groups, ceil(alloc_steps / 64)), 256 threads: wave v handles codewords v, v+4, ... of the group, lane = step of the tile
+// ---- input transposition: the kept soft bits of a group's codewords -> [row][lane] dwords ----
+// Row j of lane L = input bytes 4 j .. 4 j + 3 of L's codeword, read through the time de-interleaver
+// (cif_deinterleaver.cpp:57-68) where the codeword has a CIF ring, -128 clamped to -127 (viterbi_config.h:12-14), zero past the
+// end of the input.  None of these kernels knows the puncturing schedule any more: that is the trellis kernel's scalar bookkeeping.
+
+// -128 -> -127 in each of the four bytes (no packed byte max on gfx950): flag the bytes equal to 0x80 exactly, add the flag
+__device__ __forceinline__ uint32_t vl_clamp4(uint32_t w) {
+    const uint32_t t = w ^ 0x80808080u;                                      // zero byte <=> -128
+    const uint32_t nz = ((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t;               // bit 7 of a byte set <=> the byte of t is non-zero
+    return w + ((~nz & 0x80808080u) >> 7);                                   // 0x80 + 1 = 0x81: no carry between bytes
+}
+
+// general form (any alignment, any ring geometry, natural or class order): byte loads through the 16 ring offsets.
+// grid (n_groups, ceil(max in_rows / 64)), 256 threads: wave v handles codewords v, v + 4, ... of the group, lane = row of the tile
 __global__ __launch_bounds__(256)
-void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
-                     uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym)
 {
     __shared__ uint32_t tile[VL_TILE][65];
-    __shared__ uint16_t pi_tab[25 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const dabgpu_vit_group Gd = groups[blockIdx.x];
-    const int t0 = blockIdx.y * VL_TILE;
-    if (t0 >= (int)Gd.alloc_steps) return;
-    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
-    __syncthreads();
-
-    // position of step t in the punctured input (dab_viterbi_decoder.cpp:131-181): the same for every codeword of the group
-    const int T = (int)Gd.n_steps;
-    const int t = t0 + lane;
-    int idx0 = 0, cnt = 0;
-    if (t < T) {
-        int sstart = 0, in0 = 0, pi = 8, k = 0;
-        for (; k < 4; k++) {
-            const int len = (int)Gd.seg_steps[k];
-            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
-            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
-            sstart += len;
-        }
-        // k == 4: the 6 tail steps, PI_X == PI_8 restricted to 6 groups
-        const int sis = t - sstart;
-        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
-        cnt = e & 0xFF;
-        idx0 = in0 + (sis >> 3) * (8 + pi) + (e >> 8);
-    }
+    const int j0 = blockIdx.y * VL_TILE;
+    if (j0 >= (int)Gd.in_rows) return;
+    const unsigned n_in = dabgpu_vit_in_bytes(Gd.seg_pi, Gd.seg_steps);
+    const unsigned i0 = 4u * (unsigned)(j0 + lane);
     for (int c = wv; c < 64; c += 4) {
         uint32_t packed = 0;
         const bool have = c < (int)Gd.count;                                   // wave-uniform
@@ -383,9 +418,9 @@ void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_c
         const int8_t* src = reinterpret_cast<const int8_t*>(Dd.d_src);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const unsigned i = (unsigned)(idx0 + r);
+            const unsigned i = i0 + (unsigned)r;
             const uint32_t off = (uint32_t)__shfl((int)aoff, (int)(i & 15u));
-            if (have && Dd.n_steps != 0 && r < cnt) {
+            if (have && Dd.n_steps != 0 && i < n_in) {
                 int yv = src[(size_t)off + (i >> ish)];
                 yv = max(yv, -127);                                            // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                 packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
@@ -396,63 +431,36 @@ void vit_prep_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_c
     __syncthreads();
     uint32_t* dst = sym + Gd.sym_off;
     for (int s = wv; s < VL_TILE; s += 4) {
-        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+        if (j0 + s < (int)Gd.in_rows) dst[(size_t)(j0 + s) * 64 + lane] = tile[s][lane];
     }
 }
 
-// ---- input gather, direct form (FIC): every codeword of the group is a contiguous run of soft bits at a 16-byte aligned address ----
-// The tile's byte range (<= 272 bytes, the same for all 64 codewords: one puncturing schedule) of every codeword is staged in LDS
-// with 16-byte loads -- 1088 chunks, all in flight at once -- and thread (step, wave) picks its <= 4 soft bits per codeword there; the
-// byte-granular loads of vit_prep_kernel cost one address-coalescer slot per byte (64 byte-load instructions per thread and tile).
-// grid (n_groups, ceil(alloc_steps / 64)), 256 threads
-constexpr int VD_CHUNKS = 17, VD_PITCH = VD_CHUNKS * 16 + 16;
+// direct form (FIC): every codeword of the group is a contiguous run of soft bits at a 16-byte aligned address.  A tile = 64 rows =
+// 256 input bytes of each of the 64 codewords: 1024 sixteen-byte chunks, all in flight at once, land in LDS rows of 65 dwords
+// (conflict-free both ways) and leave transposed, one coalesced 256-byte row store per wave and row.
+// grid (n_groups, ceil(max in_rows / 64)), 256 threads
 __global__ __launch_bounds__(256)
-void vit_prep_direct_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
-                            uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+void vit_prep_direct_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym)
 {
-    __shared__ uint32_t tile[VL_TILE][65];
-    __shared__ __attribute__((aligned(16))) unsigned char rows[64][VD_PITCH];
-    __shared__ uint16_t pi_tab[25 * 8];
+    __shared__ uint32_t rows[64][65];                                          // [codeword][dword of the tile]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const dabgpu_vit_group Gd = groups[blockIdx.x];
-    const int t0 = blockIdx.y * VL_TILE;
-    if (t0 >= (int)Gd.alloc_steps) return;
-    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
-    __syncthreads();
-    const int T = (int)Gd.n_steps;
-    auto locate = [&](int t, int& cnt) {                                   // dab_viterbi_decoder.cpp:131-181
-        int sstart = 0, in0 = 0, pi = 8, k = 0;
-        for (; k < 4; k++) {
-            const int len = (int)Gd.seg_steps[k];
-            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
-            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
-            sstart += len;
-        }
-        const int sis = t - sstart;
-        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
-        cnt = e & 0xFF;
-        return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
-    };
-    int n_in = 12;
-    for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);
-    int dummy;
-    const int i_lo = ((t0 < T) ? locate(t0, dummy) : n_in) & ~15;          // (uniform) first byte of the tile, 16-byte aligned
-    int i_hi = i_lo;
-    if (t0 < T) { const int tl = min(t0 + VL_TILE, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
-    // stage: chunk q = tid + 256 h of the 64 x 17 sixteen-byte chunks
+    const int j0 = blockIdx.y * VL_TILE;
+    if (j0 >= (int)Gd.in_rows) return;
+    const int n_in = (int)dabgpu_vit_in_bytes(Gd.seg_pi, Gd.seg_steps);       // a multiple of 4
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
-    u4v v[5];
+    u4v v[4];
 #pragma unroll
-    for (int h = 0; h < 5; h++) {
-        const int q = tid + 256 * h, c = q / VD_CHUNKS, ch = q - c * VD_CHUNKS;
+    for (int h = 0; h < 4; h++) {
+        const int q = tid + 256 * h, c = q >> 4, ch = q & 15;
         v[h] = u4v{0u, 0u, 0u, 0u};
-        if (c < (int)Gd.count && c < 64) {
+        if (c < (int)Gd.count) {
             const dabgpu_cw_desc* Dd = descs + ((size_t)Gd.first + (size_t)Gd.stride * (size_t)c);
-            const int o = i_lo + 16 * ch;
-            if (Dd->n_steps != 0 && o < i_hi) {
+            const int o = 4 * j0 + 16 * ch;
+            if (Dd->n_steps != 0 && o < n_in) {
                 const gptr p = (gptr)(uintptr_t)Dd->d_src + o;
                 if (o + 16 <= n_in) v[h] = *(const __attribute__((address_space(1))) u4v*)p;
-                else {                                                     // the last chunk of the codeword: whole dwords only (n_in is a multiple of 4)
+                else {                                                     // the last chunk of the codeword: whole dwords only
                     const __attribute__((address_space(1))) uint32_t* pw = (const __attribute__((address_space(1))) uint32_t*)p;
                     v[h].x = pw[0];
                     if (o + 8 <= n_in) v[h].y = pw[1];
@@ -462,87 +470,45 @@ void vit_prep_direct_kernel(const dabgpu_vit_group* __restrict__ groups, const d
         }
     }
 #pragma unroll
-    for (int h = 0; h < 5; h++) {
-        const int q = tid + 256 * h, c = q / VD_CHUNKS, ch = q - c * VD_CHUNKS;
-        if (c < 64) *reinterpret_cast<u4v*>(&rows[c][16 * ch]) = v[h];
-    }
-    __syncthreads();
-    // pick: lane = step of the tile, wave wv takes codewords wv, wv + 4, ...
-    const int t = t0 + lane;
-    int cnt = 0, idx0 = 0;
-    if (t < T) idx0 = locate(t, cnt);
-    for (int c = wv; c < 64; c += 4) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (r < cnt) {
-                int yv = (int)(signed char)rows[c][idx0 + r - i_lo];
-                yv = max(yv, -127);                                        // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
-                packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
-            }
-        }
-        tile[lane][c] = packed;
+    for (int h = 0; h < 4; h++) {
+        const int q = tid + 256 * h, c = q >> 4, ch = q & 15;
+        rows[c][4 * ch] = v[h].x; rows[c][4 * ch + 1] = v[h].y; rows[c][4 * ch + 2] = v[h].z; rows[c][4 * ch + 3] = v[h].w;
     }
     __syncthreads();
     uint32_t* dst = sym + Gd.sym_off;
-    for (int s = wv; s < VL_TILE; s += 4) {
-        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+    for (int s = wv; s < VL_TILE; s += 4) {                                    // lane = codeword
+        if (j0 + s < (int)Gd.in_rows) dst[(size_t)(j0 + s) * 64 + lane] = vl_clamp4(rows[lane][s]);
     }
 }
 
-// ---- input gather, MSC form: lane 4 k + c of a group = CIF c of ensemble k (16 ensembles), all read through a frame-history
+// MSC form, natural order: lane 4 k + c of a group = CIF c of ensemble k (16 ensembles), all read through a frame-history
 // ring with 4 CIFs per frame.  Output CIFs c = 0..3 with ages 0..15 touch the 19 ring slots 4 nf - 15 .. 4 nf + 3; per ensemble
-// the tile's byte range of those 19 rows is staged in LDS with 16-byte loads (the byte-granular gather of vit_prep_kernel
-// costs one address-coalescer slot per BYTE), then thread (step, c) picks its <= 4 soft bits from LDS.
-// grid (n_groups, ceil(alloc_steps / 64)), 256 threads = 64 steps x 4 CIFs
-constexpr int VR_ROWS = 19, VR_CHUNKS = 17, VR_PITCH = VR_CHUNKS * 16 + 16;
+// the tile's 256-byte range of those 19 rows is staged in LDS with 16-byte loads (the byte-granular gather of vit_prep_kernel
+// costs one address-coalescer slot per BYTE), then thread (row, c) picks its 4 soft bits from LDS.
+// grid (n_groups, ceil(max in_rows / 64)), 256 threads = 64 rows x 4 CIFs
+constexpr int VR_ROWS = 19, VR_CHUNKS = 16, VR_PITCH = VR_CHUNKS * 16 + 16;
 __global__ __launch_bounds__(256)
-void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
-                           uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym)
 {
     __shared__ uint32_t tile[VL_TILE][65];
     __shared__ __attribute__((aligned(16))) unsigned char rows[2][VR_ROWS][VR_PITCH];
-    __shared__ uint16_t pi_tab[25 * 8];
-    const int tid = threadIdx.x, step = tid & 63, c = tid >> 6;
+    const int tid = threadIdx.x, rowi = tid & 63, c = tid >> 6;
     const dabgpu_vit_group Gd = groups[blockIdx.x];
-    const int t0 = blockIdx.y * VL_TILE;
-    if (t0 >= (int)Gd.alloc_steps) return;
-    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
-    __syncthreads();
-
-    const int T = (int)Gd.n_steps;
-    // input index of the first kept bit of step t (dab_viterbi_decoder.cpp:131-181) and the total input length
-    auto locate = [&](int t, int& cnt) {
-        int sstart = 0, in0 = 0, pi = 8, k = 0;
-        for (; k < 4; k++) {
-            const int len = (int)Gd.seg_steps[k];
-            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
-            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
-            sstart += len;
-        }
-        const int sis = t - sstart;
-        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
-        cnt = e & 0xFF;
-        return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
-    };
-    int n_in = 12;                                                         // total input bytes: sub-channel size, a multiple of 64
-    for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);
-    int dummy;
-    const int i_lo = (t0 < T ? locate(t0, dummy) : n_in) & ~15;            // wave-uniform: first byte of the tile, 16-byte aligned
-    int i_hi = i_lo;                                                       // one past the last byte any step of the tile reads
-    if (t0 < T) { const int tl = min(t0 + VL_TILE, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
-    const int t = t0 + step;
-    int cnt = 0, idx0 = 0;
-    if (t < T) idx0 = locate(t, cnt);
-    // LDS address of the thread's r-th kept bit: row = c - age + 15, column = i - i_lo  (the same for every ensemble)
+    const int j0 = blockIdx.y * VL_TILE;
+    if (j0 >= (int)Gd.in_rows) return;
+    const int n_in = (int)dabgpu_vit_in_bytes(Gd.seg_pi, Gd.seg_steps);       // EEP: the sub-channel size; UEP: less, the rest is padding
+    const int i_lo = 4 * j0, i_hi = min(i_lo + 4 * VL_TILE, n_in);            // the tile's byte range
+    // LDS address of the thread's r-th byte: row = c - age + 15, column = i - i_lo  (the same for every ensemble)
     int lds_off[4];
+    bool in[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const unsigned i = (unsigned)(idx0 + r);
+        const unsigned i = (unsigned)(i_lo + 4 * rowi + r);
         const int age = 15 - (int)(__brev(i & 15u) >> 28);
-        lds_off[r] = (c - age + 15) * VR_PITCH + ((int)i - i_lo);
+        lds_off[r] = (c - age + 15) * VR_PITCH + (4 * rowi + r);
+        in[r] = (int)i < i_hi;
     }
-    // staging loads: chunk q = tid, tid + 256 of the 19 x 17 sixteen-byte chunks of one ensemble
+    // staging loads: chunk q = tid, tid + 256 of the 19 x 16 sixteen-byte chunks of one ensemble
     auto fetch = [&](int k, uint4 (&v)[2]) {
         const bool have = 4 * k < (int)Gd.count;
         const dabgpu_cw_desc Dd = descs[(size_t)Gd.first + (size_t)Gd.stride * (size_t)(have ? 4 * k : 0)];
@@ -550,7 +516,7 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
         const unsigned char* src = reinterpret_cast<const unsigned char*>(Dd.d_src);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int q = tid + 256 * h, row = q / VR_CHUNKS, ch = q - row * VR_CHUNKS;
+            const int q = tid + 256 * h, row = q >> 4, ch = q & 15;
             v[h] = make_uint4(0, 0, 0, 0);
             if (on && row < VR_ROWS && i_lo + 16 * ch < i_hi) {
                 int slot = (int)Dd.newest_slot - 15 + row;                 // lane 4 k is CIF 0: its newest slot is 4 nf
@@ -564,7 +530,7 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
     auto stash = [&](int buf, const uint4 (&v)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int q = tid + 256 * h, row = q / VR_CHUNKS, ch = q - row * VR_CHUNKS;
+            const int q = tid + 256 * h, row = q >> 4, ch = q & 15;
             if (row < VR_ROWS) *reinterpret_cast<uint4*>(&rows[buf][row][16 * ch]) = v[h];
         }
     };
@@ -580,76 +546,53 @@ void vit_prep_ring4_kernel(const dabgpu_vit_group* __restrict__ groups, const da
         uint32_t packed = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            if (r < cnt) {
+            if (in[r]) {
                 int yv = (int)(signed char)rb[lds_off[r]];
                 yv = max(yv, -127);                                        // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                 packed |= ((uint32_t)yv & 0xFFu) << (8 * r);
             }
         }
-        tile[step][4 * k + c] = packed;
+        tile[rowi][4 * k + c] = packed;
         if (k + 1 < 16) stash((k + 1) & 1, v[(k + 1) & 3]);
         __syncthreads();
     }
     uint32_t* dst = sym + Gd.sym_off;
     const int lane = tid & 63, wv = tid >> 6;
     for (int s = wv; s < VL_TILE; s += 4) {
-        if (t0 + s < (int)Gd.alloc_steps) dst[(size_t)(t0 + s) * 64 + lane] = tile[s][lane];
+        if (j0 + s < (int)Gd.in_rows) dst[(size_t)(j0 + s) * 64 + lane] = tile[s][lane];
     }
 }
 
-// ---- input gather, MSC form, history in time-interleaver class order (DABGPU_CW_CLASSED) ----
-// In class order the bits an output CIF takes from one history row are contiguous: class c of output CIF q lives in row
-// q - age(c) + 15 at [c * cif_stride / 16 + i / 16].  A workgroup owns a QUARTER group (4 ensembles x 4 CIFs = 16 lanes) and walks its
-// trellis steps in tiles; the 4 x 64 byte streams it reads (ensemble x output CIF x class, all advancing together because every stream
-// is indexed by i / 16) are fetched ONE 64-BYTE MEMORY LINE AT A TIME into per-stream LDS rings of VC_RING lines: a tile loads only the
-// lines the previous tiles have not brought in yet -- every history byte crosses HBM -> LDS once (the first version staged
-// 80-byte windows per tile and fetched ~3.5 x what it used: profiles/r02/hbm_traffic_decode_v3.json).  The next tile's lines are in
-// flight while thread (step, ensemble) picks the <= 4 soft bits of its four lanes from LDS; the four threads of a step fill one
-// 64-byte sector of the [step][lane] symbol array.  Group and ring descriptors are read once per workgroup (scalar loads).
+// ---- MSC form, history in time-interleaver class order (DABGPU_CW_CLASSED) ----
+// In class order the bits an output CIF takes from one history row are contiguous: class k of output CIF q lives in row
+// q - age(k) + 15 at [k * cif_stride / 16 + i / 16].  A workgroup owns a QUARTER group (4 ensembles x 4 CIFs = 16 lanes) and walks
+// its symbol rows in tiles of 256 = 1024 input bytes per lane = 64 bytes of each of the 4 x 4 x 16 class streams (ensemble x output
+// CIF x class).  The streams are fetched ONE 64-BYTE MEMORY LINE AT A TIME into per-stream LDS rings of two lines: a tile loads only
+// the line the previous tiles have not brought in yet -- every history byte crosses HBM -> LDS once -- and the next tile's line is in
+// flight while this tile is transposed: a thread takes the same four columns of four classes (four LDS dwords), transposes the
+// 4 x 4 bytes with eight v_perm_b32 and stores four row dwords; the 16 threads (ensemble, CIF) of a quarter group fill one 64-byte
+// sector of a row.  Group and ring descriptors are read once per workgroup (scalar loads).
 // grid (4 n_groups), 256 threads: thread = (stream tid / 4 of an ensemble, 16-byte chunk tid % 4 of a line) when loading
-#ifndef VC_STEPS_
-#define VC_STEPS_ 256
-#endif
-constexpr int VC_STEPS = VC_STEPS_, VC_ENS = 4;
-constexpr int VC_NEED = (VC_STEPS / 4 + 1 + 63 + 63) / 64;                // lines a tile can touch: <= STEPS / 4 + 1 bytes at any line phase
-constexpr int VC_RING = VC_NEED <= 2 ? 2 : 4;                             // lines per LDS ring (power of two)
-constexpr int VC_NEW = (VC_STEPS / 4 + 63) / 64 + 1;                      // new lines a tile can need (the first tile: VC_NEED, loaded in rounds)
-constexpr int VC_PITCH = VC_RING * 64 + 16;                               // bytes between the rings of two classes: 36 (68) dwords apart,
-                                                                          // so the 16 classes a wave's byte reads touch fall on different banks
+constexpr int VC_ROWS = 256, VC_ENS = 4;
+constexpr int VC_PITCH = 2 * 64 + 16;                                      // bytes between the rings of two classes (36 dwords)
+constexpr int VC_CIF_PITCH = 16 * VC_PITCH + 16;                           // bytes between two output CIFs: 580 dwords = 4 mod 64 banks
+constexpr int VC_ENS_PITCH = 4 * VC_CIF_PITCH;                             // bytes between two ensembles: 2320 dwords = 16 mod 64, so the
+                                                                           // dword reads of a half wave fall two per bank
 __global__ __launch_bounds__(256)
-void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs,
-                            uint32_t* __restrict__ sym, const dabgpu_vit_tables* __restrict__ tables)
+void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[VC_ENS][4][16][VC_PITCH];     // [ensemble][output CIF][class][ring of lines]
-    __shared__ uint16_t pi_tab[25 * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char ring[VC_ENS * VC_ENS_PITCH];       // [ensemble][output CIF][class][2 lines]
     const int tid = threadIdx.x;
     const dabgpu_vit_group Gd = groups[blockIdx.x >> 2];
     const int qg = blockIdx.x & 3;
-    for (int e = tid; e < 25 * 8; e += 256) pi_tab[e] = tables->pi_tab[e];
-    __syncthreads();
-
-    const int T = (int)Gd.n_steps;
-    auto locate = [&](int t, int& cnt) {                                   // dab_viterbi_decoder.cpp:131-181
-        int sstart = 0, in0 = 0, pi = 8, k = 0;
-        for (; k < 4; k++) {
-            const int len = (int)Gd.seg_steps[k];
-            if (t < sstart + len) { pi = (int)Gd.seg_pi[k]; break; }
-            in0 += (len >> 3) * (8 + (int)Gd.seg_pi[k]);
-            sstart += len;
-        }
-        const int sis = t - sstart;
-        const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
-        cnt = e & 0xFF;
-        return in0 + (sis >> 3) * (8 + pi) + (e >> 8);
-    };
-    int n_in = 12;                                                         // input soft bits the decoder consumes (EEP: the sub-channel size;
-    for (int k = 0; k < 4; k++) n_in += ((int)Gd.seg_steps[k] >> 3) * (8 + (int)Gd.seg_pi[k]);   // UEP: less, the rest is padding)
-
+    const int n_in = (int)dabgpu_vit_in_bytes(Gd.seg_pi, Gd.seg_steps);       // input soft bits the decoder consumes (EEP: the sub-channel
+                                                                               // size; UEP: less, the rest is padding)
     // the four ensembles of this quarter group (uniform descriptors: scalar loads, once per workgroup)
     typedef const __attribute__((address_space(1))) unsigned char* gptr;
     gptr src[VC_ENS];
     unsigned newest[VC_ENS], n_slots = 16, frame_stride = 0, cif_stride = 0;
-    bool on[VC_ENS];
+    bool on[VC_ENS], any = false;
+    int phi = 0;
 #pragma unroll
     for (int e = 0; e < VC_ENS; e++) {
         const int ens = VC_ENS * qg + e;                                   // lanes 4 ens .. 4 ens + 3 of the group
@@ -658,11 +601,16 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
         on[e] = have && Dd.n_steps != 0;
         src[e] = (gptr)(uintptr_t)Dd.d_src;
         newest[e] = Dd.newest_slot;                                        // lane 4 ens is CIF 0: its newest slot is 4 nf
-        if (e == 0 || on[e]) { n_slots = Dd.n_slots; frame_stride = Dd.frame_stride; cif_stride = Dd.cif_stride; }   // one ring geometry per group
+        // one ring geometry and one line phase per group, taken from the first ensemble that HAS a frame: a skipped ensemble
+        // (ring decode, slot < 0) carries a zeroed descriptor
+        if (on[e] && !any) {
+            any = true; n_slots = Dd.n_slots; frame_stride = Dd.frame_stride; cif_stride = Dd.cif_stride;
+            // memory lines: the class segments start at multiples of 64 bytes inside a row (cif_stride / 16 = 3456 = 54 x 64), the
+            // sub-channel phi bytes into a line (4 bytes per capacity unit); line L of a stream = its bytes [64 L - phi, 64 L - phi + 64)
+            phi = (int)((uintptr_t)Dd.d_src & 63);
+        }
     }
-    // memory lines: the class segments start at multiples of 64 bytes inside a row (cif_stride / 16 = 3456 = 54 x 64), the
-    // sub-channel phi bytes into a line (4 bytes per capacity unit); line L of a stream = its bytes [64 L - phi, 64 L - phi + 64)
-    const int phi = (int)((uintptr_t)src[0] & 63);
+    if (!any) return;                                                      // nothing to decode in this quarter: its lanes are never read
     // this thread's stream when loading: piece = (output CIF, class) = tid / 4, chunk tid % 4 of the line
     const int piece = tid >> 2, chunk = tid & 3, l_c16 = piece & 15;
     const int l_rel = (piece >> 4) - (15 - (int)(__brev((unsigned)l_c16) >> 28));       // output CIF - age
@@ -674,91 +622,51 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
         if (slot >= (int)n_slots) slot -= (int)n_slots;
         l_off[e] = (size_t)(slot >> 2) * frame_stride + (size_t)(slot & 3) * cif_stride + (size_t)l_c16 * (cif_stride >> 4) + (size_t)(16 * chunk) - (size_t)phi;
     }
-    unsigned char* const l_lds = &ring[0][piece >> 4][l_c16][16 * chunk];  // + e * (4 * 16 * PITCH) + (line & (RING - 1)) * 64
+    unsigned char* const l_lds = ring + (piece >> 4) * VC_CIF_PITCH + l_c16 * VC_PITCH + 16 * chunk;   // + e * VC_ENS_PITCH + (line & 1) * 64
 
-    auto tile_lines = [&](int t0, int& la, int& lb) {                      // (uniform) memory lines [la, lb] the 256 steps from t0 read
-        int dummy;
-        const int i_lo = (t0 < T) ? locate(t0, dummy) : n_in;
-        int i_hi = i_lo + 1;
-        if (t0 < T) { const int tl = min(t0 + VC_STEPS, T) - 1; int cl; i_hi = locate(tl, cl); i_hi += cl; }
-        const int last = (((n_in - 1) >> 4) + phi) >> 6;                   // nothing past the last line that holds input of this codeword
-        lb = min((((max(i_hi, i_lo + 1) - 1) >> 4) + phi) >> 6, last);
-        la = min(((i_lo >> 4) + phi) >> 6, lb);
-    };
-    u4v v[VC_NEW][VC_ENS];
-    auto fetch = [&](int line0, int n) {                                   // lines line0 .. line0 + n - 1 (n <= VC_NEW) -> registers
+    const int real_rows = (n_in + 3) >> 2;
+    const int n_tiles = (real_rows + VC_ROWS - 1) / VC_ROWS;
+    const int last = (((n_in - 1) >> 4) + phi) >> 6;                       // nothing past the last line that holds input of this codeword
+    // tile st reads class-stream bytes [64 st, 64 st + 64): lines st .. st + (phi != 0), clamped to `last`
+    auto tile_hi = [&](int st) { return min(st + (phi ? 1 : 0), last); };
+    u4v v[VC_ENS];
+    auto fetch = [&](int line) {
 #pragma unroll
-        for (int k = 0; k < VC_NEW; k++) {
-#pragma unroll
-            for (int e = 0; e < VC_ENS; e++) {
-                v[k][e] = u4v{0u, 0u, 0u, 0u};
-                if (k < n && on[e]) v[k][e] = *(const __attribute__((address_space(1))) u4v*)(src[e] + (l_off[e] + (size_t)(64 * (line0 + k))));
-            }
+        for (int e = 0; e < VC_ENS; e++) {
+            v[e] = u4v{0u, 0u, 0u, 0u};
+            if (on[e]) v[e] = *(const __attribute__((address_space(1))) u4v*)(src[e] + (l_off[e] + (size_t)(64 * line)));
         }
     };
-    auto stash = [&](int line0, int n) {                                   // registers -> LDS rings
+    auto stash = [&](int line) {
 #pragma unroll
-        for (int k = 0; k < VC_NEW; k++) {
-            if (k < n) {
-#pragma unroll
-                for (int e = 0; e < VC_ENS; e++)
-                    *reinterpret_cast<u4v*>(l_lds + e * (4 * 16 * VC_PITCH) + ((line0 + k) & (VC_RING - 1)) * 64) = v[k][e];
-            }
-        }
+        for (int e = 0; e < VC_ENS; e++) *reinterpret_cast<u4v*>(l_lds + e * VC_ENS_PITCH + (line & 1) * 64) = v[e];
     };
-
-    const int n_tiles = ((int)Gd.alloc_steps + VC_STEPS - 1) / VC_STEPS;
-    // the line range of every tile, once, one thread per tile (a sub-channel has at most 864 CU = 55296 input bits: < 49,300 steps)
-    constexpr int VC_MAX_TILES = (49408 + VC_STEPS - 1) / VC_STEPS;
-    __shared__ int tl_a[VC_MAX_TILES], tl_b[VC_MAX_TILES];
-    if (tid < n_tiles) { int a_, b_; tile_lines(tid * VC_STEPS, a_, b_); tl_a[tid] = a_; tl_b[tid] = b_; }
-    __syncthreads();
-    int la = tl_a[0], lb, loaded;                                          // loaded = highest line in (or on its way to) the rings
-    loaded = la - 1;
-    int pend0 = 0, pendn = 0;                                              // lines in registers, not yet in LDS
+    int loaded = -1;                                                       // highest line in (or on its way to) the rings
+    bool pend = false;                                                     // line `loaded` is in registers, not yet in LDS
+    const int e = (tid >> 2) & 3, co = tid & 3;                            // when transposing: 16 adjacent threads = (ensemble, CIF)
+    const uint32_t* const wb = reinterpret_cast<const uint32_t*>(ring) + e * (VC_ENS_PITCH / 4) + co * (VC_CIF_PITCH / 4);
+    uint32_t* const obase = sym + Gd.sym_off + 16 * qg + 4 * e + co;
     for (int st = 0; st < n_tiles; st++) {
-        const int t0 = st * VC_STEPS;
-        la = tl_a[st]; lb = tl_b[st];
-        // lines of this tile that are neither in LDS nor in registers (the first tile, or a tile that needs more new lines than
-        // one fetch holds): load them now, in rounds
-        if (pendn) { stash(pend0, pendn); pendn = 0; }
-        while (loaded < lb) {
-            const int n = min(lb - loaded, VC_NEW);
-            fetch(loaded + 1, n);
-            stash(loaded + 1, n);
-            loaded += n;
-        }
+        if (pend) { stash(loaded); pend = false; }
+        while (loaded < tile_hi(st)) { loaded++; fetch(loaded); stash(loaded); }          // the first tile (later ones: prefetched)
         __syncthreads();
-        if (st + 1 < n_tiles) {                                            // the next tile's new lines: in flight while this tile is picked
-            const int n = min(tl_b[st + 1] - loaded, VC_NEW);
-            if (n > 0) { fetch(loaded + 1, n); pend0 = loaded + 1; pendn = n; loaded += n; }
-        }
-
-        // ---- pick: thread = (step, ensemble) for 64 steps at a time; byte of bit i for (ensemble e, output CIF co) sits at
-        // ring[e][co][i & 15][((i >> 4) + phi) & (64 RING - 1)] ----
-        const int e = tid & 3;
-        const unsigned char* wb = &ring[0][0][0][0] + e * (4 * 16 * VC_PITCH);
+        if (st + 1 < n_tiles && loaded < tile_hi(st + 1)) { loaded++; fetch(loaded); pend = true; }   // in flight while this tile is transposed
 #pragma unroll
-        for (int it = 0; it < VC_STEPS / 64; it++) {
-            const int t = t0 + 64 * it + (tid >> 2);
-            int cnt = 0, idx0 = 0;
-            if (t < T) idx0 = locate(t, cnt);
-            if (t < (int)Gd.alloc_steps) {
-                uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int it = 0; it < 4; it++) {
+            const int m = (tid >> 4) + 16 * it, q = m & 3, cb = m >> 2;   // class group q = row mod 4, columns 4 cb .. 4 cb + 3 of the tile
+            const int col = (64 * st + 4 * cb + phi) & 127;               // phi is a multiple of 4: an aligned dword of the two-line ring
+            const uint32_t* wp = wb + (4 * q) * (VC_PITCH / 4) + (col >> 2);
+            const uint32_t A = wp[0], B = wp[VC_PITCH / 4], C = wp[2 * (VC_PITCH / 4)], D = wp[3 * (VC_PITCH / 4)];
+            // 4 x 4 byte transpose: O[m'] = (A.b[m'], B.b[m'], C.b[m'], D.b[m']) = input bytes 4 j .. 4 j + 3 of row j = 4 (column) + q
+            const uint32_t T0 = __builtin_amdgcn_perm(B, A, 0x05010400u), T1 = __builtin_amdgcn_perm(B, A, 0x07030602u);
+            const uint32_t U0 = __builtin_amdgcn_perm(D, C, 0x05010400u), U1 = __builtin_amdgcn_perm(D, C, 0x07030602u);
+            const uint32_t O[4] = {__builtin_amdgcn_perm(U0, T0, 0x05040100u), __builtin_amdgcn_perm(U0, T0, 0x07060302u),
+                                   __builtin_amdgcn_perm(U1, T1, 0x05040100u), __builtin_amdgcn_perm(U1, T1, 0x07060302u)};
+            const int jb = VC_ROWS * st + 16 * cb + q;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (r < cnt) {
-                        const int i = idx0 + r;
-                        const unsigned char* pb = wb + ((i & 15) * VC_PITCH + (((i >> 4) + phi) & (VC_RING * 64 - 1)));
-#pragma unroll
-                        for (int co = 0; co < 4; co++) {
-                            int yv = (int)(signed char)pb[co * 16 * VC_PITCH];
-                            yv = max(yv, -127);                            // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
-                            w[co] |= ((uint32_t)yv & 0xFFu) << (8 * r);
-                        }
-                    }
-                }
-                *reinterpret_cast<u4v*>(sym + Gd.sym_off + (size_t)t * 64 + 16 * qg + 4 * e) = u4v{w[0], w[1], w[2], w[3]};
+            for (int mm = 0; mm < 4; mm++) {
+                const int j = jb + 4 * mm;
+                if (j < real_rows) obase[(size_t)j * 64] = vl_clamp4(O[mm]);
             }
         }
         __syncthreads();                                                   // the rings are rewritten by the next tile's stash
@@ -767,7 +675,7 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
 
 // ---- group tables ----
 // FIC: all codewords share one schedule; group g = codewords 64 g .. 64 g + 63
-__global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw, uint32_t n_steps, uint32_t alloc_steps,
+__global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw, uint32_t n_steps, uint32_t alloc_steps, uint32_t in_rows,
                                           uint32_t pi0, uint32_t st0, uint32_t pi1, uint32_t st1, uint32_t pi2, uint32_t st2,
                                           uint32_t pi3, uint32_t st3)
 {
@@ -779,21 +687,23 @@ __global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw,
     G.n_steps = n_steps; G.alloc_steps = alloc_steps;
     G.seg_pi[0] = pi0; G.seg_steps[0] = st0; G.seg_pi[1] = pi1; G.seg_steps[1] = st1;
     G.seg_pi[2] = pi2; G.seg_steps[2] = st2; G.seg_pi[3] = pi3; G.seg_steps[3] = st3;
-    G.sym_off = g * (size_t)alloc_steps * 64;
+    G.in_rows = in_rows;
+    G.sched_off = 0;
+    G.sym_off = g * (size_t)in_rows * 64;
     G.dec_off = g * (size_t)alloc_steps * 128;
     groups[g] = G;
 }
 
 // MSC: codeword index = (4 e + c) * n_sub + s (msc_build_descs_kernel); group (li, gq) = the li-th lane-mapped sub-channel
-// s = lane_subs[2 li] (row prefix lane_subs[2 li + 1]) of ensemble-CIFs 64 gq .. 64 gq + 63
+// s = lane_subs[3 li] (decision-row prefix lane_subs[3 li + 1], symbol-row prefix lane_subs[3 li + 2]) of ensemble-CIFs 64 gq .. 64 gq + 63
 __global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc_plan* plans, const uint64_t* lane_subs,
-                                      int n_lane_sub, int n_sub, size_t n_ens, uint32_t groups_per_sub)
+                                      int n_lane_sub, int n_sub, size_t n_ens, uint32_t groups_per_sub, uint32_t sched_stride)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (size_t)n_lane_sub * groups_per_sub) return;
     const int li = (int)(g / groups_per_sub);
     const uint32_t gq = (uint32_t)(g - (size_t)li * groups_per_sub);
-    const int s = (int)lane_subs[2 * li];
+    const int s = (int)lane_subs[3 * li];
     const dabgpu_msc_plan P = plans[s];
     const size_t n_j = n_ens * 4;
     dabgpu_vit_group G = {};
@@ -802,10 +712,30 @@ __global__ void vit_groups_msc_kernel(dabgpu_vit_group* groups, const dabgpu_msc
     G.n_steps = P.n_steps;
     G.alloc_steps = dabgpu_vit_alloc_steps(P.n_steps);
     for (int k = 0; k < 4; k++) { G.seg_pi[k] = P.seg_pi[k]; G.seg_steps[k] = P.seg_steps[k]; }
-    const size_t steps_before = (size_t)lane_subs[2 * li + 1] * groups_per_sub + (size_t)gq * G.alloc_steps;
-    G.sym_off = steps_before * 64;
-    G.dec_off = steps_before * 128;
+    G.in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(P.seg_pi, P.seg_steps));
+    G.sched_off = (uint64_t)li * sched_stride;
+    G.sym_off = ((size_t)lane_subs[3 * li + 2] * groups_per_sub + (size_t)gq * G.in_rows) * 64;
+    G.dec_off = ((size_t)lane_subs[3 * li + 1] * groups_per_sub + (size_t)gq * G.alloc_steps) * 128;
     groups[g] = G;
+}
+
+// schedule tables: one (row, selector) pair per trellis step, + the block the forward pass prefetches past the end
+// grid (ceil(sched_stride / 256), n schedules)
+__global__ void vit_sched_uniform_kernel(uint2* sched, uint32_t sched_stride, uint32_t pi0, uint32_t st0, uint32_t pi1, uint32_t st1,
+                                         uint32_t pi2, uint32_t st2, uint32_t pi3, uint32_t st3, const dabgpu_vit_tables* tables)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sched_stride) return;
+    const uint32_t seg_pi[4] = {pi0, pi1, pi2, pi3}, seg_steps[4] = {st0, st1, st2, st3};
+    sched[t] = vl_sched_entry((int)t, seg_pi, seg_steps, dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps)), tables);
+}
+__global__ void vit_sched_msc_kernel(uint2* sched, uint32_t sched_stride, const dabgpu_msc_plan* plans, const uint64_t* lane_subs,
+                                     const dabgpu_vit_tables* tables)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, li = blockIdx.y;
+    if (t >= sched_stride) return;
+    const dabgpu_msc_plan P = plans[lane_subs[3 * li]];
+    sched[(size_t)li * sched_stride + t] = vl_sched_entry((int)t, P.seg_pi, P.seg_steps, dabgpu_vit_in_rows(dabgpu_vit_in_bytes(P.seg_pi, P.seg_steps)), tables);
 }
 
 }  // namespace dabgpu
@@ -815,43 +745,60 @@ extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_group
 {
     const size_t n_groups = (n_cw + 63) / 64;
     hipLaunchKernelGGL(dabgpu::vit_groups_uniform_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
-                       d_groups, n_cw, n_steps, dabgpu_vit_alloc_steps(n_steps), seg_pi[0], seg_steps[0], seg_pi[1], seg_steps[1],
+                       d_groups, n_cw, n_steps, dabgpu_vit_alloc_steps(n_steps), dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps)),
+                       seg_pi[0], seg_steps[0], seg_pi[1], seg_steps[1],
                        seg_pi[2], seg_steps[2], seg_pi[3], seg_steps[3]);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const dabgpu_msc_plan* d_plans,
                                                    const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
-                                                   uint32_t groups_per_sub, hipStream_t stream)
+                                                   uint32_t groups_per_sub, uint32_t sched_stride, hipStream_t stream)
 {
     const size_t n_groups = (size_t)n_lane_sub * groups_per_sub;
     hipLaunchKernelGGL(dabgpu::vit_groups_msc_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
-                       d_groups, d_plans, d_lane_subs, n_lane_sub, n_sub, n_ens, groups_per_sub);
+                       d_groups, d_plans, d_lane_subs, n_lane_sub, n_sub, n_ens, groups_per_sub, sched_stride);
     return hipGetLastError();
 }
 
-extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_alloc_steps,
+extern "C" hipError_t dabgpu_launch_vit_sched_uniform(uint2* d_sched, uint32_t sched_stride, const uint32_t* seg_pi, const uint32_t* seg_steps,
+                                                      const dabgpu_vit_tables* d_tables, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dabgpu::vit_sched_uniform_kernel, dim3((sched_stride + 255) / 256), dim3(256), 0, stream, d_sched, sched_stride,
+                       seg_pi[0], seg_steps[0], seg_pi[1], seg_steps[1], seg_pi[2], seg_steps[2], seg_pi[3], seg_steps[3], d_tables);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched_stride, const dabgpu_msc_plan* d_plans,
+                                                  const uint64_t* d_lane_subs, int n_lane_sub, const dabgpu_vit_tables* d_tables, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dabgpu::vit_sched_msc_kernel, dim3((sched_stride + 255) / 256, (unsigned)n_lane_sub), dim3(256), 0, stream, d_sched,
+                       sched_stride, d_plans, d_lane_subs, d_tables);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
-                                                  int n_cu, hipStream_t stream)
+                                                  const uint2* d_sched, int n_cu, hipStream_t stream)
 {
     using namespace dabgpu;
-    const unsigned tiles = (max_alloc_steps + VL_TILE - 1) / VL_TILE;
+    const unsigned tiles = (max_in_rows + VL_TILE - 1) / VL_TILE;
     if (ring4 == 3)      // direct, contiguous, 16-byte aligned codewords (FIC)
-        hipLaunchKernelGGL(vit_prep_direct_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+        hipLaunchKernelGGL(vit_prep_direct_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else if (ring4 == 2)      // ring of 4 CIFs per frame in class order
-        hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+        hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else if (ring4)
-        hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+        hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else
-        hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym, d_tables);
+        hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
 #define VL_GO(TIE, W) hipLaunchKernelGGL((vit_lanes_kernel<TIE, W>), dim3((unsigned)((n_groups + (W) - 1) / (W))), dim3(64 * (W)), 0, stream, \
-                                         d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables)
+                                         d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables, d_sched)
     const bool four = n_groups > (size_t)n_cu && n_groups <= (size_t)4 * n_cu;
     const bool five_per_simd = n_groups > (size_t)16 * n_cu && n_groups <= (size_t)20 * n_cu;        // 4 SIMDs per CU
     if (five_per_simd) {
-        if (tie_rule) hipLaunchKernelGGL((vit_lanes_kernel<1, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables);
-        else hipLaunchKernelGGL((vit_lanes_kernel<0, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables);
+        if (tie_rule) hipLaunchKernelGGL((vit_lanes_kernel<1, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables, d_sched);
+        else hipLaunchKernelGGL((vit_lanes_kernel<0, 1, 5>), dim3((unsigned)n_groups), dim3(64), 0, stream, d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables, d_sched);
     }
     else if (tie_rule) { if (four) VL_GO(1, 4); else VL_GO(1, 1); }
     else { if (four) VL_GO(0, 4); else VL_GO(0, 1); }

@@ -237,3 +237,40 @@ def test_bad_layout_and_unsupported_format_are_refused(ctx):
         ctx.ofdm_demod_frames_history(raw, dabgpu.IQ_FORMATS.index("raw_f32l"), 1, bits, bits_layout=7)
     with pytest.raises(dabgpu.DabGpuError):
         ctx.ofdm_demod_frames_history(raw, dabgpu.IQ_FORMATS.index("raw_s16b"), 1, bits, bits_layout=1)
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["natural", "classed"])
+def test_ring_decode_with_skipped_ensembles_inside_a_quarter_group(ctx, layout):
+    """dabgpu_msc_decode_ring: ensembles without a new frame (slot -1) carry zeroed descriptors.  The class-order gather shares one
+    line phase per quarter group of 4 ensembles: it must come from an ensemble that HAS a frame -- here ensemble 0 of most quarters is
+    skipped while its neighbours decode, and the last sub-channel ends at CU 864 (the last memory line of the last class segment of a
+    row).  The lane mapping must equal the wave mapping, which reads every byte by its own index, and skipped ensembles stay untouched."""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(77)
+    subs = [dabgpu.SubChannel(3, 48, False, 0, 2, 0), dabgpu.SubChannel(804, 60, False, 0, 2, 0)]      # start CUs 3 and 804: line phases 12 and 16
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    n_ens, H = 37, 6
+    nat = rng.integers(-128, 128, (n_ens, H, 230400), dtype=np.int8)
+    hist = nat if layout == 0 else np.ascontiguousarray(nat[:, :, np.argsort(dabgpu.classed_to_natural_index())])
+    d_hist = torch.from_numpy(hist).cuda()
+    slots = rng.integers(0, H, n_ens).astype(np.int32)
+    slots[0::4] = -1                                                       # the first ensemble of every quarter group
+    slots[5] = -1; slots[6] = -1; slots[7] = -1                            # a quarter with a single active ensemble (4), one with none (8..11 below)
+    slots[8:12] = -1
+    d_slots = torch.from_numpy(slots).cuda()
+    got = {}
+    for m in (1, 2):
+        ctx.viterbi_set_mapping(m)
+        try:
+            d_out = torch.full((n_ens, 4, cif_out), 0xEE, dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+            ctx.msc_decode_ring(d_hist, n_ens, H * 230400, H, d_slots, subs, d_out, 4 * cif_out, d_res, bits_layout=layout)
+            torch.cuda.synchronize()
+            got[m] = (d_out.cpu().numpy(), d_res.cpu().numpy())
+        finally:
+            ctx.viterbi_set_mapping(0)
+    assert np.array_equal(got[1][0], got[2][0]) and np.array_equal(got[1][1], got[2][1])
+    skipped = slots < 0
+    assert (got[2][0][skipped] == 0xEE).all(), "no byte is written for an ensemble without a new frame"
+    assert (got[2][0][~skipped] != 0xEE).any()
