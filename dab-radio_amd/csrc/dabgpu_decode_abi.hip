@@ -121,27 +121,32 @@ static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, u
 }
 
 extern "C" int dabgpu_viterbi_set_mapping(dabgpu_ctx* c, int mapping) {
-    if (!c || mapping < DABGPU_VIT_MAP_AUTO || mapping > DABGPU_VIT_MAP_LANE) { dabgpu_set_error("viterbi_set_mapping: bad argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (!c || mapping < DABGPU_VIT_MAP_AUTO || mapping > DABGPU_VIT_MAP_OCTET) { dabgpu_set_error("viterbi_set_mapping: bad argument"); return DABGPU_ERR_INVALID_ARG; }
     c->vit_mapping = mapping;
     return DABGPU_OK;
 }
 
-// AUTO: a cost model of the two mappings on this part (profiles/r01/ab_notes.md; microseconds).
-//   WAVE  one wavefront per codeword keeps every SIMD busy: t = sum over codewords of (0.0189 ns x steps + 0.038 us)
-//   LANE  a group of 64 codewords is one wavefront that needs 0.5 us per trellis step however many of its lanes are used, and
-//         a SIMD works through its groups at that same rate: t = 0.5 us x max(longest schedule, rounds x mean steps) with
-//         rounds = ceil(groups / SIMDs), + the gather pass (3.3e-3 / 8.5e-3 us per codeword-kilostep, staged / byte-wise)
-// n_cw codewords in n_groups groups; sums and maximum of their trellis steps
-static bool use_lane_mapping(dabgpu_ctx* c, size_t n_cw, size_t n_groups, double sum_cw_steps, double sum_group_steps, double max_steps,
-                             bool staged_gather) {
-    if (c->vit_mapping == DABGPU_VIT_MAP_LANE) return true;
-    if (c->vit_mapping == DABGPU_VIT_MAP_WAVE || n_groups == 0) return false;
+// AUTO: a cost model of the three mappings on this part (profiles/r01/ab_notes.md, profiles/r03/ab_notes.md; microseconds).
+//   WAVE   one wavefront per codeword keeps every SIMD busy: t = sum over codewords of (0.0189 ns x steps + 0.038 us)
+//   LANE   a group of 64 codewords is one wavefront that needs 0.5 us per trellis step however many of its lanes are used, and
+//          a SIMD works through its groups at that same rate: t = 0.5 us x max(longest schedule, rounds x mean steps) with
+//          rounds = ceil(groups / SIMDs), + the gather pass (3.3e-3 / 8.5e-3 us per codeword-kilostep, staged / byte-wise)
+//   OCTET  a group is 8 wavefronts of ~57 instructions per step; two of them share a SIMD at 4 cycles per instruction (a lone one
+//          issues at half rate, so one costs what two cost): t = 0.095 us x max(2 x longest schedule, rounds8 x mean steps) with
+//          rounds8 = ceil(8 groups / SIMDs), + the same gather pass
+// n_cw codewords in n_groups groups; sums and maximum of their trellis steps.  Returns DABGPU_VIT_MAP_WAVE / _LANE / _OCTET
+static int choose_mapping(dabgpu_ctx* c, size_t n_cw, size_t n_groups, double sum_cw_steps, double sum_group_steps, double max_steps,
+                          bool staged_gather) {
+    if (c->vit_mapping != DABGPU_VIT_MAP_AUTO) return c->vit_mapping;
+    if (n_groups == 0) return DABGPU_VIT_MAP_WAVE;
     const double n_simd = (double)device_waves(c) / 8.0;
+    const double mean = sum_group_steps / (double)n_groups;
+    const double gather = (staged_gather ? 3.3e-6 : 8.5e-6) * sum_cw_steps;
     const double t_wave = 0.0189e-3 * sum_cw_steps + 0.038 * (double)n_cw;
-    const double rounds = (double)((n_groups + (size_t)n_simd - 1) / (size_t)n_simd);
-    const double t_lane = 0.5 * std::max(max_steps, rounds * (sum_group_steps / (double)n_groups)) +
-                          (staged_gather ? 3.3e-6 : 8.5e-6) * sum_cw_steps;
-    return t_lane < t_wave;
+    const double t_lane = 0.5 * std::max(max_steps, std::ceil((double)n_groups / n_simd) * mean) + gather;
+    const double t_oct = 0.095 * std::max(2.0 * max_steps, std::ceil(8.0 * (double)n_groups / n_simd) * mean) + gather;
+    if (t_wave <= t_lane && t_wave <= t_oct) return DABGPU_VIT_MAP_WAVE;
+    return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;
 }
 
 // lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (<= 768 bytes per decision
@@ -156,18 +161,19 @@ static size_t lanes_max_rows() {
 // sym_rows / dec_rows: rows of 64 dwords (kept soft bits, 4 per lane and row) and of 128 dwords (decisions, one row per step)
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
                              size_t sym_rows, size_t dec_rows, uint32_t max_in_rows, int tie_rule, int ring4, const uint2* d_sched,
-                             dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
+                             int octet, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
     int st;
     uint32_t *d_sym = nullptr, *d_dec = nullptr;
     if ((st = dabgpu_scratch(c, 18 + slot_off, sym_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
     if ((st = dabgpu_scratch(c, 19 + slot_off, dec_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_in_rows, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, device_waves(c) / 32, s), "vit_lanes_kernel launch");
+                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, octet, device_waves(c) / 32, s), "vit_lanes_kernel launch");
 }
 
 // one puncturing schedule for a whole batch (FIC, uniform codeword batches): groups of 64 consecutive codewords, in bounded slices
 static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t n_steps, const uint32_t* seg_pi,
-                             const uint32_t* seg_steps, int tie_rule, int ring4, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off) {
+                             const uint32_t* seg_steps, int tie_rule, int ring4, int octet, dabgpu_codeword_result* d_results, hipStream_t s,
+                             int slot_off) {
     int st = ensure_vit_tables(c);
     if (st) return st;
     const uint32_t dec_rows = dabgpu_vit_alloc_steps(n_steps), in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps));
@@ -181,7 +187,7 @@ static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_
         if ((st = dabgpu_scratch(c, 17 + slot_off, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, n_steps, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
         if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * in_rows, n_groups * dec_rows, in_rows, tie_rule, ring4,
-                                    d_sched, d_results + cw0, s, slot_off))) return st;
+                                    d_sched, octet, d_results + cw0, s, slot_off))) return st;
     }
     return DABGPU_OK;
 }
@@ -236,8 +242,10 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     for (size_t i = 0; i < n && uniform; i++)             // the lane mapping keeps ring offsets in 32 bits
         uniform = h_cw[i].n_slots == 0 || (uint64_t)(h_cw[i].n_slots / h_cw[i].cifs_per_frame + 1) * h_cw[i].frame_stride +
                                           (uint64_t)h_cw[i].cifs_per_frame * h_cw[i].cif_stride < ((uint64_t)1 << 32);
-    if (uniform && use_lane_mapping(c, n, (n + 63) / 64, (double)n * max_steps, (double)((n + 63) / 64) * max_steps, (double)max_steps, false))
-        return run_lanes_uniform(c, d_descs, n, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, tie_rule, 0, d_results, s, 0);
+    const int map = uniform ? choose_mapping(c, n, (n + 63) / 64, (double)n * max_steps, (double)((n + 63) / 64) * max_steps, (double)max_steps, false)
+                            : DABGPU_VIT_MAP_WAVE;
+    if (map != DABGPU_VIT_MAP_WAVE)
+        return run_lanes_uniform(c, d_descs, n, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, tie_rule, 0, map == DABGPU_VIT_MAP_OCTET, d_results, s, 0);
     return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
 }
 
@@ -256,10 +264,11 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     if (st) return st;
     // FIB groups are contiguous runs of 2304 soft bits; with 16-byte aligned frames the staged gather applies (mode 3)
     const int fic_direct = (((uintptr_t)d_bits % 16 == 0) && (frame_stride % 16 == 0)) ? 3 : 0;
-    if (use_lane_mapping(c, n, (n + 63) / 64, (double)n * 774.0, (double)((n + 63) / 64) * 774.0, 774.0, false)) {
+    const int map = choose_mapping(c, n, (n + 63) / 64, (double)n * 774.0, (double)((n + 63) / 64) * 774.0, 774.0, fic_direct != 0);
+    if (map != DABGPU_VIT_MAP_WAVE) {
         // one schedule for every FIB group
         const uint32_t seg_pi[4] = {16, 15, 0, 0}, seg_steps[4] = {32 * 21, 32 * 3, 0, 0};
-        return run_lanes_uniform(c, d_descs, n, 774, seg_pi, seg_steps, tie_rule, fic_direct, d_results, s, FIC_SLOTS);
+        return run_lanes_uniform(c, d_descs, n, 774, seg_pi, seg_steps, tie_rule, fic_direct, map == DABGPU_VIT_MAP_OCTET, d_results, s, FIC_SLOTS);
     }
     return run_viterbi(c, d_descs, n, 774, 96, tie_rule, d_results, s, FIC_SLOTS);
 }
@@ -330,25 +339,20 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     const size_t gps_all = (n_ens * 4 + 63) / 64;
     const double n_simd = (double)device_waves(c) / 8.0;
     int k_wave = n_sub;                                        // number of (longest) sub-channels left to viterbi_kernel
+    int octet = 0;                                             // the others: eight lanes per codeword instead of one
     if ((uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32) && c->vit_mapping != DABGPU_VIT_MAP_WAVE) {
-        if (c->vit_mapping == DABGPU_VIT_MAP_LANE) {
+        if (c->vit_mapping == DABGPU_VIT_MAP_LANE || c->vit_mapping == DABGPU_VIT_MAP_OCTET) {
             k_wave = 0;
+            octet = c->vit_mapping == DABGPU_VIT_MAP_OCTET;
         } else {
-            double best = 1e300;
-            for (int k = 0; k <= n_sub; k += n_sub) {
-                double t = 0.0, lane_sum = 0.0, lane_max = 0.0;
-                for (int j = 0; j < n_sub; j++) {
-                    const double steps = (double)plans[(size_t)order[(size_t)j]].n_steps;
-                    if (j < k) t += (double)(n_ens * 4) * (0.0189e-3 * steps + 0.038);
-                    else { lane_sum += steps; lane_max = std::max(lane_max, steps); }
-                }
-                if (k < n_sub) {
-                    const double groups = (double)(n_sub - k) * (double)gps_all;
-                    const double rounds = std::ceil(groups / n_simd);
-                    t += 0.5 * std::max(lane_max, rounds * lane_sum / (double)(n_sub - k)) + 3.3e-6 * lane_sum * (double)(n_ens * 4);
-                }
-                if (t < best) { best = t; k_wave = k; }
-            }
+            double sum_steps = 0.0, max_st = 0.0;
+            for (int j = 0; j < n_sub; j++) { sum_steps += (double)plans[(size_t)j].n_steps; max_st = std::max(max_st, (double)plans[(size_t)j].n_steps); }
+            const double groups = (double)n_sub * (double)gps_all, mean = sum_steps / (double)n_sub;
+            const double gather = 3.3e-6 * sum_steps * (double)(n_ens * 4);
+            const double t_wave = (double)(n_ens * 4) * (0.0189e-3 * sum_steps + 0.038 * (double)n_sub);
+            const double t_lane = 0.5 * std::max(max_st, std::ceil(groups / n_simd) * mean) + gather;
+            const double t_oct = 0.095 * std::max(2.0 * max_st, std::ceil(8.0 * groups / n_simd) * mean) + gather;
+            if (t_lane < t_wave || t_oct < t_wave) { k_wave = 0; octet = t_oct < t_lane; }
             if (const char* e = getenv("DABGPU_VIT_HYBRID_K")) { const int v = atoi(e); if (v >= 0 && v <= n_sub) k_wave = v; }   // tests
         }
     }
@@ -401,7 +405,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             const int ring4 = classed ? ((((uintptr_t)d_hist % 64 == 0) && (ens_stride % 64 == 0)) ? 2 : 0)
                                       : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
             if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, sym_rows_per_gq * gps, dec_rows_per_gq * gps, lane_max_in_rows,
-                                        tie_rule, ring4, d_sched, d_results + cw0, s))) return st;
+                                        tie_rule, ring4, d_sched, octet, d_results + cw0, s))) return st;
         }
         if (k_wave == 0) return DABGPU_OK;
     }

@@ -134,7 +134,12 @@ extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4,
-                                                  const struct dabgpu_vit_tables* d_tables, const uint2* d_sched, int n_cu, hipStream_t stream);
+                                                  const struct dabgpu_vit_tables* d_tables, const uint2* d_sched, int octet, int n_cu,
+                                                  hipStream_t stream);
+// eight lanes per codeword over prepared groups and their symbol array (viterbi_octet.hip): one 512-thread workgroup per group
+extern "C" hipError_t dabgpu_launch_viterbi_octet(const dabgpu_vit_group* d_groups, size_t n_groups, const dabgpu_cw_desc* d_descs,
+                                                  const uint32_t* d_sym, uint32_t* d_dec, dabgpu_cw_result* d_results, int tie_rule,
+                                                  const struct dabgpu_vit_tables* d_tables, const uint2* d_sched, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,

@@ -29,42 +29,9 @@
 #include <stdint.h>
 
 #include "dabgpu_internal.h"
+#include "viterbi_pk16.h"
 
 namespace dabgpu {
-
-typedef short s2 __attribute__((ext_vector_type(2)));
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-
-constexpr int VL_TILE = 64;                 // steps per prep tile
-constexpr int VL_PRBS = 511;
-
-__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
-__device__ __forceinline__ s2 add16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
-__device__ __forceinline__ s2 sub16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
-__device__ __forceinline__ s2 min16(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ s2 satsub16(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }
-__device__ __forceinline__ s2 swap16(s2 v) { return __builtin_shufflevector(v, v, 1, 0); }
-__device__ __forceinline__ s2 lo_hi(s2 lo_src, s2 hi_src) { return __builtin_shufflevector(lo_src, hi_src, 0, 3); }
-
-// (a & mask) | (b & ~mask) in one instruction (the compiler splits the expression into v_and + v_and_or)
-__device__ __forceinline__ uint32_t vl_bfi(uint32_t mask, uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
-    return r;
-}
-
-// ---- compile-time trellis tables ----
-__host__ __device__ constexpr int vl_parity(unsigned v) { v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return (int)(v & 1u); }
-// sign pattern of butterfly b (input bit 0): bit 0 = polynomials 0 and 3 (109), bit 1 = polynomial 1 (79), bit 2 = polynomial 2 (83)
-// expect +127 (dab_viterbi_decoder.cpp:25, ViterbiBranchTable)
-__host__ __device__ constexpr int vl_sigma(int b) {
-    return vl_parity((2u * (unsigned)b) & 109u) | (vl_parity((2u * (unsigned)b) & 79u) << 1) | (vl_parity((2u * (unsigned)b) & 83u) << 2);
-}
-__host__ __device__ constexpr int vl_ins_zero(int i, int q) { return ((i >> q) << (q + 1)) | (i & ((1 << q) - 1)); }
-// pattern flip between the two butterflies of a register pair in phase q: b1 = b0 | 1 << q (q < 5); phase 5: lower vs upper predecessor
-__host__ __device__ constexpr int vl_flip(int q) { return q < 5 ? (vl_sigma(0) ^ vl_sigma(1 << q)) : 7; }
 
 // ---- decision gather: sign bytes of 32 difference registers -> 2 dwords ----
 // The decision of new state n (layout L_QN after the step: register idx_QN(n), half = bit QN of n) goes to bit
@@ -202,6 +169,8 @@ __device__ __forceinline__ uint2 vl_sched_entry(int t, const uint32_t* seg_pi, c
     return r;
 }
 
+constexpr int VL_OBYTES = 100;              // codewords up to this many output bytes keep them in LDS for the CRC
+
 // Workgroups of FOUR wavefronts = four groups: the hardware puts the wavefronts of a workgroup on the four SIMDs of one CU, so
 // up to 1024 groups get a SIMD each.  Single-wavefront workgroups are placed one by one and a few per cent of them double up on
 // a SIMD -- and one doubled SIMD (1.4 ms instead of 0.9) sets the time of the whole launch (tools/ubench/hwid_probe.hip).
@@ -216,10 +185,20 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
                       const dabgpu_vit_tables* __restrict__ tables, const uint2* __restrict__ sched)
 {
     __shared__ unsigned char prbs[512];
+    __shared__ unsigned short crc_tab[256];                        // CRC16 (x^16 + x^12 + x^5 + 1), one byte at a time
+    // decoded bytes of CRC-checked codewords (FIB groups, 96 bytes): a lane re-reads its own row for the CRC -- from LDS, a byte load
+    // from HBM per CRC step was a fifth of the FIC decode; rows of 25 dwords (odd) spread the lanes over the banks
+    __shared__ unsigned char obuf[VL_WAVES][64][VL_OBYTES];
     const int lane = threadIdx.x & 63;
     for (int e = threadIdx.x; e < 512; e += 64 * VL_WAVES) prbs[e] = tables->prbs[e];
+    for (int e = threadIdx.x; e < 256; e += 64 * VL_WAVES) {
+        unsigned v = (unsigned)e << 8;
+        for (int qq = 0; qq < 8; qq++) v = (v & 0x8000u) ? (((v << 1) ^ 0x1021u) & 0xFFFFu) : ((v << 1) & 0xFFFFu);
+        crc_tab[e] = (unsigned short)v;
+    }
     __syncthreads();
-    const int group = (int)blockIdx.x * VL_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform
+    const int wvi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int group = (int)blockIdx.x * VL_WAVES + wvi;                                                           // wave-uniform
     if (group >= n_groups) return;
 
     const dabgpu_vit_group Gd = groups[group];
@@ -306,12 +285,16 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
     for (int r = 0; r < 32; r++) endm = ((es >> 1) == (uint32_t)r) ? as_u32(M[r]) : endm;
     endm = (((es & 1u) ? (endm >> 16) : endm) & 0xFFFFu) ^ 0x8000u;
 
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_s_waitcnt(0);               // decision words are re-read by this same lane: drain its stores first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);               // decision words are re-read by this same lane: drain its stores first (same CU, same
+                                                 // L2: no write-back is needed -- an agent-scope release writes the whole L2 back)
 
     // ---- chain-back over steps T-1 .. 6 (dab_viterbi_decoder.cpp:124-129): decoded bit t-6 = decision of the survivor at step t ----
     const bool raw = (Dd.flags & DABGPU_CW_RAW) != 0;
     unsigned char* out = reinterpret_cast<unsigned char*>(Dd.d_out);
+    const int n_out = (T - 6) >> 3;
+    const bool crc_lds = Dd.n_crc_blocks != 0 && n_out <= VL_OBYTES;
+    unsigned char* const ob = &obuf[wvi][lane][0];
     // The walk is done on pos = rotr6(state, QN - 3) (vl_gather).  Chunks of 24 steps: n_steps = 8 m + 6 and the last step ends in
     // layout L_0, so every chunk starts in layout L_0 at bit 7 of a byte -- phases and byte boundaries are compile-time.
     // One chunk of decision words (24 steps = 12 sixteen-byte loads per lane) is fetched, then walked.  The earlier version fetched
@@ -343,26 +326,32 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
                 const int k = (th - ub - 7 - 6) >> 3;                      // byte of bits t-6 for t = th-ub-7 .. th-ub
                 const unsigned char pb = raw ? (unsigned char)0 : prbs[k % VL_PRBS];
                 if (live) out[k] = (unsigned char)(acc ^ pb);
+                if (crc_lds) ob[k] = (unsigned char)(acc ^ pb);
             }
         }
     }
 
     // ---- optional FIB CRC16 (fic_decoder.cpp:19-31,103-116) over the lane's own bytes + result record ----
-    const int n_out = (T - 6) >> 3;
     uint32_t crc_mask = 0;
     if (live && Dd.n_crc_blocks) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_s_waitcnt(0);
+        if (!crc_lds) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+        }
         const int blk_bytes = n_out / (int)Dd.n_crc_blocks;
         for (int b = 0; b < (int)Dd.n_crc_blocks && b < 32; b++) {
-            const unsigned char* fib = out + b * blk_bytes;
-            unsigned crc = 0xFFFFu;
-            for (int i = 0; i < blk_bytes - 2; i++) {
-                crc ^= (unsigned)__builtin_nontemporal_load(&fib[i]) << 8;
-                for (int qq = 0; qq < 8; qq++) crc = (crc & 0x8000u) ? (((crc << 1) ^ 0x1021u) & 0xFFFFu) : ((crc << 1) & 0xFFFFu);
+            unsigned crc = 0xFFFFu, rx;
+            if (crc_lds) {
+                const unsigned char* fib = ob + b * blk_bytes;
+                for (int i = 0; i < blk_bytes - 2; i++) crc = ((crc << 8) ^ crc_tab[((crc >> 8) ^ fib[i]) & 0xFFu]) & 0xFFFFu;
+                rx = ((unsigned)fib[blk_bytes - 2] << 8) | fib[blk_bytes - 1];
+            } else {
+                const unsigned char* fib = out + b * blk_bytes;
+                for (int i = 0; i < blk_bytes - 2; i++)
+                    crc = ((crc << 8) ^ crc_tab[((crc >> 8) ^ __builtin_nontemporal_load(&fib[i])) & 0xFFu]) & 0xFFFFu;
+                rx = ((unsigned)__builtin_nontemporal_load(&fib[blk_bytes - 2]) << 8) | __builtin_nontemporal_load(&fib[blk_bytes - 1]);
             }
             crc ^= 0xFFFFu;
-            const unsigned rx = ((unsigned)__builtin_nontemporal_load(&fib[blk_bytes - 2]) << 8) | __builtin_nontemporal_load(&fib[blk_bytes - 1]);
             if (rx == crc) crc_mask |= 1u << b;
         }
     }
@@ -780,7 +769,7 @@ extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
-                                                  const uint2* d_sched, int n_cu, hipStream_t stream)
+                                                  const uint2* d_sched, int octet, int n_cu, hipStream_t stream)
 {
     using namespace dabgpu;
     const unsigned tiles = (max_in_rows + VL_TILE - 1) / VL_TILE;
@@ -792,6 +781,8 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
         hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else
         hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
+    // the trellis over the same symbol array: eight lanes per codeword (viterbi_octet.hip) or one
+    if (octet) return dabgpu_launch_viterbi_octet(d_groups, n_groups, d_descs, d_sym, d_dec, d_results, tie_rule, d_tables, d_sched, stream);
 #define VL_GO(TIE, W) hipLaunchKernelGGL((vit_lanes_kernel<TIE, W>), dim3((unsigned)((n_groups + (W) - 1) / (W))), dim3(64 * (W)), 0, stream, \
                                          d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables, d_sched)
     const bool four = n_groups > (size_t)n_cu && n_groups <= (size_t)4 * n_cu;

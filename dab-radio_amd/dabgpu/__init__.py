@@ -403,7 +403,7 @@ class Context:
 
     # ---- channel decode ----
     def viterbi_set_mapping(self, mapping):
-        """0 = auto, 1 = one wavefront per codeword, 2 = one lane per codeword (include/dabgpu.h DABGPU_VIT_MAP_*)."""
+        """0 = auto, 1 = one wavefront per codeword, 2 = one lane per codeword, 3 = eight lanes per codeword (include/dabgpu.h DABGPU_VIT_MAP_*)."""
         check(lib().dabgpu_viterbi_set_mapping(self._h, int(mapping)), "dabgpu_viterbi_set_mapping")
 
     def viterbi_decode_batch(self, codewords, results, tie_rule=0, stream=None):

@@ -249,20 +249,24 @@ typedef struct {
 } dabgpu_codeword_result;
 
 /*
- * Two device mappings of the same decoder (identical results, bit for bit):
- *   WAVE  one wavefront per codeword, the 64 trellis states across its lanes (viterbi.hip) -- any batch, any mix of schedules
- *   LANE  one lane per codeword, wavefronts of 64 codewords that share a puncturing schedule (viterbi_lanes.hip) -- ~3x the
- *         throughput once a batch holds thousands of codewords per schedule; needs 768 bytes of scratch per trellis step
- *         and 64 codewords
- * AUTO (default) compares a cost model of the two for the call at hand (LANE needs ~0.5 us per trellis step of its longest
- * schedule however small the batch, WAVE ~0.019 ns per codeword and step + 0.038 us per codeword): e.g. the 18 x 48 CU multiplex switches to LANE
- * from ~200 ensembles, the FIC from ~2000 frames, a multiplex with one 164 CU sub-channel from ~1000 ensembles
- * (dabgpu_viterbi_decode_batch: only when every codeword of the batch has the same n_steps / segments; forcing LANE on a
- * mixed generic batch runs WAVE).
+ * Three device mappings of the same decoder (identical results, bit for bit):
+ *   WAVE   one wavefront per codeword, the 64 trellis states across its lanes (viterbi.hip) -- any batch, any mix of schedules
+ *   LANE   one lane per codeword, wavefronts of 64 codewords that share a puncturing schedule (viterbi_lanes.hip) -- ~3x the
+ *          throughput once a batch holds thousands of codewords per schedule; needs <= 768 bytes of scratch per trellis step
+ *          and 64 codewords
+ *   OCTET  eight lanes per codeword, 8 codewords per wavefront (viterbi_octet.hip), over the same groups and scratch as LANE --
+ *          for the batches in between: when LANE would leave most SIMDs without a wavefront (64 codewords are indivisible there)
+ * AUTO (default) compares a cost model of the three for the call at hand (LANE needs ~0.5 us per trellis step of its longest
+ * schedule however small the batch, OCTET ~0.19 us, WAVE ~0.019 ns per codeword and step + 0.038 us per codeword): e.g. the FIC
+ * goes WAVE -> OCTET at ~700 frames and OCTET -> LANE at ~12000, the 18 x 48 CU multiplex WAVE -> OCTET at ~60 ensembles and
+ * OCTET -> LANE at ~600
+ * (dabgpu_viterbi_decode_batch: only when every codeword of the batch has the same n_steps / segments; forcing LANE or OCTET on
+ * a mixed generic batch runs WAVE).
  */
 #define DABGPU_VIT_MAP_AUTO 0
 #define DABGPU_VIT_MAP_WAVE 1
 #define DABGPU_VIT_MAP_LANE 2
+#define DABGPU_VIT_MAP_OCTET 3
 int dabgpu_viterbi_set_mapping(dabgpu_ctx *ctx, int mapping);
 
 /* generic batch: h_codewords is a HOST array (copied to the device on `stream`); d_results a DEVICE array [n] */

@@ -95,7 +95,7 @@ def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens,
     to_classed = np.argsort(dabgpu.classed_to_natural_index())
     hists = {0: torch.from_numpy(nat).cuda(), 1: torch.from_numpy(np.ascontiguousarray(nat[:, :, to_classed])).cuda()}
     got = {}
-    for m in (1, 2, 0):                                   # WAVE, LANE, AUTO with a forced hybrid (3 longest sub-channels by WAVE)
+    for m in (1, 2, 3, 0):                                # WAVE, LANE, OCTET, AUTO with a forced hybrid (3 longest sub-channels by WAVE)
         ctx.viterbi_set_mapping(m)
         if m == 0:
             os.environ["DABGPU_VIT_HYBRID_K"] = "3"
@@ -114,7 +114,7 @@ def test_decoder_gives_identical_results_from_either_order(ctx, tie_rule, n_ens,
     for slot in (0, 4):
         base = got[(1, 0, slot)]
         assert base[0].any()
-        for m in (1, 2, 0):
+        for m in (1, 2, 3, 0):
             for layout in (0, 1):
                 assert np.array_equal(got[(m, layout, slot)][0], base[0]), (m, layout, slot)
                 assert np.array_equal(got[(m, layout, slot)][1], base[1]), (m, layout, slot)
@@ -134,7 +134,7 @@ def test_one_sub_channel_filling_the_cif(ctx, level, type_b):
     to_classed = np.argsort(dabgpu.classed_to_natural_index())
     hists = {0: torch.from_numpy(nat).cuda(), 1: torch.from_numpy(np.ascontiguousarray(nat[:, :, to_classed])).cuda()}
     got = {}
-    for m in (1, 2):
+    for m in (1, 2, 3):
         ctx.viterbi_set_mapping(m)
         for layout in (0, 1):
             d_out = torch.zeros((n_ens, 4, nb), dtype=torch.uint8, device="cuda")
@@ -143,11 +143,11 @@ def test_one_sub_channel_filling_the_cif(ctx, level, type_b):
             torch.cuda.synchronize()
             got[(m, layout)] = (d_out.cpu().numpy(), d_res.cpu().numpy())
     ctx.viterbi_set_mapping(0)
-    for key in ((1, 1), (2, 0), (2, 1)):
+    for key in ((1, 1), (2, 0), (2, 1), (3, 0), (3, 1)):
         assert np.array_equal(got[key][0], got[(1, 0)][0]) and np.array_equal(got[key][1], got[(1, 0)][1]), key
 
 
-@pytest.mark.parametrize("mapping", [1, 2], ids=["wave", "lane"])
+@pytest.mark.parametrize("mapping", [1, 2, 3], ids=["wave", "lane", "octet"])
 def test_generic_batch_with_a_classed_ring_of_any_geometry(ctx, mapping):
     """DABGPU_CW_CLASSED through dabgpu_viterbi_decode_batch: 70 codewords of one schedule, each with its own 16-slot ring of one
     sub-channel per row (cifs_per_frame = 1, cif_stride = the sub-channel's soft bits) -- the general readers (wave-mapped decoder,
@@ -260,7 +260,7 @@ def test_ring_decode_with_skipped_ensembles_inside_a_quarter_group(ctx, layout):
     slots[8:12] = -1
     d_slots = torch.from_numpy(slots).cuda()
     got = {}
-    for m in (1, 2):
+    for m in (1, 2, 3):
         ctx.viterbi_set_mapping(m)
         try:
             d_out = torch.full((n_ens, 4, cif_out), 0xEE, dtype=torch.uint8, device="cuda")
@@ -271,6 +271,7 @@ def test_ring_decode_with_skipped_ensembles_inside_a_quarter_group(ctx, layout):
         finally:
             ctx.viterbi_set_mapping(0)
     assert np.array_equal(got[1][0], got[2][0]) and np.array_equal(got[1][1], got[2][1])
+    assert np.array_equal(got[1][0], got[3][0]) and np.array_equal(got[1][1], got[3][1])
     skipped = slots < 0
     assert (got[2][0][skipped] == 0xEE).all(), "no byte is written for an ensemble without a new frame"
     assert (got[2][0][~skipped] != 0xEE).any()

@@ -26,9 +26,9 @@ def results_np(t):
     return t.cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(-1)
 
 
-@pytest.fixture(params=[1, 2], ids=["wave", "lane"])
+@pytest.fixture(params=[1, 2, 3], ids=["wave", "lane", "octet"])
 def mapping(ctx, request):
-    """both device mappings of the decoder (include/dabgpu.h DABGPU_VIT_MAP_*), forced"""
+    """the three device mappings of the decoder (include/dabgpu.h DABGPU_VIT_MAP_*), forced"""
     ctx.viterbi_set_mapping(request.param)
     yield request.param
     ctx.viterbi_set_mapping(0)
@@ -228,7 +228,7 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
     frames[7, :9216] = 127
     d_bits = torch.from_numpy(frames).cuda()
     got = {}
-    for m in (1, 2):
+    for m in (1, 2, 3):
         ctx.viterbi_set_mapping(m)
         d_out = torch.zeros((n_frames, 4, 96), dtype=torch.uint8, device="cuda")
         d_res = torch.zeros((n_frames * 4, 16), dtype=torch.uint8, device="cuda")
@@ -237,6 +237,7 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
         got[m] = (d_out.cpu().numpy(), d_res.cpu().numpy())
     ctx.viterbi_set_mapping(0)
     assert np.array_equal(got[1][0], got[2][0]) and np.array_equal(got[1][1], got[2][1])
+    assert np.array_equal(got[1][0], got[3][0]) and np.array_equal(got[1][1], got[3][1])
     assert 0 < int((results_np(torch.from_numpy(got[2][1]))["crc_ok_mask"] == 7).sum()) < n_frames * 4
 
     subs = [dabgpu.SubChannel(0, 48, False, 0, 2, 0), dabgpu.SubChannel(48, 8, False, 0, 1, 0), dabgpu.SubChannel(60, 27, False, 0, 0, 1),
@@ -249,7 +250,7 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
     slots = torch.from_numpy(rng.integers(-1, H, n_ens).astype(np.int32)).cuda()
     got = {}
     import os
-    for m in (1, 2, 0):                                   # 0 = AUTO with a forced hybrid: the 3 longest sub-channels by WAVE, 4 by LANE
+    for m in (1, 2, 3, 0):                                # 0 = AUTO with a forced hybrid: the 3 longest sub-channels by WAVE, 4 by LANE / OCTET
         ctx.viterbi_set_mapping(m)
         if m == 0:
             os.environ["DABGPU_VIT_HYBRID_K"] = "3"
@@ -265,7 +266,7 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
     ctx.viterbi_set_mapping(0)
     os.environ.pop("DABGPU_VIT_HYBRID_K", None)
     for ring in (False, True):
-        for m in (2, 0):
+        for m in (2, 3, 0):
             assert np.array_equal(got[(1, ring)][0], got[(m, ring)][0]), (m, ring)
             assert np.array_equal(got[(1, ring)][1], got[(m, ring)][1]), (m, ring)
 
@@ -275,7 +276,7 @@ def test_lane_mapping_equals_wave_mapping_on_a_batch(ctx, oracle, tie_rule, scra
                          ids=["T142", "T86", "T14", "T2054"])
 def test_uniform_generic_batch_through_both_mappings(ctx, oracle, tie_rule, segs):
     """70 codewords of ONE schedule (segments in 8-step units, an empty segment, n_steps mod 6 = 4 / 2 / 2 / 2), random
-    soft bits (every decision is a near tie), random start / end states, raw and descrambled outputs: oracle == WAVE == LANE"""
+    soft bits (every decision is a near tie), random start / end states, raw and descrambled outputs: oracle == WAVE == LANE == OCTET"""
     import dabgpu
     import torch
     rng = np.random.default_rng(500 + tie_rule + len(segs))
@@ -303,7 +304,7 @@ def test_uniform_generic_batch_through_both_mappings(ctx, oracle, tie_rule, segs
         if not raws[i]:
             ob = ob ^ oracle.scrambler_bytes(n_bits // 8)
         expect.append((ob, oe))
-    for m in (1, 2):
+    for m in (1, 2, 3):
         ctx.viterbi_set_mapping(m)
         d_o = torch.zeros((n_cw, n_bits // 8), dtype=torch.uint8, device="cuda")
         d_res = torch.zeros((n_cw, 16), dtype=torch.uint8, device="cuda")
@@ -322,3 +323,51 @@ def test_uniform_generic_batch_through_both_mappings(ctx, oracle, tie_rule, segs
             assert np.array_equal(out[i], ob), (m, i)
             assert int(res[i]["path_error"]) == oe and int(res[i]["n_out_bytes"]) == n_bits // 8, (m, i)
     ctx.viterbi_set_mapping(0)
+
+
+@pytest.mark.parametrize("warm", ["0", "1"])
+def test_octet_mapping_when_the_split_chain_back_fails_its_check(ctx, oracle, warm):
+    """DABGPU_VIT_MAP_OCTET splits the chain-back of a codeword over its 8 lanes: each lane starts early from an arbitrary state and the
+    positions are checked link by link; a lane whose assumption was wrong walks again from the true position, round after round.
+    Without a run-in (DABGPU_VIT_OCTET_WARM=0) nearly every link fails, with 24 steps of it a few do: the bytes, CRC masks and path
+    errors must not depend on how many rounds it took.  FIB groups against the oracle, a long and a short sub-channel against the wave mapping."""
+    import os
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(31)
+    n_frames = 21
+    frames = np.zeros((n_frames, oracle.NB_FRAME_BITS), dtype=np.int8)
+    for f in range(n_frames):
+        for g in range(4):
+            enc = oracle.fic_encode_group(rng.integers(0, 256, 90, dtype=np.uint8))
+            frames[f, g * 2304:(g + 1) * 2304] = noisy(oracle, enc, rng, sigma=[0.0, 25.0, 45.0, 80.0][(f + g) % 4] + 1e-3)
+    frames[3, :2304] = 0
+    frames[4, 2304:4608] = rng.integers(-127, 128, 2304, dtype=np.int8)      # pure noise: survivors merge late
+    d_bits = torch.from_numpy(frames).cuda()
+    subs = [dabgpu.SubChannel(0, 164, False, 0, 3, 0), dabgpu.SubChannel(300, 4, False, 0, 3, 0), dabgpu.SubChannel(400, 35, True, 4, 0, 0)]
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    n_ens, H = 11, 5
+    hist = torch.from_numpy(rng.integers(-127, 128, (n_ens, H, oracle.NB_FRAME_BITS), dtype=np.int8)).cuda()
+    got = {}
+    os.environ["DABGPU_VIT_OCTET_WARM"] = warm
+    try:
+        for m in (1, 3):
+            ctx.viterbi_set_mapping(m)
+            d_out = torch.zeros((n_frames, 4, 96), dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros((n_frames * 4, 16), dtype=torch.uint8, device="cuda")
+            ctx.fic_decode_frames(d_bits, n_frames, d_out, d_res, tie_rule=0)
+            m_out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda")
+            m_res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+            ctx.msc_decode_frames(hist, n_ens, H * oracle.NB_FRAME_BITS, H, 1, subs, m_out, 4 * cif_out, m_res)
+            torch.cuda.synchronize()
+            got[m] = (d_out.cpu().numpy(), d_res.cpu().numpy(), m_out.cpu().numpy(), m_res.cpu().numpy())
+    finally:
+        os.environ.pop("DABGPU_VIT_OCTET_WARM", None)
+        ctx.viterbi_set_mapping(0)
+    for k in range(4):
+        assert np.array_equal(got[1][k], got[3][k]), k
+    out, res = got[3][0], results_np(torch.from_numpy(got[3][1]))
+    for f in range(n_frames):
+        for g in range(4):
+            eb, em, ee = oracle.fic_decode_group(frames[f, g * 2304:(g + 1) * 2304], 0)
+            assert np.array_equal(out[f, g], eb) and int(res[f * 4 + g]["crc_ok_mask"]) == em and int(res[f * 4 + g]["path_error"]) == ee

@@ -36,7 +36,7 @@ def test_product_rejects_out_of_table_profiles():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mapping", [1, 2], ids=["wave", "lane"])
+@pytest.mark.parametrize("mapping", [1, 2, 3], ids=["wave", "lane", "octet"])
 def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
     import dabgpu
     import torch

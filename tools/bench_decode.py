@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--tie-rule", type=int, default=0)
     ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed",
                     help="order of the MSC soft bits in the frame-history ring (classed = DABGPU_BITS_MSC_CLASSED)")
-    ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword (DABGPU_VIT_MAP_*)")
+    ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword, 3 eight lanes per codeword (DABGPU_VIT_MAP_*)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = dabgpu.Context(0)
