@@ -40,7 +40,8 @@ REALTIME_FRAMES_PER_S = 2.048e6 / 196608              # 10.4167
 # Viterbi kernels: VALU-issue bound.  peak trellis steps/s = SIMDs x clock x codewords per wavefront /
 # (VALU instructions per wavefront-step x cycles per instruction); instruction counts from the ISA of this build
 # (tools/isa_count.py), 4 cycles per packed-integer / cross-lane instruction (tools/ubench/pk16_rate.hip), 2.4 GHz, 1024 SIMDs.
-VIT_LANES_INSTR_PER_STEP = 181.0
+VIT_LANES_INSTR_PER_STEP = 183.0            # 181 + the de-puncturing v_perm_b32 + the row address (round 3: punctured symbol array)
+VIT_OCTET_INSTR_PER_STEP = 48.0             # vit_octet_kernel, 8 codewords per wavefront (forward pass, fast path)
 VIT_WAVE_INSTR_PER_STEP = 23.0
 VIT_CYCLES_PER_INSTR = 4.0
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
@@ -154,9 +155,12 @@ def hbm_roofline(kernel, k_ms, frames):
 
 
 def viterbi_roofline(kernel, steps, k_ms, lanes):
-    """VALU-issue bound of the trellis recursion; `lanes`: lane-per-codeword mapping (64 codewords per wavefront) or one wavefront per codeword"""
-    per_wave = 64.0 if lanes else 1.0
-    instr = VIT_LANES_INSTR_PER_STEP if lanes else VIT_WAVE_INSTR_PER_STEP
+    """VALU-issue bound of the trellis recursion; `lanes`: codewords per wavefront of the mapping -- 64 (one lane per codeword), 8 (eight
+    lanes per codeword) or 1 / False (one wavefront per codeword).  Counter evidence: profiles/r03/counters_*.json"""
+    per_wave = float(lanes) if lanes else 1.0
+    if lanes is True:
+        per_wave = 64.0
+    instr = {64.0: VIT_LANES_INSTR_PER_STEP, 8.0: VIT_OCTET_INSTR_PER_STEP}.get(per_wave, VIT_WAVE_INSTR_PER_STEP)
     peak = N_SIMD * CLOCK_HZ * per_wave / (instr * VIT_CYCLES_PER_INSTR) / 1e9
     achieved = steps / (k_ms * 1e-3) / 1e9
     return {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G trellis steps/s", "frac": achieved / peak,
@@ -296,12 +300,14 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / (2 * reps) * 1e3
     chk = p.check(dabgpu)
-    lanes_fic = E >= 2000                      # DABGPU_VIT_MAP_AUTO's switch points
+    # DABGPU_VIT_MAP_AUTO's switch points for the FIC (include/dabgpu.h): wave -> octet at ~700 frames, octet -> lane at ~12000
+    lanes_fic = 64 if E >= 12000 else (8 if E >= 700 else 0)
+    fic_kernel = {64: "vit_lanes_kernel (FIC)", 8: "vit_octet_kernel (FIC)", 0: "viterbi_kernel (FIC)"}[lanes_fic]
     c2 = {"workload": f"BASELINE configs[2]: full OFDM demod + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
           "ms_per_step": t_c2, "frames_per_s": E / t_c2 * 1e3, "x_realtime": E / t_c2 * 1e3 / REALTIME_FRAMES_PER_S,
           "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic},
           "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
-                       viterbi_roofline("vit_lanes_kernel (FIC)" if lanes_fic else "viterbi_kernel (FIC)", p.fic_steps, t_fic, lanes_fic)],
+                       viterbi_roofline(fic_kernel, p.fic_steps, t_fic, lanes_fic)],
           "check": {k: chk[k] for k in ("fib_crc_pass", "fib_crc_expected", "fib_bytes_equal_transmitted")}}
     c3 = {"workload": f"BASELINE configs[3]: full FIC + MSC demod + Viterbi, {E} concurrent synthetic ensembles, 18 x 48 CU EEP 3-A", "ensembles": E,
           "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,

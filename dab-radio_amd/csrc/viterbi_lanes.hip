@@ -13,8 +13,9 @@
 //                       survivors straight into N[2i], N[2i+1] of layout L_{q+1}: no cross-lane traffic, no shuffles, the
 //                       same register pattern in every phase; only the branch-cost pairing differs.  In L_5 a register holds
 //                       (s, s+32), i.e. both predecessors of one butterfly: that phase costs two extra ops per register.
-//   branch costs      = e = 508 - (+-(y0+y3) +- y1 +- y2) (polynomials 0 and 3 are equal): 8 values per step, packed into
-//                       8 registers C[sigma] = (e(sigma), e(sigma x f_q)); the complement pattern is C[7 - sigma]
+//   branch costs      = e = 508 - (+-(y0+y3) +- y1 +- y2) (polynomials 0 and 3 are equal): 8 values per step, packed as
+//                       C[sigma] = (e(sigma), e(sigma x f_q)) in 4 registers (4-5 v_dot4 + 4 v_pk_mad_i16, viterbi_pk16.h); the
+//                       complement pattern is C[7 - sigma]
 //   decisions         = sign bits of the saturated candidate differences, gathered with v_perm_b32 + v_bfi_b32 into
 //                       2 dwords per step and lane, streamed to HBM two steps at a time ([step / 2][lane][4], 1 KB per store)
 //   chain-back        = per lane, reading the lane's own decision words back (coalesced across the wavefront),
@@ -62,36 +63,16 @@ __device__ __forceinline__ void vl_gather(const s2 (&D)[32], uint32_t& w0, uint3
     w0 = a0; w1 = a1;
 }
 
-// 8 packed branch-cost registers of one step: C[s] = (e(s), e(s ^ FLIP)), e(s) = 508 - (+-a +- y1 +- y2) with a = y0 + y3
-// (polynomials 0 and 3 are equal), bit k of s set = '+' for a / y1 / y2.  Two v_dot4 give a + y1 and a - y1, six packed adds
-// the 8 values as pairs, 8 v_perm_b32 pair them up for this phase
-template <int FLIP>
-__device__ __forceinline__ void vl_costs(uint32_t ysym, s2 (&C)[8]) {
-    const int p = __builtin_amdgcn_sdot4((int)ysym, 0x01000101, 0, false);            // y0 + y1 + y3
-    const int q = __builtin_amdgcn_sdot4((int)ysym, 0x0100FF01, 0, false);            // y0 - y1 + y3
-    const int y2 = (int)(int8_t)((ysym >> 16) & 0xFF);
-    const s2 w1 = as_s2(__builtin_amdgcn_perm((uint32_t)q, (uint32_t)p, 0x05040100u));
-    const s2 w2 = as_s2(__builtin_amdgcn_perm((uint32_t)y2, (uint32_t)y2, 0x05040100u));
-    const s2 K = as_s2(508u | (508u << 16));
-    const s2 x1 = sub16(K, w1), x2 = add16(K, w1);                         // (e[a+ b+], e[a+ b-]) / (e[a- b-], e[a- b+]) before y2
-    uint32_t R[4];                                                         // pairs of e(): {7,5} {3,1} {4,6} {0,2}
-    R[0] = as_u32(sub16(x1, w2)); R[1] = as_u32(add16(x1, w2));
-    R[2] = as_u32(sub16(x2, w2)); R[3] = as_u32(add16(x2, w2));
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        constexpr int reg_of[8] = {3, 1, 3, 1, 2, 0, 2, 0}, half_of[8] = {0, 1, 1, 0, 0, 1, 1, 0};
-        const int v0 = s, v1 = s ^ FLIP;
-        // result low half = e(v0), high half = e(v1): v_perm_b32 selects bytes 0-3 from its second, 4-7 from its first operand
-        const uint32_t sel = (uint32_t)(half_of[v0] ? 0x0302 : 0x0100) | ((uint32_t)(half_of[v1] ? 0x0706 : 0x0504) << 16);
-        C[s] = as_s2(__builtin_amdgcn_perm(R[reg_of[v1]], R[reg_of[v0]], sel));
-    }
-}
-
 // one trellis step in phase Q: layout L_Q (M) -> L_{(Q+1) mod 6} (N)
 template <int Q, int TIE>
-__device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t ysym, uint32_t& w0, uint32_t& w1) {
+__device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t ysym, int k508, uint32_t& w0, uint32_t& w1) {
     s2 C[8], D[32];
-    vl_costs<vl_flip(Q)>(ysym, C);
+    {
+        using map = vl_costmap<vl_flip(Q)>;                     // branch costs: viterbi_pk16.h
+        constexpr int WF[4] = {map::wF(0, 1, 1, 1), map::wF(1, 1, 1, 1), map::wF(2, 1, 1, 1), map::wF(3, 1, 1, 1)};
+        constexpr int WX[4] = {map::wX(0, 1, 1, 1), map::wX(1, 1, 1, 1), map::wX(2, 1, 1, 1), map::wX(3, 1, 1, 1)};
+        vl_cost_table<vl_flip(Q), true>(ysym, WF, WX, k508, C);
+    }
     if constexpr (Q < 5) {
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -227,15 +208,17 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
         }
     }
     uint32_t total = 0;
+    int k508 = 508;
+    asm volatile("" : "+v"(k508));                          // one register for the accumulator constant of the cost dot products
     const uint2* sch = sched + Gd.sched_off;                 // (row, selector) per trellis step: scalar loads
     const uint32_t lane4 = 4u * (uint32_t)lane, lane16 = 16u * (uint32_t)lane;
     // two trellis steps t, t + 1 (t even) in phases Q, Q + 1: M -> N -> M
 #define VL_PAIR(Q, TT, YA, YB)                                                                        \
     {                                                                                                 \
         uint4 wv;                                                                                     \
-        vl_step<Q, TIE>(M, N, YA, wv.x, wv.y);                                                        \
+        vl_step<Q, TIE>(M, N, YA, k508, wv.x, wv.y);                                                        \
         vl_renorm(N, total);                                                                          \
-        vl_step<(Q) + 1, TIE>(N, M, YB, wv.z, wv.w);                                                  \
+        vl_step<(Q) + 1, TIE>(N, M, YB, k508, wv.z, wv.w);                                                  \
         vl_renorm(M, total);                                                                          \
         __builtin_nontemporal_store(u4v{wv.x, wv.y, wv.z, wv.w},                                      \
                                     reinterpret_cast<u4v*>(reinterpret_cast<char*>(grp_dec + (size_t)((TT) >> 1) * 256) + lane16)); \

@@ -21,8 +21,8 @@
 //                                                                   lane for the partner's: afterwards one register holds every lane's
 //                                                                   lower-predecessor candidate, the other the upper one
 //   branch costs      = the pattern of a butterfly is linear in the state bits: (register bits) ^ (half bit) ^ (lane bits).  The lane's
-//                       part is folded into the INPUTS -- three v_dot4 with per-lane, per-phase +-1 weights give the sign-adjusted
-//                       a + y1, a - y1, y2 -- so the table of 8 costs is indexed by compile-time patterns only; in the swap phases the
+//                       part is folded into the INPUTS -- the v_dot4 weights of the cost table (viterbi_pk16.h) carry per-lane,
+//                       per-phase signs -- so the table of 8 costs is indexed by compile-time patterns only; in the swap phases the
 //                       lanes that hold the upper predecessor flip all three signs (their table is the complement).
 //   decisions         = sign bytes of the 4 difference registers (v_perm_b32 selectors 8..11), two v_bfi per step into a word of
 //                       2 steps x 8 bits, stored as one u16 per lane and step pair: [pair][codeword][sub-lane], the same 512 bytes per
@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "dabgpu_internal.h"
 #include "viterbi_pk16.h"
@@ -65,31 +66,10 @@ __host__ __device__ constexpr int vo_flip_h(int q) { return vo_ord(q) == 0 ? 7 :
 __host__ __device__ constexpr int vo_pbit(int slot) { return slot == 0 ? 3 : (slot == 1 ? 2 : (slot == 2 ? 0 : slot + 1)); }
 
 struct vo_lane_consts {
-    int wp[6], wq[6], w2[6];          // v_dot4 weights per phase: sign-adjusted a + y1, a - y1, y2
+    int wf[6][4], wx[6][4];           // v_dot4 weights per phase (vl_costmap): the lane's part of the sign pattern folded in
     uint32_t sgn3;                    // +1 / -1 packed: orientation of the difference in phase 3 (DPP exchange)
+    int k508;                         // 508 in a register: accumulator constant of the cost dot products
 };
-
-// 8 packed branch-cost registers of one step: C[s] = (e'(s), e'(s ^ FLIP)), e' = the lane-adjusted table (see header)
-template <int FLIP>
-__device__ __forceinline__ void vo_costs(uint32_t ysym, int wp, int wq, int w2, s2 (&C)[8]) {
-    const int p = __builtin_amdgcn_sdot4((int)ysym, wp, 0, false);
-    const int q = __builtin_amdgcn_sdot4((int)ysym, wq, 0, false);
-    const int y2 = __builtin_amdgcn_sdot4((int)ysym, w2, 0, false);
-    const s2 w1 = as_s2(__builtin_amdgcn_perm((uint32_t)q, (uint32_t)p, 0x05040100u));
-    const s2 wy = as_s2(__builtin_amdgcn_perm((uint32_t)y2, (uint32_t)y2, 0x05040100u));
-    const s2 K = as_s2(508u | (508u << 16));
-    const s2 x1 = sub16(K, w1), x2 = add16(K, w1);
-    uint32_t R[4];                                                         // pairs of e(): {7,5} {3,1} {4,6} {0,2}
-    R[0] = as_u32(sub16(x1, wy)); R[1] = as_u32(add16(x1, wy));
-    R[2] = as_u32(sub16(x2, wy)); R[3] = as_u32(add16(x2, wy));
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        constexpr int reg_of[8] = {3, 1, 3, 1, 2, 0, 2, 0}, half_of[8] = {0, 1, 1, 0, 0, 1, 1, 0};
-        const int v0 = s, v1 = s ^ FLIP;
-        const uint32_t sel = (uint32_t)(half_of[v0] ? 0x0302 : 0x0100) | ((uint32_t)(half_of[v1] ? 0x0706 : 0x0504) << 16);
-        C[s] = as_s2(__builtin_amdgcn_perm(R[reg_of[v1]], R[reg_of[v0]], sel));
-    }
-}
 
 // saturating a * b (b = +-1): the difference register with the orientation the lane needs
 __device__ __forceinline__ s2 vo_satmul(s2 a, uint32_t b) {
@@ -103,7 +83,7 @@ __device__ __forceinline__ s2 vo_satmul(s2 a, uint32_t b) {
 template <int Q, int TIE>
 __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane_consts& K, uint32_t& g0, uint32_t& g1) {
     s2 C[8], D[4];
-    vo_costs<vo_flip_h(Q)>(ysym, K.wp[Q], K.wq[Q], K.w2[Q], C);
+    vl_cost_table<vo_flip_h(Q), false>(ysym, K.wf[Q], K.wx[Q], K.k508, C);
     if constexpr (Q < 2) {                                     // active = register bit R0 (Q = 0) / R1 (Q = 1)
         constexpr int rb = Q == 0 ? 1 : 2;
 #pragma unroll
@@ -218,15 +198,19 @@ void vit_octet_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
 
     // ---- per-lane constants: the lane's part of the sign pattern, as v_dot4 weights ----
     vo_lane_consts K;
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
+    auto lane_weights = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        using map = vl_costmap<vo_flip_h(q)>;
         int ls = ((l & 1) ? vo_slot_sig(3, q) : 0) ^ ((l & 2) ? vo_slot_sig(4, q) : 0) ^ ((l & 4) ? vo_slot_sig(5, q) : 0);
         if (q >= 4 && ((l >> (q - 3)) & 1)) ls ^= 7;               // swap phases: upper-predecessor lanes use the complemented table
-        const int w0 = (ls & 1) ? -1 : 1, w1 = (ls & 2) ? -1 : 1, w2 = (ls & 4) ? -1 : 1;
-        K.wp[q] = (w0 & 0xFF) | ((w1 & 0xFF) << 8) | ((w0 & 0xFF) << 24);            // y0 + y3 (polynomials 0 and 3 are equal), y1
-        K.wq[q] = (w0 & 0xFF) | (((-w1) & 0xFF) << 8) | ((w0 & 0xFF) << 24);
-        K.w2[q] = (w2 & 0xFF) << 16;
-    }
+        const int s0 = (ls & 1) ? -1 : 1, s1 = (ls & 2) ? -1 : 1, s2_ = (ls & 4) ? -1 : 1;
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) { K.wf[q][jn] = map::wF(jn, s0, s1, s2_); K.wx[q][jn] = map::wX(jn, s0, s1, s2_); }
+    };
+    lane_weights(std::integral_constant<int, 0>{}); lane_weights(std::integral_constant<int, 1>{}); lane_weights(std::integral_constant<int, 2>{});
+    lane_weights(std::integral_constant<int, 3>{}); lane_weights(std::integral_constant<int, 4>{}); lane_weights(std::integral_constant<int, 5>{});
+    K.k508 = 508;
+    asm volatile("" : "+v"(K.k508));
     {
         const bool upper3 = (l & 1) != 0;
         K.sgn3 = ((TIE ? !upper3 : upper3) ? 0xFFFFFFFFu : 0x00010001u);

@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed",
                     help="order of the MSC soft bits in the frame-history ring (classed = DABGPU_BITS_MSC_CLASSED)")
     ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword, 3 eight lanes per codeword (DABGPU_VIT_MAP_*)")
+    ap.add_argument("--no-overlap", action="store_true", help="serial stages only (profiling passes: every launch runs alone)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = dabgpu.Context(0)
@@ -180,6 +181,10 @@ def main():
         demod(k % H); fic(k % H); msc(k % H)
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / args.steps * 1e3
+
+    if args.no_overlap:
+        print(json.dumps({"ensembles": E, "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi": t_msc}, "ms_per_frame_step_wall": t_all}))
+        return
 
     # the same with the FIC on a second stream: it decodes concurrently with the MSC of the same frames (separate scratch,
     # include/dabgpu.h) and fits into the SIMD time the MSC's long trellis waves leave idle
