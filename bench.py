@@ -404,13 +404,17 @@ def main():
         units = F
 
         fmt_f32 = dabgpu.IQ_FORMATS.index("raw_f32l")
+        # symbols per workgroup: --spb 0 (default) leaves the choice to the library, which times a whole frame (75: one round of
+        # workgroups on a full chip, phase tail inside the kernel), two and three runs per frame (38, 25) once per context and batch
+        # size and keeps the fastest (include/dabgpu.h; which one wins depends on the box).  The timed loop below runs what
+        # the library chose; the three are timed here once more (untimed region) only to put the numbers in the line
         spb_timing = None
-        if args.spb == 0 and F >= 1024 and not args.dry_run:
-            # symbols per workgroup: a whole frame (75: one round of workgroups on a full chip, phase tail inside the kernel), two or
-            # three runs per frame (38, 25 = the library default) -- which is fastest depends on the box, so they are
-            # timed here (untimed region) and the fastest is used for the run
+        if args.spb == 0 and F >= 512 and not args.dry_run:
+            ctx.ofdm_demod_phase_frames(iq_f, fmt_f32, F, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=0,
+                                        beta=0.9, total_phase=d_total, fine_freq=d_fine)          # first call: the library's calibration
+            torch.cuda.synchronize()
             spb_timing = {}
-            for rep in range(3):                                       # interleaved, the last pass counts: both see the same clock state
+            for rep in range(2):                                       # interleaved, the last pass counts: all see the same clock state
                 for cand in (25, 38, 75):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -419,12 +423,11 @@ def main():
                                                     beta=0.9, total_phase=d_total, fine_freq=d_fine)
                     e1.record(); torch.cuda.synchronize()
                     spb_timing[cand] = e0.elapsed_time(e1) / 20
-            args.spb = min(spb_timing, key=spb_timing.get)
             d_fine.zero_()
 
         def demod_launch():
             # demodulation + the phase tail of the fine-frequency loop (ofdm_phase_update) as one call: one launch when a workgroup walks
-            # a whole frame (the default from 1024 frames), else the tail follows as its own small launch inside the call
+            # a whole frame (75), else the tail follows as its own small launch inside the call
             ctx.ofdm_demod_phase_frames(iq_f, fmt_f32, F, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=args.spb,
                                         beta=0.9, total_phase=d_total, fine_freq=d_fine)
 
@@ -505,7 +508,9 @@ def main():
         if args.workload == "demod":
             workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
                         "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU")
-            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": args.spb or 25,
+            chosen = args.spb or ctx.ofdm_auto_symbols_per_block(units) or 25
+            config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": chosen,
+                      "symbols_per_block_chosen_by": "caller (--spb)" if args.spb else "library (symbols_per_block = 0: one-time calibration per context and batch size)",
                       "sharding": "independent frames / ensembles per rank, no data-path collective"}
             if spb_timing:
                 config["symbols_per_block_timed_ms"] = {str(k): v for k, v in spb_timing.items()}
@@ -527,7 +532,7 @@ def main():
         }
         if region:
             line["roofline"]["timing"] = (f"one pair of HIP events around the {args.steps} back-to-back launches of the timed loop, on their stream: "
-                                          f"{k_ms_events:.4f} ms per launch" + ("" if args.spb == 75 else " (incl. the 5 us phase-tail launch of each step)"))
+                                          f"{k_ms_events:.4f} ms per launch" + ("" if (args.spb or ctx.ofdm_auto_symbols_per_block(units)) == 75 else " (incl. the 5 us phase-tail launch of each step)"))
         else:
             line["roofline"]["timing"] = (f"HIP events around {len(evs)} of the {args.steps} demod launches of the timed loop (mean {k_ms_events:.4f} ms"
                                           + ("" if k_ms_events <= ms_per_step else f", capped at ms_per_step: the event pair includes its own gap") + ")")

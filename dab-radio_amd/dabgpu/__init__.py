@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync", "dabgpu_ofdm_demod_stream_frame_sync",
     "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",
-    "dabgpu_viterbi_set_mapping", "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
+    "dabgpu_viterbi_set_mapping", "dabgpu_ofdm_auto_symbols_per_block", "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
     "dabgpu_fic_decode_group_host_sync", "dabgpu_viterbi_decode_host_sync", "dabgpu_msc_stream_create",
     "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
     "dabgpu_msc_stream_decode_sync",
@@ -178,6 +178,7 @@ def lib():
                                        C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_sync_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_viterbi_set_mapping.argtypes = [C.c_void_p, C.c_int]
+        L.dabgpu_ofdm_auto_symbols_per_block.argtypes = [C.c_void_p, C.c_size_t]
         L.dabgpu_viterbi_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_fic_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p]
@@ -402,6 +403,10 @@ class Context:
         return state, imp, frq
 
     # ---- channel decode ----
+    def ofdm_auto_symbols_per_block(self, n_frames):
+        """what symbols_per_block = 0 resolves to for batches of n_frames (0 = not measured yet)"""
+        return int(lib().dabgpu_ofdm_auto_symbols_per_block(self._h, int(n_frames)))
+
     def viterbi_set_mapping(self, mapping):
         """0 = auto, 1 = one wavefront per codeword, 2 = one lane per codeword, 3 = eight lanes per codeword (include/dabgpu.h DABGPU_VIT_MAP_*)."""
         check(lib().dabgpu_viterbi_set_mapping(self._h, int(mapping)), "dabgpu_viterbi_set_mapping")

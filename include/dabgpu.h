@@ -93,7 +93,10 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *                 display-only NULL-symbol FFT, ofdm_demodulator.cpp:701-709)
  *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
  *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
- *   symbols_per_block  data symbols handled by one workgroup (0 = default); any value gives identical results
+ *   symbols_per_block  data symbols handled by one workgroup, 1..75; any value gives identical results.  0 = the library chooses:
+ *                 25 for batches below 512 frames; for larger ones it times 25 / 38 / 75 ONCE per context and batch size (a few
+ *                 extra launches of this call on the caller's own buffers, identical outputs) and remembers the fastest --
+ *                 which one that is depends on the box.  dabgpu_ofdm_auto_symbols_per_block reports the choice.
  *   bits_frame_stride  bytes between the soft bits of consecutive frames (0 = 230400, packed); lets the kernel write
  *                 straight into slot k of a per-ensemble frame-history ring (see dabgpu_msc_decode_frames)
  */
@@ -133,7 +136,7 @@ int dabgpu_ofdm_demod_frames_history(dabgpu_ctx *ctx, const void *d_raw, int for
 
 /*
  * dabgpu_ofdm_demod_frames_history followed by dabgpu_ofdm_phase_update(d_cp_corr, ...) as one call -- and as ONE launch whenever a
- * workgroup walks a whole frame (symbols_per_block = 75, which is the default for batches of >= 1024 frames): the phase tail
+ * workgroup walks a whole frame (symbols_per_block = 75: explicit, or the library's own choice for this batch size): the phase tail
  * (per-symbol atan2, sequential sum, fine-frequency update: ofdm_demodulator.cpp:606-618, :779-840) then runs at the end of the
  * demodulation kernel, on the correlations it has just produced.  Otherwise the tail follows as its own launch.  Results are
  * identical to the two separate calls.  d_total_phase / d_fine_freq as in dabgpu_ofdm_phase_update (either may be NULL).
@@ -141,6 +144,9 @@ int dabgpu_ofdm_demod_frames_history(dabgpu_ctx *ctx, const void *d_raw, int for
 int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, const float *d_freq_offset,
                                    int8_t *d_bits, float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
                                    float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
+
+/* what symbols_per_block = 0 resolves to for batches of n_frames on this context: 25 / 38 / 75, or 0 = not measured yet */
+int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx *ctx, size_t n_frames);
 
 /*
  * Per-frame scalar tail of the fine-frequency loop: phase[i] = atan2(corr[i]), total = sum_i phase[i]

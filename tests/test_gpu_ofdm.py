@@ -223,3 +223,33 @@ def test_fused_phase_tail_equals_the_two_calls(ctx, fmt_name, layout):
     ctx.ofdm_demod_phase_frames(raw, fmt, n, torch.zeros_like(ref_bits), freq_offset=freq, symbols_per_block=75, bits_layout=layout, total_phase=total)
     torch.cuda.synchronize()
     assert torch.equal(total.view(torch.int32), ref_total.view(torch.int32))
+
+
+def test_library_choice_of_symbols_per_block_is_invisible(oracle):
+    """symbols_per_block = 0 on a chip-filling batch makes the library time 25 / 38 / 75 once (extra launches of the same call on the
+    caller's buffers) and keep the fastest: the outputs -- soft bits, correlations, total phase and the fine-frequency state the phase
+    tail UPDATES -- must be those of one explicit call, the choice must be reported, and a second call must not calibrate again."""
+    import dabgpu
+    import torch
+    ctx2 = dabgpu.Context(0)                                   # a fresh context: nothing cached
+    n = 512
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    raw = torch.randn((n, 196608, 2), generator=g, dtype=torch.float32, device="cuda")
+    freq = ((torch.rand(n, generator=g, device="cuda") * 2 - 1) * 2.0e-3).float()
+    fmt = dabgpu.IQ_FORMATS.index("raw_f32l")
+    outs = []
+    assert ctx2.ofdm_auto_symbols_per_block(n) == 0 and ctx2.ofdm_auto_symbols_per_block(100) == 25
+    for spb in (25, 0, 0):
+        bits = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
+        corr = torch.zeros((n, 76, 2), dtype=torch.float32, device="cuda")
+        total = torch.zeros(n, dtype=torch.float32, device="cuda")
+        fine = torch.full((n,), 1.0e-5, dtype=torch.float32, device="cuda")
+        ctx2.ofdm_demod_phase_frames(raw, fmt, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb, beta=0.9, total_phase=total, fine_freq=fine)
+        torch.cuda.synchronize()
+        outs.append((bits, corr.view(torch.int32), total.view(torch.int32), fine.view(torch.int32)))
+    assert ctx2.ofdm_auto_symbols_per_block(n) in (25, 38, 75)
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert torch.equal(a, b)
+    assert outs[0][0].abs().sum().item() > 0
+    ctx2.close()
