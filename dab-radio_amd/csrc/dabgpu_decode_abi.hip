@@ -596,3 +596,199 @@ extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_ou
     if (path_error) *path_error = R.path_error;
     return DABGPU_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// frame session: ONE batched decode per transmission frame behind the single-stream classes
+// ------------------------------------------------------------------------------------------------
+// The reference fans a frame out to one FIC runner + one MSC runner per sub-channel (src/basic_radio/basic_radio.cpp:41-65), each
+// calling its decoder once per FIB group / CIF: 4 + 4 x sub-channels synchronous round trips per frame behind the mirror classes.
+// A session keeps the last 8 frames of soft bits on the device; push_frame copies a frame in once and launches the FIC decode and the
+// time de-interleave + Viterbi of every registered sub-channel for its 4 CIFs (the batch entry points above, one ensemble), the
+// results return to pinned host slots asynchronously, and the classes pick theirs up by (generation, group / CIF) -- see
+// dab-radio_amd/host/dab/dabgpu_frame_batcher.h for when a class may use them.
+struct dabgpu_frame_session {
+    static constexpr int H = 8, R = 8;
+    dabgpu_ctx* ctx = nullptr;
+    int8_t* d_hist = nullptr;                       // [H][230400]
+    uint8_t* d_fib = nullptr; dabgpu_codeword_result* d_fres = nullptr;
+    uint8_t* d_msc = nullptr; dabgpu_codeword_result* d_mres = nullptr;
+    std::vector<dabgpu_subchannel> subs;
+    std::vector<uint32_t> sub_off, sub_n;           // byte offset / size of a sub-channel inside one CIF's output record
+    uint32_t cif_out = 0;
+    uint64_t next_gen = 0;
+    struct slot {
+        uint64_t gen = ~0ull; bool fic = false, pending = false;
+        std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
+        uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // pinned: [4][96], [4]
+        uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // pinned: [4][cif_out], [4][n_sub]
+        size_t h_msc_cap = 0, h_mres_cap = 0;
+        hipEvent_t done = nullptr;
+    } slots[R];
+    std::mutex mu;
+};
+
+extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int device) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    dabgpu_frame_session* s = new dabgpu_frame_session();
+    int st = dabgpu_create(&s->ctx, device, nullptr, nullptr);
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_hist, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMalloc(session history)");
+    if (!st) st = dabgpu_check_hip(hipMemset(s->d_hist, 0, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMemset(session history)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_fib, 4 * 96), "hipMalloc(session)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_fres, 4 * sizeof(dabgpu_codeword_result)), "hipMalloc(session)");
+    for (auto& sl : s->slots) {
+        if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_fib, 4 * 96, hipHostMallocDefault), "hipHostMalloc(session)");
+        if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_fres, 4 * sizeof(dabgpu_codeword_result), hipHostMallocDefault), "hipHostMalloc(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate(session)");
+    }
+    if (st) { dabgpu_frame_session_destroy(s); return st; }
+    *out = s;
+    return DABGPU_OK;
+}
+
+extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
+    if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    for (auto& sl : s->slots) {
+        if (sl.h_fib) (void)hipHostFree(sl.h_fib);
+        if (sl.h_fres) (void)hipHostFree(sl.h_fres);
+        if (sl.h_msc) (void)hipHostFree(sl.h_msc);
+        if (sl.h_mres) (void)hipHostFree(sl.h_mres);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (s->d_hist) (void)hipFree(s->d_hist);
+    if (s->d_fib) (void)hipFree(s->d_fib);
+    if (s->d_fres) (void)hipFree(s->d_fres);
+    if (s->d_msc) (void)hipFree(s->d_msc);
+    if (s->d_mres) (void)hipFree(s->d_mres);
+    if (s->ctx) dabgpu_destroy(s->ctx);
+    delete s;
+}
+
+extern "C" int dabgpu_frame_session_set_subchannels(dabgpu_frame_session* s, const dabgpu_subchannel* subs, int n) {
+    if (!s || n < 0 || n > 64 || (n && !subs)) { dabgpu_set_error("frame_session_set_subchannels: invalid argument"); return DABGPU_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lock(s->mu);
+    DABGPU_BIND(s->ctx);
+    std::vector<uint32_t> off((size_t)n), nb((size_t)n);
+    uint32_t total = 0;
+    for (int k = 0; k < n; k++) {
+        int pi[4], lx[4], bytes = 0;
+        if (dabgpu_subchannel_plan(&subs[k], pi, lx, &bytes) < 0 || subs[k].start_address < 0 || subs[k].start_address + subs[k].length > 864) {
+            dabgpu_set_error("frame_session_set_subchannels: sub-channel %d has an invalid protection profile or exceeds 864 CU", k);
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        off[(size_t)k] = total; nb[(size_t)k] = (uint32_t)bytes; total += (uint32_t)bytes;
+    }
+    int st = dabgpu_check_hip(hipStreamSynchronize(s->ctx->stream), "hipStreamSynchronize(session)");
+    if (st) return st;
+    if (s->d_msc) { (void)hipFree(s->d_msc); s->d_msc = nullptr; }
+    if (s->d_mres) { (void)hipFree(s->d_mres); s->d_mres = nullptr; }
+    if (n) {
+        if ((st = dabgpu_check_hip(hipMalloc((void**)&s->d_msc, (size_t)4 * total), "hipMalloc(session msc)"))) return st;
+        if ((st = dabgpu_check_hip(hipMalloc((void**)&s->d_mres, (size_t)4 * n * sizeof(dabgpu_codeword_result)), "hipMalloc(session msc results)"))) return st;
+    }
+    s->subs.assign(subs, subs + n); s->sub_off = off; s->sub_n = nb; s->cif_out = total;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const int8_t* h_bits, int decode_fic, int tie_rule, uint64_t* generation) {
+    if (!s || !h_bits) { dabgpu_set_error("frame_session_push_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lock(s->mu);
+    dabgpu_ctx* c = s->ctx;
+    DABGPU_BIND(c);
+    hipStream_t q = c->stream;
+    const uint64_t gen = s->next_gen;
+    const int hs = (int)(gen % dabgpu_frame_session::H);
+    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
+    int st;
+    if (sl.pending) {                                                   // the slot's previous frame (R frames ago)
+        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)"))) return st;
+        sl.pending = false;
+    }
+    int8_t* d_frame = s->d_hist + (size_t)hs * DABGPU_NB_FRAME_BITS;
+    if ((st = dabgpu_stage_h2d(c, d_frame, h_bits, DABGPU_NB_FRAME_BITS, q))) return st;
+    const int n_sub = (int)s->subs.size();
+    sl.gen = ~0ull;
+    sl.fic = decode_fic != 0;
+    sl.subs = s->subs; sl.sub_off = s->sub_off; sl.sub_n = s->sub_n; sl.cif_out = s->cif_out;
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    if (decode_fic) {
+        if ((st = dabgpu_fic_decode_frames(c, d_frame, 1, DABGPU_NB_FRAME_BITS, s->d_fib, s->d_fres, tie_rule, q))) return st;
+        CK(hipMemcpyAsync(sl.h_fib, s->d_fib, 4 * 96, hipMemcpyDeviceToHost, q));
+        CK(hipMemcpyAsync(sl.h_fres, s->d_fres, 4 * sizeof(dabgpu_codeword_result), hipMemcpyDeviceToHost, q));
+    }
+    if (n_sub) {
+        const size_t need = (size_t)4 * s->cif_out, need_r = (size_t)4 * n_sub * sizeof(dabgpu_codeword_result);
+        if (sl.h_msc_cap < need) {
+            if (sl.h_msc) (void)hipHostFree(sl.h_msc);
+            sl.h_msc = nullptr; sl.h_msc_cap = 0;
+            CK(hipHostMalloc((void**)&sl.h_msc, need, hipHostMallocDefault));
+            sl.h_msc_cap = need;
+        }
+        if (sl.h_mres_cap < need_r) {
+            if (sl.h_mres) (void)hipHostFree(sl.h_mres);
+            sl.h_mres = nullptr; sl.h_mres_cap = 0;
+            CK(hipHostMalloc((void**)&sl.h_mres, need_r, hipHostMallocDefault));
+            sl.h_mres_cap = need_r;
+        }
+        if ((st = dabgpu_msc_decode_frames(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
+                                           s->subs.data(), n_sub, s->d_msc, need, s->d_mres, tie_rule, q))) return st;
+        CK(hipMemcpyAsync(sl.h_msc, s->d_msc, need, hipMemcpyDeviceToHost, q));
+        CK(hipMemcpyAsync(sl.h_mres, s->d_mres, need_r, hipMemcpyDeviceToHost, q));
+    }
+    CK(hipEventRecord(sl.done, q));
+#undef CK
+    sl.pending = true;
+    sl.gen = gen;
+    s->next_gen = gen + 1;
+    if (generation) *generation = gen;
+    return DABGPU_OK;
+}
+
+static int session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out) {
+    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
+    if (sl.gen != gen) return DABGPU_ERR_NOT_READY;                     // never pushed, or overwritten by a later frame
+    if (sl.pending) {
+        DABGPU_BIND(s->ctx);
+        int st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)");
+        if (st) return st;
+        sl.pending = false;
+    }
+    *out = &sl;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_frame_session_fetch_fib_group(dabgpu_frame_session* s, uint64_t generation, int group, uint8_t* h_bytes,
+                                                    uint32_t* crc_ok_mask, uint64_t* path_error) {
+    if (!s || group < 0 || group > 3 || !h_bytes) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(s->mu);
+    dabgpu_frame_session::slot* sl = nullptr;
+    int st = session_slot(s, generation, &sl);
+    if (st) return st;
+    if (!sl->fic) return DABGPU_ERR_NOT_READY;
+    memcpy(h_bytes, sl->h_fib + 96 * group, 96);
+    if (crc_ok_mask) *crc_ok_mask = sl->h_fres[group].crc_ok_mask;
+    if (path_error) *path_error = sl->h_fres[group].path_error;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_frame_session_fetch_cif(dabgpu_frame_session* s, uint64_t generation, const dabgpu_subchannel* sc, int cif,
+                                              uint8_t* h_bytes, size_t capacity, size_t* n_bytes, uint64_t* path_error) {
+    if (!s || !sc || cif < 0 || cif > 3 || !h_bytes || !n_bytes) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(s->mu);
+    dabgpu_frame_session::slot* sl = nullptr;
+    int st = session_slot(s, generation, &sl);
+    if (st) return st;
+    for (size_t k = 0; k < sl->subs.size(); k++) {
+        if (memcmp(&sl->subs[k], sc, sizeof(dabgpu_subchannel)) != 0) continue;
+        if (sl->sub_n[k] > capacity) return DABGPU_ERR_INVALID_ARG;
+        memcpy(h_bytes, sl->h_msc + (size_t)cif * sl->cif_out + sl->sub_off[k], sl->sub_n[k]);
+        *n_bytes = sl->sub_n[k];
+        if (path_error) *path_error = sl->h_mres[(size_t)cif * sl->subs.size() + k].path_error;
+        return DABGPU_OK;
+    }
+    return DABGPU_ERR_NOT_READY;                                        // the sub-channel was not registered when that frame was pushed
+}

@@ -58,6 +58,8 @@ ABI_SYMBOLS = [
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
     "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout", "dabgpu_stream_bank_process_ring_layout",
     "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames",
+    "dabgpu_frame_session_create", "dabgpu_frame_session_destroy", "dabgpu_frame_session_set_subchannels", "dabgpu_frame_session_push_frame",
+    "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 

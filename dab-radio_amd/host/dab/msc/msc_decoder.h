@@ -26,4 +26,7 @@ private:
     struct dabgpu_ctx* m_ctx;          // this decoder's own device context (stream + scratch): decoders of different threads run side by side
     std::vector<uint8_t> m_decoded_bytes;
     uint64_t m_last_error = 0;
+    // frame batcher (dab/dabgpu_frame_batcher.h): the sub-channel as registered, the batcher CIF consumed last, how many in a row
+    struct BatchState;
+    BatchState* m_batch;
 };

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "dabgpu.h"
+#include "dab/dabgpu_frame_batcher.h"
 
 namespace {
 [[noreturn]] void fail(const char* what, int st) {
@@ -208,5 +209,7 @@ void OFDM_Demod::DemodulateFrame() {
     if (rc != DABGPU_OK) fail("dabgpu_ofdm_demod_stream_frame_sync", rc);
     m_freq_fine = fine;
     m_total_frames_read++;
+    // the decoders of this process get the whole frame decoded in one go (mode I: the DAB layer above the soft bits is mode I only)
+    if (m_mode == 1) dabgpu_frame_batcher::on_frame(m_frame_bits.data());
     m_on_frame.Notify(tcb::span<const viterbi_bit_t>(m_frame_bits.data(), m_frame_bits.size()));
 }

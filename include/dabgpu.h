@@ -371,6 +371,30 @@ int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream *s, int8_t *h_out);
  * DABGPU_ERR_NOT_READY (and *n_out = 0) until 16 CIFs were pushed (msc_decoder.cpp:60-63) */
 int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream *s, uint8_t *h_out, size_t *n_out, uint64_t *path_error, int tie_rule);
 
+/* --------------------------------------------------------------------------------------------------
+ * Frame session: one batched decode per transmission frame behind the single-stream classes.
+ * BasicRadio::Process fans a frame out to one FIC runner and one MSC runner per sub-channel (src/basic_radio/basic_radio.cpp:41-65),
+ * each of which calls its decoder once per FIB group / CIF -- 4 + 4 x sub-channels synchronous round trips per frame.  A session keeps
+ * the last 8 frames of soft bits on the device: push_frame copies a frame in ONCE and launches the FIC decode (4 FIB groups) and the
+ * time de-interleave + Viterbi + descramble of every registered sub-channel for the frame's 4 CIFs (the batch entry points above with
+ * one ensemble), asynchronously; the results of the last 8 frames stay available in host memory and are fetched by
+ * (generation, group / sub-channel, CIF).  The mirror classes use it through dab-radio_amd/host/dab/dabgpu_frame_batcher.h, which
+ * also decides when a class may take a session result instead of decoding itself (the bytes are identical either way).
+ * Thread-safe.  The session owns a device context of its own.
+ */
+typedef struct dabgpu_frame_session dabgpu_frame_session;
+int dabgpu_frame_session_create(dabgpu_frame_session **out, int device);
+void dabgpu_frame_session_destroy(dabgpu_frame_session *s);
+/* replaces the set of sub-channels decoded for the frames pushed from now on (n <= 64) */
+int dabgpu_frame_session_set_subchannels(dabgpu_frame_session *s, const dabgpu_subchannel *h_subchannels, int n);
+/* h_bits = the 230400 soft bits of one frame (layout of On_OFDM_Frame()); *generation counts the frames pushed, from 0 */
+int dabgpu_frame_session_push_frame(dabgpu_frame_session *s, const int8_t *h_bits, int decode_fic, int tie_rule, uint64_t *generation);
+/* DABGPU_ERR_NOT_READY: that generation is gone (more than 8 frames old), was pushed without the FIC / without this sub-channel */
+int dabgpu_frame_session_fetch_fib_group(dabgpu_frame_session *s, uint64_t generation, int group, uint8_t *h_bytes /*[96]*/,
+                                         uint32_t *crc_ok_mask, uint64_t *path_error);
+int dabgpu_frame_session_fetch_cif(dabgpu_frame_session *s, uint64_t generation, const dabgpu_subchannel *sc, int cif,
+                                   uint8_t *h_bytes, size_t capacity, size_t *n_bytes, uint64_t *path_error);
+
 /* ==================================================================================================
  * Transmission modes II, III and IV (geometries of src/ofdm/dab_ofdm_params_ref.cpp:11-60).
  * The same demodulation pipeline, frame-aligned batches, through a size-generic kernel (FFT 512 / 256 / 1024 with the mode I

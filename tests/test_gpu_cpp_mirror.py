@@ -15,10 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "tests", "cpp", "mirror_harness")
 
 
+@pytest.mark.parametrize("batch", ["1", "0"], ids=["frame_batcher", "call_by_call"])
 @pytest.mark.parametrize("decode_threads", [1, 2], ids=["one_thread", "thread_per_sub_channel"])
-def test_cpp_mirror_stream_matches_oracle(oracle, tmp_path, decode_threads):
+def test_cpp_mirror_stream_matches_oracle(oracle, tmp_path, decode_threads, batch):
     """decode_threads = 2: the two MSC_Decoders of the harness are driven from two threads at once, as basic_radio's thread pool
-    drives one task per sub-channel (each decoder owns a device context): same files, byte for byte"""
+    drives one task per sub-channel (each decoder owns a device context): same files, byte for byte.
+    batch: DABGPU_MIRROR_BATCH -- with the frame batcher (default) OFDM_Demod hands every frame to one batched device decode and the
+    classes pick their bytes up once 16 consecutive CIFs went through it (from CIF 16 of this stream on); without it every
+    DecodeFIBGroup / DecodeCIF is its own launch.  Identical files either way."""
     import stream_model as SM
     if not os.path.exists(HARNESS):
         import __graft_entry__ as g
@@ -33,7 +37,7 @@ def test_cpp_mirror_stream_matches_oracle(oracle, tmp_path, decode_threads):
     args = [HARNESS, str(iq_path), str(out), "65536"]
     for s in subs:
         args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
-    env = dict(os.environ, DABGPU_HARNESS_THREADS=str(decode_threads))
+    env = dict(os.environ, DABGPU_HARNESS_THREADS=str(decode_threads), DABGPU_MIRROR_BATCH=batch)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "dab-radio_amd")); sys.path.insert(0, os.p
 import numpy as np, torch, dabgpu, dabsynth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=40)
+ap.add_argument("--frames", type=int, default=120)
 ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
 ap.add_argument("--subchannels", type=int, default=18)
 a = ap.parse_args()
@@ -33,17 +33,21 @@ with tempfile.TemporaryDirectory() as d:
     args = [harness, path, d, "65536"]
     for s in range(a.subchannels):
         args += [str(48 * s), "48", "2", "0"]
-    runs = []
-    for threads in (1, a.threads):
-        env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(threads))
+    runs = {}
+    for name, batch, threads in (("frame_batcher_one_thread", "1", 1), ("call_by_call_one_thread", "0", 1),
+                                 ("frame_batcher_decode_threads", "1", a.threads), ("call_by_call_decode_threads", "0", a.threads)):
+        env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(threads), DABGPU_MIRROR_BATCH=batch)
         env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
         res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
         if res.returncode != 0:
             print(res.stderr[-2000:], file=sys.stderr)
             sys.exit(res.returncode)
-        runs.append(json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]))
-out = runs[0]
-out["what"] = "OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame, all synchronous, one caller thread" % a.subchannels
-out["with_decode_threads"] = dict(runs[1], what="the same with the sub-channels of a CIF decoded by %d threads, one task per sub-channel as "
-                                  "basic_radio's thread pool runs them (each MSC_Decoder owns a device context)" % a.threads)
+        runs[name] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+out = dict(runs["frame_batcher_one_thread"])
+out["what"] = ("OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame from one caller thread; the frame batcher (default) decodes a "
+               "frame's FIC and sub-channels in one batched device call when OFDM_Demod completes it, the classes pick their bytes up "
+               "(dab-radio_amd/host/dab/dabgpu_frame_batcher.h; the first 4 frames of a stream decode call by call: the time de-interleaver's 16 CIFs)" % a.subchannels)
+out["call_by_call"] = dict(runs["call_by_call_one_thread"], what="DABGPU_MIRROR_BATCH=0: every DecodeFIBGroup / DecodeCIF is a synchronous launch + two copies (round 2's path)")
+out["with_decode_threads"] = {"threads": a.threads, "frame_batcher": runs["frame_batcher_decode_threads"], "call_by_call": runs["call_by_call_decode_threads"],
+                              "what": "the sub-channels of a CIF decoded by %d threads, one task per sub-channel as basic_radio's thread pool runs them" % a.threads}
 print(json.dumps(out))
