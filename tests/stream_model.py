@@ -176,3 +176,69 @@ def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=12
     stream = np.concatenate([tx[oracle.NB_NULL_PERIOD:oracle.NB_NULL_PERIOD + 30000 + timing_pad], tx])
     stream = stream + noise * (rng.standard_normal(stream.size) + 1j * rng.standard_normal(stream.size))
     return (stream * amplitude).astype(np.complex64), dict(fibs=fibs, payload=payload, plans=plans)
+
+
+def make_offair_like_capture(oracle, n_frames, subs, seed, cfo=2.3e-3, ppm=20.0, dropouts=((14, -0.03, 14000), (33, -0.03, 60000), (45, 0.2, 30000)),
+                             noise=2.0, clip_fraction=0.004):
+    """A stand-in for the reference's off-air recording (README.md:41 is a release asset, there is no network here): one ensemble of
+    n_frames transmission frames as an RTL-SDR-style 8-bit capture with the impairments a real reception has and the plain generator
+    above lacks:
+      * multipath: two echoes inside the cyclic prefix (37 and 180 samples late, -6 dB and -12 dB, rotated),
+      * sample-clock error of `ppm` parts per million (the fine time offset walks ~4 samples per 100 ms: windowed-sinc resampling),
+      * carrier offset `cfo` (cycles per sample), a DC offset and an IQ gain / phase imbalance (1.05, 3 degrees) of the tuner,
+      * additive noise, signal drop-outs (transmission frame, position inside it, samples): the first two wipe a NULL + phase reference
+        symbol and force a failed synchronisation, a NULL search and a re-acquisition; the third only ruins data symbols,
+      * u8 quantisation with clipping of the strongest `clip_fraction` of the components.
+    Returns (capture bytes uint8 [2 x samples], truth dict of make_ensemble_stream)."""
+    clean, truth = make_ensemble_stream(oracle, n_frames, subs, seed, cfo=0.0, noise=0.0, amplitude=1.0)
+    rng = np.random.default_rng(seed + 1)
+    x = clean.astype(np.complex128)
+    y = x.copy()
+    for delay, gain, phase in ((37, 0.5, 0.7), (180, 0.25, -2.1)):
+        y[delay:] += gain * np.exp(1j * phase) * x[:-delay]
+    # resample at (1 + ppm 1e-6): output sample n sits at input time n (1 + ppm 1e-6); 8-tap Hann-windowed sinc
+    n_out = int((y.size - 16) / (1.0 + ppm * 1e-6))
+    t = np.arange(n_out, dtype=np.float64) * (1.0 + ppm * 1e-6) + 4.0
+    i0 = np.floor(t).astype(np.int64)
+    frac = t - i0
+    z = np.zeros(n_out, np.complex128)
+    for k in range(-3, 5):
+        u = k - frac
+        w = np.sinc(u) * (0.5 + 0.5 * np.cos(np.pi * u / 4.0))
+        z += w * y[i0 + k]
+    n = np.arange(n_out, dtype=np.float64)
+    z *= np.exp(2j * np.pi * (cfo * n + 0.37))
+    rms = np.sqrt(np.mean(np.abs(z) ** 2))
+    for fr, where, length in dropouts:
+        a = int((fr + where) * oracle.NB_FRAME_SAMPLES) + 31234          # (the lead-in of make_ensemble_stream)
+        z[a:a + length] = 0.0
+    z += noise * (rng.standard_normal(n_out) + 1j * rng.standard_normal(n_out))
+    z += (0.03 - 0.02j) * rms
+    g, th = 1.05, np.deg2rad(3.0)
+    i_, q_ = z.real, g * (z.imag * np.cos(th) + z.real * np.sin(th))
+    comp = np.stack([i_, q_], axis=-1).reshape(-1)
+    full = np.quantile(np.abs(comp[::17]), 1.0 - clip_fraction)           # the strongest components clip
+    u8 = np.clip(np.rint(comp / full * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    return u8, truth
+
+
+def expected_decode(oracle, frames_bits, subs):
+    """what FIC_Decoder + MSC_Decoder of basic_radio produce from a sequence of frames: (FIB bytes of every CRC-valid FIB, decoded
+    bytes per sub-channel), composed from the oracle's functions"""
+    fibs = bytearray()
+    msc = [bytearray() for _ in subs]
+    deint = [oracle.Deinterleaver(s.length * 8) for s in subs]
+    for bits in frames_bits:
+        for g in range(4):
+            eb, em, _ = oracle.fic_decode_group(bits[g * 2304:(g + 1) * 2304], 0)
+            for i in range(3):
+                if em & (1 << i):
+                    fibs += eb[32 * i:32 * i + 30].tobytes()
+        for c in range(4):
+            cif = bits[9216 + c * 55296:9216 + (c + 1) * 55296]
+            for si, s in enumerate(subs):
+                deint[si].consume(cif[s.start_address * 64:(s.start_address + s.length) * 64])
+                lf = deint[si].deinterleave()
+                if lf is not None:
+                    msc[si] += oracle.msc_decode_logical(s, lf, 0)[0].tobytes()
+    return bytes(fibs), [bytes(m) for m in msc]
