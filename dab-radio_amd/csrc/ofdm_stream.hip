@@ -11,7 +11,7 @@
 //                           assembled: the demodulator reads its head from the stream's frame buffer and the rest
 //                           straight from the caller's block (dabgpu_frame_desc); only the unfinished frame at the end
 //                           of a block is carried over, by
-//   stream_copy_kernel      many workgroups per stream (the one bulk copy a stream can request per round)
+//   stream_copy_kernel      many workgroups per stream, once per call after the last round
 //   ofdm_sync_kernel        (ofdm_sync.hip) for the streams whose correlation window just filled
 //   ofdm_demod_kernel + ofdm_phase_kernel  (ofdm_demod.hip) for the streams whose frame buffer just filled
 //
@@ -62,15 +62,15 @@ struct BankView {
     float* freq;                     // [n] coarse + fine handed to the PLL
     int* sync_active;                // [n]
     dabgpu_frame_desc* desc;         // [n] demodulation request of the round
-    long long* copy_src;             // [n] bulk copy of the round: block sample offset ...
+    long long* copy_src;             // [n] carry-over copy of the call: block sample offset ...
     int* copy_dst;                   // [n] ... frame buffer offset ...
     int* copy_cnt;                   // [n] ... samples (0 = none)
     float* win;                      // [n][win_cap] L1 windows of the current block
     long long win_cap;
-    int* not_done;                   // [2] one counter per lane
+    int* not_done;                   // [2 lanes][8 rounds]: streams of the lane that need another round; round r counts in [r % 8] and
+                                     // clears [(r + 1) % 8] (no memset between the rounds)
 };
 
-constexpr int COPY_WGS = 16;         // workgroups per stream of the bulk copy
 
 template <int SRC>
 __device__ __forceinline__ float l1_window(const uint8_t* base, long long first, int k) {           // CalculateL1Average :922-932
@@ -96,7 +96,7 @@ __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __r
 template <int SRC>
 __global__ __launch_bounds__(256)
 void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
-                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode, int* __restrict__ not_done)
+                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode, int* __restrict__ not_done, int* __restrict__ next_not_done)
 {
     __shared__ StreamState S;
     __shared__ float win[256];
@@ -104,6 +104,7 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
     __shared__ long long sh_w;
     const int s = s0 + blockIdx.x, t = threadIdx.x;       // streams s0 .. s0 + n_streams - 1 (a lane of the bank, see bank_process_impl)
     if (s >= s0 + n_streams) return;
+    if (blockIdx.x == 0 && t == 0) *next_not_done = 0;    // the next round's counter (nobody counts in it during this round)
     if (t == 0) S = B.st[s];
     __syncthreads();
     const uint8_t* block = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
@@ -114,7 +115,7 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
     const int k = cfg.signal_l1_nb_samples;
 
     if (first_round) {
-        if (t == 0) { S.pos = 0; S.n_out = 0; S.avg_done = 0; }
+        if (t == 0) { S.pos = 0; S.n_out = 0; S.avg_done = 0; B.copy_cnt[s] = 0; }
         __syncthreads();
     }
 
@@ -164,8 +165,6 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
         if (t == 0) S.avg_done = 1;
         __syncthreads();
     }
-    if (t == 0) B.copy_cnt[s] = 0;
-
     // ---- the Process() loop (:241-274) up to the next device-kernel request ----
     while (S.pos < n_samples && S.pending == PEND_NONE) {
         const long long bpos = S.pos;                                               // buf[i] of the reference = block sample bpos + i
@@ -251,7 +250,10 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
                     corr[j] = (idx < have) ? frame[idx] : sample_at<SRC>(block, bpos + (idx - have));
                 }
             } else if (t == 0) {
-                B.copy_src[s] = S.pos; B.copy_dst[s] = have; B.copy_cnt[s] = (int)take;      // carried over by stream_copy_kernel
+                // the block ends inside this frame: its samples so far are carried over into the stream's frame buffer by
+                // stream_copy_kernel, ONCE per call after the last round -- a stream that asks for it has consumed its block and takes
+                // no further part in the rounds (a copy launch per round, empty in all rounds but the last, cost 67 us each)
+                B.copy_src[s] = S.pos; B.copy_dst[s] = have; B.copy_cnt[s] = (int)take;
             }
             __syncthreads();
             if (t == 0) {
@@ -320,7 +322,8 @@ void stream_l1_kernel(BankView B, const uint8_t* __restrict__ iq, size_t stream_
     }
 }
 
-// the round's bulk copy block -> frame buffer (the unfinished frame at the end of a block), COPY_WGS workgroups per stream
+// the carry-over copy block -> frame buffer (the unfinished frame at the end of a block), COPY_WGS workgroups per stream, once per call
+constexpr int COPY_WGS = 16;
 template <int SRC>
 __global__ __launch_bounds__(256)
 void stream_copy_kernel(BankView B, int s0, const uint8_t* __restrict__ iq, size_t stream_stride) {
@@ -333,7 +336,13 @@ void stream_copy_kernel(BankView B, int s0, const uint8_t* __restrict__ iq, size
     const int per = (((cnt + COPY_WGS - 1) / COPY_WGS) + 255) & ~255;
     const int a = blockIdx.x * per;
     const int b = (a + per < cnt) ? (a + per) : cnt;
-    for (int i = a + threadIdx.x; i < b; i += 256) dst[i] = sample_at<SRC>(src, first + i);
+    int i = a + threadIdx.x;
+    for (; i + 3 * 256 < b; i += 4 * 256) {                   // four independent loads in flight
+        const f2 v0 = sample_at<SRC>(src, first + i), v1 = sample_at<SRC>(src, first + i + 256), v2 = sample_at<SRC>(src, first + i + 512),
+                 v3 = sample_at<SRC>(src, first + i + 768);
+        dst[i] = v0; dst[i + 256] = v1; dst[i + 512] = v2; dst[i + 768] = v3;
+    }
+    for (; i < b; i += 256) dst[i] = sample_at<SRC>(src, first + i);
 }
 
 __global__ void stream_report_kernel(BankView B, int n_streams, int* __restrict__ n_frames, dabgpu_stream_status* __restrict__ status,
@@ -400,10 +409,10 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     CK(hipMemsetAsync(b->view.sync, 0, b->n * sizeof(dabgpu_sync_state), s));
     CK(hipMemsetAsync(b->view.sync_active, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.desc, 0xFF, b->n * sizeof(dabgpu_frame_desc), s));
-    CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.ring, 0, b->n * (size_t)b->view.g.null_period * sizeof(f2), s));
     CK(hipMemsetAsync(b->view.corr, 0, b->n * (size_t)b->view.g.n_corr * sizeof(f2), s));
-    CK(hipMemsetAsync(b->view.not_done, 0, 2 * sizeof(int), s));
+    CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
+    CK(hipMemsetAsync(b->view.not_done, 0, 16 * sizeof(int), s));
 #undef CK
     return DABGPU_OK;
 }
@@ -443,7 +452,7 @@ int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, co
     alloc((void**)&b->view.copy_src, n_streams * sizeof(long long));
     alloc((void**)&b->view.copy_dst, n_streams * sizeof(int));
     alloc((void**)&b->view.copy_cnt, n_streams * sizeof(int));
-    alloc((void**)&b->view.not_done, 2 * sizeof(int));
+    alloc((void**)&b->view.not_done, 16 * sizeof(int));
     alloc((void**)&b->d_corr_out, n_streams * (size_t)G.n_sym * 2 * sizeof(float));
     alloc((void**)&b->d_status, n_streams * sizeof(dabgpu_stream_status));
     if (!st) st = dabgpu_check_hip(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking), "hipStreamCreate(stream bank)");
@@ -521,6 +530,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         CK(hipEventRecord(b->ev_fork, s));
         CK(hipStreamWaitEvent(b->side, b->ev_fork, 0));
     }
+    // (an error inside the rounds must not leave work on the side stream unordered with the caller's stream: the caller may free the
+    // block and the output buffers as soon as the call has returned)
+#define CKL(call) do { st = dabgpu_check_hip((call), #call); if (st) { if (n_lanes == 2) (void)hipStreamSynchronize(b->side); return st; } } while (0)
     const size_t sb = src_sample_bytes<SRC>::value;
     int h_not_done[2] = {1, 0};
     for (int round = 0; h_not_done[0] + h_not_done[1] != 0; round++) {
@@ -528,34 +540,38 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
             hipStream_t ls = lane_stream[l];
             const int s0 = lane_lo[l], cnt = lane_lo[l + 1] - lane_lo[l];
             const uint8_t* iq_l = static_cast<const uint8_t*>(d_iq) + (size_t)s0 * stream_stride_samples * sb;
-            CK(hipMemsetAsync(b->view.not_done + l, 0, sizeof(int), ls));
+            if (round == 0) CKL(hipMemsetAsync(b->view.not_done + 8 * l, 0, sizeof(int), ls));
             hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)cnt), dim3(256), 0, ls, b->view, s0, cnt, static_cast<const uint8_t*>(d_iq),
                                stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0, ring_mode,
-                               b->view.not_done + l);
-            CK(hipGetLastError());
-            hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)cnt), dim3(256), 0, ls, b->view, s0, static_cast<const uint8_t*>(d_iq),
-                               stream_stride_samples);
-            CK(hipGetLastError());
+                               b->view.not_done + 8 * l + (round & 7), b->view.not_done + 8 * l + ((round + 1) & 7));
+            CKL(hipGetLastError());
             float* corr_l = b->d_corr_out + (size_t)s0 * G.n_sym * 2;
             if (G.mode == 1) {
-                CK(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
+                CKL(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
                                             c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls));
-            } else if ((st = dabgpu_launch_ofdm_demod_mode(c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
+            } else if ((st = dabgpu_launch_ofdm_demod_mode(     /* (modes II-IV run in one lane: n_lanes == 1, s0 == 0, cnt == n) */c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
                                                            b->view.desc, d_iq, stream_stride_samples, ls))) {
+                if (n_lanes == 2) (void)hipStreamSynchronize(b->side);
                 return st;
             }
-            CK(dabgpu_launch_ofdm_phase(corr_l, cnt, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[s0].freq_fine,
+            CKL(dabgpu_launch_ofdm_phase(corr_l, cnt, b->cfg.sync.fine_freq_update_beta, nullptr, &b->view.sync[s0].freq_fine,
                                         (int)(sizeof(dabgpu_sync_state) / sizeof(float)), b->view.desc + s0, G.n_sym, G.n_fft, ls));
             // (after the phase kernel: the synchroniser of frame k sees the fine frequency the phase of frame k - 1 left, as in the reference)
-            CK(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + (size_t)s0 * NB_CORR + NB_NULL_PERIOD), NB_CORR, cnt, &b->cfg.sync,
+            CKL(dabgpu_launch_sync(reinterpret_cast<const float*>(b->view.corr + (size_t)s0 * NB_CORR + NB_NULL_PERIOD), NB_CORR, cnt, &b->cfg.sync,
                                   b->view.sync + s0, nullptr, nullptr, c->d_tw, d_prs, d_prs_time_ref, b->view.sync_active + s0, G.mode, ls));
         }
         if (round + 1 >= blind_rounds) {
-            for (int l = 0; l < n_lanes; l++) CK(hipMemcpyAsync(&h_not_done[l], b->view.not_done + l, sizeof(int), hipMemcpyDeviceToHost, lane_stream[l]));
-            for (int l = 0; l < n_lanes; l++) CK(hipStreamSynchronize(lane_stream[l]));
+            for (int l = 0; l < n_lanes; l++) CKL(hipMemcpyAsync(&h_not_done[l], b->view.not_done + 8 * l + (round & 7), sizeof(int), hipMemcpyDeviceToHost, lane_stream[l]));
+            for (int l = 0; l < n_lanes; l++) CKL(hipStreamSynchronize(lane_stream[l]));
         }
-        if (round > (1 << 22)) { dabgpu_set_error("stream_bank_process: no progress"); return DABGPU_ERR_HIP; }
+        if (round > (1 << 22)) { dabgpu_set_error("stream_bank_process: no progress"); if (n_lanes == 2) (void)hipStreamSynchronize(b->side); return DABGPU_ERR_HIP; }
     }
+    for (int l = 0; l < n_lanes; l++) {                                   // the carry-over copies of the call, every lane its own streams
+        hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)(lane_lo[l + 1] - lane_lo[l])), dim3(256), 0, lane_stream[l], b->view,
+                           lane_lo[l], static_cast<const uint8_t*>(d_iq), stream_stride_samples);
+        CKL(hipGetLastError());
+    }
+#undef CKL
     if (n_lanes == 2) {
         CK(hipEventRecord(b->ev_join, b->side));
         CK(hipStreamWaitEvent(s, b->ev_join, 0));
