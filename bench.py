@@ -185,8 +185,11 @@ class Pipeline:
         self.layout, self.fmt_f32 = layout, dabgpu.IQ_FORMATS.index("raw_f32l")
         self.H = 5 if inflight == 1 else 8
         prs, mapper, _ = dabgpu.host_tables()
+        # two stored transmission frames that repeat (8 CIFs of changing payload, time interleaved): decoded bytes then prove WHICH
+        # ring slots / ages / frames in flight they came from (tools/dabsynth.py)
         self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs)
-        self.iq_f = torch.view_as_real(self.iq)
+        self.iq_f = torch.view_as_real(self.iq)                # [2][E][196608][2]
+        self.frame_of_slot = {}                                # ring slot -> number of the frame it holds
         self.n_sub = dabsynth.N_SUB
         self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
         self.ctxs = [ctx] + [dabgpu.Context(device.index) for _ in range(inflight - 1)]
@@ -203,8 +206,12 @@ class Pipeline:
         self.ev_demod, self.ev_msc = {}, {}
 
     # the three stages of frame-slot `slot` on lane k (context k, stream k)
-    def demod(self, slot, k=0):
-        self.ctxs[k].ofdm_demod_frames_history(self.iq_f, self.fmt_f32, self.E, self.hist[:, slot], cp_corr=self.corr[k],
+    def demod(self, slot, k=0, frame=None):
+        """transmission frame `frame` (default: the next one after what the ring holds) of every ensemble into ring slot `slot`"""
+        if frame is None:
+            frame = self.frame_of_slot.get(slot, slot - self.H) + self.H       # (stage timing loops walk the ring in order)
+        self.frame_of_slot[slot] = frame
+        self.ctxs[k].ofdm_demod_frames_history(self.iq_f[frame % self.mux.n_frames], self.fmt_f32, self.E, self.hist[:, slot], cp_corr=self.corr[k],
                                                bits_frame_stride=self.stride, bits_layout=self.layout, stream=self.streams[k].cuda_stream)
 
     def fic(self, slot, k=0):
@@ -220,20 +227,22 @@ class Pipeline:
         torch, j, n = self.torch, self.j, self.inflight
         k, slot, st = j % n, j % self.H, self.streams[j % n]
         self.j += 1
+        self.last_frame_of_lane = getattr(self, "last_frame_of_lane", {})
+        self.last_frame_of_lane[k] = j
         if n == 1:
             if on_demod:
-                on_demod(lambda: self.demod(slot))
+                on_demod(lambda: self.demod(slot, 0, j))
             else:
-                self.demod(slot)
+                self.demod(slot, 0, j)
             self.fic(slot); self.msc(slot)
             return
         w = self.ev_msc.pop(j - self.H + 4, None)                    # the last reader of the slot this frame overwrites
         if w is not None:
             st.wait_event(w)
         if on_demod:
-            on_demod(lambda: self.demod(slot, k))
+            on_demod(lambda: self.demod(slot, k, j))
         else:
-            self.demod(slot, k)
+            self.demod(slot, k, j)
         ev = torch.cuda.Event(); ev.record(st)
         self.ev_demod[j] = ev
         self.fic(slot, k)
@@ -262,16 +271,23 @@ class Pipeline:
         return e0.elapsed_time(e1) / reps
 
     def check(self, dabgpu):
+        """the outputs of the last frame of every lane against what was transmitted: frame j carries fibs[j mod 2], its CIF c decodes to
+        payload[(4 j + c - 15) mod 8] -- the payload changes with every CIF, so a wrong ring slot, a wrong age or frames in flight in
+        the wrong order cannot pass"""
         import numpy as np
-        torch, E, nd = self.torch, self.E, self.mux.n
+        torch, E, nd, P = self.torch, self.E, self.mux.n, self.mux.period
         out = {"fib_crc_pass": 0, "fib_crc_expected": E * 12 * self.inflight, "fib_bytes_equal_transmitted": True,
-               "msc_bytes_equal_transmitted": True, "ensembles_checked": E, "distinct_multiplexes": nd, "frames_in_flight": self.inflight}
+               "msc_bytes_equal_transmitted": True, "ensembles_checked": E, "distinct_multiplexes": nd, "frames_in_flight": self.inflight,
+               "payload_period_cifs": P, "frames_checked": []}
         idx = torch.arange(E, device=self.hist.device) % nd
-        exp = self.mux.payload[idx].unsqueeze(1).expand(E, 4, self.n_sub, 192)
         for k in range(self.inflight):                               # the outputs of the last frame of every lane
+            j = self.last_frame_of_lane[k]
+            out["frames_checked"].append(int(j))
+            cifs = [(4 * j + c - 15) % P for c in range(4)]
+            exp = self.mux.payload[idx][:, cifs]                      # [E, 4, n_sub, 192]
             res_f = self.fic_res[k].cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
             out["fib_crc_pass"] += int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
-            out["fib_bytes_equal_transmitted"] &= bool(torch.equal(self.fic_out[k], self.mux.fibs[idx]))
+            out["fib_bytes_equal_transmitted"] &= bool(torch.equal(self.fic_out[k], self.mux.fibs[idx, j % self.mux.n_frames]))
             out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k].view(E, 4, self.n_sub, 192), exp))
         return out
 

@@ -221,7 +221,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
     for (int k = 1; k < 8; k++) w2[k - 1] = tw[4 * lane * k];
     f2 w3[7];
-    constexpr bool W3_LDS = BANK || CLASSED || (DABGPU_EXP & 16);     // (class order keeps a second set of scatter positions instead)
+    constexpr bool W3_LDS = BANK || (CLASSED && !(DABGPU_EXP & 64)) || (DABGPU_EXP & 16);     // (class order keeps a second set of scatter positions instead)
     if constexpr (W3_LDS) {
         if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
     } else {
@@ -286,7 +286,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int row_voff_c = (t / 12) * (NB_CIF_BITS / 16) + 16 * (t % 12);      // CLASSED: class t / 12, bytes 16 (t mod 12) .. + 15 of this symbol's 192
     auto row_write = [&](const int row, const u4v o) __attribute__((always_inline)) {
         if (t < NB_SYM_BITS / 16) {
-            if (CLASSED && row >= NB_FIC_SYMBOLS) {                               // (uniform) symbol s of CIF q: 192 bytes per class
+            if (CLASSED && !(DABGPU_EXP & 32) && row >= NB_FIC_SYMBOLS) {         // (uniform) symbol s of CIF q: 192 bytes per class
                 const int q = (row - NB_FIC_SYMBOLS) / NB_CIF_SYMBOLS, sy = (row - NB_FIC_SYMBOLS) % NB_CIF_SYMBOLS;
                 __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, row_voff_c, NB_FIC_SYMBOLS * NB_SYM_BITS + q * NB_CIF_BITS + sy * (NB_SYM_BITS / 16), BUF_NT);
             } else {

@@ -20,9 +20,9 @@ a = ap.parse_args()
 dev = torch.device("cuda", 0)
 prs, mapper, _ = dabgpu.host_tables()
 mux = dabsynth.Multiplex(1, 21, dev)
-frame = dabsynth.modulate(mux.frame_bits, prs, mapper)[0]                      # PRS + 75 symbols, NULL (zeros) last
+frames2 = dabsynth.modulate(mux.frame_bits[0], prs, mapper)                     # the two transmission frames that repeat (PRS + 75 symbols, NULL last)
 n = torch.arange(a.frames * dabsynth.NB_FRAME_SAMPLES + 2656 + 5000, device=dev, dtype=torch.float64)
-x = torch.cat([torch.zeros(5000 + 2656, dtype=torch.complex64, device=dev), frame.repeat(a.frames)])
+x = torch.cat([torch.zeros(5000 + 2656, dtype=torch.complex64, device=dev), frames2.reshape(-1).repeat((a.frames + 1) // 2)[:a.frames * dabsynth.NB_FRAME_SAMPLES]])
 x = x * torch.polar(torch.ones_like(n), 2 * np.pi * 1.3e-3 * n).to(torch.complex64)
 x[:5000] = x[-5000:]                                                              # some signal before the first NULL
 x = x + 0.02 * torch.view_as_complex(torch.randn((x.numel(), 2), device=dev))

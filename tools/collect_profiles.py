@@ -37,7 +37,7 @@ def counter_average(path, counter, kernel="ofdm_demod_kernel"):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
-    rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
     out = os.path.join(root, f"summary_{tag}")
     os.makedirs(out, exist_ok=True)
     stats = find(os.path.join(root, "prof"), "*kernel_stats.csv")
@@ -72,8 +72,8 @@ def main():
             path = find(os.path.join(root, f"pmc_dec_{name}_{layout}"), "*counter_collection.csv")
             if not path:
                 continue
-            for kern in ("vit_prep_ring4c_kernel", "vit_prep_ring4_kernel", "vit_lanes_kernel<0, 1, 4>", "vit_lanes_kernel<0, 1, 5>", "vit_lanes_kernel<0, 4, 4>",
-                         "ofdm_demod_kernel"):
+            for kern in ("vit_prep_ring4c_kernel", "vit_prep_ring4_kernel", "vit_prep_direct_kernel", "vit_lanes_kernel<0, 1, 4>", "vit_lanes_kernel<0, 1, 5>",
+                         "vit_lanes_kernel<0, 4, 4>", "vit_octet_kernel<0>", "ofdm_demod_kernel"):
                 avg, n, _ = counter_average(path, counter, kern)
                 if avg is not None:
                     per.setdefault(kern, {})[f"{name}_kb_avg"] = avg

@@ -119,43 +119,59 @@ def random_frames(n_frames, seed, device, mapper, prs, chunk=32):
 
 class Multiplex:
     """The canonical multiplex of SURVEY 8(d) config 4 for `n` distinct ensembles: CRC-valid FIBs and 18 x 192-byte sub-channel
-    payloads per ensemble, channel coded; every CIF of an ensemble repeats the same logical frames, so the 16-CIF time
-    interleaver is in steady state from one stored transmission frame."""
+    payloads per ensemble, channel coded and TIME INTERLEAVED (clause 12): the payload changes with every CIF, with a period of
+    `period` CIFs = period / 4 transmission frames, so that a sequence of period / 4 stored frames repeats a legal, steady-state
+    transmission in which every decoded logical frame tells which CIFs it was assembled from (a wrong ring slot or age, or two frames
+    in flight in the wrong order, decode to another CIF's payload or to garbage -- with one repeated frame they would not show).
+    Decoded CIF r (counted from the first frame) carries payload[(r - 15) mod period]; frame j carries fibs[j mod (period / 4)]."""
 
-    def __init__(self, n, seed, device):
+    def __init__(self, n, seed, device, period=8):
+        assert period % 4 == 0 and period >= 4
         g = torch.Generator(device=device)
         g.manual_seed(seed)
-        self.n = n
-        fib_data = torch.randint(0, 256, (n, 4, 3, 30), generator=g, device=device, dtype=torch.uint8)
-        self.fibs = torch.cat([fib_data, crc16(fib_data)], dim=-1).reshape(n, 4, 96)
+        self.n, self.period, self.n_frames = n, period, period // 4
+        nf = self.n_frames
+        fib_data = torch.randint(0, 256, (n, nf, 4, 3, 30), generator=g, device=device, dtype=torch.uint8)
+        self.fibs = torch.cat([fib_data, crc16(fib_data)], dim=-1).reshape(n, nf, 4, 96)
         pr96 = torch.from_numpy(prbs_bytes(96)).to(device)
         fic_mother = conv_encode(bytes_to_bits(self.fibs ^ pr96))
-        fic_tx = fic_mother[..., torch.from_numpy(kept_index([(16, 21), (15, 3)])).to(device)]        # [n,4,2304]
-        self.payload = torch.randint(0, 256, (n, N_SUB, SUB_BYTES), generator=g, device=device, dtype=torch.uint8)
+        fic_tx = fic_mother[..., torch.from_numpy(kept_index([(16, 21), (15, 3)])).to(device)]        # [n,nf,4,2304]
+        self.payload = torch.randint(0, 256, (n, period, N_SUB, SUB_BYTES), generator=g, device=device, dtype=torch.uint8)
         pr192 = torch.from_numpy(prbs_bytes(SUB_BYTES)).to(device)
         kidx = torch.from_numpy(kept_index([(8, 45), (7, 3)])).to(device)                               # EEP 3-A, n = 8
-        msc_tx = torch.empty((n, N_SUB, 3072), dtype=torch.uint8, device=device)
-        for e0 in range(0, n, 256):
-            msc_tx[e0:e0 + 256] = conv_encode(bytes_to_bits(self.payload[e0:e0 + 256] ^ pr192))[..., kidx]
-        cif = msc_tx.reshape(n, 55296)
-        self.frame_bits = torch.cat([fic_tx.reshape(n, 9216), cif.repeat(1, 4)], dim=1).reshape(n, 75, 3072)
+        logical = torch.empty((n, period, N_SUB, 3072), dtype=torch.uint8, device=device)
+        for e0 in range(0, n, 64):
+            logical[e0:e0 + 64] = conv_encode(bytes_to_bits(self.payload[e0:e0 + 64] ^ pr192))[..., kidx]
+        # time interleaver: transmitted CIF s carries bit i of the logical frame that is bitrev4(i mod 16) CIFs older
+        # (the receiver takes bit i from the CIF that is 15 - bitrev4(i mod 16) CIFs old, cif_deinterleaver.cpp:57-68)
+        tx = torch.empty_like(logical)
+        for k in range(16):
+            d = int("{:04b}".format(k)[::-1], 2)
+            for s_ in range(period):
+                tx[:, s_, :, k::16] = logical[:, (s_ - d) % period, :, k::16]
+        cifs = tx.reshape(n, nf, 4 * 55296)
+        self.frame_bits = torch.cat([fic_tx.reshape(n, nf, 9216), cifs], dim=2).reshape(n, nf, 75, 3072)
 
     def subchannels(self, dabgpu):
         return [dabgpu.SubChannel(SUB_CU * s, SUB_CU, 0, 0, 2, 0) for s in range(N_SUB)]
 
 
-def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05):
+def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8):
     """IQ of n_ensembles ensembles built from n_distinct (<= 64) seeded multiplexes: ensemble e carries
-    multiplex e % n_distinct; every ensemble gets its own noise realisation.  Returns (iq [E,196608] complex64, Multiplex)."""
-    mux = Multiplex(n_distinct, seed, device)
-    base = modulate(mux.frame_bits, prs, mapper)
-    iq = torch.empty((n_ensembles, NB_FRAME_SAMPLES), dtype=torch.complex64, device=device)
+    multiplex e % n_distinct; every ensemble gets its own noise realisation.  Returns (iq [period / 4][E][196608] complex64 -- the
+    period / 4 transmission frames that repeat -- and the Multiplex)."""
+    mux = Multiplex(n_distinct, seed, device, period)
+    nf = mux.n_frames
+    iq = torch.empty((nf, n_ensembles, NB_FRAME_SAMPLES), dtype=torch.complex64, device=device)
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1)
-    for e0 in range(0, n_ensembles, n_distinct):
-        m = min(n_distinct, n_ensembles - e0)
-        iq[e0:e0 + m] = base[:m]
-        if noise:
-            nz = torch.randn((m, NB_FRAME_SAMPLES, 2), generator=g, dtype=torch.float32, device=device)
-            iq[e0:e0 + m] += noise * torch.view_as_complex(nz)
+    for f in range(nf):
+        base = modulate(mux.frame_bits[:, f].contiguous(), prs, mapper)
+        for e0 in range(0, n_ensembles, n_distinct):
+            m = min(n_distinct, n_ensembles - e0)
+            iq[f, e0:e0 + m] = base[:m]
+            if noise:
+                nz = torch.randn((m, NB_FRAME_SAMPLES, 2), generator=g, dtype=torch.float32, device=device)
+                iq[f, e0:e0 + m] += noise * torch.view_as_complex(nz)
+        del base
     return iq, mux

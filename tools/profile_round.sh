@@ -1,18 +1,17 @@
 #!/bin/bash
 # Round profile pass on the GPU box: kernel stats + the two HBM counter passes of the bench workload, and the
 # side benches.  Summaries land under gpurun_out/ (scratch); tools/collect_profiles.py copies them to profiles/.
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh v1 r02'
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh v1 r03'
 set -u
 TAG=${1:-vX}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
 BENCH_ARGS="--no-cpu-baseline --no-check --no-extras"
-ROUND=${2:-r02}
+ROUND=${2:-r03}
 python3 bench.py > $OUT/bench_n1_$TAG.json 2> $OUT/bench_n1_$TAG.err
 # the profiled runs use the workgroup size the bench run chose on this box (its set-up timing would add launches of the other sizes)
-SPB=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench_n1_$TAG.json').read().strip().splitlines()[-1])['config']['symbols_per_block'])" 2>/dev/null || echo 25)
-BENCH_ARGS="$BENCH_ARGS --spb $SPB"
+# (symbols_per_block = 0: the library's own one-time calibration picks the run length in every process)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python3 bench.py --steps 20 --warmup 3 $BENCH_ARGS > $OUT/prof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 bench.py --steps 3 --warmup 1 $BENCH_ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 bench.py --steps 3 --warmup 1 $BENCH_ARGS > $OUT/pmc_write.log 2>&1
@@ -30,6 +29,11 @@ for L in classed natural; do
 done
 python3 tools/bench_decode.py --ensembles 4096 --steps 6 --hist-layout natural > $OUT/bench_decode_4096_natural_$TAG.json 2> $OUT/bench_decode_4096_natural_$TAG.err
 python3 tools/bench_io.py > $OUT/bench_io_$TAG.json 2> $OUT/bench_io_$TAG.err
+for F in 1024 4096 16384; do python3 tools/bench_fic.py --frames $F; done > $OUT/bench_fic_$TAG.json 2> $OUT/bench_fic_$TAG.err
+LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devices 0 --ensembles 8192 --steps 10 > $OUT/bench_cpp_host_$TAG.json 2> $OUT/bench_cpp_host_$TAG.err
+LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devices 0,0 --ensembles 4096 --steps 10 >> $OUT/bench_cpp_host_$TAG.json 2>> $OUT/bench_cpp_host_$TAG.err
+# SQ / GRBM / TCC counters of the decoder and the demodulator at 4096 ensembles (own passes, program directly after --)
+bash tools/prof_counters.sh $TAG > $OUT/prof_counters_$TAG.log 2>&1
 python3 tools/bench_stream.py > $OUT/bench_stream_$TAG.json 2> $OUT/bench_stream_$TAG.err
 python3 tools/bench_dabplus.py > $OUT/bench_dabplus_$TAG.json 2> $OUT/bench_dabplus_$TAG.err
 # keep the merge-back small: reduce on the box, then drop the raw dumps
