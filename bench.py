@@ -35,13 +35,17 @@ for _p in (ROOT, os.path.join(ROOT, "dab-radio_amd"), os.path.join(ROOT, "tools"
         sys.path.insert(0, _p)
 
 ALGO_BYTES_PER_FRAME = 196608 * 8 + 230400          # c32 IQ read + int8 soft bits written
+NULL_SYMBOL_BYTES = 2656 * 8                          # the null symbol is part of SURVEY 8(d)'s figure but no demodulator reads it
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8 TB/s spec
 REALTIME_FRAMES_PER_S = 2.048e6 / 196608              # 10.4167
 # Viterbi kernels: VALU-issue bound.  peak trellis steps/s = SIMDs x clock x codewords per wavefront /
 # (VALU instructions per wavefront-step x cycles per instruction); instruction counts from the ISA of this build
 # (tools/isa_count.py), 4 cycles per packed-integer / cross-lane instruction (tools/ubench/pk16_rate.hip), 2.4 GHz, 1024 SIMDs.
-VIT_LANES_INSTR_PER_STEP = 183.0            # 181 + the de-puncturing v_perm_b32 + the row address (round 3: punctured symbol array)
-VIT_OCTET_INSTR_PER_STEP = 48.0             # vit_octet_kernel, 8 codewords per wavefront (forward pass, fast path)
+# Round 3: the two batch mappings are priced with the MEASURED instruction count of a whole wavefront (prologue, forward pass,
+# chain-back, CRC) -- SQ_INSTS_VALU / SQ_WAVES / trellis steps per codeword of profiles/r03/counters_v1.json:
+#   vit_lanes_kernel  280790.7 / 1542 = 182.1 (its forward loop alone is 169 in the ISA), vit_octet_kernel 31036.1 / 774 = 40.1
+VIT_LANES_INSTR_PER_STEP = 182.1
+VIT_OCTET_INSTR_PER_STEP = 40.1
 VIT_WAVE_INSTR_PER_STEP = 23.0
 VIT_CYCLES_PER_INSTR = 4.0
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
@@ -150,13 +154,14 @@ def cpu_baseline(seconds_target=12.0):
 def hbm_roofline(kernel, k_ms, frames):
     achieved = ALGO_BYTES_PER_FRAME * frames / (k_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+            "frac": achieved / HBM_PEAK_GBS, "achieved_excl_null": achieved * (1.0 - NULL_SYMBOL_BYTES / ALGO_BYTES_PER_FRAME),
+            "traffic": None, "kernel_ms": k_ms,
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * frames}
 
 
 def viterbi_roofline(kernel, steps, k_ms, lanes):
     """VALU-issue bound of the trellis recursion; `lanes`: codewords per wavefront of the mapping -- 64 (one lane per codeword), 8 (eight
-    lanes per codeword) or 1 / False (one wavefront per codeword).  Counter evidence: profiles/r03/counters_*.json"""
+    lanes per codeword) or 1 / False (one wavefront per codeword).  Counter evidence (VALU instructions per wavefront, issue share, clock under the profiler): profiles/r03/counters_*.json"""
     per_wave = float(lanes) if lanes else 1.0
     if lanes is True:
         per_wave = 64.0
@@ -303,7 +308,15 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     for k in range(reps):
         p.demod(k % p.H); p.fic(k % p.H)
     e1.record(); torch.cuda.synchronize()
-    t_c2 = e0.elapsed_time(e1) / reps
+    t_c2_seq = e0.elapsed_time(e1) / reps
+    # configs[2] with two frames in flight like configs[3]: frame j on lane j mod 2 (demod -> FIC in stream order; slot j mod 8 is reused
+    # by frame j + 8 on the same lane), so the FIC trellis of frame j (two wavefronts per SIMD) runs beside the demodulation of j + 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(4 * reps):
+        p.demod(k % p.H, k % 2, k); p.fic(k % p.H, k % 2)
+    torch.cuda.synchronize()
+    t_c2 = (time.perf_counter() - t0) / (4 * reps) * 1e3
     t0 = time.perf_counter()
     for k in range(reps):                                     # one frame at a time on one stream
         p.demod(k % p.H); p.fic(k % p.H); p.msc(k % p.H)
@@ -321,6 +334,7 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     fic_kernel = {64: "vit_lanes_kernel (FIC)", 8: "vit_octet_kernel (FIC)", 0: "viterbi_kernel (FIC)"}[lanes_fic]
     c2 = {"workload": f"BASELINE configs[2]: full OFDM demod + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
           "ms_per_step": t_c2, "frames_per_s": E / t_c2 * 1e3, "x_realtime": E / t_c2 * 1e3 / REALTIME_FRAMES_PER_S,
+          "frames_in_flight": 2, "ms_per_step_one_frame_at_a_time": t_c2_seq, "frames_per_s_one_frame_at_a_time": E / t_c2_seq * 1e3,
           "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic},
           "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
                        viterbi_roofline(fic_kernel, p.fic_steps, t_fic, lanes_fic)],

@@ -249,42 +249,49 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 // symbols_per_block = 0: which run length is fastest depends on the batch and on the box (a whole frame per workgroup
 // is one static round of workgroups on a full chip -- fastest where all CUs run at one speed, much slower where they do not; three
 // runs per frame let the dispatcher rebalance but transform two halo symbols more).  Small batches take 25.  A batch that fills the chip
-// is timed once per context and batch size -- 3 candidates x 3 launches on the caller's own buffers (the outputs are the same whatever
-// the run length; the phase tail, which updates the caller's fine-frequency state, is left out) -- and the winner is cached.
-static int demod_auto_spb(dabgpu_ctx* c, size_t n_frames, hipStream_t s, const std::function<hipError_t(int)>& launch) {
+// is timed once per context, batch size and kernel variant on the caller's own buffers (the outputs are the same whatever the run
+// length; the phase tail, which updates the caller's fine-frequency state, is left out) and the winner is cached.  The clock of an
+// idle GPU takes tens of milliseconds of load to settle (profiles/r01/ab_notes.md), and it keeps drifting afterwards: untimed rounds
+// until 40 ms of kernels have run (at most 12 rounds), then three timed rounds that visit the candidates in turn (2 launches each), summed per candidate --
+// a candidate is never judged by one moment of the clock.
+static int demod_auto_spb(dabgpu_ctx* c, size_t n_frames, int variant, hipStream_t s, const std::function<hipError_t(int)>& launch) {
     if (n_frames < 512) return 25;
     {
         DABGPU_HOST_LOCK(c);
-        for (const auto& e : c->spb_cache) if (e.n_frames == n_frames) return e.spb;
+        for (const auto& e : c->spb_cache) if (e.n_frames == n_frames && e.variant == variant) return e.spb;
     }
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 25; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); (void)hipGetLastError(); return 25; }
     static const int cand[3] = {25, 38, 75};
-    float best_ms = 0.0f;
-    int best = 25;
+    float sum_ms[3] = {0.0f, 0.0f, 0.0f}, warm_ms = 0.0f;
     bool ok = true;
-    for (int pass = 0; pass < 2 && ok; pass++)                       // the second pass counts: both see the same clock state
+    for (int pass = 0, timed = 0; timed < 3 && pass < 16 && ok; pass++) {
+        const bool counts = warm_ms >= 40.0f || pass >= 12;
         for (int k = 0; k < 3 && ok; k++) {
-            ok = launch(cand[k]) == hipSuccess && hipEventRecord(e0, s) == hipSuccess;
-            for (int r = 0; r < 3 && ok; r++) ok = launch(cand[k]) == hipSuccess;
+            ok = hipEventRecord(e0, s) == hipSuccess;
+            for (int r = 0; r < 2 && ok; r++) ok = launch(cand[k]) == hipSuccess;
             float ms = 0.0f;
             ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-            if (ok && pass == 1 && (k == 0 || ms < best_ms)) { best_ms = ms; best = cand[k]; }
+            if (counts) sum_ms[k] += ms; else warm_ms += ms;
         }
+        timed += counts;
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (!ok) { (void)hipGetLastError(); return 25; }
+    int best = 0;
+    for (int k = 1; k < 3; k++) if (sum_ms[k] < sum_ms[best]) best = k;
     DABGPU_HOST_LOCK(c);
-    if (c->spb_cache.size() >= 16) c->spb_cache.erase(c->spb_cache.begin());
-    c->spb_cache.push_back({n_frames, best});
-    return best;
+    if (c->spb_cache.size() >= 32) c->spb_cache.erase(c->spb_cache.begin());
+    c->spb_cache.push_back({n_frames, variant, cand[best]});
+    return cand[best];
 }
 
 extern "C" int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx* c, size_t n_frames) {
     if (!c) return 0;
     DABGPU_HOST_LOCK(c);
-    for (const auto& e : c->spb_cache) if (e.n_frames == n_frames) return e.spb;
+    for (auto e = c->spb_cache.rbegin(); e != c->spb_cache.rend(); ++e) if (e->n_frames == n_frames) return e->spb;      // the latest
     return n_frames < 512 ? 25 : 0;
 }
 
@@ -309,7 +316,7 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     if (symbols_per_block <= 0)
-        symbols_per_block = demod_auto_spb(c, n_frames, s, [&](int spb) {
+        symbols_per_block = demod_auto_spb(c, n_frames, src * 2 + (bits_layout == DABGPU_BITS_MSC_CLASSED), s, [&](int spb) {
             return dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map, (int)n_frames, spb, bits_frame_stride,
                                             nullptr, nullptr, 0, bits_layout == DABGPU_BITS_MSC_CLASSED, s, nullptr, nullptr, 0.0f);
         });

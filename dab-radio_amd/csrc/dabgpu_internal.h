@@ -20,8 +20,9 @@ struct dabgpu_ctx {
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
     int vit_mapping = 0;             // DABGPU_VIT_MAP_* (dabgpu_viterbi_set_mapping)
-    // symbols_per_block = 0 of the mode I demodulator: measured once per batch size on this device (dabgpu_abi.hip, demod_auto_spb)
-    struct spb_choice { size_t n_frames; int spb; };
+    // symbols_per_block = 0 of the mode I demodulator: measured once per batch size and kernel variant (source format, soft-bit
+    // layout) on this device (dabgpu_abi.hip, demod_auto_spb)
+    struct spb_choice { size_t n_frames; int variant; int spb; };
     std::vector<spb_choice> spb_cache;
     int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
     int* d_mode_inv_map[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // their inverses (ofdm_wave512.hip)

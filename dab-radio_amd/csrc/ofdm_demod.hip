@@ -252,7 +252,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     pos[5] = inv_map[512 + Kb];
     int posc[6];                                  // the same positions in class order: (b mod 16) * 192 + b / 16; the imaginary half sits 96 further
 #pragma unroll
-    for (int k = 0; k < 6; k++) posc[k] = CLASSED ? ((pos[k] & 15) * 192 + (pos[k] >> 4)) : 0;
+    for (int k = 0; k < 6; k++) posc[k] = CLASSED ? ((DABGPU_EXP & 128) ? pos[k] : ((pos[k] & 15) * 192 + (pos[k] >> 4))) : 0;      // (128: timing only)
 
     f2 prev[6], keep[6];
 #pragma unroll
@@ -494,7 +494,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             if constexpr (CLASSED) {
                 if (i - 1 >= NB_FIC_SYMBOLS) {                                    // (uniform) MSC symbol in class order
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + 96] = (int8_t)by[k]; }
+                    for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + ((DABGPU_EXP & 128) ? 1536 : 96)] = (int8_t)by[k]; }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 6; k++) { obuf[pos[k]] = (int8_t)bx[k]; obuf[pos[k] + 1536] = (int8_t)by[k]; }

@@ -94,9 +94,10 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
  *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
  *   symbols_per_block  data symbols handled by one workgroup, 1..75; any value gives identical results.  0 = the library chooses:
- *                 25 for batches below 512 frames; for larger ones it times 25 / 38 / 75 ONCE per context and batch size (a few
- *                 extra launches of this call on the caller's own buffers, identical outputs) and remembers the fastest --
- *                 which one that is depends on the box.  dabgpu_ofdm_auto_symbols_per_block reports the choice.
+ *                 25 for batches below 512 frames; for larger ones it times 25 / 38 / 75 ONCE per context, batch size and kernel
+ *                 variant (source format, bits_layout): ~40 ms of warm-up launches of this call on the caller's own buffers, then
+ *                 three timed rounds over the candidates -- identical outputs -- and remembers the fastest; which one that is
+ *                 depends on the box.  dabgpu_ofdm_auto_symbols_per_block reports the choice.
  *   bits_frame_stride  bytes between the soft bits of consecutive frames (0 = 230400, packed); lets the kernel write
  *                 straight into slot k of a per-ensemble frame-history ring (see dabgpu_msc_decode_frames)
  */

@@ -270,6 +270,7 @@ def main():
                          "ms_per_frame_step_two_frames_in_flight": t_pp, "frames_per_s_two_frames_in_flight": E / t_pp * 1e3, "two_frames_in_flight_outputs_ok": pp_ok,
                          "msc_trellis_steps_per_s": E * msc_steps / t_msc * 1e3},
         "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi": t_msc},
+        "history_layout": args.hist_layout, "symbols_per_block_chosen_by_library": ctx.ofdm_auto_symbols_per_block(E),
         "check": {"fib_crc_pass": crc_ok, "fib_crc_expected": E * 12, "fib_bytes_equal_transmitted": fib_eq,
                   "msc_bytes_equal_transmitted": msc_eq},
     }
