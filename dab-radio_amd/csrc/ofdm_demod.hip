@@ -364,8 +364,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             f2 b0, b1, b2, b3, c0, c1, c2, c3;
             dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
             dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
+#if !(DABGPU_EXP & 512)                   // (512 / 256: timing-only builds without the twiddle products of pass 1 / passes 2 and 3)
             b1 = cmul(b1, mk2(w1_1.x, w1_1.y)); b2 = cmul(b2, mk2(w1_2.x, w1_2.y)); b3 = cmul(b3, mk2(w1_3.x, w1_3.y));
             c1 = cmul(c1, mk2(w1_1.z, w1_1.w)); c2 = cmul(c2, mk2(w1_2.z, w1_2.w)); c3 = cmul(c3, mk2(w1_3.z, w1_3.w));
+#endif
             PHASE_STAMP(0);                    // PLL + correlation + radix 4
             // (the empty statement orders the arithmetic above against the barrier below: the compiler is otherwise free to sink
             // the PLL behind it, which puts the skew wait back in front of the longest arithmetic phase)
@@ -413,7 +415,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         PHASE_STAMP(3);                        // prefetch issue + pass-2 reads + radix 8
         patch[ta_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = (DABGPU_EXP & 256) ? a[k] : cmul(a[k], w2[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
@@ -424,7 +426,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         PHASE_STAMP(4);                        // transpose A + radix 8
         patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], W3_LDS ? w3p[8 * (k - 1)] : w3[k - 1]);
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = (DABGPU_EXP & 256) ? a[k] : cmul(a[k], W3_LDS ? w3p[8 * (k - 1)] : w3[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
