@@ -161,13 +161,14 @@ static size_t lanes_max_rows() {
 // sym_rows / dec_rows: rows of 64 dwords (kept soft bits, 4 per lane and row) and of 128 dwords (decisions, one row per step)
 static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const dabgpu_vit_group* d_groups, size_t n_groups,
                              size_t sym_rows, size_t dec_rows, uint32_t max_in_rows, int tie_rule, int ring4, const uint2* d_sched,
-                             int octet, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
+                             int octet, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0, uint32_t groups_per_sub = 0) {
     int st;
     uint32_t *d_sym = nullptr, *d_dec = nullptr;
     if ((st = dabgpu_scratch(c, 18 + slot_off, sym_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
     if ((st = dabgpu_scratch(c, 19 + slot_off, dec_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_in_rows, d_descs, d_sym, d_dec, d_results,
-                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, octet, device_waves(c) / 32, s), "vit_lanes_kernel launch");
+                                                        tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, octet, device_waves(c) / 32, groups_per_sub, s),
+                            "vit_lanes_kernel launch");
 }
 
 // one puncturing schedule for a whole batch (FIC, uniform codeword batches): groups of 64 consecutive codewords, in bounded slices
@@ -405,7 +406,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             const int ring4 = classed ? ((((uintptr_t)d_hist % 64 == 0) && (ens_stride % 64 == 0)) ? 2 : 0)
                                       : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
             if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, sym_rows_per_gq * gps, dec_rows_per_gq * gps, lane_max_in_rows,
-                                        tie_rule, ring4, d_sched, octet, d_results + cw0, s))) return st;
+                                        tie_rule, ring4, d_sched, octet, d_results + cw0, s, 0, gps))) return st;
         }
         if (k_wave == 0) return DABGPU_OK;
     }

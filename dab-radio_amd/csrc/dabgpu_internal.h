@@ -139,6 +139,7 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4,
                                                   const struct dabgpu_vit_tables* d_tables, const uint2* d_sched, int octet, int n_cu,
+                                                  uint32_t groups_per_sub /* MSC: groups[li * groups_per_sub + gq]; 0 = any order */,
                                                   hipStream_t stream);
 // eight lanes per codeword over prepared groups and their symbol array (viterbi_octet.hip): one 512-thread workgroup per group
 extern "C" hipError_t dabgpu_launch_viterbi_octet(const dabgpu_vit_group* d_groups, size_t n_groups, const dabgpu_cw_desc* d_descs,

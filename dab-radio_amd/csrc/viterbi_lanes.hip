@@ -551,12 +551,25 @@ constexpr int VC_CIF_PITCH = 16 * VC_PITCH + 16;                           // by
 constexpr int VC_ENS_PITCH = 4 * VC_CIF_PITCH;                             // bytes between two ensembles: 2320 dwords = 16 mod 64, so the
                                                                            // dword reads of a half wave fall two per bank
 __global__ __launch_bounds__(256)
-void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym)
+void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_cw_desc* __restrict__ descs, uint32_t* __restrict__ sym,
+                            uint32_t groups_per_sub, uint32_t n_lane_sub)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ring[VC_ENS * VC_ENS_PITCH];       // [ensemble][output CIF][class][2 lines]
     const int tid = threadIdx.x;
-    const dabgpu_vit_group Gd = groups[blockIdx.x >> 2];
-    const int qg = blockIdx.x & 3;
+    // Which (group, quarter) this workgroup gathers.  groups_per_sub != 0 (MSC: groups[li * groups_per_sub + gq] = sub-channel li of
+    // ensembles 16 gq ..): XCD-aware order.  The sub-channels of one quarter group of ensembles read neighbouring pieces of the same
+    // class rows -- the 64-byte lines at both ends of a piece are shared with the neighbour -- and workgroups are dealt round-robin to
+    // the 8 XCDs, each with its own L2: unit (gq, quarter) u goes to XCD u mod 8 with its n_lane_sub sub-channels back to back.
+    unsigned g_idx = blockIdx.x >> 2;
+    int qg = (int)(blockIdx.x & 3);
+    if (groups_per_sub != 0) {
+        const unsigned x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const unsigned li = j % n_lane_sub, u = (j / n_lane_sub) * 8 + x;
+        if (u >= 4 * groups_per_sub) return;
+        g_idx = li * groups_per_sub + (u >> 2);
+        qg = (int)(u & 3);
+    }
+    const dabgpu_vit_group Gd = groups[g_idx];
     const int n_in = (int)dabgpu_vit_in_bytes(Gd.seg_pi, Gd.seg_steps);       // input soft bits the decoder consumes (EEP: the sub-channel
                                                                                // size; UEP: less, the rest is padding)
     // the four ensembles of this quarter group (uniform descriptors: scalar loads, once per workgroup)
@@ -752,14 +765,20 @@ extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched
 extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
                                                   const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
                                                   dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
-                                                  const uint2* d_sched, int octet, int n_cu, hipStream_t stream)
+                                                  const uint2* d_sched, int octet, int n_cu, uint32_t groups_per_sub, hipStream_t stream)
 {
     using namespace dabgpu;
     const unsigned tiles = (max_in_rows + VL_TILE - 1) / VL_TILE;
     if (ring4 == 3)      // direct, contiguous, 16-byte aligned codewords (FIC)
         hipLaunchKernelGGL(vit_prep_direct_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else if (ring4 == 2)      // ring of 4 CIFs per frame in class order
-        hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym);
+        if (groups_per_sub != 0 && n_groups % groups_per_sub == 0) {
+            const unsigned n_lane_sub = (unsigned)(n_groups / groups_per_sub);
+            hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3(8 * ((4 * groups_per_sub + 7) / 8) * n_lane_sub), dim3(256), 0, stream, d_groups, d_descs,
+                               d_sym, groups_per_sub, n_lane_sub);
+        } else {
+            hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym, 0u, 1u);
+        }
     else if (ring4)
         hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else
