@@ -564,8 +564,16 @@ def main():
             line["roofline"]["timing"] = (f"one pair of HIP events around the {args.steps} back-to-back launches of the timed loop, on their stream: "
                                           f"{k_ms_events:.4f} ms per launch" + ("" if (args.spb or ctx.ofdm_auto_symbols_per_block(units)) == 75 else " (incl. the 5 us phase-tail launch of each step)"))
         else:
-            line["roofline"]["timing"] = (f"HIP events around {len(evs)} of the {args.steps} demod launches of the timed loop (mean {k_ms_events:.4f} ms"
-                                          + ("" if k_ms_events <= ms_per_step else f", capped at ms_per_step: the event pair includes its own gap") + ")")
+            # configs[4]: inside the timed loop the demodulation of frame j + 1 runs BESIDE the trellis kernel of frame j (two frames in
+            # flight), so its launches last longer than the kernel needs; the rooflines are taken one stage at a time after the loop
+            pipe.timed(pipe.msc, 4); pipe.timed(pipe.demod, 8)              # (the clock has dropped during the host-side check above)
+            t_d, t_f, t_m = pipe.timed(pipe.demod, 6), pipe.timed(pipe.fic, 6), pipe.timed(pipe.msc, 6)
+            line["roofline"] = hbm_roofline("ofdm_demod_kernel", t_d, units)
+            line["roofline"]["timing"] = (f"one stage at a time after the timed loop: HIP events around 6 launches, {t_d:.4f} ms each (inside the loop, "
+                                          f"overlapped with the other frame's trellis kernel: {k_ms_events:.4f} ms, mean of {len(evs)} launches)")
+            line["roofline_decode"] = viterbi_roofline(("vit_prep_ring4c_kernel" if pipe.layout else "vit_prep_ring4_kernel") + " + vit_lanes_kernel (MSC)",
+                                                       pipe.msc_steps, t_m, True)
+            line["stage_ms_one_at_a_time"] = {"ofdm_demod": t_d, "fic_viterbi": t_f, "msc_viterbi_incl_deinterleave": t_m}
         # PMC-derived HBM traffic per launch, when a profiles/ summary of this round exists (see profiles/README.md)
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
