@@ -200,6 +200,31 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     // (stream banks: iq = the complex-float frame buffers, SRC describes the tail source only)
     const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * NB_FRAME_SAMPLES * (BANK ? 8 : src_bytes<SRC>::value);
 
+    constexpr unsigned SB = BANK ? 8u : (unsigned)src_bytes<SRC>::value;                              // bytes per sample of the frame
+    const unsigned lane_off = 2u * SB * (unsigned)t, head_off = 2u * SB * (unsigned)((t >= 4) ? t - 4 : 0);   // byte offsets of this lane
+    const __amdgpu_buffer_rsrc_t iq_rs = frame_rsrc(fbase, NB_FRAME_SAMPLES * SB);
+    // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head (threads 0..3 have no head
+    // sample: they load a valid address and never use it, so that the load stays unconditional inside the wave)
+    auto load_symbol = [&](int i, f4 (&v)[4], f4& h) __attribute__((always_inline)) {
+        const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
+        const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+        if constexpr (BANK) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
+            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0));   // uniform per workgroup
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(iq_rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * SB);
+            if (dc) h = load_pair_buf<SRC>(iq_rs, head_off, (unsigned)sym * SB);
+        }
+    };
+    // the first symbol's samples are requested before anything else: the table reads and the barrier of the set-up below run while
+    // they are on their way (they were issued behind them: two memory latencies in series at the start of every workgroup)
+    f4 v[4], h = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#if !(DABGPU_EXP & 1024)
+    load_symbol(out0, v, h);
+#endif
+
     // PLL constants: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
     const int k0 = 2 * (t & 1);
     const float ss0 = (float)k0 * f, ss1 = (float)(k0 + 1) * f;          // apply_pll.cpp:95-99
@@ -258,25 +283,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 #pragma unroll
     for (int k = 0; k < 6; k++) prev[k] = mk2(0.0f, 0.0f);
 
-    constexpr unsigned SB = BANK ? 8u : (unsigned)src_bytes<SRC>::value;                              // bytes per sample of the frame
-    const unsigned lane_off = 2u * SB * (unsigned)t, head_off = 2u * SB * (unsigned)((t >= 4) ? t - 4 : 0);   // byte offsets of this lane
-    const __amdgpu_buffer_rsrc_t iq_rs = frame_rsrc(fbase, NB_FRAME_SAMPLES * SB);
     const __amdgpu_buffer_rsrc_t bits_rs = frame_rsrc(bits + out_frame * bits_frame_stride, (NB_FRAME_SYMBOLS - 1) * NB_SYM_BITS);
-    // coalesced loads of one symbol: 16 B per lane, 4 for the FFT body + 1 for the cyclic-prefix head (threads 0..3 have no head
-    // sample: they load a valid address and never use it, so that the load stays unconditional inside the wave)
-    auto load_symbol = [&](int i, f4 (&v)[4], f4& h) __attribute__((always_inline)) {
-        const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
-        const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
-        if constexpr (BANK) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
-            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0));   // uniform per workgroup
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(iq_rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * SB);
-            if (dc) h = load_pair_buf<SRC>(iq_rs, head_off, (unsigned)sym * SB);
-        }
-    };
     // the 3072 soft bits of data symbol `row` + 1 sit de-interleaved in obuf: 192 lanes x 16-byte stores (LDS read and HBM store are
     // separate steps so that the read can be issued ahead of the radix-4 exchange writes and the store behind them)
     auto row_read = [&]() __attribute__((always_inline)) -> u4v {
@@ -296,8 +303,9 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     };
     auto store_row = [&](const int row) __attribute__((always_inline)) { row_write(row, row_read()); };
 
-    f4 v[4], h = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    load_symbol(out0, v, h);
+#if DABGPU_EXP & 1024
+    load_symbol(out0, v, h);          // (A/B build: the first load behind the set-up, as before round 3)
+#endif
 #if DABGPU_EXP & 8
     unsigned long long ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}, ph_last, ph_t0, ph_r0;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_r0), "=s"(ph_t0) :: "memory");
