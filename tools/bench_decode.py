@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed",
                     help="order of the MSC soft bits in the frame-history ring (classed = DABGPU_BITS_MSC_CLASSED)")
     ap.add_argument("--mapping", type=int, default=0, help="0 auto, 1 wave per codeword, 2 lane per codeword, 3 eight lanes per codeword (DABGPU_VIT_MAP_*)")
+    ap.add_argument("--spb", type=int, default=0, help="data symbols per demodulator workgroup (0 = the library's own choice; counter passes fix it so that every launch is alike)")
     ap.add_argument("--no-overlap", action="store_true", help="serial stages only (profiling passes: every launch runs alone)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -151,7 +152,7 @@ def main():
     subs = [dabgpu.SubChannel(48 * s, 48, 0, 0, 2, 0) for s in range(n_sub)]
 
     def demod(slot):
-        ctx.ofdm_demod_frames_history(iq_f, F32, E, hist[:, slot], cp_corr=corr, bits_frame_stride=H * 230400, bits_layout=LAYOUT)
+        ctx.ofdm_demod_frames_history(iq_f, F32, E, hist[:, slot], cp_corr=corr, symbols_per_block=args.spb, bits_frame_stride=H * 230400, bits_layout=LAYOUT)
 
     def fic(slot):
         ctx.fic_decode_frames(hist[:, slot], E, fic_out, fic_res, frame_stride=H * 230400, tie_rule=args.tie_rule)
@@ -230,7 +231,7 @@ def main():
         c, st = ctxs[k], streams[k]
         slot = j % H2
         with torch.cuda.stream(st):
-            c.ofdm_demod_frames_history(iq_f, F32, E, hist2[:, slot], cp_corr=corr2[k], bits_frame_stride=H2 * 230400, bits_layout=LAYOUT,
+            c.ofdm_demod_frames_history(iq_f, F32, E, hist2[:, slot], cp_corr=corr2[k], symbols_per_block=args.spb, bits_frame_stride=H2 * 230400, bits_layout=LAYOUT,
                                         stream=st.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(st)

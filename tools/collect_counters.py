@@ -72,7 +72,7 @@ for k, d in out.items():
         d["duration_us_median"] = du[len(du) // 2]
         d["duration_us_min"] = du[0]
     derive(d)
-res = {"command": "tools/bench_decode.py --ensembles 4096 --steps 2 --no-overlap", "note": __doc__.split("\n\n")[0] if False else
+res = {"command": "tools/bench_decode.py --ensembles 4096 --steps 2 --no-overlap --spb 75", "note": __doc__.split("\n\n")[0] if False else
        "means per launch; separate rocprofv3 passes (kernel trace; two SQ passes; FETCH_SIZE; WRITE_SIZE); GRBM_GUI_ACTIVE is the sum over 8 XCDs", "kernels": out}
 path = os.path.join(root, f"counters_{tag}.json")
 json.dump(res, open(path, "w"), indent=1)

@@ -7,7 +7,7 @@ TAG=${1:-vX}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-CMD="tools/bench_decode.py --ensembles 4096 --steps 2 --no-overlap"
+CMD="tools/bench_decode.py --ensembles 4096 --steps 2 --no-overlap --spb 75"     # (a fixed run length: every demodulator launch alike)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cnt_trace -o t -- python3 $CMD > $OUT/cnt_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/cnt_sq -o pmc -- python3 $CMD > $OUT/cnt_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/cnt_sq2 -o pmc -- python3 $CMD > $OUT/cnt_sq2.log 2>&1
