@@ -285,10 +285,15 @@ extern "C" int dabgpu_fic_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_
     return fic_decode_any(c, d_hist, n_ens, ens_stride, d_newest_slot, d_fib_bytes, d_results, tie_rule, stream);
 }
 
+// fic: also decode the FIC of the newest frame of every ensemble (dabgpu_decode_frames_layout).  When every sub-channel runs in a batch
+// mapping and the call is one slice, the FIB groups join the MSC launch as further groups of 64 codewords with their own schedule: the
+// MSC's groups rarely fill the last round of wavefront slots (4096 ensembles x 18 sub-channels = 4608 groups on 5120 slots), so the FIC
+// then costs its 20 us gather and nothing else.  Otherwise it is decoded first, by the FIC entry point's own path.
+struct fic_request { uint8_t* d_fib_bytes; dabgpu_codeword_result* d_results; };
 static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
                           int newest_frame_slot, const int32_t* d_slots, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_out,
                           size_t out_ens_stride, dabgpu_codeword_result* d_results, int tie_rule, void* stream,
-                          int bits_layout = DABGPU_BITS_NATURAL) {
+                          int bits_layout = DABGPU_BITS_NATURAL, const fic_request* fic = nullptr) {
     if (!c || !d_hist || !h_sub || !d_out || !d_results) { dabgpu_set_error("msc_decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
         dabgpu_set_error("msc_decode_frames: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG;
@@ -323,9 +328,11 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     const size_t n = n_ens * 4 * (size_t)n_sub;
+    const size_t n_fic = fic ? n_ens * 4 : 0;                   // FIB groups of the newest frames (appended to the MSC's descriptors)
+    const int8_t* fic_bits = d_slots ? d_hist : d_hist + (size_t)newest_frame_slot * DABGPU_NB_FRAME_BITS;
     dabgpu_cw_desc* d_descs = nullptr;
     dabgpu_msc_plan* d_plans = nullptr;
-    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    int st = dabgpu_scratch(c, 10, (n + n_fic) * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
     if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
     // (the plans are staged and the descriptors built once the mapping of every sub-channel is known, below)
@@ -358,6 +365,14 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         }
     }
     const int n_lane = n_sub - k_wave;
+    // the FIC inside the MSC launch?  (every sub-channel in a batch mapping, one slice -- checked again below where the slices are known)
+    bool fic_inside = fic != nullptr && k_wave == 0 && n_lane > 0;
+    if (fic_inside) {
+        size_t rows = 0;
+        for (int j = 0; j < n_sub; j++) rows += dabgpu_vit_alloc_steps(plans[(size_t)j].n_steps);
+        fic_inside = n_ens <= std::max<size_t>(1, lanes_max_rows() / rows) * 16;
+    }
+    if (fic && !fic_inside && (st = fic_decode_any(c, fic_bits, n_ens, ens_stride, d_slots, fic->d_fib_bytes, fic->d_results, tie_rule, stream))) return st;
     // flag the lane-mapped sub-channels in the plans the descriptor builder reads, then stage the plans and build the descriptors
     for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
     if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
@@ -389,15 +404,18 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         if ((st = dabgpu_stage_h2d(c, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
         // the schedule table of every lane-mapped sub-channel, once per call
         const uint32_t sched_stride = dabgpu_vit_alloc_steps(lane_max_steps);
+        const uint32_t fic_pi[4] = {16, 15, 0, 0}, fic_steps[4] = {32 * 21, 32 * 3, 0, 0};
+        const uint32_t fic_dec_rows = dabgpu_vit_alloc_steps(774), fic_in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(fic_pi, fic_steps));
         uint2* d_sched = nullptr;
-        if ((st = dabgpu_scratch(c, 25, (size_t)n_lane * sched_stride * sizeof(uint2), (void**)&d_sched))) return st;
+        if ((st = dabgpu_scratch(c, 25, ((size_t)n_lane * sched_stride + (fic_inside ? fic_dec_rows : 0)) * sizeof(uint2), (void**)&d_sched))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_msc(d_sched, sched_stride, d_plans, d_lane_subs, n_lane, c->d_vit_tables, s), "vit_sched launch"))) return st;
         for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
             const size_t ne = std::min(n_ens - e0, ens_per_slice);
             const uint32_t gps = (uint32_t)((ne * 4 + 63) / 64);
             const size_t n_groups = (size_t)n_lane * gps;
+            const size_t n_fic_groups = fic_inside ? (n_fic + 63) / 64 : 0;
             dabgpu_vit_group* d_groups = nullptr;
-            if ((st = dabgpu_scratch(c, 17, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_scratch(c, 17, (n_groups + n_fic_groups) * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, sched_stride, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
             // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / aligned 64-byte lines (class order)
@@ -405,8 +423,33 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             // past the end of a row, 230400 = 3600 x 64)
             const int ring4 = classed ? ((((uintptr_t)d_hist % 64 == 0) && (ens_stride % 64 == 0)) ? 2 : 0)
                                       : ((((uintptr_t)d_hist % 16 == 0) && (ens_stride % 16 == 0)) ? 1 : 0);
-            if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, sym_rows_per_gq * gps, dec_rows_per_gq * gps, lane_max_in_rows,
-                                        tie_rule, ring4, d_sched, octet, d_results + cw0, s, 0, gps))) return st;
+            if (!fic_inside) {
+                if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, sym_rows_per_gq * gps, dec_rows_per_gq * gps, lane_max_in_rows,
+                                            tie_rule, ring4, d_sched, octet, d_results + cw0, s, 0, gps))) return st;
+                continue;
+            }
+            // one slice (e0 = 0): the FIB groups of the newest frames behind the MSC's groups -- descriptors n .., schedule, symbol and
+            // decision areas behind the MSC's, results into the caller's FIC array
+            const size_t sym_rows = sym_rows_per_gq * gps, dec_rows = dec_rows_per_gq * gps;
+            if ((st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs + n, fic_bits, n_ens, ens_stride, fic->d_fib_bytes, d_slots, s), "fic_build_descs launch"))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_uniform(d_sched + (size_t)n_lane * sched_stride, fic_dec_rows, fic_pi, fic_steps, c->d_vit_tables, s),
+                                       "vit_sched launch"))) return st;
+            dabgpu_vit_group_base base;
+            base.first = (uint32_t)n;
+            base.sched_off = (uint64_t)n_lane * sched_stride;
+            base.sym_off = (uint64_t)sym_rows * 64;
+            base.dec_off = (uint64_t)dec_rows * 128;
+            base.res_delta = (int64_t)(reinterpret_cast<const char*>(fic->d_results) - reinterpret_cast<const char*>(d_results + n));
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform_at(d_groups + n_groups, n_fic, 774, fic_pi, fic_steps, base, s), "vit_groups launch"))) return st;
+            uint32_t *d_sym = nullptr, *d_dec = nullptr;
+            if ((st = dabgpu_scratch(c, 18, (sym_rows + n_fic_groups * fic_in_rows) * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
+            if ((st = dabgpu_scratch(c, 19, (dec_rows + n_fic_groups * fic_dec_rows) * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+            // FIB groups are contiguous runs of 2304 soft bits; with 16-byte aligned frames the staged gather applies
+            const int fic_kind = (((uintptr_t)fic_bits % 16 == 0) && (ens_stride % 16 == 0)) ? 3 : 0;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_prep(ring4, d_groups, n_groups, lane_max_in_rows, d_descs, d_sym, gps, s), "vit_prep launch"))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_prep(fic_kind, d_groups + n_groups, n_fic_groups, fic_in_rows, d_descs, d_sym, 0, s), "vit_prep launch"))) return st;
+            if ((st = dabgpu_check_hip(dabgpu_launch_vit_trellis(d_groups, n_groups + n_fic_groups, d_descs, d_sym, d_dec, d_results, tie_rule ? 1 : 0,
+                                                                 c->d_vit_tables, d_sched, octet, device_waves(c) / 32, s), "vit_lanes_kernel launch"))) return st;
         }
         if (k_wave == 0) return DABGPU_OK;
     }
@@ -435,6 +478,38 @@ extern "C" int dabgpu_msc_decode_ring_layout(dabgpu_ctx* c, const int8_t* d_hist
     if (!d_newest_slot) { dabgpu_set_error("msc_decode_ring: null slot array"); return DABGPU_ERR_INVALID_ARG; }
     return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, 0, d_newest_slot, h_sub, n_sub, d_out, out_ens_stride, d_results,
                           tie_rule, stream, bits_layout);
+}
+
+// FIC + MSC of one transmission frame of every ensemble in one call (what BasicRadio::Process fans out to its FIC runner and MSC
+// runners, src/basic_radio/basic_radio.cpp:41-65)
+extern "C" int dabgpu_decode_frames_layout(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                           int newest_frame_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_fib_bytes,
+                                           dabgpu_codeword_result* d_fic_results, uint8_t* d_msc_out, size_t out_ens_stride,
+                                           dabgpu_codeword_result* d_msc_results, int tie_rule, int bits_layout, void* stream) {
+    if (!c || !d_hist || !d_fib_bytes || !d_fic_results) { dabgpu_set_error("decode_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (ens_stride < DABGPU_NB_FIC_BITS) { dabgpu_set_error("decode_frames: ensemble_stride %zu < 9216", ens_stride); return DABGPU_ERR_INVALID_ARG; }
+    if (n_ens == 0) return DABGPU_OK;
+    if (hist_frames < 1 || newest_frame_slot < 0 || newest_frame_slot >= hist_frames) {
+        dabgpu_set_error("decode_frames: 0 <= newest_frame_slot < history_frames"); return DABGPU_ERR_INVALID_ARG;
+    }
+    if (n_sub == 0)       // nothing but the FIC
+        return dabgpu_fic_decode_frames(c, d_hist + (size_t)newest_frame_slot * DABGPU_NB_FRAME_BITS, n_ens, ens_stride, d_fib_bytes, d_fic_results, tie_rule, stream);
+    const fic_request fic = {d_fib_bytes, d_fic_results};
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, nullptr, h_sub, n_sub, d_msc_out, out_ens_stride,
+                          d_msc_results, tie_rule, stream, bits_layout, &fic);
+}
+
+extern "C" int dabgpu_decode_ring_layout(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                         const int32_t* d_newest_slot, const dabgpu_subchannel* h_sub, int n_sub, uint8_t* d_fib_bytes,
+                                         dabgpu_codeword_result* d_fic_results, uint8_t* d_msc_out, size_t out_ens_stride,
+                                         dabgpu_codeword_result* d_msc_results, int tie_rule, int bits_layout, void* stream) {
+    if (!c || !d_hist || !d_fib_bytes || !d_fic_results || !d_newest_slot) { dabgpu_set_error("decode_ring: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (ens_stride < DABGPU_NB_FIC_BITS) { dabgpu_set_error("decode_ring: ensemble_stride %zu < 9216", ens_stride); return DABGPU_ERR_INVALID_ARG; }
+    if (n_ens == 0) return DABGPU_OK;
+    if (n_sub == 0) return dabgpu_fic_decode_ring(c, d_hist, n_ens, ens_stride, d_newest_slot, d_fib_bytes, d_fic_results, tie_rule, stream);
+    const fic_request fic = {d_fib_bytes, d_fic_results};
+    return msc_decode_any(c, d_hist, n_ens, ens_stride, hist_frames, 0, d_newest_slot, h_sub, n_sub, d_msc_out, out_ens_stride, d_msc_results,
+                          tie_rule, stream, bits_layout, &fic);
 }
 
 extern "C" int dabgpu_msc_decode_ring(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,

@@ -113,6 +113,8 @@ struct dabgpu_vit_group {
     uint64_t sched_off;             // entries into the schedule tables: (symbol row, v_perm_b32 selector) per trellis step
     uint64_t sym_off;               // dwords into the symbol scratch   [in_rows][64]
     uint64_t dec_off;               // dwords into the decision scratch [alloc_steps][64][2]
+    int64_t res_delta;              // bytes added to &results[first + L * stride]: groups of ONE launch may report into different arrays
+                                    // (the FIB groups of a frame decoded inside the MSC launch, dabgpu_decode_frames_layout)
 };
 // decisions are stored two steps per row pair; the chain-back reads whole 24-step chunks
 static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_steps) { return (n_steps + 6u + 63u) & ~63u; }
@@ -126,6 +128,17 @@ static inline __host__ __device__ uint32_t dabgpu_vit_in_bytes(const uint32_t* s
 static inline __host__ __device__ uint32_t dabgpu_vit_in_rows(uint32_t n_in) { return (n_in + 3u) / 4u + 2u; }
 extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
                                                        const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream);
+// the same groups appended to another launch's: descriptor index, schedule entries, symbol / decision dwords and result bytes they start at
+struct dabgpu_vit_group_base { uint32_t first; uint64_t sched_off, sym_off, dec_off; int64_t res_delta; };
+extern "C" hipError_t dabgpu_launch_vit_groups_uniform_at(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps, const uint32_t* seg_pi,
+                                                          const uint32_t* seg_steps, dabgpu_vit_group_base base, hipStream_t stream);
+// the two halves of dabgpu_launch_viterbi_lanes: the gather of `kind` (0 general, 1 ring of 4 CIFs, 2 the same in class order, 3 direct)
+// over some groups, and the trellis over groups that were gathered
+extern "C" hipError_t dabgpu_launch_vit_prep(int kind, const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
+                                             const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t groups_per_sub, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_vit_trellis(const dabgpu_vit_group* d_groups, size_t n_groups, const dabgpu_cw_desc* d_descs, uint32_t* d_sym,
+                                                uint32_t* d_dec, dabgpu_cw_result* d_results, int tie_rule, const struct dabgpu_vit_tables* d_tables,
+                                                const uint2* d_sched, int octet, int n_cu, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const struct dabgpu_msc_plan* d_plans,
                                                    const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
                                                    uint32_t groups_per_sub, uint32_t sched_stride, hipStream_t stream);

@@ -343,7 +343,7 @@ void vit_lanes_kernel(const dabgpu_vit_group* __restrict__ groups, int n_groups,
         R.path_error = live ? (uint64_t)total + endm : 0;
         R.crc_ok_mask = crc_mask;
         R.n_out_bytes = live ? (uint32_t)n_out : 0u;
-        results[cw] = R;
+        *reinterpret_cast<dabgpu_cw_result*>(reinterpret_cast<char*>(results + cw) + Gd.res_delta) = R;
     }
 }
 
@@ -662,20 +662,21 @@ void vit_prep_ring4c_kernel(const dabgpu_vit_group* __restrict__ groups, const d
 // FIC: all codewords share one schedule; group g = codewords 64 g .. 64 g + 63
 __global__ void vit_groups_uniform_kernel(dabgpu_vit_group* groups, size_t n_cw, uint32_t n_steps, uint32_t alloc_steps, uint32_t in_rows,
                                           uint32_t pi0, uint32_t st0, uint32_t pi1, uint32_t st1, uint32_t pi2, uint32_t st2,
-                                          uint32_t pi3, uint32_t st3)
+                                          uint32_t pi3, uint32_t st3, dabgpu_vit_group_base base)
 {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g * 64 >= n_cw) return;
     dabgpu_vit_group G = {};
-    G.first = (uint32_t)(g * 64); G.stride = 1;
+    G.first = base.first + (uint32_t)(g * 64); G.stride = 1;
     G.count = (uint32_t)((n_cw - g * 64 < 64) ? (n_cw - g * 64) : 64);
     G.n_steps = n_steps; G.alloc_steps = alloc_steps;
     G.seg_pi[0] = pi0; G.seg_steps[0] = st0; G.seg_pi[1] = pi1; G.seg_steps[1] = st1;
     G.seg_pi[2] = pi2; G.seg_steps[2] = st2; G.seg_pi[3] = pi3; G.seg_steps[3] = st3;
     G.in_rows = in_rows;
-    G.sched_off = 0;
-    G.sym_off = g * (size_t)in_rows * 64;
-    G.dec_off = g * (size_t)alloc_steps * 128;
+    G.sched_off = base.sched_off;
+    G.sym_off = base.sym_off + g * (size_t)in_rows * 64;
+    G.dec_off = base.dec_off + g * (size_t)alloc_steps * 128;
+    G.res_delta = base.res_delta;
     groups[g] = G;
 }
 
@@ -725,15 +726,21 @@ __global__ void vit_sched_msc_kernel(uint2* sched, uint32_t sched_stride, const 
 
 }  // namespace dabgpu
 
-extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
-                                                       const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream)
+extern "C" hipError_t dabgpu_launch_vit_groups_uniform_at(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps, const uint32_t* seg_pi,
+                                                          const uint32_t* seg_steps, dabgpu_vit_group_base base, hipStream_t stream)
 {
     const size_t n_groups = (n_cw + 63) / 64;
     hipLaunchKernelGGL(dabgpu::vit_groups_uniform_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, stream,
                        d_groups, n_cw, n_steps, dabgpu_vit_alloc_steps(n_steps), dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps)),
                        seg_pi[0], seg_steps[0], seg_pi[1], seg_steps[1],
-                       seg_pi[2], seg_steps[2], seg_pi[3], seg_steps[3]);
+                       seg_pi[2], seg_steps[2], seg_pi[3], seg_steps[3], base);
     return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
+                                                       const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream)
+{
+    return dabgpu_launch_vit_groups_uniform_at(d_groups, n_cw, n_steps, seg_pi, seg_steps, dabgpu_vit_group_base{0, 0, 0, 0, 0}, stream);
 }
 
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const dabgpu_msc_plan* d_plans,
@@ -762,16 +769,14 @@ extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched
     return hipGetLastError();
 }
 
-extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
-                                                  const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
-                                                  dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
-                                                  const uint2* d_sched, int octet, int n_cu, uint32_t groups_per_sub, hipStream_t stream)
+extern "C" hipError_t dabgpu_launch_vit_prep(int kind, const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
+                                             const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t groups_per_sub, hipStream_t stream)
 {
     using namespace dabgpu;
     const unsigned tiles = (max_in_rows + VL_TILE - 1) / VL_TILE;
-    if (ring4 == 3)      // direct, contiguous, 16-byte aligned codewords (FIC)
+    if (kind == 3)      // direct, contiguous, 16-byte aligned codewords (FIC)
         hipLaunchKernelGGL(vit_prep_direct_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
-    else if (ring4 == 2)      // ring of 4 CIFs per frame in class order
+    else if (kind == 2)      // ring of 4 CIFs per frame in class order
         if (groups_per_sub != 0 && n_groups % groups_per_sub == 0) {
             const unsigned n_lane_sub = (unsigned)(n_groups / groups_per_sub);
             hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3(8 * ((4 * groups_per_sub + 7) / 8) * n_lane_sub), dim3(256), 0, stream, d_groups, d_descs,
@@ -779,11 +784,19 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
         } else {
             hipLaunchKernelGGL(vit_prep_ring4c_kernel, dim3((unsigned)(4 * n_groups)), dim3(256), 0, stream, d_groups, d_descs, d_sym, 0u, 1u);
         }
-    else if (ring4)
+    else if (kind)
         hipLaunchKernelGGL(vit_prep_ring4_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
     else
         hipLaunchKernelGGL(vit_prep_kernel, dim3((unsigned)n_groups, tiles), dim3(256), 0, stream, d_groups, d_descs, d_sym);
-    // the trellis over the same symbol array: eight lanes per codeword (viterbi_octet.hip) or one
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_vit_trellis(const dabgpu_vit_group* d_groups, size_t n_groups, const dabgpu_cw_desc* d_descs, uint32_t* d_sym,
+                                                uint32_t* d_dec, dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
+                                                const uint2* d_sched, int octet, int n_cu, hipStream_t stream)
+{
+    using namespace dabgpu;
+    // eight lanes per codeword (viterbi_octet.hip) or one
     if (octet) return dabgpu_launch_viterbi_octet(d_groups, n_groups, d_descs, d_sym, d_dec, d_results, tie_rule, d_tables, d_sched, stream);
 #define VL_GO(TIE, W) hipLaunchKernelGGL((vit_lanes_kernel<TIE, W>), dim3((unsigned)((n_groups + (W) - 1) / (W))), dim3(64 * (W)), 0, stream, \
                                          d_groups, (int)n_groups, d_descs, d_sym, d_dec, d_results, d_tables, d_sched)
@@ -797,4 +810,14 @@ extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_grou
     else { if (four) VL_GO(0, 4); else VL_GO(0, 1); }
 #undef VL_GO
     return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_viterbi_lanes(const dabgpu_vit_group* d_groups, size_t n_groups, uint32_t max_in_rows,
+                                                  const dabgpu_cw_desc* d_descs, uint32_t* d_sym, uint32_t* d_dec,
+                                                  dabgpu_cw_result* d_results, int tie_rule, int ring4, const dabgpu_vit_tables* d_tables,
+                                                  const uint2* d_sched, int octet, int n_cu, uint32_t groups_per_sub, hipStream_t stream)
+{
+    hipError_t e = dabgpu_launch_vit_prep(ring4, d_groups, n_groups, max_in_rows, d_descs, d_sym, groups_per_sub, stream);
+    if (e != hipSuccess) return e;
+    return dabgpu_launch_vit_trellis(d_groups, n_groups, d_descs, d_sym, d_dec, d_results, tie_rule, d_tables, d_sched, octet, n_cu, stream);
 }

@@ -429,7 +429,7 @@ void vit_octet_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
         R.path_error = live ? (uint64_t)total + endm : 0;
         R.crc_ok_mask = crc_mask;
         R.n_out_bytes = live ? (uint32_t)n_out : 0u;
-        results[cw] = R;
+        *reinterpret_cast<dabgpu_cw_result*>(reinterpret_cast<char*>(results + cw) + Gd.res_delta) = R;
     }
 }
 

@@ -57,7 +57,7 @@ ABI_SYMBOLS = [
     "dabgpu_ofdm_sync_mode", "dabgpu_ofdm_demod_stream_frame_sync_mode", "dabgpu_ofdm_sync_host_sync_mode",
     "dabgpu_stream_bank_process_ring", "dabgpu_fic_decode_ring", "dabgpu_msc_decode_ring", "dabgpu_dabplus_bank_process_masked",
     "dabgpu_ofdm_demod_frames_history", "dabgpu_msc_decode_frames_layout", "dabgpu_stream_bank_process_ring_layout",
-    "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames",
+    "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames", "dabgpu_decode_frames_layout", "dabgpu_decode_ring_layout",
     "dabgpu_frame_session_create", "dabgpu_frame_session_destroy", "dabgpu_frame_session_set_subchannels", "dabgpu_frame_session_push_frame",
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
@@ -169,6 +169,10 @@ def lib():
                                                      C.c_int, C.c_size_t, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_msc_decode_frames_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
                                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dabgpu_decode_frames_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dabgpu_decode_ring_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dabgpu_ofdm_demod_stream_frame_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float,
                                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_ofdm_phase_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p,
@@ -440,6 +444,23 @@ class Context:
         check(lib().dabgpu_msc_decode_ring(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, _ptr(newest_slot), arr, n,
                                            _ptr(out), out_ensemble_stride, _ptr(results), tie_rule, self._stream(stream)),
               "dabgpu_msc_decode_ring")
+
+    def decode_frames(self, history, n_ensembles, ensemble_stride, history_frames, newest_frame_slot, subchannels, fib_bytes, fic_results,
+                      out, out_ensemble_stride, results, tie_rule=0, stream=None, bits_layout=BITS_NATURAL):
+        """FIC (ring slot newest_frame_slot) + MSC of one transmission frame of every ensemble in one call (dabgpu_decode_frames_layout)"""
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels) if n else None
+        check(lib().dabgpu_decode_frames_layout(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, newest_frame_slot, arr, n,
+                                                _ptr(fib_bytes), _ptr(fic_results), _ptr(out), out_ensemble_stride, _ptr(results), tie_rule,
+                                                int(bits_layout), self._stream(stream)), "dabgpu_decode_frames_layout")
+
+    def decode_ring(self, history, n_ensembles, ensemble_stride, history_frames, newest_slot, subchannels, fib_bytes, fic_results,
+                    out, out_ensemble_stride, results, tie_rule=0, stream=None, bits_layout=BITS_NATURAL):
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels) if n else None
+        check(lib().dabgpu_decode_ring_layout(self._h, _ptr(history), n_ensembles, ensemble_stride, history_frames, _ptr(newest_slot), arr, n,
+                                              _ptr(fib_bytes), _ptr(fic_results), _ptr(out), out_ensemble_stride, _ptr(results), tie_rule,
+                                              int(bits_layout), self._stream(stream)), "dabgpu_decode_ring_layout")
 
     def msc_decode_frames(self, history, n_ensembles, ensemble_stride, history_frames, newest_frame_slot, subchannels,
                           out, out_ensemble_stride, results, tie_rule=0, stream=None, bits_layout=BITS_NATURAL):

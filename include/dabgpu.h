@@ -331,6 +331,21 @@ int dabgpu_msc_decode_frames_layout(dabgpu_ctx *ctx, const int8_t *d_bits_histor
                                     int n_subchannels, uint8_t *d_out, size_t out_ensemble_stride,
                                     dabgpu_codeword_result *d_results, int tie_rule, int bits_layout, void *stream);
 
+/*
+ * FIC + MSC of one transmission frame of every ensemble in ONE call: dabgpu_fic_decode_frames on ring slot newest_frame_slot and
+ * dabgpu_msc_decode_frames_layout on the ring, with the arguments and outputs of those two (identical bytes and result records).
+ * Replaces BasicRadio::Process's fan-out of a frame to its FIC runner and its MSC runners (src/basic_radio/basic_radio.cpp:41-65).
+ * When every sub-channel of the batch runs in a batch mapping (LANE / OCTET) the FIB groups are decoded INSIDE the MSC launch, as
+ * further groups of codewords with their own puncturing schedule -- the MSC's groups rarely fill their last round of wavefront
+ * slots, so the FIC then costs its gather only; otherwise the two run one after the other as if called separately.
+ *   d_fib_bytes [n_ensembles][4][96], d_fic_results [n_ensembles][4]; d_msc_out / d_msc_results as in dabgpu_msc_decode_frames.
+ */
+int dabgpu_decode_frames_layout(dabgpu_ctx *ctx, const int8_t *d_bits_history, size_t n_ensembles, size_t ensemble_stride,
+                                int history_frames, int newest_frame_slot, const dabgpu_subchannel *h_subchannels, int n_subchannels,
+                                uint8_t *d_fib_bytes, dabgpu_codeword_result *d_fic_results, uint8_t *d_msc_out,
+                                size_t out_ensemble_stride, dabgpu_codeword_result *d_msc_results, int tie_rule, int bits_layout,
+                                void *stream);
+
 /* Ring forms: ensemble e decodes the frame in slot d_newest_slot[e] of its own frame-history ring d_hist + e*ensemble_stride
  * (each ensemble at its own ring position, as dabgpu_stream_bank_process_ring leaves them); a negative slot skips the ensemble
  * (its result records come back with n_out_bytes = 0).  FIB bytes [n_ensembles][4][96], results [n_ensembles][4]. */
@@ -340,6 +355,12 @@ int dabgpu_fic_decode_ring(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensem
 int dabgpu_msc_decode_ring(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride, int history_frames,
                            const int32_t *d_newest_slot, const dabgpu_subchannel *subchannels, int n_subchannels, uint8_t *d_out,
                            size_t out_ensemble_stride, dabgpu_codeword_result *d_results, int tie_rule, void *stream);
+
+/* dabgpu_decode_frames_layout for rings (dabgpu_fic_decode_ring + dabgpu_msc_decode_ring_layout in one call) */
+int dabgpu_decode_ring_layout(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride, int history_frames,
+                              const int32_t *d_newest_slot, const dabgpu_subchannel *subchannels, int n_subchannels,
+                              uint8_t *d_fib_bytes, dabgpu_codeword_result *d_fic_results, uint8_t *d_msc_out, size_t out_ensemble_stride,
+                              dabgpu_codeword_result *d_msc_results, int tie_rule, int bits_layout, void *stream);
 
 /* msc_decode_ring for rings whose MSC part is in `bits_layout` (dabgpu_stream_bank_process_ring_layout) */
 int dabgpu_msc_decode_ring_layout(dabgpu_ctx *ctx, const int8_t *d_hist, size_t n_ensembles, size_t ensemble_stride, int history_frames,

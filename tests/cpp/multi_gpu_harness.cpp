@@ -248,10 +248,10 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
         DABCK(dabgpu_ofdm_demod_frames_history(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, nullptr, d_hist + (size_t)slot * FRAME_BITS, d_corr[(size_t)k], 0, stride,
                                                DABGPU_BITS_MSC_CLASSED, s));
         HIPCK(hipEventRecord(ev_demod[(size_t)(j % NEV)], s));
-        DABCK(dabgpu_fic_decode_frames(ctx[(size_t)k], d_hist + (size_t)slot * FRAME_BITS, E, stride, d_fib[(size_t)k], d_fres[(size_t)k], 0, s));
         for (int d = 1; d < inflight; d++) if (j - d >= 0) HIPCK(hipStreamWaitEvent(s, ev_demod[(size_t)((j - d) % NEV)], 0));
-        DABCK(dabgpu_msc_decode_frames_layout(ctx[(size_t)k], d_hist, E, stride, H, slot, subs.data(), N_SUB, d_msc[(size_t)k], 4 * cif_out, d_mres[(size_t)k], 0,
-                                              DABGPU_BITS_MSC_CLASSED, s));
+        // FIC + MSC of the frame in one call: the FIB groups are decoded inside the MSC launch
+        DABCK(dabgpu_decode_frames_layout(ctx[(size_t)k], d_hist, E, stride, H, slot, subs.data(), N_SUB, d_fib[(size_t)k], d_fres[(size_t)k], d_msc[(size_t)k],
+                                          4 * cif_out, d_mres[(size_t)k], 0, DABGPU_BITS_MSC_CLASSED, s));
         HIPCK(hipEventRecord(ev_msc[(size_t)(j % NEV)], s));
         j++;
         return true;
