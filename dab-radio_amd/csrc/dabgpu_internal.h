@@ -61,6 +61,10 @@ struct dabgpu_frame_desc {
     int slot;               // output slot of the completed frame, < 0: nothing to demodulate
     int split;              // samples [0, split) come from the stream's frame buffer (even)
     long long tail_off;     // sample offset inside the stream's current block of frame sample `split`
+    // retained blocks (dabgpu_stream_bank_process_retained): frame samples [carry_dst, carry_end) (even bounds, inside [0, split)) are read
+    // from the stream's PREVIOUS block, frame sample n at block sample carry_off + n; carry_end = 0: none
+    int carry_dst, carry_end;
+    long long carry_off;
 };
 
 extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const float* d_freq, int8_t* d_bits, float* d_cp_corr,
@@ -68,7 +72,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                int classed, hipStream_t stream, float* d_total_phase = nullptr, float* d_fine_freq = nullptr,
-                                               float beta = 0.0f);
+                                               float beta = 0.0f, const void* d_prev_tail = nullptr /* stream banks, retained blocks */);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
                                                float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
                                                hipStream_t stream);

@@ -92,15 +92,20 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
 
 // stream banks: head of the frame from the (complex float) frame buffer, tail from the caller's block in its capture format SRC
 // (tail_base is pre-biased so that frame sample n sits at tail_base + n * bytes per sample; only naturally 2/4/8-byte aligned)
+// (retained blocks: frame samples [cd, ce) -- even bounds inside [0, split) -- come from the stream's PREVIOUS block, pre-biased like the
+// tail; ce = 0 when nothing is carried)
 template <int SRC>
-__device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_base, const uint8_t* __restrict__ tail_base, int split, size_t n) {
+__device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_base, const uint8_t* __restrict__ tail_base, int split, size_t n,
+                                             const uint8_t* __restrict__ prev_base, int cd, int ce) {
+    const bool head = (int)n < split;
+    const bool carried = (int)n >= cd && (int)n < ce;
     if constexpr (SRC == SRC_C32) {
-        const uint8_t* p = (((int)n < split) ? frame_base : tail_base) + n * 8;
+        const uint8_t* p = (head ? (carried ? prev_base : frame_base) : tail_base) + n * 8;
         const f4u v = *reinterpret_cast<const f4u*>(p);
         return f4{v.x, v.y, v.z, v.w};
     } else {
-        if ((int)n < split) return *reinterpret_cast<const f4*>(frame_base + n * 8);
-        const uint8_t* p = tail_base + n * src_bytes<SRC>::value;
+        if (head && !carried) return *reinterpret_cast<const f4*>(frame_base + n * 8);
+        const uint8_t* p = (head ? prev_base : tail_base) + n * src_bytes<SRC>::value;
         if constexpr (SRC == SRC_S16) {
             typedef uint32_t u32a4 __attribute__((aligned(4)));
             raw_words<2> r;
@@ -151,7 +156,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
-                       const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride, demod_phase_tail pt)
+                       const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride, demod_phase_tail pt,
+                       const void* __restrict__ prev_tail)
 {
     f2* const fft_out = VIEWS ? fft_out_ : nullptr;
     f2* const dqpsk_out = VIEWS ? dqpsk_out_ : nullptr;
@@ -179,14 +185,18 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     if (frame >= n_frames) return;
     // stream banks: frame = stream index; desc[stream].slot = output slot of its completed frame, < 0 = nothing to do
     size_t out_frame = (size_t)frame;
-    int split = 0;
-    const uint8_t* tbase = nullptr;
+    int split = 0, cd = 0, ce = 0;
+    const uint8_t *tbase = nullptr, *pbase = nullptr;
     if constexpr (BANK) {
         const dabgpu_frame_desc d = desc[frame];
         if (d.slot < 0) return;
         out_frame = (size_t)d.slot;
         split = d.split;
         tbase = static_cast<const uint8_t*>(tail) + ((long long)frame * (long long)tail_stride + d.tail_off - (long long)d.split) * src_bytes<SRC>::value;
+        if (prev_tail != nullptr && d.carry_end > d.carry_dst) {     // part of the head still sits in the stream's previous block
+            cd = d.carry_dst; ce = d.carry_end;
+            pbase = static_cast<const uint8_t*>(prev_tail) + ((long long)frame * (long long)tail_stride + d.carry_off) * src_bytes<SRC>::value;
+        }
     }
 
     // DQPSK outputs [out0, out1) need FFTs of symbols [out0, out1]; the last chunk also owns the
@@ -210,8 +220,8 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
         if constexpr (BANK) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k);
-            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0));   // uniform per workgroup
+            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k, pbase, cd, ce);
+            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0), pbase, cd, ce);   // uniform per workgroup
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(iq_rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * SB);
@@ -579,7 +589,8 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                float* d_fft, float* d_dqpsk, const float* d_tw, const uint16_t* d_inv_map,
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
-                                               int classed, hipStream_t stream, float* d_total_phase, float* d_fine_freq, float beta)
+                                               int classed, hipStream_t stream, float* d_total_phase, float* d_fine_freq, float beta,
+                                               const void* d_prev_tail)
 {
     using namespace dabgpu;
     if (classed && (d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits only
@@ -599,7 +610,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 #define DABGPU_LAUNCH_V(SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail)
 #if DABGPU_EXP & 8
     const bool views = false;                  // d_fft is the phase-clock buffer of the soft-bits-only instantiation
 #else
@@ -608,7 +619,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
 #define DABGPU_LAUNCH_CB(SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, false, true>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \
-                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt)
+                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail)
 #define DABGPU_LAUNCH_C(SRC) do { if (d_desc != nullptr) DABGPU_LAUNCH_CB(SRC, true); else DABGPU_LAUNCH_CB(SRC, false); } while (0)
     switch (src) {
     case SRC_C32: if (classed) DABGPU_LAUNCH_C(SRC_C32); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;

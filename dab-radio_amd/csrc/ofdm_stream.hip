@@ -50,6 +50,11 @@ struct StreamState {
     int total_frames_read, total_frames_desync;
     int avg_done;                    // UpdateSignalAverage already applied to the current block
     long long pos;                   // samples of the current block consumed
+    // retained blocks (dabgpu_stream_bank_process_retained): frame samples [carry_dst, carry_end) of the frame under collection were
+    // NOT copied into the frame buffer at the end of the previous call -- they still sit in the previous block, frame sample n at block
+    // sample carry_src + (n - carry_dst).  Both bounds are even (the loaders fetch sample pairs); 0, 0 = nothing carried
+    int carry_dst, carry_end;
+    long long carry_src;
 };
 
 struct BankView {
@@ -96,7 +101,8 @@ __device__ __forceinline__ void copy_samples(f2* __restrict__ dst, const f2* __r
 template <int SRC>
 __global__ __launch_bounds__(256)
 void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __restrict__ iq, size_t stream_stride, long long n_samples,
-                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode, int* __restrict__ not_done, int* __restrict__ next_not_done)
+                           dabgpu_stream_cfg cfg, int max_frames, int first_round, int ring_mode, int* __restrict__ not_done, int* __restrict__ next_not_done,
+                           const uint8_t* __restrict__ prev_iq, int retain)
 {
     __shared__ StreamState S;
     __shared__ float win[256];
@@ -108,6 +114,8 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
     if (t == 0) S = B.st[s];
     __syncthreads();
     const uint8_t* block = iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value;
+    // the previous call's block, still valid (retained mode), or null: then nothing is carried
+    const uint8_t* prev_block = prev_iq ? prev_iq + (size_t)s * stream_stride * src_sample_bytes<SRC>::value : nullptr;
     const int NB_NULL_PERIOD = B.g.null_period, NB_CORR = B.g.n_corr, NB_FRAME_SAMPLES = B.g.frame_samples;
     f2* ring = B.ring + (size_t)s * NB_NULL_PERIOD;
     f2* corr = B.corr + (size_t)s * NB_CORR;
@@ -115,7 +123,14 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
     const int k = cfg.signal_l1_nb_samples;
 
     if (first_round) {
-        if (t == 0) { S.pos = 0; S.n_out = 0; S.avg_done = 0; B.copy_cnt[s] = 0; }
+        if (t == 0) {
+            S.pos = 0; S.n_out = 0; S.avg_done = 0;
+            // what the previous call left in its block instead of copying it (retained mode) is this call's carry
+            const int left = B.copy_cnt[s];
+            if (prev_block != nullptr && left > 0) { S.carry_dst = B.copy_dst[s]; S.carry_end = B.copy_dst[s] + left; S.carry_src = B.copy_src[s]; }
+            else { S.carry_dst = 0; S.carry_end = 0; S.carry_src = 0; }
+            B.copy_cnt[s] = 0;
+        }
         __syncthreads();
     }
 
@@ -239,21 +254,33 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
             const long long want = NB_FRAME_SAMPLES - have;
             const bool full = (want <= rest);
             const long long take = full ? want : rest;
+            const int cd = S.carry_dst, ce = S.carry_end;                       // (retained mode) part of [0, have) still in the previous block
+            const long long csrc = S.carry_src;
             if (full) {
                 // the frame completes inside this block: no assembly, the demodulator reads [0, split) from the frame
-                // buffer and the rest from the block; one sample is moved over when the boundary would split a pair
+                // buffer (or, retained mode, the previous block) and the rest from the block; one sample is moved over when the boundary
+                // would split a pair
                 if ((have & 1) && t == 0) frame[have] = sample_at<SRC>(block, bpos);
                 // the NULL symbol at the end of this frame heads the next correlation window (:558-562)
                 const int null_at = B.g.n_sym * B.g.period;
                 for (int j = t; j < NB_NULL_PERIOD; j += 256) {
                     const int idx = null_at + j;
-                    corr[j] = (idx < have) ? frame[idx] : sample_at<SRC>(block, bpos + (idx - have));
+                    corr[j] = (idx < have) ? ((idx >= cd && idx < ce) ? sample_at<SRC>(prev_block, csrc + (idx - cd)) : frame[idx])
+                                           : sample_at<SRC>(block, bpos + (idx - have));
                 }
             } else if (t == 0) {
                 // the block ends inside this frame: its samples so far are carried over into the stream's frame buffer by
                 // stream_copy_kernel, ONCE per call after the last round -- a stream that asks for it has consumed its block and takes
-                // no further part in the rounds (a copy launch per round, empty in all rounds but the last, cost 67 us each)
-                B.copy_src[s] = S.pos; B.copy_dst[s] = have; B.copy_cnt[s] = (int)take;
+                // no further part in the rounds (a copy launch per round, empty in all rounds but the last, cost 67 us each).
+                // Retained mode: no copy at all -- the record becomes the next call's carry; its bounds are made even here (the
+                // demodulator loads sample pairs), the odd samples at either end go to the frame buffer now.
+                int a = have, e = have + (int)take;
+                long long src = S.pos;
+                if (retain) {
+                    if ((a & 1) && a < e) { frame[a] = sample_at<SRC>(block, src); a++; src++; }
+                    if ((e & 1) && a < e) { frame[e - 1] = sample_at<SRC>(block, S.pos + take - 1); e--; }
+                }
+                B.copy_src[s] = src; B.copy_dst[s] = a; B.copy_cnt[s] = e - a;
             }
             __syncthreads();
             if (t == 0) {
@@ -270,7 +297,9 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
                     d.slot = s * max_frames + slot;
                     d.split = have + (have & 1);
                     d.tail_off = pos0 + (have & 1);
+                    d.carry_dst = cd; d.carry_end = ce; d.carry_off = csrc - cd;
                     B.desc[s] = d;
+                    S.carry_dst = 0; S.carry_end = 0; S.carry_src = 0;
                     // The demodulation of this frame runs in THIS round (the round's kernel order is advance, copy, demod, phase, sync),
                     // so the state machine does the frame's bookkeeping now (:563-576) and reads on into the next NULL + PRS window: one
                     // round per frame instead of two.  The reference's order is kept -- the fine-frequency update of frame k - 1 (phase
@@ -377,6 +406,11 @@ struct dabgpu_stream_bank {
     std::vector<void*> allocs;
     hipStream_t side = nullptr;        // second lane of a call (mode I banks of >= 1024 streams): half of the streams run their rounds here
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // retained blocks: the last call left the unfinished frames' samples in ITS block (no carry-over copy); the next call must be handed
+    // that block again (dabgpu_stream_bank_process_retained), or dabgpu_stream_bank_release must copy them out of it first
+    bool carry_pending = false;
+    int carry_src = 0;                 // loader kind (SRC) and stream stride of that block
+    size_t carry_stride = 0;
 };
 
 extern "C" {
@@ -414,6 +448,7 @@ int dabgpu_stream_bank_reset(dabgpu_stream_bank* b, void* stream) {
     CK(hipMemsetAsync(b->view.copy_cnt, 0, b->n * sizeof(int), s));
     CK(hipMemsetAsync(b->view.not_done, 0, 16 * sizeof(int), s));
 #undef CK
+    b->carry_pending = false;
     return DABGPU_OK;
 }
 
@@ -472,9 +507,14 @@ int dabgpu_stream_bank_create_mode(dabgpu_ctx* c, int mode, size_t n_streams, co
 template <int SRC>
 static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t stream_stride_samples, size_t n_samples,
                              int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream, int ring_mode = 0,
-                             int classed = 0) {
+                             int classed = 0, const void* d_prev = nullptr, int retain = 0) {
     if (!b || !d_iq || !d_bits) { dabgpu_set_error("stream_bank_process: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n_samples == 0) return DABGPU_OK;
+    if (b->carry_pending && (!d_prev || b->carry_src != SRC || b->carry_stride != stream_stride_samples)) {
+        dabgpu_set_error("stream_bank_process: the previous call retained its block -- pass that block (same format and stride) to "
+                         "dabgpu_stream_bank_process_retained, or call dabgpu_stream_bank_release first");
+        return DABGPU_ERR_INVALID_ARG;
+    }
     const BankGeom& G = b->view.g;
     const int NB_FRAME_SAMPLES = G.frame_samples, NB_CORR = G.n_corr, NB_NULL_PERIOD = G.null_period;
     // a frame needs at least n_sym symbols + a NULL minus the sync's pull-back of new samples
@@ -494,6 +534,18 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     const int n = (int)b->n;
     int st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    // Retained blocks (mode I, not the ring form): the unfinished frame at the end of a block is not copied into the stream's frame
+    // buffer -- the next call reads it where it is.  That needs every pending frame to complete inside the next block (a frame then
+    // spans two blocks at most); a shorter block copies the carried samples out of the previous block first, like a release.
+    const bool use_retain = retain && G.mode == 1 && !ring_mode;
+    const bool prev_valid = b->carry_pending && n_samples >= (size_t)NB_FRAME_SAMPLES;
+    if (b->carry_pending && !prev_valid) {
+        hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, 0, static_cast<const uint8_t*>(d_prev),
+                           stream_stride_samples);
+        CK(hipGetLastError());
+    }
+    b->carry_pending = false;
+    const uint8_t* prev_iq = prev_valid ? static_cast<const uint8_t*>(d_prev) : nullptr;
     // L1 windows of the signal-level IIR for every stream (grow-only scratch)
     const int k = b->cfg.signal_l1_nb_samples;
     if (n_samples >= (size_t)k) {
@@ -543,12 +595,13 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
             if (round == 0) CKL(hipMemsetAsync(b->view.not_done + 8 * l, 0, sizeof(int), ls));
             hipLaunchKernelGGL(stream_advance_kernel<SRC>, dim3((unsigned)cnt), dim3(256), 0, ls, b->view, s0, cnt, static_cast<const uint8_t*>(d_iq),
                                stream_stride_samples, (long long)n_samples, b->cfg, (int)max_frames_per_stream, round == 0 ? 1 : 0, ring_mode,
-                               b->view.not_done + 8 * l + (round & 7), b->view.not_done + 8 * l + ((round + 1) & 7));
+                               b->view.not_done + 8 * l + (round & 7), b->view.not_done + 8 * l + ((round + 1) & 7), prev_iq, use_retain ? 1 : 0);
             CKL(hipGetLastError());
             float* corr_l = b->d_corr_out + (size_t)s0 * G.n_sym * 2;
             if (G.mode == 1) {
                 CKL(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
-                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls));
+                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls, nullptr, nullptr, 0.0f,
+                                            prev_iq ? prev_iq + (size_t)s0 * stream_stride_samples * sb : nullptr));
             } else if ((st = dabgpu_launch_ofdm_demod_mode(     /* (modes II-IV run in one lane: n_lanes == 1, s0 == 0, cnt == n) */c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
                                                            b->view.desc, d_iq, stream_stride_samples, ls))) {
                 if (n_lanes == 2) (void)hipStreamSynchronize(b->side);
@@ -566,7 +619,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         }
         if (round > (1 << 22)) { dabgpu_set_error("stream_bank_process: no progress"); if (n_lanes == 2) (void)hipStreamSynchronize(b->side); return DABGPU_ERR_HIP; }
     }
-    for (int l = 0; l < n_lanes; l++) {                                   // the carry-over copies of the call, every lane its own streams
+    for (int l = 0; l < n_lanes && !use_retain; l++) {                    // the carry-over copies of the call, every lane its own streams
         hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)(lane_lo[l + 1] - lane_lo[l])), dim3(256), 0, lane_stream[l], b->view,
                            lane_lo[l], static_cast<const uint8_t*>(d_iq), stream_stride_samples);
         CKL(hipGetLastError());
@@ -582,10 +635,61 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
         CK(hipGetLastError());
     }
 #undef CK
+    if (use_retain) { b->carry_pending = true; b->carry_src = SRC; b->carry_stride = stream_stride_samples; }
+    return DABGPU_OK;
+}
+
+// dabgpu_stream_bank_release: copies what the last retained call left in its block into the frame buffers
+template <int SRC>
+static int bank_release_impl(dabgpu_stream_bank* b, const void* d_prev, size_t stream_stride_samples, void* stream) {
+    if (b->carry_src != SRC || b->carry_stride != stream_stride_samples) {
+        dabgpu_set_error("stream_bank_release: not the format / stride of the retained block"); return DABGPU_ERR_INVALID_ARG;
+    }
+    DABGPU_BIND(b->ctx);
+    hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)b->n), dim3(256), 0, (hipStream_t)stream, b->view, 0,
+                       static_cast<const uint8_t*>(d_prev), stream_stride_samples);
+    const int st = dabgpu_check_hip(hipGetLastError(), "stream_copy_kernel launch");
+    if (st) return st;
+    // (the copy records stay set; the next call's first round clears them -- it is handed no previous block, so nothing is carried)
+    b->carry_pending = false;
     return DABGPU_OK;
 }
 
 extern "C" {
+
+int dabgpu_stream_bank_process_retained(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                        const void* d_prev_raw, int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {
+    if (!b || !d_raw) { dabgpu_set_error("stream_bank_process_retained: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_samples == 0) return DABGPU_OK;
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32:
+        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream, 0, 0, d_prev_raw, 1);
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8:
+        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream, 0, 0, d_prev_raw, 1);
+    case DABGPU_IQ_RAW_S8:
+        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream, 0, 0, d_prev_raw, 1);
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16:
+        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_bits, max_frames_per_stream, d_n_frames, stream, 0, 0, d_prev_raw, 1);
+    default: break;
+    }
+    dabgpu_set_error("stream_bank_process_retained: format %d is not read by the bank's kernels directly (raw_f32l, raw_u8, raw_s8, raw_s16l, wav PCM8 / PCM16 / float32)", format);
+    return DABGPU_ERR_INVALID_ARG;
+}
+
+int dabgpu_stream_bank_release(dabgpu_stream_bank* b, const void* d_prev_raw, int format, size_t stream_stride_samples, void* stream) {
+    if (!b) { dabgpu_set_error("stream_bank_release: null bank"); return DABGPU_ERR_INVALID_ARG; }
+    if (!b->carry_pending) return DABGPU_OK;
+    if (!d_prev_raw) { dabgpu_set_error("stream_bank_release: null block"); return DABGPU_ERR_INVALID_ARG; }
+    switch (format) {
+    case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32: return bank_release_impl<0>(b, d_prev_raw, stream_stride_samples, stream);
+    case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8: return bank_release_impl<1>(b, d_prev_raw, stream_stride_samples, stream);
+    case DABGPU_IQ_RAW_S8: return bank_release_impl<2>(b, d_prev_raw, stream_stride_samples, stream);
+    case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16: return bank_release_impl<3>(b, d_prev_raw, stream_stride_samples, stream);
+    default: break;
+    }
+    dabgpu_set_error("stream_bank_release: not the format of the retained block");
+    return DABGPU_ERR_INVALID_ARG;
+}
 
 int dabgpu_stream_bank_process(dabgpu_stream_bank* b, const float* d_iq, size_t stream_stride_samples, size_t n_samples,
                                int8_t* d_bits, size_t max_frames_per_stream, int32_t* d_n_frames, void* stream) {

@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "dabgpu_soft_bits_to_hard_bytes_host_sync", "dabgpu_hard_bytes_to_soft_bits_host_sync",
     "dabgpu_stream_cfg_default", "dabgpu_stream_bank_create", "dabgpu_stream_bank_create_mode", "dabgpu_stream_bank_destroy", "dabgpu_stream_bank_reset",
     "dabgpu_stream_bank_process", "dabgpu_stream_bank_process_raw", "dabgpu_stream_bank_status",
+    "dabgpu_stream_bank_process_retained", "dabgpu_stream_bank_release",
     "dabgpu_dabplus_bank_create", "dabgpu_dabplus_bank_destroy", "dabgpu_dabplus_bank_reset", "dabgpu_dabplus_bank_process",
     "dabgpu_dabplus_process_frame_host_sync",
     "dabgpu_get_ofdm_params", "dabgpu_ofdm_demod_frames_mode", "dabgpu_ofdm_phase_update_mode",
@@ -208,6 +209,9 @@ def lib():
         L.dabgpu_stream_bank_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_process_retained.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                          C.c_void_p, C.c_void_p]
+        L.dabgpu_stream_bank_release.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.dabgpu_stream_bank_process_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                                      C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
@@ -546,6 +550,16 @@ class StreamBank:
     def process_raw(self, raw, fmt, stream_stride_samples, n_samples, bits, max_frames, n_frames=None, stream=None):
         check(lib().dabgpu_stream_bank_process_raw(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(bits), max_frames,
                                                    _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process_raw")
+
+    def process_retained(self, raw, fmt, stream_stride_samples, n_samples, prev_raw, bits, max_frames, n_frames=None, stream=None):
+        """process_raw for callers that keep `raw` valid and unchanged until the NEXT call has returned: no carry-over copy at the end of
+        the block; prev_raw = the block of the previous retained call (None at the first)"""
+        check(lib().dabgpu_stream_bank_process_retained(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(prev_raw), _ptr(bits),
+                                                        max_frames, _ptr(n_frames), Context._stream(stream)), "dabgpu_stream_bank_process_retained")
+
+    def release(self, prev_raw, fmt, stream_stride_samples, stream=None):
+        check(lib().dabgpu_stream_bank_release(self._h, _ptr(prev_raw), int(fmt), stream_stride_samples, Context._stream(stream)),
+              "dabgpu_stream_bank_release")
 
     def process_ring(self, raw, fmt, stream_stride_samples, n_samples, hist, hist_frames, newest_slot, stream=None, bits_layout=BITS_NATURAL):
         if bits_layout != BITS_NATURAL:

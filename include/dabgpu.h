@@ -500,6 +500,24 @@ int dabgpu_stream_bank_process(dabgpu_stream_bank *bank, const float *d_iq, size
  * dequantised (dabgpu_iq_convert) into bank-owned scratch (then d_raw and the byte offset between streams must be multiples of 16). */
 int dabgpu_stream_bank_process_raw(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
                                    size_t n_samples, int8_t *d_bits, size_t max_frames_per_stream, int32_t *d_n_frames, void *stream);
+/*
+ * Retained blocks: dabgpu_stream_bank_process_raw for callers that keep a block's device memory valid and unchanged until the NEXT call
+ * has returned -- a ring of device buffers (dabgpu_ingest_* with depth >= 2 is one).  OFDM_Demod::Process copies every sample it is
+ * handed into its frame buffer (ofdm_demodulator.cpp:550-577); the bank already reads completed frames where they lie and copies only
+ * the unfinished frame at a block's end; here that copy goes too: the next call's demodulator reads the frame's head from d_prev_raw,
+ * its tail from d_raw.  Same frames, same state, bit for bit.
+ *   d_prev_raw  the block of the previous retained call (same format and stride), NULL at the first call / after a release or reset
+ *   format      one the kernels read directly: raw_f32l, raw_u8, raw_s8, raw_s16l, wav PCM8 / PCM16 / float32; mode I banks (banks of
+ *               other modes process the call like dabgpu_stream_bank_process_raw)
+ * A block shorter than a frame first copies what the previous block still holds (a frame then spans more than two blocks).
+ * After a retained call the bank refuses any other process call until dabgpu_stream_bank_release (copies the carried samples out of the
+ * last block, which may then be freed) or dabgpu_stream_bank_reset.
+ */
+int dabgpu_stream_bank_process_retained(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
+                                        size_t n_samples, const void *d_prev_raw, int8_t *d_bits, size_t max_frames_per_stream,
+                                        int32_t *d_n_frames, void *stream);
+int dabgpu_stream_bank_release(dabgpu_stream_bank *bank, const void *d_prev_raw, int format, size_t stream_stride_samples, void *stream);
+
 /* Ring form for a device-resident pipeline: a completed frame of stream s is written to slot (frames demodulated so far) mod
  * hist_frames of d_hist [n_streams][hist_frames][230400] -- the per-ensemble frame-history ring dabgpu_fic_decode_ring /
  * dabgpu_msc_decode_ring read -- and d_newest_slot[s] receives that slot, or -1 when the stream completed no frame in this

@@ -311,3 +311,105 @@ def test_bank_of_1024_streams_in_two_lanes_equals_the_small_bank(oracle):
                                   np.tile(s4[name].view(np.uint32) if s4[name].dtype == np.float32 else s4[name], N // 4)), (k, name)
         frames += int(n4.sum())
     assert frames >= 5
+
+
+@pytest.mark.parametrize("block", [300000, 196608, 500001, 65536])
+@pytest.mark.parametrize("name", ["raw_f32l", "raw_u8", "raw_s16l"])
+def test_retained_blocks_equal_the_copying_bank(oracle, name, block):
+    """dabgpu_stream_bank_process_retained (the caller keeps a block valid until the next call has returned; no carry-over copy: the
+    next call's demodulator reads a frame's head from the previous block) against dabgpu_stream_bank_process_raw on the same blocks:
+    frame counts, every frame's soft bits and every status field after every call, for blocks longer than, equal to and shorter than
+    a frame (the short ones copy the carried samples out of the previous block first), odd block lengths (pair boundaries), drop-outs
+    (re-acquisition with a frame under collection) and a noise-only stream."""
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    base = [make_stream(oracle, 21, 4, 1.8e-3, 1235, 3.0), make_stream(oracle, 22, 4, -7.3e-3, 78, 6.0),
+            make_stream(oracle, 23, 4, 2.0e-4, 2551, 1.0, dropout=(215000, 235000)), noise_with_dips(24, streams_len=850000)]
+    n = min(s.size for s in base)
+    E = len(base)
+    fmt = dabgpu.IQ_FORMATS.index(name)
+    if name == "raw_f32l":
+        q = np.stack([np.stack([s[:n].real, s[:n].imag], axis=-1).astype(np.float32) for s in base])
+    elif name == "raw_u8":
+        q = np.stack([np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 127.0 + 127.5), 0, 255).astype(np.uint8) for s in base])
+    else:
+        q = np.stack([np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 30000.0), -32768, 32767).astype(np.int16) for s in base])
+    max_frames = block // 191400 + 2
+    banks = [dabgpu.StreamBank(ctx, E), dabgpu.StreamBank(ctx, E)]                 # [0] copies, [1] retained
+    bufs = [torch.zeros((E, block, 2), dtype=torch.from_numpy(q[:1, :1]).dtype, device="cuda") for _ in range(3)]
+    bits = [torch.zeros((E, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda") for _ in range(2)]
+    nf = [torch.zeros(E, dtype=torch.int32, device="cuda") for _ in range(2)]
+    prev = None
+    frames, call = 0, 0
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        cur = bufs[1 + call % 2]                                                 # the retained bank's two alternating buffers
+        cur[:, :m] = torch.from_numpy(q[:, k:k + m]).cuda()
+        bufs[0][:, :m] = cur[:, :m]
+        for b in bits:
+            b.zero_()
+        banks[0].process_raw(bufs[0], fmt, block, m, bits[0], max_frames, nf[0])
+        banks[1].process_retained(cur, fmt, block, m, prev, bits[1], max_frames, nf[1])
+        torch.cuda.synchronize()
+        bufs[0].fill_(0 if name != "raw_u8" else 7)                              # the copying bank's block is free to go
+        assert torch.equal(nf[0], nf[1]), (k, nf[0].tolist(), nf[1].tolist())
+        assert torch.equal(bits[0], bits[1]), k
+        s0, s1 = banks[0].status(), banks[1].status()
+        for f in s0.dtype.names:
+            a, b = (x[f].view(np.uint32) if x[f].dtype == np.float32 else x[f] for x in (s0, s1))
+            assert np.array_equal(a, b), (k, f)
+        frames += int(nf[0].sum().item())
+        prev, call = cur, call + 1
+    assert frames >= 6
+    # a plain call while a block is retained is refused; after a release the bank goes on as a copying bank, identically
+    with pytest.raises(RuntimeError):
+        banks[1].process_raw(bufs[0], fmt, block, 1000, bits[1], max_frames, nf[1])
+    banks[1].release(prev, fmt, block)
+    tail = torch.from_numpy(q[:, :min(block, 250000)]).cuda()
+    for bk, bt, cnt in ((banks[0], bits[0], nf[0]), (banks[1], bits[1], nf[1])):
+        bufs[0][:, :tail.shape[1]] = tail
+        bt.zero_()
+        bk.process_raw(bufs[0], fmt, block, tail.shape[1], bt, max_frames, cnt)
+    torch.cuda.synchronize()
+    assert torch.equal(nf[0], nf[1]) and torch.equal(bits[0], bits[1])
+    for bk in banks:
+        bk.close()
+
+
+def test_retained_blocks_in_two_lanes(oracle):
+    """1024 streams (two lanes), raw_u8, 4-frame-sized blocks: the retained bank equals the copying bank stream by stream"""
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    base = [make_stream(oracle, 31, 6, 1.8e-3, 1234, 3.0), make_stream(oracle, 32, 6, -7.3e-3, 77, 6.0),
+            make_stream(oracle, 33, 6, 2.0e-4, 2551, 1.0, dropout=(415000, 435000)), make_stream(oracle, 34, 6, 5.0e-3, 100001, 2.0)]
+    n = min(s.size for s in base)
+    q = np.stack([np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 127.0 + 127.5), 0, 255).astype(np.uint8) for s in base])
+    N, block, max_frames = 1024, 400001, 4
+    fmt = dabgpu.IQ_FORMATS.index("raw_u8")
+    banks = [dabgpu.StreamBank(ctx, N), dabgpu.StreamBank(ctx, N)]
+    bufs = [torch.zeros((N, block, 2), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    bits = [torch.zeros((N, max_frames, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda") for _ in range(2)]
+    nf = [torch.zeros(N, dtype=torch.int32, device="cuda") for _ in range(2)]
+    prev, call, frames = None, 0, 0
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        cur = bufs[1 + call % 2]
+        cur[:, :m] = torch.from_numpy(q[:, k:k + m]).cuda().repeat(N // 4, 1, 1)
+        bufs[0][:, :m] = cur[:, :m]
+        for b in bits:
+            b.zero_()
+        banks[0].process_raw(bufs[0], fmt, block, m, bits[0], max_frames, nf[0])
+        banks[1].process_retained(cur, fmt, block, m, prev, bits[1], max_frames, nf[1])
+        torch.cuda.synchronize()
+        assert torch.equal(nf[0], nf[1]) and torch.equal(bits[0], bits[1]), k
+        s0, s1 = banks[0].status(), banks[1].status()
+        for f in s0.dtype.names:
+            a, b = (x[f].view(np.uint32) if x[f].dtype == np.float32 else x[f] for x in (s0, s1))
+            assert np.array_equal(a, b), (k, f)
+        frames += int(nf[0][:4].sum().item())
+        prev, call = cur, call + 1
+    assert frames >= 10
+    for bk in banks:
+        bk.close()

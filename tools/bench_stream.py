@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--block-frames", type=int, default=2)
     ap.add_argument("--calls", type=int, default=6)
     ap.add_argument("--format", type=str, default="c32", help="c32 | raw_u8 | raw_s16l : capture format of the blocks")
+    ap.add_argument("--retained", action="store_true", help="dabgpu_stream_bank_process_retained: every block stays valid until the next call "
+                                                            "has returned (the stream sits in one device array here), no carry-over copy")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     ctx = dabgpu.Context(0)
@@ -84,7 +86,10 @@ def main():
     for k in range(args.calls):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if fmt is None:
+        if args.retained:
+            f_, base_, sb_ = (dabgpu.IQ_FORMATS.index("raw_f32l"), sv.data_ptr(), 8) if fmt is None else (fmt, raw.data_ptr(), sb)
+            bank.process_retained(base_ + k * n_block * sb_, f_, total, n_block, (base_ + (k - 1) * n_block * sb_) if k else None, bits, max_frames, nf)
+        elif fmt is None:
             bank.process(sv[:, k * n_block:(k + 1) * n_block], total, n_block, bits, max_frames, nf)
         else:
             bank.process_raw(raw.data_ptr() + k * n_block * sb, fmt, total, n_block, bits, max_frames, nf)
@@ -96,7 +101,7 @@ def main():
     st = bank.status()
     steady = times[2:] if len(times) > 3 else times
     fps = sum(g_ for _, g_ in steady) / sum(t for t, _ in steady)
-    print(json.dumps({"streams": E, "format": args.format, "block_samples": n_block, "calls": args.calls, "frames_total": frames_total,
+    print(json.dumps({"streams": E, "format": args.format, "retained_blocks": bool(args.retained), "block_samples": n_block, "calls": args.calls, "frames_total": frames_total,
                       "frames_desync_total": int(st["total_frames_desync"].sum()), "steady_frames_per_s": fps,
                       "steady_x_realtime_per_stream": fps / E / (2.048e6 / 196608),
                       "per_call_ms": [round(t * 1e3, 3) for t, _ in times], "per_call_frames": [g_ for _, g_ in times]}))
