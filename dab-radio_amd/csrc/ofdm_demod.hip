@@ -219,9 +219,28 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
         const size_t sym = (size_t)i * NB_SYMBOL_PERIOD;
         const bool dc = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
         if constexpr (BANK) {
+            // A symbol lies in ONE of the frame's sources -- frame buffer, previous block, current block -- except the one or two that
+            // hold a boundary: the choice is uniform, so the symbol is loaded through a buffer descriptor of that source like an aligned
+            // frame's (scalar symbol offset + loop-invariant lane offset); only a boundary symbol selects per lane.
+            const int lo = (int)sym, hi = lo + NB_SYMBOL_PERIOD;
+            const bool in_tail = lo >= split, in_prev = lo >= cd && hi <= ce, in_fb = hi <= split && (hi <= cd || lo >= ce);
+            if (in_fb) {
+                const __amdgpu_buffer_rsrc_t rs = frame_rsrc(fbase, NB_FRAME_SAMPLES * 8u);
 #pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k, pbase, cd, ce);
-            if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0), pbase, cd, ce);   // uniform per workgroup
+                for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC_C32>(rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * 8u);
+                if (dc) h = load_pair_buf<SRC_C32>(rs, head_off, (unsigned)sym * 8u);
+            } else if (in_tail || in_prev) {
+                constexpr unsigned SS = (unsigned)src_bytes<SRC>::value;
+                const __amdgpu_buffer_rsrc_t rs = frame_rsrc(in_tail ? tbase : pbase, NB_FRAME_SAMPLES * SS);
+                const unsigned lane_s = 2u * SS * (unsigned)t, head_s = 2u * SS * (unsigned)((t >= 4) ? t - 4 : 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(rs, lane_s, (unsigned)(sym + NB_CP + 512 * k) * SS);
+                if (dc) h = load_pair_buf<SRC>(rs, head_s, (unsigned)sym * SS);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = load_pair_bank<SRC>(fbase, tbase, split, sym + NB_CP + 2 * t + 512 * k, pbase, cd, ce);
+                if (dc) h = load_pair_bank<SRC>(fbase, tbase, split, sym + 2 * ((t >= 4) ? t - 4 : 0), pbase, cd, ce);   // uniform per workgroup
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = load_pair_buf<SRC>(iq_rs, lane_off, (unsigned)(sym + NB_CP + 512 * k) * SB);
