@@ -35,6 +35,9 @@ LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devi
 # SQ / GRBM / TCC counters of the decoder and the demodulator at 4096 ensembles (own passes, program directly after --)
 bash tools/prof_counters.sh $TAG > $OUT/prof_counters_$TAG.log 2>&1
 python3 tools/bench_stream.py > $OUT/bench_stream_$TAG.json 2> $OUT/bench_stream_$TAG.err
+# retained blocks (no carry-over copy): c32 and raw_u8 at 1024 x 4 frames, c32 at 256 x 2
+{ python3 tools/bench_stream.py --streams 1024 --block-frames 4 --retained; python3 tools/bench_stream.py --streams 1024 --block-frames 4 --format raw_u8 --retained; \
+  python3 tools/bench_stream.py --streams 1024 --block-frames 4 --format raw_u8; python3 tools/bench_stream.py --retained; } > $OUT/bench_stream_retained_$TAG.json 2> $OUT/bench_stream_retained_$TAG.err
 python3 tools/bench_dabplus.py > $OUT/bench_dabplus_$TAG.json 2> $OUT/bench_dabplus_$TAG.err
 # keep the merge-back small: reduce on the box, then drop the raw dumps
 python3 tools/collect_profiles.py $OUT $TAG $ROUND > $OUT/collect_$TAG.log 2>&1

@@ -12,7 +12,7 @@ cp $S/kernel_stats_$TAG.csv $S/pmc_fetch_size_$TAG.csv $S/pmc_write_size_$TAG.cs
 cp $S/hbm_traffic.json $D/hbm_traffic_$TAG.json
 cp $S/hbm_traffic.json profiles/hbm_traffic.json
 for f in counters kernel_stats_decode4096; do for e in json csv; do [ -f gpurun_out/${f}_$TAG.$e ] && cp gpurun_out/${f}_$TAG.$e $D/; done; done
-for f in bench_n1 bench_decode bench_decode_4096 bench_decode_4096_natural bench_full bench_ingest bench_mirror bench_stream bench_stream_1024x4 bench_io bench_fic \
+for f in bench_n1 bench_decode bench_decode_4096 bench_decode_4096_natural bench_full bench_ingest bench_mirror bench_stream bench_stream_1024x4 bench_stream_retained bench_io bench_fic \
          bench_cpp_host bench_dabplus; do
   [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json $D/
 done
