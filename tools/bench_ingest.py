@@ -58,7 +58,7 @@ def aligned(ctx, fmt_name, frames, batches, depth, copy_back):
             "hard_bits_equal_transmitted": ok}
 
 
-def bank(ctx, streams, block_frames, calls, depth):
+def bank(ctx, streams, block_frames, calls, depth, retained=False):
     dev = torch.device("cuda", 0)
     prs, mapper, _ = dabgpu.host_tables()
     iq, _, _ = dabsynth.random_frames(min(streams, 32), 5, dev, mapper, prs)
@@ -92,6 +92,7 @@ def bank(ctx, streams, block_frames, calls, depth):
         return pipe.submit(nbytes)
     d_next = submit(0)
     t0 = None
+    d_prev = None                                  # retained blocks: the twin of the previous call stays untouched until this call is queued
     for k in range(calls + 3):
         if k == 3:
             torch.cuda.synchronize(); t0 = time.perf_counter(); got = []
@@ -99,13 +100,22 @@ def bank(ctx, streams, block_frames, calls, depth):
         if k + 1 < calls + 3:
             d_next = submit(k + 1)               # the next block crosses PCIe while this one is processed
         pipe.wait(d)
-        sb.process_raw(d, fmt, n_block, n_block, bits, max_frames, nf)
-        pipe.consumed(d)
+        if retained:                               # (depth >= 3: one twin being filled, the current one, the previous one)
+            sb.process_retained(d, fmt, n_block, n_block, d_prev, bits, max_frames, nf)
+            if d_prev is not None:
+                pipe.consumed(d_prev)
+            d_prev = d
+        else:
+            sb.process_raw(d, fmt, n_block, n_block, bits, max_frames, nf)
+            pipe.consumed(d)
         got.append(int(nf.sum().item()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if retained:
+        sb.release(d_prev, fmt, n_block)
+        pipe.consumed(d_prev)
     st = sb.status()
-    return {"path": "stream bank (unsynchronised front end)", "format": "raw_u8", "streams": streams, "block_frames": block_frames, "depth": depth,
+    return {"path": "stream bank (unsynchronised front end)" + (", retained blocks" if retained else ""), "format": "raw_u8", "streams": streams, "block_frames": block_frames, "depth": depth,
             "frames_per_s": sum(got) / dt, "x_realtime_per_stream": sum(got) / dt / streams / (2.048e6 / L), "h2d_GBps": nbytes * calls / dt / 1e9,
             "frames": sum(got), "desync": int(st["total_frames_desync"].sum()), "includes_host_fill_memcpy": True,
             "pcie_ceiling_frames_per_s": 63e9 / (2 * L)}
@@ -124,6 +134,7 @@ def main():
     out.append(aligned(ctx, "raw_u8", a.frames, a.batches, 3, True))
     out.append(bank(ctx, 1, 4, 8, 2))
     out.append(bank(ctx, 256, 1, 8, 2))
+    out.append(bank(ctx, 256, 1, 8, 3, retained=True))
     for o in out:
         print(json.dumps(o))
 
