@@ -586,6 +586,9 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     // block and the output buffers as soon as the call has returned)
 #define CKL(call) do { st = dabgpu_check_hip((call), #call); if (st) { if (n_lanes == 2) (void)hipStreamSynchronize(b->side); return st; } } while (0)
     const size_t sb = src_sample_bytes<SRC>::value;
+    // run length of the bank's demodulation: four workgroups per frame (19 + 19 + 19 + 18 symbols).  Shorter-lived workgroups hand
+    // their slots to the round's small kernels sooner: 256 streams +8 % against three per frame, 1024 streams +1 %; six per frame loses again
+    const int bank_spb = 19;
     int h_not_done[2] = {1, 0};
     for (int round = 0; h_not_done[0] + h_not_done[1] != 0; round++) {
         for (int l = 0; l < n_lanes; l++) {
@@ -600,7 +603,7 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
             float* corr_l = b->d_corr_out + (size_t)s0 * G.n_sym * 2;
             if (G.mode == 1) {
                 CKL(dabgpu_launch_ofdm_demod(b->view.frame + (size_t)s0 * G.frame_samples, SRC, b->view.freq + s0, d_bits, corr_l, nullptr, nullptr,
-                                            c->d_tw, c->d_inv_map, cnt, 0, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls, nullptr, nullptr, 0.0f,
+                                            c->d_tw, c->d_inv_map, cnt, bank_spb, 0, b->view.desc + s0, iq_l, stream_stride_samples, classed, ls, nullptr, nullptr, 0.0f,
                                             prev_iq ? prev_iq + (size_t)s0 * stream_stride_samples * sb : nullptr));
             } else if ((st = dabgpu_launch_ofdm_demod_mode(     /* (modes II-IV run in one lane: n_lanes == 1, s0 == 0, cnt == n) */c, G.mode, b->view.frame, SRC, b->view.freq, d_bits, b->d_corr_out, nullptr, n, 0,
                                                            b->view.desc, d_iq, stream_stride_samples, ls))) {
