@@ -151,3 +151,30 @@ def test_one_call_against_the_oracle(ctx, oracle):
                 dec, err = oracle.msc_decode_logical(s, lf, 0)
                 assert np.array_equal(out[e, c, off:off + dec.size], dec), (e, si, c)
                 assert int(res["path_error"][e, c, si]) == err
+
+
+def test_degenerate_arguments(ctx):
+    """no ensembles: nothing happens; no sub-channels: the FIC alone; a slot outside the ring, a missing FIC array: refused"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(1)
+    n_ens, H = 9, 5
+    hist = torch.from_numpy(rng.integers(-127, 128, (n_ens, H, 230400), dtype=np.int8)).cuda()
+    subs = _subs(dabgpu)[:2]
+    cif_out = sum(dabgpu.subchannel_plan(g)[2] for g in subs)
+    fib = torch.zeros((n_ens, 4, 96), dtype=torch.uint8, device="cuda"); fres = torch.zeros((n_ens * 4, 16), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((n_ens, 4, cif_out), dtype=torch.uint8, device="cuda"); res = torch.zeros((n_ens * 4 * len(subs), 16), dtype=torch.uint8, device="cuda")
+    ctx.decode_frames(hist, 0, H * 230400, H, 4, subs, fib, fres, out, 4 * cif_out, res)
+    torch.cuda.synchronize()
+    assert not fib.any() and not out.any()
+    ctx.decode_frames(hist, n_ens, H * 230400, H, 4, [], fib, fres, None, 0, None)            # FIC only
+    ref_f = torch.zeros_like(fib); ref_r = torch.zeros_like(fres)
+    ctx.fic_decode_frames(hist[:, 4], n_ens, ref_f, ref_r, frame_stride=H * 230400)
+    torch.cuda.synchronize()
+    assert torch.equal(fib, ref_f) and torch.equal(fres, ref_r) and fib.any()
+    with pytest.raises(RuntimeError):
+        ctx.decode_frames(hist, n_ens, H * 230400, H, H, subs, fib, fres, out, 4 * cif_out, res)       # newest slot outside the ring
+    with pytest.raises(RuntimeError):
+        ctx.decode_frames(hist, n_ens, H * 230400, H, 4, subs, None, fres, out, 4 * cif_out, res)       # no FIB array
+    with pytest.raises(RuntimeError):
+        ctx.decode_frames(hist, n_ens, H * 230400, H, 4, subs, fib, fres, out, cif_out, res)            # output stride too small
