@@ -159,6 +159,24 @@ def hbm_roofline(kernel, k_ms, frames):
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME * frames}
 
 
+def _counter_evidence():
+    """VALU instructions per wavefront and the clock under the profiler of the batch Viterbi kernels, from the newest
+    profiles/r03/counters_v*.json (tools/prof_counters.sh: rocprofv3 --pmc passes at 4096 ensembles); {} when no summary is there"""
+    import glob
+    out = {}
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "counters_v*.json")), key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))[-1]
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]
+        for name, steps, key in (("vit_lanes_kernel<0, 1, 5>", 1542.0, 64.0), ("vit_octet_kernel<0>", 774.0, 8.0)):
+            if name in k and k[name].get("valu_per_wave"):
+                out[key] = {"instr_per_step": k[name]["valu_per_wave"] / steps, "clock_ghz_profiled": k[name].get("clock_ghz_profiled"),
+                            "valu_issue_cycles_frac": k[name].get("valu_issue_cycles_frac"), "source": os.path.relpath(path, ROOT)}
+    except Exception:
+        pass
+    return out
+
+
 def viterbi_roofline(kernel, steps, k_ms, lanes):
     """VALU-issue bound of the trellis recursion; `lanes`: codewords per wavefront of the mapping -- 64 (one lane per codeword), 8 (eight
     lanes per codeword) or 1 / False (one wavefront per codeword).  Counter evidence (VALU instructions per wavefront, issue share, clock under the profiler): profiles/r03/counters_*.json"""
@@ -166,12 +184,20 @@ def viterbi_roofline(kernel, steps, k_ms, lanes):
     if lanes is True:
         per_wave = 64.0
     instr = {64.0: VIT_LANES_INSTR_PER_STEP, 8.0: VIT_OCTET_INSTR_PER_STEP}.get(per_wave, VIT_WAVE_INSTR_PER_STEP)
+    ev = _counter_evidence().get(per_wave)
+    if ev:                                            # measured: SQ_INSTS_VALU / SQ_WAVES / trellis steps per codeword
+        instr = round(ev["instr_per_step"], 2)
     peak = N_SIMD * CLOCK_HZ * per_wave / (instr * VIT_CYCLES_PER_INSTR) / 1e9
     achieved = steps / (k_ms * 1e-3) / 1e9
-    return {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G trellis steps/s", "frac": achieved / peak,
-            "kernel_ms": k_ms, "trellis_steps_per_launch": steps,
-            "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU instructions per "
-                               f"wavefront-step x {VIT_CYCLES_PER_INSTR} cycles)"}
+    out = {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G trellis steps/s", "frac": achieved / peak,
+           "kernel_ms": k_ms, "trellis_steps_per_launch": steps,
+           "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU instructions per "
+                              f"wavefront-step x {VIT_CYCLES_PER_INSTR} cycles)"}
+    if ev:
+        out["counters"] = {"source": ev["source"], "valu_instructions_per_wavefront_step": ev["instr_per_step"],
+                           "clock_ghz_under_profiler": ev["clock_ghz_profiled"], "valu_issue_share_of_simd_cycles": ev["valu_issue_cycles_frac"],
+                           "peak_at_that_clock": peak * (ev["clock_ghz_profiled"] or 0.0) * 1e9 / CLOCK_HZ if ev["clock_ghz_profiled"] else None}
+    return out
 
 
 class Pipeline:
