@@ -66,6 +66,8 @@ __device__ __forceinline__ float fine_freq_add(float fine, float delta, int n_ff
 
 // ---- 2048-point transform between natural-order LDS arrays (x -> y), same pass structure as ofdm_demod_kernel ----
 // conj_io: inverse transform as conj(FFT(conj(x))), unnormalised like FFTW_BACKWARD
+// x, bufA and y may all be ONE array (in place): a thread writes bufA at exactly the eight positions it has read x at, and the results
+// are written behind a barrier
 __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* __restrict__ tw, bool conj_io) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int la = lane & 7, lb = lane >> 3;
@@ -109,6 +111,8 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
     wave_lds_fence();
     dft8(a);
     const int Kb = wave + 4 * lb + 32 * la;
+    // (y may be the array bufA lives in: every wave has taken its 512-point block out of it before anybody writes a result)
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         f2 v = a[k];
@@ -141,15 +145,22 @@ __device__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __re
     if (conj_io) { for (int i = t; i < N; i += 256) y[i].y = -y[i].y; __syncthreads(); }
 }
 
+// LDS of a synchroniser workgroup: 34.6 KB, so that four fit on a CU and one retiring demodulator workgroup (35.3 KB, stream-bank rounds)
+// makes room for one (it was 75.8 KB -- three natural-order arrays, the patches and the dB response side by side: two per CU, and a
+// synchroniser workgroup of a stream-bank round had to wait for TWO demodulator workgroups to retire).
+//   N = 2048 (mode I): every transform runs in place in A; the waves' transpose patches live in P during a transform, the dB response
+//                      R in P after it
+//   N <= 1024:         x = A, y = A + 1024 (Stockham passes ping-pong), tmp = P, R = P + 1024
 struct SyncLds {
-    f2 X[NB_FFT];
-    f2 Y[NB_FFT];
-    f2 bufA[NB_FFT];
-    f2 patch[4 * WAVE_PATCH];
-    float R[NB_FFT];
+    f2 A[NB_FFT];
+    f2 P[4 * WAVE_PATCH];
     float redv[4];
     int redi[4];
     float reds[4];
+    __device__ f2* x() { return A; }
+    __device__ f2* y(int N) { return N == NB_FFT ? A : A + 1024; }
+    __device__ f2* tmp(int N) { return N == NB_FFT ? A : P; }
+    __device__ float* R(int N) { return reinterpret_cast<float*>(N == NB_FFT ? P : P + 1024); }
 };
 
 // (value, index) reduction with "largest value, ties -> lowest index" == first maximum of a sequential strict-> scan
@@ -179,10 +190,10 @@ void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2*
     SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
     const int t = threadIdx.x;
     for (int i = t; i < N; i += 256)
-        S->X[i] = (i < N - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);           // CalculateRelativePhase :901-909
+        S->x()[i] = (i < N - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);         // CalculateRelativePhase :901-909
     __syncthreads();
-    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);
-    for (int i = t; i < N; i += 256) prs_time_ref[i] = mk2(S->Y[i].x, -S->Y[i].y);
+    fft_lds(N, S->x(), S->y(N), S->tmp(N), S->P, tw, true);
+    for (int i = t; i < N; i += 256) prs_time_ref[i] = mk2(S->y(N)[i].x, -S->y(N)[i].y);
 }
 
 __global__ __launch_bounds__(256)
@@ -202,20 +213,39 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     const int N = g.n_fft, M = N / 2;
 
     // ================= coarse frequency sync (:360-471) =================
+    f2* const X = S->x();
+    f2* const Y = S->y(N);
+    f2* const T = S->tmp(N);
+    float* const R = S->R(N);
     if (cfg.is_coarse_freq_correction) {
-        for (int i = t; i < N; i += 256) S->X[i] = prs_sym[i];
+        for (int i = t; i < N; i += 256) X[i] = prs_sym[i];
         __syncthreads();
-        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                               // :377
-        for (int i = t; i < N; i += 256)
-            S->X[i] = (i < N - 1) ? conj_mul(S->Y[i + 1], S->Y[i]) : mk2(0.0f, 0.0f);       // :380
+        fft_lds(N, X, Y, T, S->P, tw, false);                                               // :377
+        {   // X[i] = Y[i + 1] * conj(Y[i]) (:380) -- X and Y may be one array: through registers, behind a barrier
+            f2 q[NB_FFT / 256];
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) {
+                const int i = t + 256 * j;
+                q[j] = (i < N - 1) ? conj_mul(Y[i + 1], Y[i]) : mk2(0.0f, 0.0f);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
+        }
         __syncthreads();
-        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);                                // :383
-        for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], prs_time_ref[i]);          // :387-389
+        fft_lds(N, X, Y, T, S->P, tw, true);                                                // :383
+        {   // (same index in and out; X and Y may be one array or two)
+            f2 q[NB_FFT / 256];
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) q[j] = cmul(Y[i], prs_time_ref[i]); }   // :387-389
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
+        }
         __syncthreads();
-        fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                               // :392
+        fft_lds(N, X, Y, T, S->P, tw, false);                                               // :392
         for (int i = t; i < N; i += 256) {                                                  // :911-920
-            const float r = db20_det(cabs_det(S->Y[(i + M) % N]));
-            S->R[i] = r;
+            const float r = db20_det(cabs_det(Y[(i + M) % N]));
+            R[i] = r;
             if (freq_out) freq_out[(size_t)sidx * N + i] = r;
         }
         __syncthreads();
@@ -226,7 +256,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         for (int idx = t; idx < N; idx += 256) {                                            // :405-413, idx == N never occurs
             const int i = idx - M;
             if (i < -max_off || i > max_off) continue;
-            const float v = S->R[idx];
+            const float v = R[idx];
             if (v > bv || (v == bv && idx < bi)) { bv = v; bi = idx; }
         }
         argmax_reduce(bv, bi, S);
@@ -241,7 +271,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
                 int fi = index + M;
                 if (fi >= N) fi = N - 1;
                 pidx[j] = fi - M;
-                pmag[j] = undb20_det(S->R[fi]);
+                pmag[j] = undb20_det(R[fi]);
             }
             float peak_sum = 0.0f, lerp = 0.0f;
 #pragma unroll
@@ -273,16 +303,22 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         const int k = i & 3;
         const float ss = (float)k * f;
         const float base = 0.0f + (float)(i & ~3) * f;
-        S->X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
+        X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
     }
     __syncthreads();
-    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, false);                                   // :487
-    for (int i = t; i < N; i += 256) S->X[i] = cmul(S->Y[i], mk2(prs_fft[i].x, -prs_fft[i].y));   // :488-490
+    fft_lds(N, X, Y, T, S->P, tw, false);                                                   // :487
+    {
+        f2 q[NB_FFT / 256];
+#pragma unroll
+        for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) q[j] = cmul(Y[i], mk2(prs_fft[i].x, -prs_fft[i].y)); }   // :488-490
+#pragma unroll
+        for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
+    }
     __syncthreads();
-    fft_lds(N, S->X, S->Y, S->bufA, S->patch, tw, true);                                    // :493
+    fft_lds(N, X, Y, T, S->P, tw, true);                                                    // :493
     for (int i = t; i < N; i += 256) {                                                      // :494-498
-        const float r = db20_det(cabs_det(S->Y[i]));
-        S->R[i] = r;
+        const float r = db20_det(cabs_det(Y[i]));
+        R[i] = r;
         if (impulse_out) impulse_out[(size_t)sidx * N + i] = r;
     }
     __syncthreads();
@@ -292,7 +328,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     float leaf = 0.0f;
     for (int j = 0; j < N / 256; j++) {
         const int i = t + 256 * j;
-        const float r = S->R[i];
+        const float r = R[i];
         leaf = (j == 0) ? r : (leaf + r);
         const int dist = abs(g.n_cp - i);
         const float norm_dist = (float)dist / (float)g.period;
@@ -307,7 +343,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     if (t == 0) {
         const float total = (S->reds[0] + S->reds[1]) + (S->reds[2] + S->reds[3]);
         const float avg = total / (float)N;
-        const float r0 = S->R[0];                                                           // scan starts from the unweighted [0] (:503)
+        const float r0 = R[0];                                                           // scan starts from the unweighted [0] (:503)
         float max_value = r0; int max_index = 0;
         if (bv > r0) { max_value = bv; max_index = bi; }
         const bool valid = !((max_value - avg) < cfg.impulse_peak_threshold_db);            // :529
