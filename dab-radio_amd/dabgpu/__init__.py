@@ -617,6 +617,65 @@ class IngestPipe:
         check(lib().dabgpu_ingest_consumed(self._h, C.c_void_p(d_buffer), Context._stream(stream)), "dabgpu_ingest_consumed")
 
 
+class FrameSession:
+    """dabgpu_frame_session: one receiver's frames decoded one batched device call each (FIC + every registered sub-channel), results
+    fetched by (generation, FIB group / sub-channel, CIF) -- what the mirror classes use through dabgpu_frame_batcher"""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        L = lib()
+        L.dabgpu_frame_session_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.dabgpu_frame_session_destroy.argtypes = [C.c_void_p]
+        L.dabgpu_frame_session_destroy.restype = None
+        L.dabgpu_frame_session_set_subchannels.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.dabgpu_frame_session_push_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.dabgpu_frame_session_fetch_fib_group.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.dabgpu_frame_session_fetch_cif.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                                     C.POINTER(C.c_uint64)]
+        check(L.dabgpu_frame_session_create(C.byref(self._h), device), "dabgpu_frame_session_create")
+
+    def close(self):
+        if self._h:
+            lib().dabgpu_frame_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_subchannels(self, subchannels):
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels) if n else None
+        check(lib().dabgpu_frame_session_set_subchannels(self._h, arr, n), "dabgpu_frame_session_set_subchannels")
+
+    def push_frame(self, bits, decode_fic=True, tie_rule=0):
+        """bits: numpy int8[230400] (host) -> generation number of the frame"""
+        import numpy as np
+        b = np.ascontiguousarray(bits, dtype=np.int8)
+        assert b.size == NB_FRAME_BITS
+        gen = C.c_uint64()
+        check(lib().dabgpu_frame_session_push_frame(self._h, _ptr(b), int(bool(decode_fic)), tie_rule, C.byref(gen)), "dabgpu_frame_session_push_frame")
+        return gen.value
+
+    def fetch_fib_group(self, generation, group):
+        """-> (bytes uint8[96], crc_ok_mask, path_error), or None when that generation is gone / was pushed without the FIC"""
+        import numpy as np
+        out = np.empty(96, dtype=np.uint8)
+        m, e = C.c_uint32(), C.c_uint64()
+        st = lib().dabgpu_frame_session_fetch_fib_group(self._h, generation, group, _ptr(out), C.byref(m), C.byref(e))
+        if st == 4:                                   # DABGPU_ERR_NOT_READY
+            return None
+        check(st, "dabgpu_frame_session_fetch_fib_group")
+        return out, m.value, e.value
+
+    def fetch_cif(self, generation, subchannel, cif, capacity=8192):
+        """-> (bytes uint8[n], path_error), or None (generation gone / sub-channel not registered when that frame was pushed)"""
+        import numpy as np
+        out = np.empty(capacity, dtype=np.uint8)
+        n, e = C.c_size_t(), C.c_uint64()
+        st = lib().dabgpu_frame_session_fetch_cif(self._h, generation, C.byref(subchannel), cif, _ptr(out), capacity, C.byref(n), C.byref(e))
+        if st == 4:
+            return None
+        check(st, "dabgpu_frame_session_fetch_cif")
+        return out[:n.value].copy(), e.value
+
+
 class DabPlusBank:
     """dabgpu_dabplus_bank: n AAC_Frame_Processor states resident on the device"""
 
