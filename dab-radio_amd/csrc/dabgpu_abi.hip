@@ -239,6 +239,17 @@ int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes
     return DABGPU_OK;
 }
 
+// host buffers a caller hands to the *_host_sync entry points again and again (the mirror classes' frame buffers): page-locked, their
+// copies run at PCIe speed instead of through the runtime's staging
+int dabgpu_host_pin(void* p, size_t bytes) {
+    if (!p || bytes == 0) { dabgpu_set_error("host_pin: null buffer"); return DABGPU_ERR_INVALID_ARG; }
+    return dabgpu_check_hip(hipHostRegister(p, bytes, hipHostRegisterPortable), "hipHostRegister");
+}
+int dabgpu_host_unpin(void* p) {
+    if (!p) return DABGPU_OK;
+    return dabgpu_check_hip(hipHostUnregister(p), "hipHostUnregister");
+}
+
 int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
     if (!c) return DABGPU_ERR_INVALID_ARG;
     DABGPU_BIND(c);
@@ -254,8 +265,17 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 // idle GPU takes tens of milliseconds of load to settle (profiles/r01/ab_notes.md), and it keeps drifting afterwards: untimed rounds
 // until 40 ms of kernels have run (at most 12 rounds), then three timed rounds that visit the candidates in turn (2 launches each), summed per candidate --
 // a candidate is never judged by one moment of the clock.
+// batches too small to fill the chip with three workgroups per frame: more, shorter runs -- a single frame in three runs of 25 symbols is
+// three workgroups 25 symbols long (130 us); in 25 runs of 3 symbols (4 transforms each, one of them the halo) it is 25 workgroups 20 us
+// long.  Aim at ~256 workgroups, at most 25 runs per frame; from 86 frames on the usual three runs.
+static int small_batch_spb(size_t n_frames) {
+    if (n_frames >= 86) return 25;
+    const size_t chunks = std::min<size_t>(25, (256 + n_frames - 1) / n_frames);
+    return (int)((75 + chunks - 1) / chunks);
+}
+
 static int demod_auto_spb(dabgpu_ctx* c, size_t n_frames, int variant, hipStream_t s, const std::function<hipError_t(int)>& launch) {
-    if (n_frames < 512) return 25;
+    if (n_frames < 512) return small_batch_spb(n_frames);
     {
         DABGPU_HOST_LOCK(c);
         for (const auto& e : c->spb_cache) if (e.n_frames == n_frames && e.variant == variant) return e.spb;
@@ -292,7 +312,7 @@ extern "C" int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx* c, size_t n_frames
     if (!c) return 0;
     DABGPU_HOST_LOCK(c);
     for (auto e = c->spb_cache.rbegin(); e != c->spb_cache.rend(); ++e) if (e->n_frames == n_frames) return e->spb;      // the latest
-    return n_frames < 512 ? 25 : 0;
+    return n_frames < 512 ? small_batch_spb(n_frames) : 0;
 }
 
 static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_frames, const float* d_freq, int8_t* d_bits,

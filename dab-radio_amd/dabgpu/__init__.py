@@ -37,7 +37,7 @@ def classed_to_natural_index():
 # every symbol include/dabgpu.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
     "dabgpu_strerror", "dabgpu_last_error", "dabgpu_abi_version", "dabgpu_device_count",
-    "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize",
+    "dabgpu_create", "dabgpu_destroy", "dabgpu_synchronize", "dabgpu_host_pin", "dabgpu_host_unpin",
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync", "dabgpu_ofdm_demod_stream_frame_sync",
     "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",

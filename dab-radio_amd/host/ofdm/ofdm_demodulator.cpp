@@ -53,9 +53,17 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     m_frame_dqpsk.assign((params.nb_frame_symbols - 1) * params.nb_fft, {0.0f, 0.0f});
     m_impulse_response.assign(params.nb_fft, 0.0f);
     m_frequency_response.assign(params.nb_fft, 0.0f);
+    // the frame's samples go to the device and its soft bits come back once per frame: page-locked, the two copies run at PCIe speed
+    // (best effort: an unpinned buffer works too)
+    m_pinned_frame = dabgpu_host_pin(m_frame.data(), m_frame.size() * sizeof(m_frame[0])) == DABGPU_OK;
+    m_pinned_bits = dabgpu_host_pin(m_frame_bits.data(), m_frame_bits.size() * sizeof(m_frame_bits[0])) == DABGPU_OK;
 }
 
-OFDM_Demod::~OFDM_Demod() { dabgpu_destroy(m_ctx); }
+OFDM_Demod::~OFDM_Demod() {
+    if (m_pinned_frame) (void)dabgpu_host_unpin(m_frame.data());
+    if (m_pinned_bits) (void)dabgpu_host_unpin(m_frame_bits.data());
+    dabgpu_destroy(m_ctx);
+}
 
 // :235-275
 void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {

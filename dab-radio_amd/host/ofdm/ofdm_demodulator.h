@@ -120,6 +120,7 @@ private:
     size_t m_frame_length = 0;
     // results
     std::vector<viterbi_bit_t> m_frame_bits;
+    bool m_pinned_frame = false, m_pinned_bits = false;      // m_frame / m_frame_bits page-locked (dabgpu_host_pin)
     std::vector<std::complex<float>> m_frame_fft;
     std::vector<std::complex<float>> m_frame_dqpsk;
     std::vector<float> m_impulse_response;

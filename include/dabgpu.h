@@ -69,6 +69,10 @@ int dabgpu_device_count(void);
  */
 int dabgpu_create(dabgpu_ctx **out, int device, const float *h_prs_fft_ref, const int *h_carrier_mapper);
 void dabgpu_destroy(dabgpu_ctx *ctx);
+/* Page-lock / release a host buffer that is handed to the *_host_sync entry points repeatedly (hipHostRegister): the copies then run at
+ * PCIe speed.  Optional -- unpinned buffers work, slower. */
+int dabgpu_host_pin(void *h_buffer, size_t bytes);
+int dabgpu_host_unpin(void *h_buffer);
 int dabgpu_synchronize(dabgpu_ctx *ctx, void *stream);
 
 /* Built-in Mode I tables, host side (replace get_DAB_PRS_reference src/ofdm/dab_prs_ref.cpp:140,
@@ -94,7 +98,8 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
  *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
  *   symbols_per_block  data symbols handled by one workgroup, 1..75; any value gives identical results.  0 = the library chooses:
- *                 25 for batches below 512 frames; for larger ones it times 25 / 38 / 75 ONCE per context, batch size and kernel
+ *                 batches below 512 frames: 25, below 86 frames shorter runs (down to 3) so that the batch still spreads over the
+ *                 chip; for larger ones it times 25 / 38 / 75 ONCE per context, batch size and kernel
  *                 variant (source format, bits_layout): ~40 ms of warm-up launches of this call on the caller's own buffers, then
  *                 three timed rounds over the candidates -- identical outputs -- and remembers the fastest; which one that is
  *                 depends on the box.  dabgpu_ofdm_auto_symbols_per_block reports the choice.
@@ -146,7 +151,8 @@ int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx *ctx, const void *d_raw, int forma
                                    int8_t *d_bits, float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
                                    float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
 
-/* what symbols_per_block = 0 resolves to for batches of n_frames on this context: 25 / 38 / 75, or 0 = not measured yet */
+/* what symbols_per_block = 0 resolves to for batches of n_frames on this context: 25 / 38 / 75 (3 .. 25 below 86 frames), or 0 = not
+ * measured yet */
 int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx *ctx, size_t n_frames);
 
 /*
