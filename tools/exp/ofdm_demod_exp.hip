@@ -25,10 +25,19 @@
 #include "iq_decode.h"
 #include "ofdm_device.h"
 
+// development builds (tools/build_exp.sh + tools/kbench2.py; never set in the product build): timing-only ablations,
+//   2 = memory traffic only (loads, barriers, stores; no arithmetic)      4 = arithmetic only (one symbol loaded once)
+//   8 = phase clock: every wave accumulates core-clock cycles per phase of the symbol loop and writes them (with the elapsed
+//       constant-rate clock) to the buffer passed as d_fft; results stay valid (tools/kphase.py)
+#ifndef DABGPU_EXP
+#define DABGPU_EXP 0
+#endif
 // wave priority by phase of the symbol loop, one hex digit per point (F = leave as it is): start of symbol, before the
 // correlation, after barrier 1, after barrier 2, after the last radix-8 pass, end of the demapper
-constexpr int DEMOD_PRIO = 0x0F3FFF;       // measured choice (profiles/r02/ab_notes.md): 3 from the exchange barrier to the end of the demapper, 0 for PLL + radix 4
-#define PRIO_AT(k) do { constexpr int prio_ = (DEMOD_PRIO >> (4 * (k))) & 0xF; if (prio_ != 0xF) __builtin_amdgcn_s_setprio(prio_); } while (0)
+#ifndef DABGPU_PRIO
+#define DABGPU_PRIO 0x0F3FFF
+#endif
+#define PRIO_AT(k) do { constexpr int prio_ = (DABGPU_PRIO >> (4 * (k))) & 0xF; if (prio_ != 0xF) __builtin_amdgcn_s_setprio(prio_); } while (0)
 
 namespace dabgpu {
 
@@ -137,8 +146,12 @@ constexpr size_t DEMOD_LDS_BYTES = (4 * WAVE_PATCH) * sizeof(f2) + NB_SYM_BITS +
 // in contiguous pieces instead of one byte in sixteen.  The permutation rides on the frequency de-interleave scatter (a second
 // set of LDS positions) and on the row store's addresses: no extra pass, no extra instructions.  The FIC symbols stay as they are.
 template <int SRC, bool BANK, bool VIEWS = true, bool CLASSED = false>
+#if DABGPU_EXP & 16
+__global__ __launch_bounds__(256, 5)
+#else
 __global__ __launch_bounds__(256, (VIEWS || (BANK && CLASSED)) ? 3 : 4)      // (the display views, and the stream-bank loader with the
                                                                             // second position set, need a few more registers: 3 workgroups per CU instead of spills)
+#endif
 void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ freq_offset,
                        int8_t* __restrict__ bits, f2* __restrict__ cp_corr, f2* __restrict__ fft_out_,
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
@@ -237,7 +250,9 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     // the first symbol's samples are requested before anything else: the table reads and the barrier of the set-up below run while
     // they are on their way (they were issued behind them: two memory latencies in series at the start of every workgroup)
     f4 v[4], h = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#if !(DABGPU_EXP & 1024)
     load_symbol(out0, v, h);
+#endif
 
     // PLL constants: this thread always touches sample pairs (n, n+1) with n & 3 == 2*(t&1)
     const int k0 = 2 * (t & 1);
@@ -252,13 +267,15 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     // whole run of symbols: they are used between two LDS round trips of the transform, where a table read would add a third.
     // The six pass-1 twiddles w_2048^{p k} (p = 2t, 2t+1; k = 1..3) are parked in a private LDS slot of the thread and read back
     // at the start of every symbol: the PLL in front of their use hides the latency.  Same table entries either way.
+#if !(DABGPU_EXP & 16)
 #pragma unroll
     for (int k = 1; k < 4; k++) { tw1l[6 * t + 2 * (k - 1)] = tw[(2 * t) * k]; tw1l[6 * t + 2 * (k - 1) + 1] = tw[(2 * t + 1) * k]; }
+#endif
     f2 w2[7];
 #pragma unroll
     for (int k = 1; k < 8; k++) w2[k - 1] = tw[4 * lane * k];
     f2 w3[7];
-    constexpr bool W3_LDS = BANK || CLASSED;     // (class order keeps a second set of scatter positions instead)
+    constexpr bool W3_LDS = BANK || (CLASSED && !(DABGPU_EXP & 64)) || (DABGPU_EXP & 16);     // (class order keeps a second set of scatter positions instead)
     if constexpr (W3_LDS) {
         if (t < LDS_TW3) tw3l[t] = tw[32 * (t & 7) * ((t >> 3) + 1)];
     } else {
@@ -289,7 +306,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     pos[5] = inv_map[512 + Kb];
     int posc[6];                                  // the same positions in class order: (b mod 16) * 192 + b / 16; the imaginary half sits 96 further
 #pragma unroll
-    for (int k = 0; k < 6; k++) posc[k] = CLASSED ? ((pos[k] & 15) * 192 + (pos[k] >> 4)) : 0;
+    for (int k = 0; k < 6; k++) posc[k] = CLASSED ? ((DABGPU_EXP & 128) ? pos[k] : ((pos[k] & 15) * 192 + (pos[k] >> 4))) : 0;      // (128: timing only)
 
     f2 prev[6], keep[6];
 #pragma unroll
@@ -305,7 +322,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const int row_voff_c = (t / 12) * (NB_CIF_BITS / 16) + 16 * (t % 12);      // CLASSED: class t / 12, bytes 16 (t mod 12) .. + 15 of this symbol's 192
     auto row_write = [&](const int row, const u4v o) __attribute__((always_inline)) {
         if (t < NB_SYM_BITS / 16) {
-            if (CLASSED && row >= NB_FIC_SYMBOLS) {         // (uniform) symbol s of CIF q: 192 bytes per class
+            if (CLASSED && !(DABGPU_EXP & 32) && row >= NB_FIC_SYMBOLS) {         // (uniform) symbol s of CIF q: 192 bytes per class
                 const int q = (row - NB_FIC_SYMBOLS) / NB_CIF_SYMBOLS, sy = (row - NB_FIC_SYMBOLS) % NB_CIF_SYMBOLS;
                 __builtin_amdgcn_raw_buffer_store_b128(o, bits_rs, row_voff_c, NB_FIC_SYMBOLS * NB_SYM_BITS + q * NB_CIF_BITS + sy * (NB_SYM_BITS / 16), BUF_NT);
             } else {
@@ -315,13 +332,48 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     };
     auto store_row = [&](const int row) __attribute__((always_inline)) { row_write(row, row_read()); };
 
+#if DABGPU_EXP & 1024
+    load_symbol(out0, v, h);          // (A/B build: the first load behind the set-up, as before round 3)
+#endif
+#if DABGPU_EXP & 8
+    unsigned long long ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}, ph_last, ph_t0, ph_r0;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_r0), "=s"(ph_t0) :: "memory");
+    ph_last = ph_t0;
+#define PHASE_STAMP(k) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                            ph_acc[k] += now_ - ph_last; ph_last = now_; } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#endif
+
     // one symbol; pv = the six active bins of symbol i - 1 (in), cur = those of symbol i (out)
     auto symbol = [&](const int i, const f2 (&pv)[6], f2 (&cur)[6]) __attribute__((always_inline)) {
         const float dt0 = (float)(i * NB_SYMBOL_PERIOD) * f;             // ofdm_demodulator.cpp:675-676
         const bool do_corr = (i < NB_FRAME_SYMBOLS) && (i < out1 || i == NB_FRAME_SYMBOLS - 1);
+#if DABGPU_EXP & 2
+        {   // timing-only build: the memory traffic and the barriers of the kernel without its arithmetic
+            float s0 = h.x + h.y + h.z + h.w;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s0 += v[k].x + v[k].y + v[k].z + v[k].w;
+            if (i - 1 > out0 && i - 1 < NB_FRAME_SYMBOLS) store_row(i - 2);
+            __syncthreads();
+            if (i < sym_end) load_symbol(i + 1, v, h);
+            if (i > out0 && i < NB_FRAME_SYMBOLS) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) reinterpret_cast<float*>(obuf)[t * 3 + k] = s0;
+            }
+            __syncthreads();
+            if (i > out0 && i < NB_FRAME_SYMBOLS && i == sym_end) store_row(i - 1);
+            return;
+        }
+#endif
+
         // ---- PLL ----
         PRIO_AT(0);
+#if DABGPU_EXP & 16
+        const f4 w1_1 = f4{0.6f, 0.8f, 0.8f, 0.6f}, w1_2 = w1_1, w1_3 = w1_1;       // timing only
+#else
         const f4 w1_1 = w1p[0], w1_2 = w1p[1], w1_3 = w1p[2];
+#endif
         f2 a[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -349,8 +401,11 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             f2 b0, b1, b2, b3, c0, c1, c2, c3;
             dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
             dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
+#if !(DABGPU_EXP & 512)                   // (512 / 256: timing-only builds without the twiddle products of pass 1 / passes 2 and 3)
             b1 = cmul(b1, mk2(w1_1.x, w1_1.y)); b2 = cmul(b2, mk2(w1_2.x, w1_2.y)); b3 = cmul(b3, mk2(w1_3.x, w1_3.y));
             c1 = cmul(c1, mk2(w1_1.z, w1_1.w)); c2 = cmul(c2, mk2(w1_2.z, w1_2.w)); c3 = cmul(c3, mk2(w1_3.z, w1_3.w));
+#endif
+            PHASE_STAMP(0);                    // PLL + correlation + radix 4
             // (the empty statement orders the arithmetic above against the barrier below: the compiler is otherwise free to sink
             // the PLL behind it, which puts the skew wait back in front of the longest arithmetic phase)
             asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b1.x), "+v"(b1.y), "+v"(b2.x), "+v"(b2.y), "+v"(b3.x), "+v"(b3.y),
@@ -359,6 +414,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             // at the end of the symbol: the PLL and the radix-4 arithmetic above need no LDS, so a wave that finished the previous
             // symbol early runs them while the slower waves catch up -- one skew-absorbing barrier per symbol instead of two
             __syncthreads();
+            PHASE_STAMP(1);                    // skew barrier
             PRIO_AT(2);
             // the previous symbol's soft bits leave from here, not from the end of that symbol: a store issued after the prefetch
             // below would have to complete before the prefetched samples count as arrived (in-order vmcnt).  obuf is complete since
@@ -375,6 +431,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             if (row_due) row_write(i - 2, row);
         }
         __syncthreads();                       // the only cross-wave exchange of the transform
+        PHASE_STAMP(2);                        // exchange writes + previous row store + barrier
         PRIO_AT(3);
         if (do_corr && t == 0) {
             const f2* rr = red + 4 * (i & 1);
@@ -384,15 +441,18 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             if (phase_tail) ph_corr[i] = rsum;
         }
         // this symbol's samples are consumed: the next symbol's loads go into the same registers now
+#if !(DABGPU_EXP & 4)
         if (i < sym_end) load_symbol(i + 1, v, h);
+#endif
 
         // ---- pass 2: radix 8 inside this wave's 512-point block ----
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = bufA[rd2 + 64 * j];
         dft8(a);
+        PHASE_STAMP(3);                        // prefetch issue + pass-2 reads + radix 8
         patch[ta_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = cmul(a[k], w2[k - 1]);
+        for (int k = 1; k < 8; k++) patch[ta_w + 72 * k] = (DABGPU_EXP & 256) ? a[k] : cmul(a[k], w2[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[ta_r + 8 * j];
@@ -400,9 +460,10 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 
         // ---- pass 3: radix 8 inside 64-point blocks ----
         dft8(a);
+        PHASE_STAMP(4);                        // transpose A + radix 8
         patch[tb_w] = a[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = cmul(a[k], W3_LDS ? w3p[8 * (k - 1)] : w3[k - 1]);
+        for (int k = 1; k < 8; k++) patch[tb_w + 9 * k] = (DABGPU_EXP & 256) ? a[k] : cmul(a[k], W3_LDS ? w3p[8 * (k - 1)] : w3[k - 1]);
         wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j] = patch[tb_r + j];
@@ -410,6 +471,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 
         // ---- pass 4: radix 8; thread ends with bins Kb + 256 k ----
         dft8(a);
+        PHASE_STAMP(5);                        // transpose B + radix 8
         PRIO_AT(4);
 
         if (fft_out != nullptr) {
@@ -471,7 +533,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             if constexpr (CLASSED) {
                 if (i - 1 >= NB_FIC_SYMBOLS) {                                    // (uniform) MSC symbol in class order
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + 96] = (int8_t)by[k]; }
+                    for (int k = 0; k < 6; k++) { obuf[posc[k]] = (int8_t)bx[k]; obuf[posc[k] + ((DABGPU_EXP & 128) ? 1536 : 96)] = (int8_t)by[k]; }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 6; k++) { obuf[pos[k]] = (int8_t)bx[k]; obuf[pos[k] + 1536] = (int8_t)by[k]; }
@@ -479,6 +541,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             }
         }
         if (emit && i == sym_end) { __syncthreads(); store_row(i - 1); }  // (otherwise stored by the next symbol, ahead of its prefetch)
+        PHASE_STAMP(6);                        // demapper
         PRIO_AT(5);
     };
     // two symbols per trip so that the bins kept for the next DQPSK change hands by name, not by 12 register moves
@@ -498,6 +561,20 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             if (pt.fine_freq) pt.fine_freq[frame] = fine_freq_update(pt.fine_freq[frame], total, pt.beta, NB_FRAME_SYMBOLS, NB_FFT);
         }
     }
+#if DABGPU_EXP & 8
+    {
+        unsigned long long ph_r1, ph_t1;
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_r1), "=s"(ph_t1) :: "memory");
+        if (lane == 0 && fft_out_ != nullptr) {
+            float* dbg = reinterpret_cast<float*>(fft_out_) + ((size_t)unit * 4 + wave) * 12;
+#pragma unroll
+            for (int k = 0; k < 7; k++) dbg[k] = (float)ph_acc[k];
+            dbg[7] = (float)(ph_t1 - ph_t0); dbg[8] = (float)(ph_r1 - ph_r0); dbg[9] = (float)(sym_end - out0 + 1);
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            dbg[10] = (float)hwid; dbg[11] = (float)(ph_r0 & 0xFFFFFF);
+        }
+    }
+#endif
 }
 
 // one thread per frame: sequential sum of the 76 per-symbol phase errors, then the fine-frequency IIR
@@ -553,7 +630,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
                        n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail)
+#if DABGPU_EXP & 8
+    const bool views = false;                  // d_fft is the phase-clock buffer of the soft-bits-only instantiation
+#else
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
+#endif
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
 #define DABGPU_LAUNCH_CB(SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, false, true>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \

@@ -45,6 +45,10 @@
 #include "dabgpu_internal.h"
 #include "viterbi_pk16.h"
 
+#ifndef DABGPU_EXP
+#define DABGPU_EXP 0          // timing-only ablation switches of development builds (tools/build_exp.sh); 0 in the product
+#endif
+
 namespace dabgpu {
 
 // position bits: H = 0 (half), R0 = 1, R1 = 2 (register = R1 R0), L3 = 3, L4 = 4, L5 = 5 (sub-lane l = position >> 3)
@@ -123,8 +127,12 @@ __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane
             // candidate for the PARTNER's new state, their y the one for their own)
             const uint32_t x = as_u32(add16(M[r], C[s])), y = as_u32(add16(M[r], C[7 - s]));
             s2 lo, up;
+#if DABGPU_EXP & 8
+            lo = as_s2(x); up = as_s2(y);
+#else
             if constexpr (Q == 4) { const auto v = __builtin_amdgcn_permlane16_swap(x, y, false, false); lo = as_s2(v[0]); up = as_s2(v[1]); }
             else { const auto v = __builtin_amdgcn_permlane32_swap(x, y, false, false); lo = as_s2(v[0]); up = as_s2(v[1]); }
+#endif
             M[r] = min16(lo, up);                                              // lo / up: the candidate through the lower / upper predecessor
             D[r] = TIE ? satsub16(lo, up) : satsub16(up, lo);
         }
@@ -250,10 +258,14 @@ void vit_octet_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
         acc &= 0x0F0F0F0Fu;                                                                           \
         acc |= acc >> 12;                                                                             \
         if (TIE) acc = ~acc;                                                                          \
+        if (!(DABGPU_EXP & 16) || acc == 0x12345678u)                                                 \
         *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(grp_dec + (size_t)((TT) >> 1) * 512) + dec2) = (unsigned short)acc; \
     }
     // metric[0] = position 0 = sub-lane 0, register 0, low half: the lanes 0..7 of the wavefront hold it for their codewords
     auto vo_check_renorm = [&]() {
+#if DABGPU_EXP & 1
+        return;
+#endif
         const uint64_t m = __ballot((int)M[0].x >= (int)(60455 - 32768)) & 0xFFull;
         if (m != 0) vo_renorm(M, total, ((m >> c) & 1ull) != 0, lane);
     };
@@ -333,7 +345,7 @@ void vit_octet_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
     const int i_own = min(l * seg, n_chunks), i_end = min((l + 1) * seg, n_chunks);    // this lane's chunks
     uint32_t P_own = 0, P_exit = P_end;                            // position assumed at the first own step / reached after the last
     bool redo = true;                                              // this lane walks in the current round
-    for (int round = 0; round < 9; round++) {
+    for (int round = (DABGPU_EXP & 2) ? 9 : 0; round < 9; round++) {
         const int i_beg = round == 0 ? max(i_own - warm_chunks, 0) : i_own;
         // (a run-in that reaches the top starts from the end state itself and is exact)
         uint32_t P = round == 0 ? (i_beg == 0 ? P_end : 2u) : P_own;
@@ -386,7 +398,7 @@ void vit_octet_kernel(const dabgpu_vit_group* __restrict__ groups, const dabgpu_
 
     // ---- optional FIB CRC16 (fic_decoder.cpp:19-31,103-116): sub-lane l checks blocks l, l + 8, ... of its codeword ----
     uint32_t crc_mask = 0;
-    if (__ballot(live && Dd.n_crc_blocks != 0)) {
+    if (!(DABGPU_EXP & 4) && __ballot(live && Dd.n_crc_blocks != 0)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                             // the bytes were written by other lanes of this wavefront
         if (live && Dd.n_crc_blocks) {
