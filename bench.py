@@ -6,7 +6,11 @@ Workloads
         frames of synthetic IQ per GPU, resident in HBM as complex float32, through the fused PLL + cyclic-prefix phase +
         2048-pt FFT + DQPSK + frequency de-interleave + soft-bit kernel and the per-frame phase / fine-frequency tail.
         One "step" = one pass over the batch.  At N = 1 the line also carries `extra.configs2` / `extra.configs3`
-        (demod + FIC Viterbi, and full FIC + MSC for 4096 concurrent ensembles) with their own roofline blocks.
+        (demod + FIC Viterbi, and full FIC + MSC for 4096 concurrent ensembles) with their own roofline blocks -- the path SURVEY 8(d)
+        defines for them: every receiver has its own carrier offset (+-5 kHz) and timing offset (+-100 samples), and every frame runs
+        PRS synchronisation (coarse + fine) -> demodulation where and with the offset the synchroniser found -> fine-frequency update
+        (dabgpu_ofdm_sync_demod_frames) -> FIC / MSC decode -- and `extra.chain`: 4096 UNSYNCHRONISED raw_u8 streams through the
+        device-resident chain stream bank -> history rings -> FIC + MSC -> DAB+ outer code (tools/bench_chain.py).
   full  (BASELINE.json configs[4], per GPU): 8192 ensembles per GPU (built on the device from <= 64 seeded multiplexes),
         one step = demodulate one transmission frame of every ensemble into its frame-history ring + FIC Viterbi (4 FIB groups)
         + MSC time de-interleave, Viterbi and descrambling of 18 sub-channels x 4 CIFs.
@@ -19,8 +23,9 @@ torch.distributed (RCCL) carries only the timing barrier and the max over ranks 
 torch.distributed.run -- as a child process, before this process touches the GPU -- and exits with the child's status.
 
 `roofline` (dominant kernel ofdm_demod_kernel): achieved = algorithmic bytes per launch (1,803,264 B/frame x frames) /
-mean launch duration measured with HIP events INSIDE the timed loop (an event pair around every 8th demod launch on the launch
-stream; around every launch when K <= 100); `cpu_baseline` = the oracle (C port of the reference algorithm) timed on this box's host cores on a bounded sample.
+mean launch duration measured with ONE pair of HIP events around the back-to-back launches of the timed loop, on their stream;
+`cpu_baseline` = the oracle (C port of the reference algorithm) timed on this box's host cores on a bounded sample of the metric's
+workload; `cpu_baseline_full` = the oracle's whole receive chain (sync + demod + FIC + 18 x MSC per frame) beside configs[2]/[3].
 """
 import argparse
 import json
@@ -49,6 +54,14 @@ VIT_OCTET_INSTR_PER_STEP = 40.1
 VIT_WAVE_INSTR_PER_STEP = 23.0
 VIT_CYCLES_PER_INSTR = 4.0
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
+# instruction-count-free bound of the trellis recursion (whatever the mapping): 32 butterflies x 8 packed-u16 operations (4 adds, 2 mins,
+# 2 saturated differences for the decisions) / 2 states per packed operation = 128 issue-4 instructions per step of 64 codewords
+VIT_ALGO_INSTR_PER_64_STEPS = 128.0
+VIT_ALGO_PEAK_GSTEPS = N_SIMD * CLOCK_HZ * 64.0 / (VIT_ALGO_INSTR_PER_64_STEPS * VIT_CYCLES_PER_INSTR) / 1e9      # 307.2
+# sync-enabled configurations: a receiver's slice of a frame = LEAD samples of the preceding NULL symbol, then the frame; the PRS is
+# expected at LEAD and found within +-100 samples of it
+SLICE_LEAD = 1024
+SLICE_SAMPLES = SLICE_LEAD + 1544 + 196608
 
 
 def parse_args():
@@ -70,6 +83,9 @@ def parse_args():
     ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="demod, N = 1: skip extra.chain (the unsynchronised-stream chain at --extra-ensembles)")
+    ap.add_argument("--aligned", action="store_true",
+                    help="full / extras: frame-aligned input with synchronisation bypassed (what rounds 1-3 timed) instead of the sync-enabled path")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true",
@@ -161,25 +177,40 @@ def hbm_roofline(kernel, k_ms, frames):
 
 def _counter_evidence():
     """VALU instructions per wavefront and the clock under the profiler of the batch Viterbi kernels, from the newest
-    profiles/r03/counters_v*.json (tools/prof_counters.sh: rocprofv3 --pmc passes at 4096 ensembles); {} when no summary is there"""
+    profiles/r*/counters_v*.json (tools/prof_counters.sh: rocprofv3 --pmc passes at 4096 ensembles); {} when no summary is there.
+    Keys: codewords per wavefront (64 = lane mapping, 8 = octet mapping); any instantiation of the kernel found in the summary counts
+    (the one with the most wavefronts = the one the 4096-ensemble run was dominated by)."""
     import glob
+    import re
     out = {}
     try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "counters_v*.json")), key=lambda p: int(p.rsplit("_v", 1)[1].split(".")[0]))[-1]
+        def order(p):
+            m = re.search(r"profiles/r(\d+)/counters_v(\d+)\.json$", p.replace(os.sep, "/"))
+            return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters_v*.json")), key=order)[-1]
         with open(path) as fh:
             k = json.load(fh)["kernels"]
-        for name, steps, key in (("vit_lanes_kernel<0, 1, 5>", 1542.0, 64.0), ("vit_octet_kernel<0>", 774.0, 8.0)):
-            if name in k and k[name].get("valu_per_wave"):
-                out[key] = {"instr_per_step": k[name]["valu_per_wave"] / steps, "clock_ghz_profiled": k[name].get("clock_ghz_profiled"),
-                            "valu_issue_cycles_frac": k[name].get("valu_issue_cycles_frac"), "source": os.path.relpath(path, ROOT)}
+        for prefix, steps, key in (("vit_lanes_kernel", 1542.0, 64.0), ("vit_octet_kernel", 774.0, 8.0)):
+            cands = [(n, v) for n, v in k.items() if n.startswith(prefix) and v.get("valu_per_wave")]
+            if not cands:
+                continue
+            name, v = max(cands, key=lambda nv: nv[1].get("SQ_WAVES", 0) or 0)
+            out[key] = {"instr_per_step": v["valu_per_wave"] / steps, "clock_ghz_profiled": v.get("clock_ghz_profiled"),
+                        "valu_issue_cycles_frac": v.get("valu_issue_cycles_frac"), "source": os.path.relpath(path, ROOT), "kernel": name}
     except Exception:
         pass
     return out
 
 
 def viterbi_roofline(kernel, steps, k_ms, lanes):
-    """VALU-issue bound of the trellis recursion; `lanes`: codewords per wavefront of the mapping -- 64 (one lane per codeword), 8 (eight
-    lanes per codeword) or 1 / False (one wavefront per codeword).  Counter evidence (VALU instructions per wavefront, issue share, clock under the profiler): profiles/r03/counters_*.json"""
+    """Two bounds of the trellis recursion, both VALU issue (no dense contraction, far from HBM):
+      frac               against the ALGORITHM's bound: 128 issue-4 packed-u16 instructions per step of 64 codewords -> 307 G trellis steps/s,
+                         whatever the mapping and however many instructions the kernel at hand spends (decision gather, de-puncturing,
+                         chain-back, CRC all count against it)
+      issue_efficiency   against the kernel's OWN measured instruction stream (SQ_INSTS_VALU / SQ_WAVES / steps of the newest counter
+                         summary under profiles/, else the ISA count): how close the wavefronts come to back-to-back issue
+    `lanes`: codewords per wavefront of the mapping -- 64 (one lane per codeword), 8 (eight lanes per codeword) or 1 / False (one wavefront
+    per codeword)."""
     per_wave = float(lanes) if lanes else 1.0
     if lanes is True:
         per_wave = 64.0
@@ -187,16 +218,19 @@ def viterbi_roofline(kernel, steps, k_ms, lanes):
     ev = _counter_evidence().get(per_wave)
     if ev:                                            # measured: SQ_INSTS_VALU / SQ_WAVES / trellis steps per codeword
         instr = round(ev["instr_per_step"], 2)
-    peak = N_SIMD * CLOCK_HZ * per_wave / (instr * VIT_CYCLES_PER_INSTR) / 1e9
+    own_peak = N_SIMD * CLOCK_HZ * per_wave / (instr * VIT_CYCLES_PER_INSTR) / 1e9
     achieved = steps / (k_ms * 1e-3) / 1e9
-    out = {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G trellis steps/s", "frac": achieved / peak,
-           "kernel_ms": k_ms, "trellis_steps_per_launch": steps,
-           "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU instructions per "
-                              f"wavefront-step x {VIT_CYCLES_PER_INSTR} cycles)"}
+    out = {"bound": "valu_issue", "kernel": kernel, "achieved": achieved, "peak": VIT_ALGO_PEAK_GSTEPS, "unit": "G trellis steps/s",
+           "frac": achieved / VIT_ALGO_PEAK_GSTEPS, "kernel_ms": k_ms, "trellis_steps_per_launch": steps,
+           "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x 64 codewords / ({int(VIT_ALGO_INSTR_PER_64_STEPS)} packed-u16 add / min / "
+                              f"saturated-difference instructions per step of 64 codewords x {VIT_CYCLES_PER_INSTR} cycles): the algorithm's bound",
+           "issue_efficiency": {"frac": achieved / own_peak, "peak": own_peak,
+                                "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU "
+                                                   f"instructions per wavefront-step of THIS kernel x {VIT_CYCLES_PER_INSTR} cycles)"}}
     if ev:
-        out["counters"] = {"source": ev["source"], "valu_instructions_per_wavefront_step": ev["instr_per_step"],
-                           "clock_ghz_under_profiler": ev["clock_ghz_profiled"], "valu_issue_share_of_simd_cycles": ev["valu_issue_cycles_frac"],
-                           "peak_at_that_clock": peak * (ev["clock_ghz_profiled"] or 0.0) * 1e9 / CLOCK_HZ if ev["clock_ghz_profiled"] else None}
+        out["issue_efficiency"]["counters"] = {"source": ev["source"], "kernel": ev["kernel"], "valu_instructions_per_wavefront_step": ev["instr_per_step"],
+                                               "clock_ghz_under_profiler": ev["clock_ghz_profiled"],
+                                               "valu_issue_share_of_simd_cycles": ev["valu_issue_cycles_frac"]}
     return out
 
 
@@ -205,14 +239,22 @@ class Pipeline:
     A step decodes the FIC and the MSC of a frame with ONE call (dabgpu_decode_frames_layout): the 4 FIB groups of every ensemble join the
     MSC's trellis launch, whose last round of wavefront slots the MSC's own groups do not fill.
 
+    synced = True (the path SURVEY 8(d) defines for configs 3 / 4 / 5): receiver e has its own carrier offset (uniform in +-5 kHz) and its
+    frames begin toff[e] (uniform in +-100) samples away from where it expects them; every frame goes through
+    dabgpu_ofdm_sync_demod_frames -- RunCoarseFreqSync + RunFineTimeSync on the expected PRS position, demodulation from the position and
+    with the offset (coarse + fine) just tracked, fine-frequency update from the cyclic-prefix phase -- with the per-receiver sync records
+    resident on the device from frame to frame (ofdm_demodulator.cpp:360-548, :650-766, :606-618).  synced = False: frame-aligned input,
+    no carrier offset, synchronisation bypassed (what rounds 1-3 timed; an upper bound).
+
     `inflight` frames are in flight at once, frame j on stream / context j mod inflight (a context owns its scratch, so concurrent
     calls need one each): the next frame's HBM-bound demodulation and gather kernels fill the wavefront slots that the trellis kernel's
     last, partial round leaves idle.  Dependencies kept with events: msc(j) reads the ring slots of frames j-4..j -> waits for
-    demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it."""
+    demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it; synced: the synchroniser of
+    frame j reads the fine-frequency word frame j-1's phase tail wrote -> demod(j) waits for demod(j-1)."""
 
-    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1):
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1, synced=True, noise=0.05):
         import dabsynth
-        self.torch, self.E, self.inflight = torch, E, inflight
+        self.torch, self.E, self.inflight, self.synced, self.dabgpu = torch, E, inflight, synced, dabgpu
         # layout of the MSC soft bits in the history ring: 1 = time-interleaver class order (DABGPU_BITS_MSC_CLASSED: the demodulator
         # writes it for free and the decoder's gather then reads ~1.3 instead of 4.75 history bytes per soft bit), 0 = On_OFDM_Frame()
         self.layout, self.fmt_f32 = layout, dabgpu.IQ_FORMATS.index("raw_f32l")
@@ -220,8 +262,16 @@ class Pipeline:
         prs, mapper, _ = dabgpu.host_tables()
         # two stored transmission frames that repeat (8 CIFs of changing payload, time interleaved): decoded bytes then prove WHICH
         # ring slots / ages / frames in flight they came from (tools/dabsynth.py)
-        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs)
-        self.iq_f = torch.view_as_real(self.iq)                # [2][E][196608][2]
+        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs, noise=0.0 if synced else noise)
+        if synced:
+            self.slices, self.cfo, self.toff = dabsynth.ensemble_slices(self.iq, self.mux.n, seed + 2, SLICE_LEAD, SLICE_SAMPLES, noise=noise)
+            del self.iq
+            torch.cuda.empty_cache()
+            self.slices_f = torch.view_as_real(self.slices)        # [2][E][SLICE_SAMPLES][2]
+            self.states = torch.zeros(E * 24, dtype=torch.uint8, device=device)        # dabgpu_sync_state records, persistent
+            self.sync_cfg = dabgpu.sync_cfg_default()
+        else:
+            self.iq_f = torch.view_as_real(self.iq)                # [2][E][196608][2]
         self.frame_of_slot = {}                                # ring slot -> number of the frame it holds
         self.n_sub = dabsynth.N_SUB
         self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
@@ -237,15 +287,41 @@ class Pipeline:
         self.stride = self.H * 230400
         self.j = 0                                  # next frame number
         self.ev_demod, self.ev_msc = {}, {}
+        self.spb = 0
 
-    # the three stages of frame-slot `slot` on lane k (context k, stream k)
+    def tune(self):
+        """dabgpu_ofdm_tune once per context for this call shape (explicit, blocking, outside every timed region); the run length it
+        records is what symbols_per_block = 0 resolves to afterwards"""
+        src = self.slices_f[0] if self.synced else self.iq_f[0]
+        chosen = []
+        for c in self.ctxs:
+            # (synced: the slices are longer than a frame; the calibration demodulates their first 196608 samples as frame-aligned
+            # frames, which costs what the positioned frames cost)
+            chosen.append(c.ofdm_tune(src, self.fmt_f32, self.E, self.hist[:, 0], bits_frame_stride=self.stride, bits_layout=self.layout,
+                                      with_phase_tail=self.synced))
+        self.torch.cuda.synchronize()
+        return chosen
+
+    # the stages of frame-slot `slot` on lane k (context k, stream k)
     def demod(self, slot, k=0, frame=None):
         """transmission frame `frame` (default: the next one after what the ring holds) of every ensemble into ring slot `slot`"""
         if frame is None:
             frame = self.frame_of_slot.get(slot, slot - self.H) + self.H       # (stage timing loops walk the ring in order)
         self.frame_of_slot[slot] = frame
-        self.ctxs[k].ofdm_demod_frames_history(self.iq_f[frame % self.mux.n_frames], self.fmt_f32, self.E, self.hist[:, slot], cp_corr=self.corr[k],
-                                               bits_frame_stride=self.stride, bits_layout=self.layout, stream=self.streams[k].cuda_stream)
+        if self.synced:
+            self.ctxs[k].ofdm_sync_demod_frames(self.slices_f[frame % self.mux.n_frames], self.E, SLICE_SAMPLES, SLICE_LEAD, self.states, self.hist[:, slot],
+                                                cfg=self.sync_cfg, cp_corr=self.corr[k], bits_frame_stride=self.stride, bits_layout=self.layout,
+                                                stream=self.streams[k].cuda_stream)
+        else:
+            self.ctxs[k].ofdm_demod_frames_history(self.iq_f[frame % self.mux.n_frames], self.fmt_f32, self.E, self.hist[:, slot], cp_corr=self.corr[k],
+                                                   bits_frame_stride=self.stride, bits_layout=self.layout, stream=self.streams[k].cuda_stream)
+
+    def sync_only(self, slot, k=0):
+        """the synchroniser alone (5 transforms per receiver) on scratch records: what it costs inside demod()"""
+        if not hasattr(self, "_scratch_states"):
+            self._scratch_states = self.states.clone()
+        self.ctxs[k].ofdm_sync(self.slices_f[slot % self.mux.n_frames].view(-1)[2 * SLICE_LEAD:], self.E, SLICE_SAMPLES, self._scratch_states,
+                               cfg=self.sync_cfg, stream=self.streams[k].cuda_stream)
 
     def fic(self, slot, k=0):
         self.ctxs[k].fic_decode_frames(self.hist[:, slot], self.E, self.fic_out[k], self.fic_res[k], frame_stride=self.stride,
@@ -260,10 +336,11 @@ class Pipeline:
         self.ctxs[k].decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.fic_out[k], self.fic_res[k], self.msc_out[k],
                                    4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
 
-    def step(self, on_demod=None):
-        """one transmission frame of every ensemble: demod -> FIC + MSC"""
+    def step(self, on_demod=None, decode=None):
+        """one transmission frame of every ensemble: (sync ->) demod -> FIC + MSC   (decode = self.fic: configs[2])"""
         torch, j, n = self.torch, self.j, self.inflight
         k, slot, st = j % n, j % self.H, self.streams[j % n]
+        decode = decode or self.decode
         self.j += 1
         self.last_frame_of_lane = getattr(self, "last_frame_of_lane", {})
         self.last_frame_of_lane[k] = j
@@ -272,11 +349,15 @@ class Pipeline:
                 on_demod(lambda: self.demod(slot, 0, j))
             else:
                 self.demod(slot, 0, j)
-            self.decode(slot)
+            decode(slot)
             return
         w = self.ev_msc.pop(j - self.H + 4, None)                    # the last reader of the slot this frame overwrites
         if w is not None:
             st.wait_event(w)
+        if self.synced:                                              # frame j's synchroniser reads what frame j - 1's phase tail wrote
+            w = self.ev_demod.get(j - 1)
+            if w is not None:
+                st.wait_event(w)
         if on_demod:
             on_demod(lambda: self.demod(slot, k, j))
         else:
@@ -288,7 +369,7 @@ class Pipeline:
             if w is not None:
                 st.wait_event(w)
         self.ev_demod.pop(j - n, None)
-        self.decode(slot, k)
+        decode(slot, k)
         ev = torch.cuda.Event(); ev.record(st)
         self.ev_msc[j] = ev
 
@@ -307,10 +388,10 @@ class Pipeline:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    def check(self, dabgpu):
+    def check(self, dabgpu, fic_only=False):
         """the outputs of the last frame of every lane against what was transmitted: frame j carries fibs[j mod 2], its CIF c decodes to
         payload[(4 j + c - 15) mod 8] -- the payload changes with every CIF, so a wrong ring slot, a wrong age or frames in flight in
-        the wrong order cannot pass"""
+        the wrong order cannot pass.  synced: plus what the synchroniser tracked, against what the generator put in."""
         import numpy as np
         torch, E, nd, P = self.torch, self.E, self.mux.n, self.mux.period
         out = {"fib_crc_pass": 0, "fib_crc_expected": E * 12 * self.inflight, "fib_bytes_equal_transmitted": True,
@@ -325,33 +406,51 @@ class Pipeline:
             res_f = self.fic_res[k].cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
             out["fib_crc_pass"] += int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
             out["fib_bytes_equal_transmitted"] &= bool(torch.equal(self.fic_out[k], self.mux.fibs[idx, j % self.mux.n_frames]))
-            out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k].view(E, 4, self.n_sub, 192), exp))
+            if not fic_only:
+                out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k].view(E, 4, self.n_sub, 192), exp))
+        if fic_only:
+            del out["msc_bytes_equal_transmitted"]
+        if self.synced:
+            st = self.states.cpu().numpy().view(np.dtype(dabgpu.SYNC_STATE_DTYPE))
+            net = st["freq_coarse"].astype(np.float64) + st["freq_fine"].astype(np.float64)
+            out["sync"] = {"receivers_with_valid_impulse_peak": int((st["sync_valid"] != 0).sum()),
+                           "fine_time_offset_equals_generated": bool(np.array_equal(st["fine_time_offset"], self.toff.cpu().numpy())),
+                           "carrier_offset_range_hz": [float(self.cfo.min().item()) * 2.048e6, float(self.cfo.max().item()) * 2.048e6],
+                           "timing_offset_range_samples": [int(self.toff.min().item()), int(self.toff.max().item())],
+                           # the PLL multiplies by e^{+j 2 pi f n}: a locked loop sits at minus the generator's offset
+                           "max_abs_tracking_error_hz": float(np.abs(net + self.cfo.cpu().numpy().astype(np.float64)).max() * 2.048e6)}
         return out
 
 
-def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1):
-    """BASELINE configs[2] (demod + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
-    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2, layout=layout)
+def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1, synced=True):
+    """BASELINE configs[2] (full demod incl. sync + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2, layout=layout, synced=synced)
+    chosen = p.tune()
     p.fill()
     torch.cuda.synchronize()
     t_demod, t_fic, t_msc = p.timed(p.demod, reps), p.timed(p.fic, reps), p.timed(p.msc, reps)      # one stage at a time, stream 0
+    t_sync = p.timed(p.sync_only, reps) if synced else None
     t_dec = p.timed(p.decode, reps)                                            # FIC + MSC as one call (what the pipeline runs)
+    # configs[2]: (sync ->) demod -> FIC, one frame at a time on one stream ...
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for k in range(reps):
         p.demod(k % p.H); p.fic(k % p.H)
     e1.record(); torch.cuda.synchronize()
     t_c2_seq = e0.elapsed_time(e1) / reps
-    # configs[2] with two frames in flight like configs[3]: frame j on lane j mod 2 (demod -> FIC in stream order; slot j mod 8 is reused
-    # by frame j + 8 on the same lane), so the FIC trellis of frame j (two wavefronts per SIMD) runs beside the demodulation of j + 1
+    # ... and with two frames in flight like configs[3]: frame j on lane j mod 2, the FIC trellis of frame j beside the demodulation of j + 1
+    p.fill()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(4 * reps):
-        p.demod(k % p.H, k % 2, k); p.fic(k % p.H, k % 2)
+        p.step(decode=p.fic)
     torch.cuda.synchronize()
     t_c2 = (time.perf_counter() - t0) / (4 * reps) * 1e3
+    chk2 = p.check(dabgpu, fic_only=True)
+    # configs[3]
+    p.fill()
     t0 = time.perf_counter()
-    for k in range(reps):                                     # one frame at a time on one stream
+    for k in range(reps):                                     # one frame at a time (both lanes' work serialised by the events of step())
         p.demod(k % p.H); p.decode(k % p.H)
     torch.cuda.synchronize()
     t_seq = (time.perf_counter() - t0) / reps * 1e3
@@ -365,26 +464,80 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     # DABGPU_VIT_MAP_AUTO's switch points for the FIC (include/dabgpu.h): wave -> octet at ~700 frames, octet -> lane at ~12000
     lanes_fic = 64 if E >= 12000 else (8 if E >= 700 else 0)
     fic_kernel = {64: "vit_lanes_kernel (FIC)", 8: "vit_octet_kernel (FIC)", 0: "viterbi_kernel (FIC)"}[lanes_fic]
-    c2 = {"workload": f"BASELINE configs[2]: full OFDM demod + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
-          "ms_per_step": t_c2, "frames_per_s": E / t_c2 * 1e3, "x_realtime": E / t_c2 * 1e3 / REALTIME_FRAMES_PER_S,
+    path = ("per frame and receiver: dabgpu_ofdm_sync_demod_frames (coarse + fine PRS synchronisation -> demodulation at the position and with the "
+            "carrier offset found -> fine-frequency update; carrier offsets +-5 kHz, timing offsets +-100 samples)" if synced else
+            "frame-aligned input, synchronisation bypassed (upper bound of the configuration)")
+    kms = {"sync_and_demod_one_call": t_demod, "ofdm_sync_alone": t_sync} if synced else {"ofdm_demod": t_demod}
+    c2 = {"workload": f"BASELINE configs[2]: full OFDM demod incl. sync + FIC Viterbi (4 x 774 trellis steps per frame), {E} frames", "frames": E,
+          "path": path, "ms_per_step": t_c2, "frames_per_s": E / t_c2 * 1e3, "x_realtime": E / t_c2 * 1e3 / REALTIME_FRAMES_PER_S,
           "frames_in_flight": 2, "ms_per_step_one_frame_at_a_time": t_c2_seq, "frames_per_s_one_frame_at_a_time": E / t_c2_seq * 1e3,
-          "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic},
-          "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
+          "kernel_ms": dict(kms, fic_viterbi=t_fic), "symbols_per_block": chosen[0],
+          "roofline": [hbm_roofline("ofdm_sync_kernel + ofdm_demod_kernel" if synced else "ofdm_demod_kernel", t_demod, E),
                        viterbi_roofline(fic_kernel, p.fic_steps, t_fic, lanes_fic)],
-          "check": {k: chk[k] for k in ("fib_crc_pass", "fib_crc_expected", "fib_bytes_equal_transmitted")}}
+          "check": chk2}
     c3 = {"workload": f"BASELINE configs[3]: full FIC + MSC demod + Viterbi, {E} concurrent synthetic ensembles, 18 x 48 CU EEP 3-A", "ensembles": E,
-          "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,
+          "path": path, "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S,
           "frames_in_flight": 2, "history_layout": "time-interleaver class order" if layout else "natural",
           "ms_per_step_one_frame_at_a_time": t_seq, "frames_per_s_one_frame_at_a_time": E / t_seq * 1e3,
-          "kernel_ms": {"ofdm_demod": t_demod, "fic_viterbi": t_fic, "msc_viterbi_incl_deinterleave": t_msc,
-                        "fic_and_msc_one_call": t_dec},
+          "kernel_ms": dict(kms, fic_viterbi=t_fic, msc_viterbi_incl_deinterleave=t_msc, fic_and_msc_one_call=t_dec), "symbols_per_block": chosen[0],
           "algorithmic_hbm_GBps": 2.27e6 * E / (t_all * 1e-3) / 1e9,
-          "roofline": [hbm_roofline("ofdm_demod_kernel", t_demod, E),
+          "roofline": [hbm_roofline("ofdm_sync_kernel + ofdm_demod_kernel" if synced else "ofdm_demod_kernel", t_demod, E),
                        viterbi_roofline(("vit_prep_ring4c_kernel" if layout else "vit_prep_ring4_kernel") + " + vit_lanes_kernel (MSC)", p.msc_steps, t_msc, True)],
           "check": chk}
+    host_sample = None
+    if synced:                                                # a few receivers' slices for the CPU baseline of the same path (untimed copy)
+        import numpy as np
+        ne = min(4, E)
+        host_sample = {"slices": p.slices[:, :ne].cpu().numpy(), "fibs": p.mux.fibs[:ne].cpu().numpy(), "payload": p.mux.payload[:ne].cpu().numpy(),
+                       "period": p.mux.period, "n_frames": p.mux.n_frames}
     del p
     torch.cuda.empty_cache()
-    return c2, c3
+    return c2, c3, host_sample
+
+
+def cpu_baseline_full(sample, seconds_target=14.0):
+    """the oracle's whole receive chain per frame -- coarse + fine synchronisation, demodulation, fine-frequency update, 4 FIB groups,
+    18 sub-channels x 4 CIFs through CIF de-interleaver + Viterbi + descrambler (oracle/dab_oracle_chain.c: ONE C call per thread, no
+    interpreter inside) -- on this box's host cores, on the very slices the GPU just decoded; bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import concurrent.futures as cf
+    import numpy as np
+    import oracle as O
+    O.lib()
+    slices, nf, period = sample["slices"], sample["n_frames"], sample["period"]
+    ne = slices.shape[1]
+    subs = [O.subchannel(48 * s_, 48, eep_level=2, eep_type=0) for s_ in range(18)]
+    per = [np.ascontiguousarray(slices[:, e]) for e in range(ne)]                   # receiver e: its nf stored slices
+    warm = 6                                                                         # loops settle, time de-interleavers fill (>= 4 frames)
+    t0 = time.perf_counter()
+    r1 = O.receive_frames(per[0], SLICE_SAMPLES, SLICE_LEAD, warm, subs)
+    dt1 = (time.perf_counter() - t0) / warm
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    per_thread = int(max(warm + 2, min(4096, seconds_target / dt1 / 1.3)))            # (all cores busy: expect ~1.3 x the lone-thread time per frame)
+
+    def work(i):
+        return O.receive_frames(per[i % ne], SLICE_SAMPLES, SLICE_LEAD, per_thread, subs)
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    ok = True
+    for i, r in enumerate(res):                                                     # every thread's last frame against what was transmitted
+        e, j = i % ne, per_thread - 1
+        ok &= bool(r["sync_failed"] == 0 and np.array_equal(r["fib"], sample["fibs"][e, j % nf]))
+        cifs = [(4 * j + c - 15) % period for c in range(4)]
+        ok &= bool(np.array_equal(r["msc"], sample["payload"][e][cifs].reshape(4, -1)))
+    done = per_thread * cores
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": 1.0 / dt1,
+            "decoded_bytes_equal_transmitted": ok,
+            "sample": f"{done} frames through oracle/dab_oracle_chain.c dab_receive_frames (coarse + fine sync, PLL + CP phase + 76 x FFT2048 + DQPSK + demap, "
+                      f"fine-frequency update, 4 FIB groups, 18 sub-channels x 4 CIFs: CIF de-interleaver + K=7 Viterbi + descrambler), "
+                      f"{cores} host threads x {per_thread} frames of the receivers the GPU decoded (incl. {warm} settling frames each), {dt:.1f} s wall"}
 
 
 def dry_run(args, rank, world):
@@ -468,14 +621,14 @@ def main():
         units = F
 
         fmt_f32 = dabgpu.IQ_FORMATS.index("raw_f32l")
-        # symbols per workgroup: --spb 0 (default) leaves the choice to the library, which times a whole frame (75: one round of
-        # workgroups on a full chip, phase tail inside the kernel), two and three runs per frame (38, 25) once per context and batch
-        # size and keeps the fastest (include/dabgpu.h; which one wins depends on the box).  The timed loop below runs what
-        # the library chose; the three are timed here once more (untimed region) only to put the numbers in the line
+        # symbols per workgroup: --spb 0 (default) leaves the choice to the library: dabgpu_ofdm_tune (called here, in the warm-up) times
+        # a whole frame (75: one round of workgroups on a full chip, phase tail inside the kernel), two and three runs per frame (38, 25)
+        # and records the fastest for this call shape (include/dabgpu.h; which one wins depends on the box); the data path
+        # only looks the record up.  The three are timed here once more (untimed region) only to put the numbers in the line
         spb_timing = None
         if args.spb == 0 and F >= 512 and not args.dry_run:
-            ctx.ofdm_demod_phase_frames(iq_f, fmt_f32, F, d_bits, freq_offset=d_freq, cp_corr=d_corr, symbols_per_block=0,
-                                        beta=0.9, total_phase=d_total, fine_freq=d_fine)          # first call: the library's calibration
+            # explicit, blocking calibration (dabgpu_ofdm_tune), outside every timed region; symbols_per_block = 0 below then resolves to it
+            ctx.ofdm_tune(iq_f, fmt_f32, F, d_bits, with_phase_tail=True)
             torch.cuda.synchronize()
             spb_timing = {}
             for rep in range(2):                                       # interleaved, the last pass counts: all see the same clock state
@@ -502,7 +655,8 @@ def main():
         first_unit, n_units = shard.shard_range(E * world, rank, world)
         assert n_units == E
         pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit, inflight=args.inflight,
-                        layout=int(args.hist_layout == "classed"))
+                        layout=int(args.hist_layout == "classed"), synced=not args.aligned)
+        pipe_spb = pipe.tune()
         pipe.fill()
         units = E
 
@@ -572,17 +726,19 @@ def main():
         if args.workload == "demod":
             workload = ("BASELINE configs[1]: batched 1024 Mode-I frames of synthetic IQ (c32, HBM-resident), "
                         "PLL+CP-phase+FFT2048+DQPSK+demap, per GPU")
-            chosen = args.spb or ctx.ofdm_auto_symbols_per_block(units) or 25
+            chosen = args.spb or ctx.ofdm_tuned_symbols_per_block(fmt_f32, units, with_phase_tail=True)
             config = {"workload": workload, "frames_per_gpu_per_step": units, "symbols_per_block": chosen,
-                      "symbols_per_block_chosen_by": "caller (--spb)" if args.spb else "library (symbols_per_block = 0: one-time calibration per context and batch size)",
+                      "symbols_per_block_chosen_by": "caller (--spb)" if args.spb else "library (symbols_per_block = 0 resolves to what dabgpu_ofdm_tune recorded in the warm-up)",
                       "sharding": "independent frames / ensembles per rank, no data-path collective"}
             if spb_timing:
                 config["symbols_per_block_timed_ms"] = {str(k): v for k, v in spb_timing.items()}
         else:
             workload = (f"BASELINE configs[4]: {units * world} synthetic ensembles ({units} per GPU, built on the device from "
-                        f"{min(args.distinct, units)} seeded multiplexes), full FIC+MSC: OFDM demod + FIC Viterbi + 18 x 48 CU EEP 3-A "
-                        "time de-interleave / Viterbi / descramble per transmission frame")
-            config = {"workload": workload, "ensembles_per_gpu": units, "frames_per_gpu_per_step": units,
+                        f"{min(args.distinct, units)} seeded multiplexes), full FIC+MSC: " +
+                        ("frame-aligned OFDM demod (sync bypassed)" if args.aligned else
+                         "PRS synchronisation (coarse + fine) + OFDM demod at the tracked carrier / timing offset + fine-frequency update") +
+                        " + FIC Viterbi + 18 x 48 CU EEP 3-A time de-interleave / Viterbi / descramble per transmission frame")
+            config = {"workload": workload, "ensembles_per_gpu": units, "frames_per_gpu_per_step": units, "symbols_per_block": pipe_spb[0],
                       "sharding": "independent ensembles per rank, no data-path collective"}
         line = {
             "metric": "dab_mode1_frames_per_sec", "value": value, "unit": "frames/s",
@@ -596,18 +752,20 @@ def main():
         }
         if region:
             line["roofline"]["timing"] = (f"one pair of HIP events around the {args.steps} back-to-back launches of the timed loop, on their stream: "
-                                          f"{k_ms_events:.4f} ms per launch" + ("" if (args.spb or ctx.ofdm_auto_symbols_per_block(units)) == 75 else " (incl. the 5 us phase-tail launch of each step)"))
+                                          f"{k_ms_events:.4f} ms per launch" + ("" if (args.spb or ctx.ofdm_tuned_symbols_per_block(fmt_f32, units, with_phase_tail=True)) == 75 else " (incl. the 5 us phase-tail launch of each step)"))
         else:
             # configs[4]: inside the timed loop the demodulation of frame j + 1 runs BESIDE the trellis kernel of frame j (two frames in
             # flight), so its launches last longer than the kernel needs; the rooflines are taken one stage at a time after the loop
             pipe.timed(pipe.msc, 4); pipe.timed(pipe.demod, 8)              # (the clock has dropped during the host-side check above)
             t_d, t_f, t_m = pipe.timed(pipe.demod, 6), pipe.timed(pipe.fic, 6), pipe.timed(pipe.msc, 6)
-            line["roofline"] = hbm_roofline("ofdm_demod_kernel", t_d, units)
+            line["roofline"] = hbm_roofline("ofdm_demod_kernel" if args.aligned else "ofdm_sync_kernel + ofdm_demod_kernel", t_d, units)
             line["roofline"]["timing"] = (f"one stage at a time after the timed loop: HIP events around 6 launches, {t_d:.4f} ms each (inside the loop, "
                                           f"overlapped with the other frame's trellis kernel: {k_ms_events:.4f} ms, mean of {len(evs)} launches)")
             line["roofline_decode"] = viterbi_roofline(("vit_prep_ring4c_kernel" if pipe.layout else "vit_prep_ring4_kernel") + " + vit_lanes_kernel (MSC)",
                                                        pipe.msc_steps, t_m, True)
-            line["stage_ms_one_at_a_time"] = {"ofdm_demod": t_d, "fic_viterbi": t_f, "msc_viterbi_incl_deinterleave": t_m}
+            line["stage_ms_one_at_a_time"] = {("ofdm_demod" if args.aligned else "sync_and_demod_one_call"): t_d, "fic_viterbi": t_f, "msc_viterbi_incl_deinterleave": t_m}
+            if not args.aligned:
+                line["stage_ms_one_at_a_time"]["ofdm_sync_alone"] = pipe.timed(pipe.sync_only, 6)
         # PMC-derived HBM traffic per launch, when a profiles/ summary of this round exists (see profiles/README.md)
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
@@ -617,13 +775,21 @@ def main():
                 line["roofline"]["traffic_source"] = tr.get("source")
         except Exception:
             pass
+        host_sample = None
         if world == 1 and args.workload == "demod" and not args.no_extras:
             del iq, iq_f, tx_bits, d_bits
             torch.cuda.empty_cache()
-            c2, c3 = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"))
+            c2, c3, host_sample = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"),
+                                                   synced=not args.aligned)
             line["extra"] = {"configs2": c2, "configs3": c3}
+            if not args.no_chain:
+                import bench_chain
+                line["extra"]["chain"] = bench_chain.run_chain(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct,
+                                                               layout=int(args.hist_layout == "classed"))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+            if host_sample is not None:
+                line["cpu_baseline_full"] = cpu_baseline_full(host_sample)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

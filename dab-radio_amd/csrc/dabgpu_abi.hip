@@ -259,12 +259,9 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 // ---- OFDM ----
 // symbols_per_block = 0: which run length is fastest depends on the batch and on the box (a whole frame per workgroup
 // is one static round of workgroups on a full chip -- fastest where all CUs run at one speed, much slower where they do not; three
-// runs per frame let the dispatcher rebalance but transform two halo symbols more).  Small batches take 25.  A batch that fills the chip
-// is timed once per context, batch size and kernel variant on the caller's own buffers (the outputs are the same whatever the run
-// length; the phase tail, which updates the caller's fine-frequency state, is left out) and the winner is cached.  The clock of an
-// idle GPU takes tens of milliseconds of load to settle (profiles/r01/ab_notes.md), and it keeps drifting afterwards: untimed rounds
-// until 40 ms of kernels have run (at most 12 rounds), then three timed rounds that visit the candidates in turn (2 launches each), summed per candidate --
-// a candidate is never judged by one moment of the clock.
+// runs per frame let the dispatcher rebalance but transform two halo symbols more).  The data path never measures: it takes what
+// dabgpu_ofdm_tune has recorded for the kernel variant and the batch's size bucket (nearest recorded bucket of that variant), else 25;
+// small batches take shorter runs.
 // batches too small to fill the chip with three workgroups per frame: more, shorter runs -- a single frame in three runs of 25 symbols is
 // three workgroups 25 symbols long (130 us); in 25 runs of 3 symbols (4 transforms each, one of them the halo) it is 25 workgroups 20 us
 // long.  Aim at ~256 workgroups, at most 25 runs per frame; from 86 frames on the usual three runs.
@@ -274,45 +271,36 @@ static int small_batch_spb(size_t n_frames) {
     return (int)((75 + chunks - 1) / chunks);
 }
 
-static int demod_auto_spb(dabgpu_ctx* c, size_t n_frames, int variant, hipStream_t s, const std::function<hipError_t(int)>& launch) {
+// size bucket of a batch: ceil(log2(n_frames)) -- 513..1024 frames share a bucket, 1025..2048 the next
+static int spb_bucket(size_t n_frames) {
+    int b = 0;
+    while (((size_t)1 << b) < n_frames && b < 40) b++;
+    return b;
+}
+// kernel variant of a call: loader (0..3), soft-bit layout, whether the phase tail runs with it (fused at 75, a second launch otherwise)
+static int spb_variant(int src, int bits_layout, bool tail) { return src * 4 + (bits_layout == DABGPU_BITS_MSC_CLASSED ? 2 : 0) + (tail ? 1 : 0); }
+
+// what symbols_per_block = 0 resolves to; never blocks, never launches
+static int demod_cached_spb(dabgpu_ctx* c, size_t n_frames, int variant) {
     if (n_frames < 512) return small_batch_spb(n_frames);
-    {
-        DABGPU_HOST_LOCK(c);
-        for (const auto& e : c->spb_cache) if (e.n_frames == n_frames && e.variant == variant) return e.spb;
-    }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 25; }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); (void)hipGetLastError(); return 25; }
-    static const int cand[3] = {25, 38, 75};
-    float sum_ms[3] = {0.0f, 0.0f, 0.0f}, warm_ms = 0.0f;
-    bool ok = true;
-    for (int pass = 0, timed = 0; timed < 3 && pass < 16 && ok; pass++) {
-        const bool counts = warm_ms >= 40.0f || pass >= 12;
-        for (int k = 0; k < 3 && ok; k++) {
-            ok = hipEventRecord(e0, s) == hipSuccess;
-            for (int r = 0; r < 2 && ok; r++) ok = launch(cand[k]) == hipSuccess;
-            float ms = 0.0f;
-            ok = ok && hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-            if (counts) sum_ms[k] += ms; else warm_ms += ms;
-        }
-        timed += counts;
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (!ok) { (void)hipGetLastError(); return 25; }
-    int best = 0;
-    for (int k = 1; k < 3; k++) if (sum_ms[k] < sum_ms[best]) best = k;
+    const int want = spb_bucket(n_frames);
     DABGPU_HOST_LOCK(c);
-    if (c->spb_cache.size() >= 32) c->spb_cache.erase(c->spb_cache.begin());
-    c->spb_cache.push_back({n_frames, variant, cand[best]});
-    return cand[best];
+    int best = 25, best_d = 1 << 30;
+    for (const auto& e : c->spb_cache) {
+        if (e.variant != variant) continue;
+        const int d = e.bucket > want ? e.bucket - want : want - e.bucket;
+        if (d < best_d) { best_d = d; best = e.spb; }
+    }
+    return best;
 }
 
 extern "C" int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx* c, size_t n_frames) {
     if (!c) return 0;
+    if (n_frames < 512) return small_batch_spb(n_frames);
+    const int want = spb_bucket(n_frames);
     DABGPU_HOST_LOCK(c);
-    for (auto e = c->spb_cache.rbegin(); e != c->spb_cache.rend(); ++e) if (e->n_frames == n_frames) return e->spb;      // the latest
-    return n_frames < 512 ? small_batch_spb(n_frames) : 0;
+    for (auto e = c->spb_cache.rbegin(); e != c->spb_cache.rend(); ++e) if (e->bucket == want) return e->spb;      // the latest of any variant
+    return 0;
 }
 
 static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_frames, const float* d_freq, int8_t* d_bits,
@@ -336,10 +324,8 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     if (symbols_per_block <= 0)
-        symbols_per_block = demod_auto_spb(c, n_frames, src * 2 + (bits_layout == DABGPU_BITS_MSC_CLASSED), s, [&](int spb) {
-            return dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map, (int)n_frames, spb, bits_frame_stride,
-                                            nullptr, nullptr, 0, bits_layout == DABGPU_BITS_MSC_CLASSED, s, nullptr, nullptr, 0.0f);
-        });
+        symbols_per_block = (d_fft || d_dqpsk) ? small_batch_spb(n_frames)      /* display views: three workgroups per CU, not tuned */
+                                               : demod_cached_spb(c, n_frames, spb_variant(src, bits_layout, d_total_phase || d_fine_freq));
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
                                                      (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0,
                                                      bits_layout == DABGPU_BITS_MSC_CLASSED, s, d_total_phase, d_fine_freq, beta),
@@ -391,6 +377,115 @@ int dabgpu_ofdm_demod_frames_history(dabgpu_ctx* c, const void* d_raw, int forma
     const int src = fused_loader_of(format);
     if (src < 0) { dabgpu_set_error("ofdm_demod_frames_history: format %d has no fused loader (float32, u8, s8, s16 little endian do)", format); return DABGPU_ERR_INVALID_ARG; }
     return ofdm_demod_any(c, d_raw, src, n_frames, d_freq, d_bits, d_cp_corr, nullptr, nullptr, symbols_per_block, bits_frame_stride, stream, bits_layout);
+}
+
+// Explicit calibration of symbols_per_block = 0 (the data path never measures).  Blocks the calling thread: untimed launches until
+// 40 ms of kernels have run (the clock of an idle GPU settles over tens of milliseconds, profiles/r01/ab_notes.md; at most 12 rounds),
+// then three timed rounds that visit the candidates in turn, two launches each, summed per candidate -- a candidate is never judged by one
+// moment of the clock.  Every candidate is timed as it will run: with_phase_tail adds the tail (inside the kernel at 75, a second launch
+// at 25 / 38) on context scratch, not on the caller's fine-frequency state.  d_bits receives valid soft bits (identical for every run length).
+int dabgpu_ofdm_tune(dabgpu_ctx* c, const void* d_raw, int format, size_t n_frames, int8_t* d_bits, size_t bits_frame_stride, int bits_layout,
+                     int with_phase_tail, void* stream, int* chosen) {
+    const int src = fused_loader_of(format);
+    if (chosen) *chosen = 0;
+    if (src < 0) { dabgpu_set_error("ofdm_tune: format %d has no fused loader (float32, u8, s8, s16 little endian do)", format); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) { dabgpu_set_error("ofdm_tune: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG; }
+    if (!c || !d_raw || !d_bits) { dabgpu_set_error("ofdm_tune: null ctx/iq/bits"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames == 0 || n_frames > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_tune: n_frames out of range"); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_frame_stride != 0 && (bits_frame_stride < DABGPU_NB_FRAME_BITS || (bits_frame_stride & 15))) {
+        dabgpu_set_error("ofdm_tune: bits_frame_stride must be 0 or a multiple of 16 >= 230400"); return DABGPU_ERR_INVALID_ARG;
+    }
+    if (((uintptr_t)d_raw & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_tune: d_raw and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_frames < 512) { if (chosen) *chosen = small_batch_spb(n_frames); return DABGPU_OK; }      // nothing to measure: the small-batch rule
+    DABGPU_BIND(c);
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError(); dabgpu_set_error("ofdm_tune: the stream is capturing"); return DABGPU_ERR_INVALID_ARG;
+    }
+    float *corr, *tail = nullptr;
+    int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
+    if (st) return st;
+    if (with_phase_tail) {
+        if ((st = dabgpu_scratch(c, 23, 2 * n_frames * sizeof(float), (void**)&tail))) return st;
+        if ((st = dabgpu_check_hip(hipMemsetAsync(tail, 0, 2 * n_frames * sizeof(float), s), "hipMemsetAsync(tune)"))) return st;
+    }
+    auto launch = [&](int spb) {
+        return dabgpu_launch_ofdm_demod(d_raw, src, nullptr, d_bits, corr, nullptr, nullptr, c->d_tw, c->d_inv_map, (int)n_frames, spb, bits_frame_stride,
+                                        nullptr, nullptr, 0, bits_layout == DABGPU_BITS_MSC_CLASSED, s, tail, tail ? tail + n_frames : nullptr, 0.9f);
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((st = dabgpu_check_hip(hipEventCreate(&e0), "hipEventCreate(tune)"))) return st;
+    if ((st = dabgpu_check_hip(hipEventCreate(&e1), "hipEventCreate(tune)"))) { (void)hipEventDestroy(e0); return st; }
+    static const int cand[3] = {25, 38, 75};
+    float sum_ms[3] = {0.0f, 0.0f, 0.0f}, warm_ms = 0.0f;
+    hipError_t err = hipSuccess;
+    for (int pass = 0, timed = 0; timed < 3 && pass < 16 && err == hipSuccess; pass++) {
+        const bool counts = warm_ms >= 40.0f || pass >= 12;
+        for (int k = 0; k < 3 && err == hipSuccess; k++) {
+            err = hipEventRecord(e0, s);
+            for (int r = 0; r < 2 && err == hipSuccess; r++) err = launch(cand[k]);
+            float ms = 0.0f;
+            if (err == hipSuccess) err = hipEventRecord(e1, s);
+            if (err == hipSuccess) err = hipEventSynchronize(e1);
+            if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+            if (counts) sum_ms[k] += ms; else warm_ms += ms;
+        }
+        timed += counts;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return dabgpu_check_hip(err, "ofdm_tune");
+    int best = 0;
+    for (int k = 1; k < 3; k++) if (sum_ms[k] < sum_ms[best]) best = k;
+    const int bucket = spb_bucket(n_frames), variant = spb_variant(src, bits_layout, with_phase_tail != 0);
+    {
+        DABGPU_HOST_LOCK(c);
+        bool found = false;
+        for (auto& e : c->spb_cache) if (e.bucket == bucket && e.variant == variant) { e.spb = cand[best]; found = true; }
+        if (!found) c->spb_cache.push_back({bucket, variant, cand[best]});
+    }
+    if (chosen) *chosen = cand[best];
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_tuned_symbols_per_block(dabgpu_ctx* c, int format, size_t n_frames, int bits_layout, int with_phase_tail) {
+    const int src = fused_loader_of(format);
+    if (!c || src < 0 || n_frames == 0) return 0;
+    return demod_cached_spb(c, n_frames, spb_variant(src, bits_layout, with_phase_tail != 0));
+}
+
+// One steady-state frame of n receivers: PRS synchronisation, then the demodulation it positions and corrects, then the fine-frequency
+// update -- three dependent steps of OFDM_Demod per frame (ofdm_demodulator.cpp:360-548, :650-766, :606-618) with the records of the
+// first read by the second and third on the device.
+int dabgpu_ofdm_sync_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_streams, size_t stream_stride_samples, size_t prs_offset_samples,
+                                  const dabgpu_sync_cfg* cfg, dabgpu_sync_state* d_states, int8_t* d_bits, float* d_cp_corr, int symbols_per_block,
+                                  size_t bits_frame_stride, int bits_layout, float* d_total_phase, void* stream) {
+    if (!c || !d_iq || !cfg || !d_states || !d_bits) { dabgpu_set_error("ofdm_sync_demod_frames: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) { dabgpu_set_error("ofdm_sync_demod_frames: unknown bits_layout %d", bits_layout); return DABGPU_ERR_INVALID_ARG; }
+    if (n_streams == 0) return DABGPU_OK;
+    if (n_streams > (size_t)(1 << 24)) { dabgpu_set_error("ofdm_sync_demod_frames: n_streams too large"); return DABGPU_ERR_INVALID_ARG; }
+    // the impulse peak lies in [0, 2048): the frame starts between 504 samples before and 1543 after the expected position
+    if (prs_offset_samples < DABGPU_NB_CYCLIC_PREFIX || prs_offset_samples > (size_t)(1 << 30) ||
+        stream_stride_samples < prs_offset_samples + (DABGPU_NB_FFT - DABGPU_NB_CYCLIC_PREFIX) + (size_t)DABGPU_NB_FRAME_SYMBOLS * DABGPU_NB_SYMBOL_PERIOD) {
+        dabgpu_set_error("ofdm_sync_demod_frames: needs prs_offset_samples >= 504 and stream_stride_samples >= prs_offset_samples + 1544 + 76 * 2552");
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    if (bits_frame_stride != 0 && (bits_frame_stride < DABGPU_NB_FRAME_BITS || (bits_frame_stride & 15))) {
+        dabgpu_set_error("ofdm_sync_demod_frames: bits_frame_stride must be 0 or a multiple of 16 >= 230400"); return DABGPU_ERR_INVALID_ARG;
+    }
+    if (((uintptr_t)d_iq & 7) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_sync_demod_frames: d_iq must be 8-byte, d_bits 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(c);
+    hipStream_t s = (hipStream_t)stream;
+    float* corr = d_cp_corr;
+    int st;
+    if (!corr && (st = dabgpu_scratch(c, 0, n_streams * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr))) return st;
+    if ((st = dabgpu_check_hip(dabgpu_launch_sync(d_iq + 2 * prs_offset_samples, stream_stride_samples, (int)n_streams, cfg, d_states, nullptr, nullptr,
+                                                 c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, 1, s), "ofdm_sync_kernel launch"))) return st;
+    if (symbols_per_block <= 0) symbols_per_block = demod_cached_spb(c, n_streams, spb_variant(0, bits_layout, true));
+    return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, 0, nullptr, d_bits, corr, nullptr, nullptr, c->d_tw, c->d_inv_map, (int)n_streams, symbols_per_block,
+                                                     bits_frame_stride, nullptr, nullptr, 0, bits_layout == DABGPU_BITS_MSC_CLASSED, s, d_total_phase, nullptr,
+                                                     cfg->fine_freq_update_beta, nullptr, stream_stride_samples, d_states, (int)prs_offset_samples),
+                            "ofdm_demod_kernel launch (synchronised frames)");
 }
 
 int dabgpu_ofdm_phase_update_mode(dabgpu_ctx* c, int mode, const float* d_cp_corr, size_t n_frames, float beta, float* d_total_phase,

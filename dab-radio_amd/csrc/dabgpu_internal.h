@@ -20,9 +20,9 @@ struct dabgpu_ctx {
     float* d_prs_time_ref = nullptr; // conj(IFFT(relative_phase(PRS))), coarse-sync reference
     struct dabgpu_vit_tables* d_vit_tables = nullptr;
     int vit_mapping = 0;             // DABGPU_VIT_MAP_* (dabgpu_viterbi_set_mapping)
-    // symbols_per_block = 0 of the mode I demodulator: measured once per batch size and kernel variant (source format, soft-bit
-    // layout) on this device (dabgpu_abi.hip, demod_auto_spb)
-    struct spb_choice { size_t n_frames; int variant; int spb; };
+    // symbols_per_block = 0 of the mode I demodulator: what dabgpu_ofdm_tune measured on this device, per size bucket (ceil log2 of the
+    // batch) and kernel variant (loader, soft-bit layout, phase tail); the data path only looks it up (dabgpu_abi.hip)
+    struct spb_choice { int bucket; int variant; int spb; };
     std::vector<spb_choice> spb_cache;
     int* d_mode_mapper[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // carrier mappers of modes II-IV, built on first use
     int* d_mode_inv_map[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // their inverses (ofdm_wave512.hip)
@@ -72,7 +72,11 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                int classed, hipStream_t stream, float* d_total_phase = nullptr, float* d_fine_freq = nullptr,
-                                               float beta = 0.0f, const void* d_prev_tail = nullptr /* stream banks, retained blocks */);
+                                               float beta = 0.0f, const void* d_prev_tail = nullptr /* stream banks, retained blocks */,
+                                               size_t frame_stride_samples = 0 /* 0 = 196608, frame after frame */,
+                                               dabgpu_sync_state* d_sync = nullptr /* frame k starts prs_offset + d_sync[k].fine_time_offset samples into its
+                                                                                      slice, PLL offset and fine-frequency word are the record's */,
+                                               int prs_offset = 0);
 extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_frames, float beta, float* d_total_phase,
                                                float* d_fine_freq, int fine_freq_stride, const dabgpu_frame_desc* d_desc, int n_sym, int n_fft,
                                                hipStream_t stream);

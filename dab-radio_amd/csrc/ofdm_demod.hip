@@ -112,8 +112,15 @@ __device__ __forceinline__ f4 load_pair_bank(const uint8_t* __restrict__ frame_b
     }
 }
 
-// optional fused tail of the kernel = ofdm_phase_kernel of the frame (total_phase / fine_freq may each be null)
-struct demod_phase_tail { float* total_phase; float* fine_freq; float beta; };
+// optional fused tail of the kernel = ofdm_phase_kernel of the frame (total_phase / fine_freq may each be null);
+// frame k's fine-frequency word is fine_freq[k * fine_stride] (1: a plain array; 6: the freq_fine members of dabgpu_sync_state records)
+struct demod_phase_tail { float* total_phase; float* fine_freq; float beta; int fine_stride; };
+
+// where a frame's samples start (frame-aligned batches; stream banks use dabgpu_frame_desc instead): frame k begins `stride` samples
+// after frame k - 1.  sync != nullptr (dabgpu_ofdm_sync_demod_frames): the frame of receiver k begins prs_offset + fine_time_offset
+// samples into its slice, is skipped when the impulse-peak test failed (the caller resets that receiver, ofdm_demodulator.cpp:529-532)
+// and is corrected by freq_coarse + freq_fine (:672) -- the record ofdm_sync_kernel has just written, read on the device
+struct demod_frame_src { size_t stride; const dabgpu_sync_state* sync; int prs_offset; };
 
 // LDS of one workgroup (float2 elements unless noted)
 constexpr int LDS_TW1 = 6 * 256;           // pass-1 twiddles [thread][6]: a private 48-byte slot per thread (registers parked in LDS)
@@ -144,7 +151,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
                        f2* __restrict__ dqpsk_out_, const f2* __restrict__ tw, const uint16_t* __restrict__ inv_map,
                        int n_frames, int sym_per_chunk, int chunks_per_frame, size_t bits_frame_stride,
                        const dabgpu_frame_desc* __restrict__ desc, const void* __restrict__ tail, size_t tail_stride, demod_phase_tail pt,
-                       const void* __restrict__ prev_tail)
+                       const void* __restrict__ prev_tail, demod_frame_src fs)
 {
     f2* const fft_out = VIEWS ? fft_out_ : nullptr;
     f2* const dqpsk_out = VIEWS ? dqpsk_out_ : nullptr;
@@ -193,9 +200,17 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
     const bool last_chunk = (out1 == NB_FRAME_SYMBOLS - 1);
     const int sym_end = (last_chunk && fft_out != nullptr) ? NB_FRAME_SYMBOLS : out1;   // inclusive
 
-    const float f = freq_offset ? freq_offset[frame] : 0.0f;
+    float f = freq_offset ? freq_offset[frame] : 0.0f;
     // (stream banks: iq = the complex-float frame buffers, SRC describes the tail source only)
-    const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * NB_FRAME_SAMPLES * (BANK ? 8 : src_bytes<SRC>::value);
+    const uint8_t* fbase = static_cast<const uint8_t*>(iq) + (size_t)frame * (BANK ? (size_t)NB_FRAME_SAMPLES * 8 : fs.stride * src_bytes<SRC>::value);
+    if constexpr (!BANK) {
+        if (fs.sync != nullptr) {                                            // (uniform; scalar loads)
+            const dabgpu_sync_state st = fs.sync[frame];
+            if (!st.sync_valid) return;
+            f = st.freq_coarse + st.freq_fine;                               // ofdm_demodulator.cpp:672
+            fbase += ((long long)fs.prs_offset + (long long)st.fine_time_offset) * (long long)src_bytes<SRC>::value;   // :536-545
+        }
+    }
 
     constexpr unsigned SB = BANK ? 8u : (unsigned)src_bytes<SRC>::value;                              // bytes per sample of the frame
     const unsigned lane_off = 2u * SB * (unsigned)t, head_off = 2u * SB * (unsigned)((t >= 4) ? t - 4 : 0);   // byte offsets of this lane
@@ -495,7 +510,7 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
             float total = 0.0f;
             for (int k = 0; k < NB_FRAME_SYMBOLS; k++) total += ang[k];                 // the reference's sequential sum (:606-618)
             if (pt.total_phase) pt.total_phase[frame] = total;
-            if (pt.fine_freq) pt.fine_freq[frame] = fine_freq_update(pt.fine_freq[frame], total, pt.beta, NB_FRAME_SYMBOLS, NB_FFT);
+            if (pt.fine_freq) { float* ff = pt.fine_freq + (size_t)frame * pt.fine_stride; *ff = fine_freq_update(*ff, total, pt.beta, NB_FRAME_SYMBOLS, NB_FFT); }
         }
     }
 }
@@ -507,12 +522,13 @@ void ofdm_demod_kernel(const void* __restrict__ iq, const float* __restrict__ fr
 __global__ __launch_bounds__(64)
 void ofdm_phase_kernel(const f2* __restrict__ cp_corr, int n_frames, float beta,
                        float* __restrict__ total_phase, float* __restrict__ fine_freq, int fine_freq_stride,
-                       const dabgpu_frame_desc* __restrict__ desc, int n_sym, int n_fft)
+                       const dabgpu_frame_desc* __restrict__ desc, int n_sym, int n_fft, const dabgpu_sync_state* __restrict__ sync)
 {
     __shared__ float ph[160];                       // n_sym <= 153
     const int fr = blockIdx.x, lane = threadIdx.x;
     if (fr >= n_frames) return;
     if (desc != nullptr && desc[fr].slot < 0) return;
+    if (sync != nullptr && !sync[fr].sync_valid) return;       // dabgpu_ofdm_sync_demod_frames: no frame was demodulated
     const f2* c = cp_corr + (size_t)fr * n_sym;
     for (int i = lane; i < n_sym; i += 64) { const f2 v = c[i]; ph[i] = atan2_det(v.y, v.x); }
     __syncthreads();
@@ -532,7 +548,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
                                                int n_frames, int sym_per_chunk, size_t bits_frame_stride,
                                                const dabgpu_frame_desc* d_desc, const void* d_tail, size_t tail_stride,
                                                int classed, hipStream_t stream, float* d_total_phase, float* d_fine_freq, float beta,
-                                               const void* d_prev_tail)
+                                               const void* d_prev_tail, size_t frame_stride_samples, dabgpu_sync_state* d_sync, int prs_offset)
 {
     using namespace dabgpu;
     if (classed && (d_fft != nullptr || d_dqpsk != nullptr)) return hipErrorInvalidValue;   // soft bits only
@@ -546,18 +562,23 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     const size_t lds = DEMOD_LDS_BYTES;
     const bool views_ = (d_fft != nullptr) || (d_dqpsk != nullptr);
     // the phase tail runs inside the kernel when one workgroup walks the whole frame; otherwise as its own launch below
+    // frames one after the other unless the caller gives a stride; with sync records the fine-frequency words are theirs
+    if (d_desc != nullptr && (d_sync != nullptr || frame_stride_samples != 0)) return hipErrorInvalidValue;
+    const demod_frame_src fs = {frame_stride_samples ? frame_stride_samples : (size_t)NB_FRAME_SAMPLES, d_sync, prs_offset};
+    int fine_stride = 1;
+    if (d_sync != nullptr) { d_fine_freq = &d_sync->freq_fine; fine_stride = (int)(sizeof(dabgpu_sync_state) / sizeof(float)); }
     const bool fuse = (d_total_phase != nullptr || d_fine_freq != nullptr) && chunks == 1 && d_desc == nullptr && !views_;
-    const demod_phase_tail pt = {fuse ? d_total_phase : nullptr, fuse ? d_fine_freq : nullptr, beta};
+    const demod_phase_tail pt = {fuse ? d_total_phase : nullptr, fuse ? d_fine_freq : nullptr, beta, fine_stride};
     const dim3 grid((unsigned)(n_frames * chunks));
 #define DABGPU_LAUNCH_V(SRC, BANK, VIEWS) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, VIEWS>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), \
                        reinterpret_cast<f2*>(d_fft), reinterpret_cast<f2*>(d_dqpsk), reinterpret_cast<const f2*>(d_tw), d_inv_map, \
-                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail)
+                       n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail, fs)
     const bool views = (d_fft != nullptr) || (d_dqpsk != nullptr);
 #define DABGPU_LAUNCH(SRC, BANK) do { if (views) DABGPU_LAUNCH_V(SRC, BANK, true); else DABGPU_LAUNCH_V(SRC, BANK, false); } while (0)
 #define DABGPU_LAUNCH_CB(SRC, BANK) hipLaunchKernelGGL((ofdm_demod_kernel<SRC, BANK, false, true>), grid, dim3(256), lds, stream, \
                        d_iq, d_freq, d_bits, reinterpret_cast<f2*>(d_cp_corr), static_cast<f2*>(nullptr), static_cast<f2*>(nullptr), \
-                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail)
+                       reinterpret_cast<const f2*>(d_tw), d_inv_map, n_frames, sym_per_chunk, chunks, bits_frame_stride, d_desc, d_tail, tail_stride, pt, d_prev_tail, fs)
 #define DABGPU_LAUNCH_C(SRC) do { if (d_desc != nullptr) DABGPU_LAUNCH_CB(SRC, true); else DABGPU_LAUNCH_CB(SRC, false); } while (0)
     switch (src) {
     case SRC_C32: if (classed) DABGPU_LAUNCH_C(SRC_C32); else if (d_desc != nullptr) DABGPU_LAUNCH(SRC_C32, true); else DABGPU_LAUNCH(SRC_C32, false); break;
@@ -573,7 +594,8 @@ extern "C" hipError_t dabgpu_launch_ofdm_demod(const void* d_iq, int src, const 
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && !fuse && (d_total_phase != nullptr || d_fine_freq != nullptr) && d_desc == nullptr) {
         hipLaunchKernelGGL(ofdm_phase_kernel, dim3((unsigned)n_frames), dim3(64), 0, stream, reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta,
-                           d_total_phase, d_fine_freq, 1, static_cast<const dabgpu_frame_desc*>(nullptr), NB_FRAME_SYMBOLS, NB_FFT);
+                           d_total_phase, d_fine_freq, fine_stride, static_cast<const dabgpu_frame_desc*>(nullptr), NB_FRAME_SYMBOLS, NB_FFT,
+                           static_cast<const dabgpu_sync_state*>(d_sync));
         e = hipGetLastError();
     }
     return e;
@@ -586,6 +608,7 @@ extern "C" hipError_t dabgpu_launch_ofdm_phase(const float* d_cp_corr, int n_fra
     using namespace dabgpu;
     const dim3 grid((unsigned)n_frames);
     hipLaunchKernelGGL(ofdm_phase_kernel, grid, dim3(64), 0, stream,
-                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc, n_sym, n_fft);
+                       reinterpret_cast<const f2*>(d_cp_corr), n_frames, beta, d_total_phase, d_fine_freq, fine_freq_stride, d_desc, n_sym, n_fft,
+                       static_cast<const dabgpu_sync_state*>(nullptr));
     return hipGetLastError();
 }

@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames", "dabgpu_decode_frames_layout", "dabgpu_decode_ring_layout",
     "dabgpu_frame_session_create", "dabgpu_frame_session_destroy", "dabgpu_frame_session_set_subchannels", "dabgpu_frame_session_push_frame",
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
+    "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
@@ -186,6 +187,10 @@ def lib():
         L.dabgpu_ofdm_sync_host_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dabgpu_viterbi_set_mapping.argtypes = [C.c_void_p, C.c_int]
         L.dabgpu_ofdm_auto_symbols_per_block.argtypes = [C.c_void_p, C.c_size_t]
+        L.dabgpu_ofdm_tune.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.dabgpu_ofdm_tuned_symbols_per_block.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
+        L.dabgpu_ofdm_sync_demod_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_viterbi_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.dabgpu_fic_decode_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p]
@@ -412,9 +417,29 @@ class Context:
               "dabgpu_ofdm_sync_host_sync")
         return state, imp, frq
 
+    def ofdm_sync_demod_frames(self, iq, n_streams, stream_stride_samples, prs_offset_samples, states, bits, cfg=None, cp_corr=None,
+                               symbols_per_block=0, bits_frame_stride=0, bits_layout=BITS_NATURAL, total_phase=None, stream=None):
+        """PRS synchronisation -> demodulation at the position / with the offset it found -> fine-frequency update, one call (device
+        buffers, asynchronous); `states` = [n_streams] dabgpu_sync_state records on the device, in/out"""
+        cfg = cfg or sync_cfg_default()
+        check(lib().dabgpu_ofdm_sync_demod_frames(self._h, _ptr(iq), n_streams, stream_stride_samples, prs_offset_samples, C.byref(cfg),
+                                                  _ptr(states), _ptr(bits), _ptr(cp_corr), symbols_per_block, bits_frame_stride,
+                                                  int(bits_layout), _ptr(total_phase), self._stream(stream)), "dabgpu_ofdm_sync_demod_frames")
+
+    def ofdm_tune(self, raw, fmt, n_frames, bits, bits_frame_stride=0, bits_layout=BITS_NATURAL, with_phase_tail=False, stream=None):
+        """explicit (blocking) calibration of symbols_per_block = 0 for this call shape; returns the run length recorded"""
+        chosen = C.c_int(0)
+        check(lib().dabgpu_ofdm_tune(self._h, _ptr(raw), int(fmt), n_frames, _ptr(bits), bits_frame_stride, int(bits_layout),
+                                     int(bool(with_phase_tail)), self._stream(stream), C.byref(chosen)), "dabgpu_ofdm_tune")
+        return chosen.value
+
+    def ofdm_tuned_symbols_per_block(self, fmt, n_frames, bits_layout=BITS_NATURAL, with_phase_tail=False):
+        """what symbols_per_block = 0 resolves to for that call shape right now"""
+        return int(lib().dabgpu_ofdm_tuned_symbols_per_block(self._h, int(fmt), int(n_frames), int(bits_layout), int(bool(with_phase_tail))))
+
     # ---- channel decode ----
     def ofdm_auto_symbols_per_block(self, n_frames):
-        """what symbols_per_block = 0 resolves to for batches of n_frames (0 = not measured yet)"""
+        """the run length dabgpu_ofdm_tune last recorded for the size bucket of n_frames (0 = nothing recorded)"""
         return int(lib().dabgpu_ofdm_auto_symbols_per_block(self._h, int(n_frames)))
 
     def viterbi_set_mapping(self, mapping):

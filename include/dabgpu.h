@@ -97,12 +97,10 @@ int dabgpu_get_fft_twiddles(float *h_out /*[2*2048]*/);
  *                 display-only NULL-symbol FFT, ofdm_demodulator.cpp:701-709)
  *   d_dqpsk       [n_frames][75][1536] complex float = GetFrameDataVec() content (X_i * conj(X_{i+1}) per carrier,
  *                 natural carrier order, ofdm_demodulator.cpp:842-865), may be NULL
- *   symbols_per_block  data symbols handled by one workgroup, 1..75; any value gives identical results.  0 = the library chooses:
- *                 batches below 512 frames: 25, below 86 frames shorter runs (down to 3) so that the batch still spreads over the
- *                 chip; for larger ones it times 25 / 38 / 75 ONCE per context, batch size and kernel
- *                 variant (source format, bits_layout): ~40 ms of warm-up launches of this call on the caller's own buffers, then
- *                 three timed rounds over the candidates -- identical outputs -- and remembers the fastest; which one that is
- *                 depends on the box.  dabgpu_ofdm_auto_symbols_per_block reports the choice.
+ *   symbols_per_block  data symbols handled by one workgroup, 1..75; any value gives identical results.  0 = the library chooses, WITHOUT
+ *                 measuring (the call stays asynchronous): batches below 512 frames take 25, below 86 frames shorter runs (down to 3) so
+ *                 that the batch still spreads over the chip; larger ones take what dabgpu_ofdm_tune recorded for this kernel variant in
+ *                 the nearest size bucket, else 25.  Which of 25 / 38 / 75 is fastest depends on the box.
  *   bits_frame_stride  bytes between the soft bits of consecutive frames (0 = 230400, packed); lets the kernel write
  *                 straight into slot k of a per-ensemble frame-history ring (see dabgpu_msc_decode_frames)
  */
@@ -151,8 +149,20 @@ int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx *ctx, const void *d_raw, int forma
                                    int8_t *d_bits, float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
                                    float fine_freq_update_beta, float *d_total_phase, float *d_fine_freq, void *stream);
 
-/* what symbols_per_block = 0 resolves to for batches of n_frames on this context: 25 / 38 / 75 (3 .. 25 below 86 frames), or 0 = not
- * measured yet */
+/*
+ * Calibration of symbols_per_block = 0, explicit and out of the data path: times the run lengths 25 / 38 / 75 of the demodulation of
+ * n_frames frames (>= 512; smaller batches follow a fixed rule and return at once) on the caller's buffers -- ~40 ms of warm-up launches,
+ * then three timed rounds over the candidates -- and records the fastest for (loader of `format`, bits_layout, with_phase_tail, size bucket
+ * = ceil(log2(n_frames))).  BLOCKS the calling thread (hipEventSynchronize on `stream`; refused while the stream is capturing); d_bits
+ * receives valid soft bits; with_phase_tail times the candidates with the phase tail of dabgpu_ofdm_demod_phase_frames (on context
+ * scratch, not on caller state).  *chosen (may be NULL) = the run length recorded.  Typical use: once at start-up per batch size.
+ */
+int dabgpu_ofdm_tune(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, int8_t *d_bits, size_t bits_frame_stride,
+                     int bits_layout, int with_phase_tail, void *stream, int *chosen);
+/* what symbols_per_block = 0 resolves to for that call shape right now (never 0 for valid arguments) */
+int dabgpu_ofdm_tuned_symbols_per_block(dabgpu_ctx *ctx, int format, size_t n_frames, int bits_layout, int with_phase_tail);
+/* the run length most recently recorded by dabgpu_ofdm_tune for the size bucket of n_frames, whatever the variant: 25 / 38 / 75
+ * (3 .. 25 below 86 frames: the fixed rule), or 0 = nothing recorded for that bucket */
 int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx *ctx, size_t n_frames);
 
 /*
@@ -219,6 +229,28 @@ int dabgpu_ofdm_sync(dabgpu_ctx *ctx, const float *d_prs_syms, size_t n_streams,
 /* single stream from host memory, synchronous; used by the OFDM_Demod mirror class once per frame */
 int dabgpu_ofdm_sync_host_sync(dabgpu_ctx *ctx, const float *h_prs_sym, const dabgpu_sync_cfg *cfg,
                                dabgpu_sync_state *h_state, float *h_impulse_response, float *h_freq_response);
+
+/*
+ * One steady-state frame of n receivers in ONE call: PRS synchronisation at the expected position, demodulation from where the impulse
+ * peak puts the frame with the offset the synchroniser has just tracked, fine-frequency update -- OFDM_Demod's per-frame sequence
+ * RunCoarseFreqSync -> RunFineTimeSync -> PipelineThread (PLL with m_freq_coarse_offset + m_freq_fine_offset) -> CoordinatorThread's
+ * UpdateFineFrequencyOffset (src/ofdm/ofdm_demodulator.cpp:360-471, :473-548, :650-766, :606-618), the sync records staying on the device:
+ * dabgpu_ofdm_sync followed by a demodulation that reads d_states[k] for its position, its PLL offset and its fine-frequency word.
+ *   d_iq      receiver k's samples: complex float at d_iq + 2 * k * stream_stride_samples (8-byte aligned); sample prs_offset_samples of the
+ *             slice is where the receiver expects the PRS to begin (what m_correlation_time_buffer[nb_null_period] holds).  The frame's 76
+ *             symbols are read from prs_offset_samples + fine_time_offset on; fine_time_offset lies in [-504, 1543], hence
+ *             prs_offset_samples >= 504 and stream_stride_samples >= prs_offset_samples + 1544 + 76 * 2552 (also for the last receiver).
+ *   d_states  [n_streams] in/out: freq_coarse / freq_fine / is_found_coarse persist from frame to frame; after the call freq_fine holds
+ *             the value updated by this frame's cyclic-prefix phase error.  sync_valid = 0: the impulse-peak test failed, nothing was
+ *             demodulated for that receiver (d_bits / d_cp_corr / d_total_phase rows untouched) and the caller resets it (:529-532).
+ *   d_bits, d_cp_corr (may be NULL), symbols_per_block, bits_frame_stride, bits_layout: as dabgpu_ofdm_demod_frames_history
+ *   d_total_phase [n_streams] sum of the 76 cyclic-prefix angles, may be NULL;  beta of the update = cfg->fine_freq_update_beta
+ * Results equal dabgpu_ofdm_sync + dabgpu_ofdm_demod_frames_history on the shifted frames + dabgpu_ofdm_phase_update, bit for bit.
+ */
+int dabgpu_ofdm_sync_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_streams, size_t stream_stride_samples,
+                                  size_t prs_offset_samples, const dabgpu_sync_cfg *cfg, dabgpu_sync_state *d_states, int8_t *d_bits,
+                                  float *d_cp_corr, int symbols_per_block, size_t bits_frame_stride, int bits_layout,
+                                  float *d_total_phase, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Channel decoding: punctured K=7 rate-1/4 Viterbi (+ time de-interleave, energy dispersal, FIB CRC16),

@@ -283,6 +283,17 @@ void dab_coarse_freq_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32
 int dab_fine_time_sync_mode(int mode, const dab_cf32 *prs_sym, const dab_cf32 *prs_fft_conj, const dab_sync_cfg *cfg,
                             float freq_offset, int *offset, float *impulse_response);
 
+/* ---------------------------------------------------------------------------------------------
+ * One receiver's per-frame sequence as one call (dab_oracle_chain.c): n_total frames cycling over n_distinct stored slices of `stride`
+ * samples whose PRS is expected at sample prs_offset (>= 504; stride >= prs_offset + 1544 + 196608): coarse + fine synchronisation,
+ * demodulation at the position found with the tracked offset, fine-frequency update, the 4 FIB groups, and every listed sub-channel of
+ * the 4 CIFs through its own CIF_Deinterleaver and MSC decode.  `state` persists across calls (zero it for a new receiver).
+ * fib_last [4][96] / msc_last [4][sum of decoded bytes per CIF] (optional) receive the last frame's outputs; returns 0, or -1 on
+ * invalid arguments.  bench.py's cpu_baseline_full times this on every host core. */
+int dab_receive_frames(const dab_cf32 *slices, size_t n_distinct, size_t stride, size_t prs_offset, size_t n_total,
+                       const dab_subchannel *subs, int n_subs, int tie_rule, dab_sync_state *state,
+                       uint32_t *n_fib_crc_ok, uint32_t *n_sync_failed, uint8_t *fib_last, uint8_t *msc_last, uint64_t *digest);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ def build(force=False):
     """Compile the oracle (and _ref when /root/reference exists). Building the checker is not using it."""
     if force or not os.path.exists(_ORACLE_SO) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_ORACLE_SO)
-        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle_dabplus.c", "dab_oracle.h")
+        for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle_dabplus.c", "dab_oracle_chain.c", "dab_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "libdab_oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF_SO) or any(
@@ -84,6 +84,8 @@ def lib():
         L.dab_demod_frame.restype = C.c_float
         L.dab_demod_frame.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dab_demod_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dab_receive_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.dab_update_fine_freq.restype = C.c_float
         L.dab_update_fine_freq.argtypes = [C.c_float, C.c_float]
         L.dab_fine_freq_add.restype = C.c_float
@@ -401,6 +403,24 @@ def demod_frames_timing(frames, n_total, freq_offset, m=None):
     scratch = np.empty(NB_FRAME_BITS, dtype=np.int8)
     lib().dab_demod_frames(_p(frames), frames.shape[0], n_total, np.float32(freq_offset), _p(m), _p(scratch), None)
     return scratch
+
+
+def receive_frames(slices, stride, prs_offset, n_total, subs, state=None, tie_rule=0):
+    """n_total steady-state frames of one receiver (sync -> demod -> fine update -> FIC -> MSC of `subs`) cycling over the stored
+    slices [k][stride] c64, in ONE C call (releases the GIL).  Returns dict(state, fib_crc_ok, sync_failed, fib [4,96], msc [4,B], digest)."""
+    slices = c64(slices).reshape(-1, stride)
+    arr = (SubChannel * max(1, len(subs)))(*subs)
+    state = state if state is not None else SyncState(0.0, 0.0, 0, 0, 0, 0)
+    nb = sum(subchannel_plan(s_)[2] for s_ in subs)
+    fib = np.zeros((4, 96), np.uint8)
+    msc = np.zeros((4, max(nb, 1)), np.uint8)
+    ok, bad, dg = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    rc = lib().dab_receive_frames(_p(slices), slices.shape[0], stride, prs_offset, n_total, C.cast(arr, C.c_void_p), len(subs), tie_rule,
+                                  C.cast(C.pointer(state), C.c_void_p), C.cast(C.pointer(ok), C.c_void_p), C.cast(C.pointer(bad), C.c_void_p),
+                                  _p(fib), _p(msc), C.cast(C.pointer(dg), C.c_void_p))
+    if rc != 0:
+        raise ValueError("dab_receive_frames: invalid arguments")
+    return {"state": state, "fib_crc_ok": ok.value, "sync_failed": bad.value, "fib": fib, "msc": msc[:, :nb], "digest": dg.value}
 
 
 def update_fine_freq(fine, total_phase):

@@ -226,30 +226,54 @@ def test_fused_phase_tail_equals_the_two_calls(ctx, fmt_name, layout):
 
 
 def test_library_choice_of_symbols_per_block_is_invisible(oracle):
-    """symbols_per_block = 0 on a chip-filling batch makes the library time 25 / 38 / 75 once (extra launches of the same call on the
-    caller's buffers) and keep the fastest: the outputs -- soft bits, correlations, total phase and the fine-frequency state the phase
-    tail UPDATES -- must be those of one explicit call, the choice must be reported, and a second call must not calibrate again."""
+    """symbols_per_block = 0 never measures inside the data path: on a fresh context the first call of a chip-filling batch returns
+    without a host-side wait (it only enqueues) and runs 25; dabgpu_ofdm_tune -- explicit, blocking -- times 25 / 38 / 75 for a call shape
+    and records the fastest per size bucket and variant; afterwards 0 resolves to the recorded value for every batch of the bucket (and,
+    lacking its own record, of the neighbouring buckets).  The outputs -- soft bits, correlations, total phase and the fine-frequency
+    state the phase tail UPDATES -- are those of one explicit call whatever was chosen, and tuning does not touch the caller's state."""
+    import time
     import dabgpu
     import torch
-    ctx2 = dabgpu.Context(0)                                   # a fresh context: nothing cached
+    ctx2 = dabgpu.Context(0)                                   # a fresh context: nothing recorded
     n = 512
     g = torch.Generator(device="cuda"); g.manual_seed(3)
     raw = torch.randn((n, 196608, 2), generator=g, dtype=torch.float32, device="cuda")
     freq = ((torch.rand(n, generator=g, device="cuda") * 2 - 1) * 2.0e-3).float()
     fmt = dabgpu.IQ_FORMATS.index("raw_f32l")
-    outs = []
     assert ctx2.ofdm_auto_symbols_per_block(n) == 0 and ctx2.ofdm_auto_symbols_per_block(100) == 25
-    for spb in (25, 0, 0):
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, n, with_phase_tail=True) == 25 and ctx2.ofdm_tuned_symbols_per_block(fmt, 1) == 3
+
+    def run(spb):
         bits = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
         corr = torch.zeros((n, 76, 2), dtype=torch.float32, device="cuda")
         total = torch.zeros(n, dtype=torch.float32, device="cuda")
         fine = torch.full((n,), 1.0e-5, dtype=torch.float32, device="cuda")
-        ctx2.ofdm_demod_phase_frames(raw, fmt, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb, beta=0.9, total_phase=total, fine_freq=fine)
         torch.cuda.synchronize()
-        outs.append((bits, corr.view(torch.int32), total.view(torch.int32), fine.view(torch.int32)))
-    assert ctx2.ofdm_auto_symbols_per_block(n) in (25, 38, 75)
-    for k in (1, 2):
-        for a, b in zip(outs[0], outs[k]):
-            assert torch.equal(a, b)
-    assert outs[0][0].abs().sum().item() > 0
+        t0 = time.perf_counter()
+        ctx2.ofdm_demod_phase_frames(raw, fmt, n, bits, freq_offset=freq, cp_corr=corr, symbols_per_block=spb, beta=0.9, total_phase=total, fine_freq=fine)
+        host_s = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (bits, corr.view(torch.int32), total.view(torch.int32), fine.view(torch.int32)), host_s
+
+    ref, _ = run(25)
+    first, host_s = run(0)                                     # fresh context, chip-filling batch, symbols_per_block = 0
+    # the old in-call calibration ran >= 40 ms of kernels behind a hipEventSynchronize; an enqueue returns in well under 5 ms
+    assert host_s < 0.02, f"symbols_per_block = 0 blocked the host for {host_s * 1e3:.1f} ms"
+    for a, b in zip(ref, first):
+        assert torch.equal(a, b)
+    scratch_bits = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
+    chosen = ctx2.ofdm_tune(raw, fmt, n, scratch_bits, with_phase_tail=True)
+    assert chosen in (25, 38, 75)
+    assert torch.equal(scratch_bits, ref[0])                   # tuning leaves valid soft bits behind
+    assert ctx2.ofdm_auto_symbols_per_block(n) == chosen and ctx2.ofdm_auto_symbols_per_block(300) == 25
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, n, with_phase_tail=True) == chosen
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, 400 + 112, with_phase_tail=True) == chosen     # same bucket (257..512)
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, 4096, with_phase_tail=True) == chosen         # nearest recorded bucket of the variant
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, n, with_phase_tail=False) == 25               # another variant: nothing recorded
+    assert ctx2.ofdm_tuned_symbols_per_block(fmt, n, bits_layout=dabgpu.BITS_MSC_CLASSED, with_phase_tail=True) == 25
+    again, _ = run(0)
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+    assert ref[0].abs().sum().item() > 0
+    assert ctx2.ofdm_tune(raw, fmt, 100, scratch_bits) == 25   # small batches: the fixed rule, nothing to measure
     ctx2.close()

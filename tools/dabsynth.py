@@ -117,6 +117,71 @@ def random_frames(n_frames, seed, device, mapper, prs, chunk=32):
     return iq, bits, freq
 
 
+# ---- DAB+ audio super frames (ETSI TS 102 563 clauses 5.2, 6): generator side only ----
+_GF_EXP = np.zeros(512, np.int64)
+_GF_LOG = np.zeros(256, np.int64)
+_x = 1
+for _i in range(255):
+    _GF_EXP[_i] = _GF_EXP[_i + 255] = _x
+    _GF_LOG[_x] = _i
+    _x <<= 1
+    if _x & 0x100:
+        _x ^= 0x11D
+
+
+def _gmul(a, b):
+    return 0 if a == 0 or b == 0 else int(_GF_EXP[_GF_LOG[a] + _GF_LOG[b]])
+
+
+def rs_parity(data):
+    """RS(120,110) parity of 110 data bytes: generator with roots alpha^0..alpha^9 over GF(2^8), p(x) = x^8+x^4+x^3+x^2+1"""
+    g = [1] + [0] * 10
+    for i in range(10):
+        for j in range(i + 1, 0, -1):
+            g[j] = g[j - 1] ^ _gmul(g[j], int(_GF_EXP[i]))
+        g[0] = _gmul(g[0], int(_GF_EXP[i]))
+    rem = [0] * 10
+    for d in data:
+        fb = int(d) ^ rem[9]
+        for i in range(9, 0, -1):
+            rem[i] = rem[i - 1] ^ _gmul(fb, g[i])
+        rem[0] = _gmul(fb, g[0])
+    return rem[::-1]
+
+
+def _crc16(data, poly, init, xorout):
+    crc = init
+    for b in data:
+        crc ^= int(b) << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ poly) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc ^ xorout
+
+
+def make_superframe(rng, n):
+    """one audio super frame of 5 logical frames of n bytes (48 kHz, SBR: 3 access units with valid CRCs, fire code, RS parity)"""
+    n_rs = 5 * n // 120
+    data_len = 110 * n_rs
+    sf = np.zeros(5 * n, np.uint8)
+    sf[2] = 0x60
+    first = 3 + 3
+    cuts = [first, first + (data_len - first) // 3, first + 2 * (data_len - first) // 3, data_len]
+    bits = []
+    for v in cuts[1:3]:
+        bits += [(v >> (11 - b)) & 1 for b in range(12)]
+    sf[3:6] = np.packbits(np.array(bits, np.uint8))
+    for i in range(3):
+        a, b = cuts[i], cuts[i + 1]
+        sf[a:b - 2] = rng.integers(0, 256, b - a - 2, dtype=np.uint8)
+        c = _crc16(sf[a:b - 2], 0x1021, 0xFFFF, 0xFFFF)
+        sf[b - 2], sf[b - 1] = c >> 8, c & 0xFF
+    fc = _crc16(sf[2:11], 0x782F, 0, 0)
+    sf[0], sf[1] = fc >> 8, fc & 0xFF
+    for i in range(n_rs):
+        sf[i + 110 * n_rs::n_rs] = rs_parity(sf[i:i + 110 * n_rs:n_rs])
+    return sf
+
+
 class Multiplex:
     """The canonical multiplex of SURVEY 8(d) config 4 for `n` distinct ensembles: CRC-valid FIBs and 18 x 192-byte sub-channel
     payloads per ensemble, channel coded and TIME INTERLEAVED (clause 12): the payload changes with every CIF, with a period of
@@ -125,8 +190,12 @@ class Multiplex:
     in flight in the wrong order, decode to another CIF's payload or to garbage -- with one repeated frame they would not show).
     Decoded CIF r (counted from the first frame) carries payload[(r - 15) mod period]; frame j carries fibs[j mod (period / 4)]."""
 
-    def __init__(self, n, seed, device, period=8):
+    def __init__(self, n, seed, device, period=8, superframes=False, rs_errors=0):
+        """superframes: every sub-channel carries DAB+ audio super frames (5 logical frames each; period must be a multiple of 20 CIFs so
+        that the stored frames repeat whole super frames) drawn from 32 generated ones, each RS codeword with rs_errors damaged symbols
+        -- the payload the DAB+ outer code downstream of the channel decoder has real work on"""
         assert period % 4 == 0 and period >= 4
+        assert not superframes or period % 20 == 0
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         self.n, self.period, self.n_frames = n, period, period // 4
@@ -136,7 +205,22 @@ class Multiplex:
         pr96 = torch.from_numpy(prbs_bytes(96)).to(device)
         fic_mother = conv_encode(bytes_to_bits(self.fibs ^ pr96))
         fic_tx = fic_mother[..., torch.from_numpy(kept_index([(16, 21), (15, 3)])).to(device)]        # [n,nf,4,2304]
-        self.payload = torch.randint(0, 256, (n, period, N_SUB, SUB_BYTES), generator=g, device=device, dtype=torch.uint8)
+        if superframes:
+            rng = np.random.default_rng(seed + 17)
+            base = np.stack([make_superframe(rng, SUB_BYTES) for _ in range(32)])                  # [32][5 * 192]
+            self.superframes_clean = base
+            n_rs = 5 * SUB_BYTES // 120
+            pick = rng.integers(0, 32, (n, N_SUB, period // 5))
+            sfs = base[pick].copy()                                                                 # [n][sub][q][960]
+            for k in range(rs_errors):         # distinct symbols of every codeword, away from the fire-code bytes at the start
+                col = (rng.integers(2, 24, pick.shape + (n_rs,)) + 24 * k) * n_rs + np.arange(n_rs)
+                np.put_along_axis(sfs, col, np.take_along_axis(sfs, col, axis=-1) ^ rng.integers(1, 256, col.shape, dtype=np.uint8), axis=-1)
+            self.superframe_pick = pick
+            pl = sfs.reshape(n, N_SUB, period // 5, 5, SUB_BYTES).reshape(n, N_SUB, period, SUB_BYTES).transpose(0, 2, 1, 3)
+            self.payload = torch.from_numpy(np.ascontiguousarray(pl)).to(device)
+            torch.randint(0, 256, (1,), generator=g, device=device)                                # (keeps the generator's stream position simple)
+        else:
+            self.payload = torch.randint(0, 256, (n, period, N_SUB, SUB_BYTES), generator=g, device=device, dtype=torch.uint8)
         pr192 = torch.from_numpy(prbs_bytes(SUB_BYTES)).to(device)
         kidx = torch.from_numpy(kept_index([(8, 45), (7, 3)])).to(device)                               # EEP 3-A, n = 8
         logical = torch.empty((n, period, N_SUB, 3072), dtype=torch.uint8, device=device)
@@ -156,11 +240,11 @@ class Multiplex:
         return [dabgpu.SubChannel(SUB_CU * s, SUB_CU, 0, 0, 2, 0) for s in range(N_SUB)]
 
 
-def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8):
+def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8, superframes=False, rs_errors=0):
     """IQ of n_ensembles ensembles built from n_distinct (<= 64) seeded multiplexes: ensemble e carries
     multiplex e % n_distinct; every ensemble gets its own noise realisation.  Returns (iq [period / 4][E][196608] complex64 -- the
     period / 4 transmission frames that repeat -- and the Multiplex)."""
-    mux = Multiplex(n_distinct, seed, device, period)
+    mux = Multiplex(n_distinct, seed, device, period, superframes=superframes, rs_errors=rs_errors)
     nf = mux.n_frames
     iq = torch.empty((nf, n_ensembles, NB_FRAME_SAMPLES), dtype=torch.complex64, device=device)
     g = torch.Generator(device=device)
@@ -175,3 +259,83 @@ def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, 
                 iq[f, e0:e0 + m] += noise * torch.view_as_complex(nz)
         del base
     return iq, mux
+
+
+def add_noise_(iq, noise, seed, chunk=64):
+    """in place: every receiver's own noise realisation on frame-aligned iq [nf][E][196608] built with noise = 0"""
+    g = torch.Generator(device=iq.device)
+    g.manual_seed(seed)
+    for f in range(iq.shape[0]):
+        for e0 in range(0, iq.shape[1], chunk):
+            e1 = min(e0 + chunk, iq.shape[1])
+            iq[f, e0:e1] += noise * torch.view_as_complex(torch.randn((e1 - e0, iq.shape[2], 2), generator=g, dtype=torch.float32, device=iq.device))
+    return iq
+
+
+def ensemble_slices(iq, n_distinct, seed, lead, stride, max_cfo_hz=5000.0, max_toff=100, noise=0.05, chunk=64):
+    """The sync-enabled configurations of SURVEY 8(d): from the frame-aligned iq [nf][E][196608] of ensemble_iq (noise-free there: pass the
+    noise here) build per-receiver slices [nf][E][stride] in which frame f of receiver e begins at sample lead + toff[e] (toff uniform in
+    [-max_toff, max_toff]: the receiver expects the PRS at `lead`), rotated by a carrier offset cfo[e] (uniform in +-max_cfo_hz, cycles
+    per sample, continuous over the repeating frames), with the receiver's own noise over the whole slice (the NULL symbol included).
+    Returns (slices, cfo [E] float32, toff [E] int32)."""
+    nf, E, L = iq.shape[0], iq.shape[1], 76 * 2552
+    device = iq.device
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cfo = ((torch.rand(E, generator=g, device=device) * 2 - 1) * (max_cfo_hz / 2.048e6)).double()
+    # the stored frames repeat: a carrier offset that is a whole number of cycles per repetition keeps the phase continuous
+    rep = nf * NB_FRAME_SAMPLES
+    cfo = torch.round(cfo * rep) / rep
+    toff = torch.randint(-max_toff, max_toff + 1, (E,), generator=g, device=device, dtype=torch.int64)
+    out = torch.empty((nf, E, stride), dtype=torch.complex64, device=device)
+    n = torch.arange(stride, device=device, dtype=torch.int64)
+    for f in range(nf):
+        for e0 in range(0, E, chunk):
+            e1 = min(e0 + chunk, E)
+            src = n[None, :] - (lead + toff[e0:e1, None])                      # frame sample that lands on slice sample n
+            inside = (src >= 0) & (src < L)
+            x = torch.gather(iq[f, e0:e1], 1, src.clamp(0, L - 1))
+            ph = (2.0 * np.pi) * cfo[e0:e1, None] * (src + f * NB_FRAME_SAMPLES).double()
+            x = x * torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
+            x = torch.where(inside, x, torch.zeros_like(x))
+            if noise:
+                x = x + noise * torch.view_as_complex(torch.randn((e1 - e0, stride, 2), generator=g, dtype=torch.float32, device=device))
+            out[f, e0:e1] = x
+    return out, cfo.float(), toff.int()
+
+
+def ensemble_streams_u8(iq, seed, block, max_cfo_hz=5000.0, noise=0.05, chunk=32):
+    """Unsynchronised capture streams for the device-resident chain (stream bank -> ring -> decoders -> DAB+): from the frame-aligned
+    iq [nf][E][196608] (noise-free) build, per receiver, the repeating transmission -- [76 symbols | NULL] x nf -- starting at a random
+    sample (the receiver knows nothing about where frames begin), with its own carrier offset and noise, quantised like an RTL-SDR
+    capture (raw_u8: (x / full_scale) * 127.5 + 127.5, rounded, clipped).  The buffer repeats its first `block` samples at the end so that
+    any block of `block` samples starting inside one repetition is contiguous.
+    Returns (raw [E][nf * 196608 + block][2] uint8, start [E] int64 = stream sample at which frame 0's PRS begins, cfo [E])."""
+    nf, E = iq.shape[0], iq.shape[1]
+    device = iq.device
+    rep = nf * NB_FRAME_SAMPLES
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cfo = ((torch.rand(E, generator=g, device=device) * 2 - 1) * (max_cfo_hz / 2.048e6)).double()
+    cfo = torch.round(cfo * rep) / rep
+    start = torch.randint(0, rep, (E,), generator=g, device=device, dtype=torch.int64)
+    raw = torch.empty((E, rep + block, 2), dtype=torch.uint8, device=device)
+    flat = iq.permute(1, 0, 2).reshape(E, rep) if nf > 1 else iq[0]         # [E][rep]: frames back to back (a view when nf == 1)
+    n = torch.arange(rep, device=device, dtype=torch.int64)
+    full_scale = 4.0 * float(iq[0, :min(E, 8)].abs().square().mean().sqrt().item()) + 4.0 * noise
+    for e0 in range(0, E, chunk):
+        e1 = min(e0 + chunk, E)
+        src = (n[None, :] - start[e0:e1, None]) % rep
+        if nf > 1:
+            x = torch.gather(iq.permute(1, 0, 2)[e0:e1].reshape(e1 - e0, rep), 1, src)
+        else:
+            x = torch.gather(flat[e0:e1], 1, src)
+        ph = (2.0 * np.pi) * cfo[e0:e1, None] * n[None, :].double()
+        x = x * torch.polar(torch.ones_like(ph), ph).to(torch.complex64)
+        x = torch.view_as_real(x)
+        if noise:
+            x = x + noise * torch.randn(x.shape, generator=g, dtype=torch.float32, device=device)
+        q = torch.clamp(torch.round(x * (127.5 / full_scale) + 127.5), 0, 255).to(torch.uint8)
+        raw[e0:e1, :rep] = q
+        raw[e0:e1, rep:] = q[:, :block]
+    return raw, start, cfo.float()
