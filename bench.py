@@ -517,15 +517,15 @@ def cpu_baseline_full(sample, seconds_target=14.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
-    per_thread = int(max(warm + 2, min(4096, seconds_target / dt1 / 1.3)))            # (all cores busy: expect ~1.3 x the lone-thread time per frame)
+    def run(per_thread):
+        t0_ = time.perf_counter()
+        with cf.ThreadPoolExecutor(cores) as ex:
+            r_ = list(ex.map(lambda i: O.receive_frames(per[i % ne], SLICE_SAMPLES, SLICE_LEAD, per_thread, subs), range(cores)))
+        return r_, time.perf_counter() - t0_
 
-    def work(i):
-        return O.receive_frames(per[i % ne], SLICE_SAMPLES, SLICE_LEAD, per_thread, subs)
-
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:
-        res = list(ex.map(work, range(cores)))
-    dt = time.perf_counter() - t0
+    _, probe = run(warm + 2)                                                        # calibrate: all cores busy scale far from linearly on some hosts
+    per_thread = int(max(warm + 2, min(4096, (warm + 2) * seconds_target / probe)))
+    res, dt = run(per_thread)
     ok = True
     for i, r in enumerate(res):                                                     # every thread's last frame against what was transmitted
         e, j = i % ne, per_thread - 1

@@ -210,10 +210,26 @@ int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes
     if (bytes == 0) return DABGPU_OK;
     int st;
     // The ring is for small, short-lived sources (plans, lane tables, one CIF, one descriptor).  A large table (the descriptor
-    // array of dabgpu_viterbi_decode_batch: tens of MB) goes through the runtime's own pageable path, which has consumed h_src
-    // when it returns: no second host copy, and no pinned slot grows to the largest table ever seen.
+    // array of dabgpu_viterbi_decode_batch: tens of MB) goes through the runtime's own path: no second host copy, and no pinned slot
+    // grows to the largest table ever seen.  The contract is "h_src is consumed when this returns": the runtime guarantees that for
+    // PAGEABLE memory only (it stages the bytes itself before returning).  A page-locked source (hipHostMalloc, hipHostRegister --
+    // dabgpu_host_pin --, a pinned torch tensor) is read by the DMA engine after the call has returned, so the copy is waited for.
     constexpr size_t STAGE_MAX = (size_t)1 << 20;
-    if (bytes > STAGE_MAX) return dabgpu_check_hip(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(pageable)");
+    if (bytes > STAGE_MAX) {
+        hipPointerAttribute_t at;
+        bool page_locked = true;                                       // unknown -> assume the worse
+        const hipError_t qa = hipPointerGetAttributes(&at, h_src);
+        if (qa == hipSuccess) page_locked = (at.type != hipMemoryTypeUnregistered);
+        else { (void)hipGetLastError(); page_locked = (qa != hipErrorInvalidValue); }      // invalid value = a pointer HIP has never seen: pageable
+        if ((st = dabgpu_check_hip(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync(large table)"))) return st;
+        if (!page_locked) return DABGPU_OK;
+        hipEvent_t ev = nullptr;
+        if ((st = dabgpu_check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate(large table)"))) return st;
+        st = dabgpu_check_hip(hipEventRecord(ev, s), "hipEventRecord(large table)");
+        if (!st) st = dabgpu_check_hip(hipEventSynchronize(ev), "hipEventSynchronize(large table)");
+        (void)hipEventDestroy(ev);
+        return st;
+    }
     dabgpu_ctx::stage_slot* sl;
     {
         std::lock_guard<std::mutex> g(c->stage_mu);

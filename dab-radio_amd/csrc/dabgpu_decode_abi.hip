@@ -235,7 +235,8 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
     if (st) return st;
     if ((st = dabgpu_stage_h2d(c, d_descs, h_cw, n * sizeof(dabgpu_cw_desc), s))) return st;
-    // (through the pinned staging ring: h_cw is consumed when this returns, the caller may reuse it)
+    // (h_cw is consumed when this returns, the caller may reuse it: small tables go through the pinned staging ring, large ones through
+    // the runtime's pageable path -- or, when the caller's array is page-locked, a copy that is waited for; dabgpu_stage_h2d)
     bool uniform = true;                                  // one puncturing schedule for the whole batch?
     for (size_t i = 1; i < n && uniform; i++)
         uniform = h_cw[i].n_steps == h_cw[0].n_steps && !memcmp(h_cw[i].seg_pi, h_cw[0].seg_pi, sizeof(h_cw[0].seg_pi)) &&
@@ -370,6 +371,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if (fic_inside) {
         size_t rows = 0;
         for (int j = 0; j < n_sub; j++) rows += dabgpu_vit_alloc_steps(plans[(size_t)j].n_steps);
+        rows += dabgpu_vit_alloc_steps(774);           // 16 ensembles = 64 FIB groups = one more group of codewords in the launch's scratch
         fic_inside = n_ens <= std::max<size_t>(1, lanes_max_rows() / rows) * 16;
     }
     if (fic && !fic_inside && (st = fic_decode_any(c, fic_bits, n_ens, ens_stride, d_slots, fic->d_fib_bytes, fic->d_results, tie_rule, stream))) return st;

@@ -126,6 +126,9 @@ struct dabgpu_vit_group {
 };
 // decisions are stored two steps per row pair; the chain-back reads whole 24-step chunks
 static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_steps) { return (n_steps + 6u + 63u) & ~63u; }
+#define DABGPU_VIT_SCHED_PREFETCH 6u          // entries past the last step the trellis loops may load (viterbi_lanes.hip, viterbi_octet.hip)
+static_assert(((0u + 6u + 63u) & ~63u) >= 0u + DABGPU_VIT_SCHED_PREFETCH && ((58u + 6u + 63u) & ~63u) >= 58u + DABGPU_VIT_SCHED_PREFETCH,
+              "dabgpu_vit_alloc_steps must leave room for the schedule prefetch");
 // soft bits a codeword consumes (dab_viterbi_decoder.cpp:131-181): 8 + PI per 8 steps, 12 for the tail
 static inline __host__ __device__ uint32_t dabgpu_vit_in_bytes(const uint32_t* seg_pi, const uint32_t* seg_steps) {
     uint32_t n = 12;
@@ -150,7 +153,9 @@ extern "C" hipError_t dabgpu_launch_vit_trellis(const dabgpu_vit_group* d_groups
 extern "C" hipError_t dabgpu_launch_vit_groups_msc(dabgpu_vit_group* d_groups, const struct dabgpu_msc_plan* d_plans,
                                                    const uint64_t* d_lane_subs, int n_lane_sub, int n_sub, size_t n_ens,
                                                    uint32_t groups_per_sub, uint32_t sched_stride, hipStream_t stream);
-// schedule tables (one per puncturing schedule of the call): sched_stride entries each, >= n_steps + 12
+// schedule tables (one per puncturing schedule of the call): sched_stride entries each.  The trellis kernels read entry t for the steps
+// t < n_steps and prefetch up to DABGPU_VIT_SCHED_PREFETCH entries beyond the last step, so sched_stride >= n_steps + DABGPU_VIT_SCHED_PREFETCH;
+// callers size the tables with dabgpu_vit_alloc_steps (>= n_steps + 6, static check below)
 extern "C" hipError_t dabgpu_launch_vit_sched_uniform(uint2* d_sched, uint32_t sched_stride, const uint32_t* seg_pi, const uint32_t* seg_steps,
                                                       const struct dabgpu_vit_tables* d_tables, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_vit_sched_msc(uint2* d_sched, uint32_t sched_stride, const struct dabgpu_msc_plan* d_plans,

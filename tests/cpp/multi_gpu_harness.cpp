@@ -187,13 +187,15 @@ struct Barrier {
 
 struct Result {
     int device = 0; bool ok = false; double ms_per_step = 0.0;
+    size_t free_at_probe = 0, free_at_end = 0;      // hipMemGetInfo of the worker's device after step --mem-probe-step and after the last step
+    int spb = 0;
     long fib_mismatch = 0, msc_mismatch = 0, crc_pass = 0, crc_expected = 0;
     uint64_t digest = 0;
 };
 
 uint64_t fnv1a(uint64_t h, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001B3ull; } return h; }
 
-bool worker(int rank, int device, size_t E, int steps, int n_distinct, int inflight, Barrier* bar, Result* R) {
+bool worker(int rank, int device, size_t E, int steps, int n_distinct, int inflight, int probe_step, Barrier* bar, Result* R) {
     // rank < 0 (--identical): every worker carries the same ensembles (equal digests), else worker r starts at multiplex r
     if (rank < 0) rank = 0;
     R->device = device;
@@ -256,13 +258,26 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
         j++;
         return true;
     };
+    // explicit calibration of the demodulator's run length for this batch size, once per context, before anything is timed
+    // (symbols_per_block = 0 in step() resolves to what is recorded here; the data path never measures)
+    for (int k = 0; k < inflight; k++) DABCK(dabgpu_ofdm_tune(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, d_hist, stride, DABGPU_BITS_MSC_CLASSED, 0, st[(size_t)k], &R->spb));
     for (int i = 0; i < H + inflight; i++) if (!step()) return false;   // fill the history ring: the time de-interleaver needs 16 CIFs
     HIPCK(hipDeviceSynchronize());
     bar->wait();                                                       // all workers start their timed steps together
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < steps; i++) if (!step()) return false;
+    for (int i = 0; i < steps; i++) {
+        if (!step()) return false;
+        if (i + 1 == probe_step) {                                     // every scratch buffer of the library has its final size long before this
+            size_t total = 0;
+            for (int k = 0; k < inflight; k++) HIPCK(hipStreamSynchronize(st[(size_t)k]));
+            bar->wait();                                               // (all workers are past their allocations when any of them measures)
+            HIPCK(hipMemGetInfo(&R->free_at_probe, &total));
+            bar->wait();
+        }
+    }
     for (int k = 0; k < inflight; k++) HIPCK(hipStreamSynchronize(st[(size_t)k]));
     R->ms_per_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
+    if (probe_step > 0) { size_t total = 0; bar->wait(); HIPCK(hipMemGetInfo(&R->free_at_end, &total)); bar->wait(); }
 
     // ---- every byte of the last frame of every lane against what was transmitted ----
     std::vector<uint8_t> h_fib(E * 4 * 96), h_msc(E * 4 * cif_out);
@@ -299,7 +314,7 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
 int main(int argc, char** argv) {
     std::vector<int> devices;
     size_t E = 8192;
-    int steps = 10, distinct = 8, inflight = 2;
+    int steps = 10, distinct = 8, inflight = 2, probe_step = 0;
     bool identical = false;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
@@ -310,10 +325,11 @@ int main(int argc, char** argv) {
         else if (k == "--distinct") distinct = std::atoi(val());
         else if (k == "--inflight") inflight = std::atoi(val());
         else if (k == "--identical") identical = true;
+        else if (k == "--mem-probe-step") probe_step = std::atoi(val());      // soak: device memory free after this step and after the last one
         else { std::fprintf(stderr, "usage: %s --devices 0,1,... [--ensembles E] [--steps K] [--distinct D] [--inflight 1|2]\n", argv[0]); return 2; }
     }
     if (devices.empty()) devices.push_back(0);
-    if (E == 0 || steps < 1 || distinct < 1 || inflight < 1 || inflight > 4) { std::fprintf(stderr, "bad arguments\n"); return 2; }
+    if (E == 0 || steps < 1 || distinct < 1 || inflight < 1 || inflight > 4 || probe_step < 0 || probe_step >= steps) { std::fprintf(stderr, "bad arguments\n"); return 2; }
     if (dabgpu_device_count() <= 0) { std::fprintf(stderr, "no gfx950 device (this path has no CPU fallback)\n"); return 1; }
     Barrier bar; bar.n = (int)devices.size();
     std::vector<Result> res(devices.size());
@@ -321,7 +337,7 @@ int main(int argc, char** argv) {
     std::atomic<int> failed{0};
     for (size_t r = 0; r < devices.size(); r++)
         th.emplace_back([&, r] {
-            if (!worker(identical ? -1 : (int)r, devices[r], E, steps, distinct, inflight, &bar, &res[r])) {
+            if (!worker(identical ? -1 : (int)r, devices[r], E, steps, distinct, inflight, probe_step, &bar, &res[r])) {
                 failed++;
                 // a worker that failed before the start line must not leave the others waiting at it
                 std::unique_lock<std::mutex> lk(bar.mu);
@@ -335,12 +351,13 @@ int main(int argc, char** argv) {
     std::printf("{\"program\": \"multi_gpu_harness\", \"workload\": \"BASELINE configs[4] per device: OFDM demod + FIC Viterbi + 18 x 48 CU EEP 3-A MSC per transmission frame\", "
                 "\"workers\": %zu, \"ensembles_per_worker\": %zu, \"steps\": %d, \"frames_in_flight\": %d, \"distinct_multiplexes\": %d, "
                 "\"scaling\": \"weak: independent ensembles per device, one host thread + contexts + streams per device, no collective\", "
-                "\"frames_per_s\": %.1f, \"ms_per_step_slowest_worker\": %.4f, \"all_outputs_equal_transmitted\": %s, \"per_worker\": [",
-                devices.size(), E, steps, inflight, distinct, all_ok && worst > 0.0 ? (double)devices.size() * (double)E / worst * 1e3 : 0.0, worst, all_ok ? "true" : "false");
+                "\"frames_per_s\": %.1f, \"ms_per_step_slowest_worker\": %.4f, \"all_outputs_equal_transmitted\": %s, \"mem_probe_step\": %d, \"per_worker\": [",
+                devices.size(), E, steps, inflight, distinct, all_ok && worst > 0.0 ? (double)devices.size() * (double)E / worst * 1e3 : 0.0, worst, all_ok ? "true" : "false", probe_step);
     for (size_t r = 0; r < res.size(); r++)
-        std::printf("%s{\"device\": %d, \"ok\": %s, \"ms_per_step\": %.4f, \"fib_groups_wrong\": %ld, \"msc_cifs_wrong\": %ld, \"fib_crc_pass\": %ld, \"fib_crc_expected\": %ld, \"digest\": \"%016llx\"}",
+        std::printf("%s{\"device\": %d, \"ok\": %s, \"ms_per_step\": %.4f, \"fib_groups_wrong\": %ld, \"msc_cifs_wrong\": %ld, \"fib_crc_pass\": %ld, \"fib_crc_expected\": %ld, \"digest\": \"%016llx\", "
+                    "\"symbols_per_block\": %d, \"device_free_bytes_at_probe\": %zu, \"device_free_bytes_at_end\": %zu}",
                     r ? ", " : "", res[r].device, res[r].ok ? "true" : "false", res[r].ms_per_step, res[r].fib_mismatch, res[r].msc_mismatch, res[r].crc_pass, res[r].crc_expected,
-                    (unsigned long long)res[r].digest);
+                    (unsigned long long)res[r].digest, res[r].spb, res[r].free_at_probe, res[r].free_at_end);
     std::printf("]}\n");
     return all_ok ? 0 : 1;
 }

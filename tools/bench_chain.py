@@ -115,22 +115,6 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
     torch.cuda.synchronize()
     dt_seq = time.perf_counter() - t0
     f2 = frames_read()
-    # stage times, one at a time (front end alone, decoders alone, DAB+ alone)
-    def timed(fn, reps):
-        torch.cuda.synchronize()
-        t0_ = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0_) / reps * 1e3
-    jj = [j]
-    def only_front():
-        front(jj[0], sA); jj[0] += 1
-    t_front = timed(only_front, 4)
-    j = jj[0]
-    t_dec = timed(lambda: ctx2.decode_ring(hist, E, H * dabgpu.NB_FRAME_BITS, H, slots[(j - 1) % 2], subs, fib, fres, msc, 4 * nsub * nb, mres,
-                                           stream=sA.cuda_stream, bits_layout=layout), 4)
-
     # ---- check (untimed): more steps, read back after each: every frame completed in them must decode to what was transmitted ----
     status0 = bank.status()
     chk = {"frames_checked": 0, "fib_crc_pass": 0, "fib_crc_expected": 0, "fib_bytes_equal_transmitted": True, "msc_bytes_equal_transmitted": True,
@@ -141,6 +125,7 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
     clean = torch.from_numpy(mux.superframes_clean).to(device)                                     # [32][960]
     pick = torch.from_numpy(mux.superframe_pick).to(device)                                        # [n][sub][period / 5]
     for _ in range(6):
+        cnt.zero_()                                                  # (the bank writes a stream's counters only when it processes the stream)
         step_sequential(j); j += 1
         torch.cuda.synchronize()
         sl = slots[(j - 1) % 2]
@@ -163,7 +148,7 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
         if dp is not None:
             c = cnt.cpu().numpy()
             r = rec.cpu().numpy().view(rec_dt).reshape(S)
-            att = c[:, 0] > 0
+            att = (c[:, 0] > 0) & np.repeat(dm, nsub)
             chk["superframes_checked"] += int(att.sum())
             if att.any():
                 ok = (r["header_valid"][att] == 1) & (r["au_crc_ok_mask"][att] == 7) & (r["rs_failed_index"][att] == -1) & (r["firecode_ok"][att] == 1)
@@ -175,6 +160,22 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
                 want = clean[pick[idx[:, None], torch.arange(nsub, device=device)[None, :], q]]     # [E][nsub][960]
                 same = (sf.view(E, nsub, 5 * nb) == want).all(dim=2).reshape(-1)
                 chk["superframe_bytes_equal_transmitted"] &= bool(same[att_t].all().item())
+    # stage times, one at a time -- AFTER the check: a front end run without its decoders drops logical frames the DAB+ stage is collecting
+    def timed(fn, reps):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0_) / reps * 1e3
+    jj = [j]
+    def only_front():
+        front(jj[0], sA); jj[0] += 1
+    t_front = timed(only_front, 4)
+    j = jj[0]
+    t_dec = timed(lambda: ctx2.decode_ring(hist, E, H * dabgpu.NB_FRAME_BITS, H, slots[(j - 1) % 2], subs, fib, fres, msc, 4 * nsub * nb, mres,
+                                           stream=sA.cuda_stream, bits_layout=layout), 4)
+
     frames_timed = f1 - f0
     out = {"workload": f"device-resident chain, {E} unsynchronised raw_u8 streams ({mux.n} seeded multiplexes of 18 x 48 CU EEP 3-A DAB+ sub-channels, "
                        f"{rs_errors} damaged symbol(s) per RS codeword): stream bank -> history rings -> FIC + MSC ring decode -> DAB+ outer code",
