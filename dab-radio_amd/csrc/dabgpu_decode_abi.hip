@@ -194,6 +194,13 @@ static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_
 }
 
 static int validate_codeword(const dabgpu_codeword& d, size_t i) {
+    if (d.flags & DABGPU_CW_DEPUNCTURED) {            // mother code handed over: no segment tables, any length, direct source only
+        if (d.n_steps < 1 || d.n_steps > (1u << 24) || d.n_slots != 0 || !d.d_src || !d.d_out) {
+            dabgpu_set_error("codeword %zu: DABGPU_CW_DEPUNCTURED needs 1 <= n_steps <= 2^24, n_slots = 0 and non-null addresses", i);
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        return DABGPU_OK;
+    }
     uint64_t steps = 0;
     for (int k = 0; k < 4; k++) {
         if (d.seg_steps[k] == 0) continue;
@@ -238,6 +245,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     // (h_cw is consumed when this returns, the caller may reuse it: small tables go through the pinned staging ring, large ones through
     // the runtime's pageable path -- or, when the caller's array is page-locked, a copy that is waited for; dabgpu_stage_h2d)
     bool uniform = true;                                  // one puncturing schedule for the whole batch?
+    for (size_t i = 0; i < n && uniform; i++) uniform = !(h_cw[i].flags & DABGPU_CW_DEPUNCTURED);      // (mother-code sources: wave mapping only)
     for (size_t i = 1; i < n && uniform; i++)
         uniform = h_cw[i].n_steps == h_cw[0].n_steps && !memcmp(h_cw[i].seg_pi, h_cw[0].seg_pi, sizeof(h_cw[0].seg_pi)) &&
                   !memcmp(h_cw[i].seg_steps, h_cw[0].seg_steps, sizeof(h_cw[0].seg_steps));
@@ -248,7 +256,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
                             : DABGPU_VIT_MAP_WAVE;
     if (map != DABGPU_VIT_MAP_WAVE)
         return run_lanes_uniform(c, d_descs, n, max_steps, h_cw[0].seg_pi, h_cw[0].seg_steps, tie_rule, 0, map == DABGPU_VIT_MAP_OCTET, d_results, s, 0);
-    return run_viterbi(c, d_descs, n, max_steps, (max_steps - 6) / 8, tie_rule, d_results, s);
+    return run_viterbi(c, d_descs, n, max_steps, max_steps > 6 ? (max_steps - 6) / 8 : 0, tie_rule, d_results, s);
 }
 
 static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, size_t frame_stride, const int32_t* d_slots,
@@ -530,7 +538,9 @@ static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src,
     int st;
     int8_t* d_src = nullptr; uint8_t* d_out; dabgpu_codeword_result* d_res; dabgpu_cw_desc* d_desc;
     if (h_src && (st = dabgpu_scratch(c, 14, n_src, (void**)&d_src))) return st;
-    if ((st = dabgpu_scratch(c, 15, std::max<size_t>(n_out, 16), (void**)&d_out))) return st;
+    // (the kernel writes (n_steps - 6) / 8 bytes whatever part of them the caller wants back)
+    const size_t kernel_out = D.n_steps > 6 ? (size_t)(D.n_steps - 6) / 8 : 0;
+    if ((st = dabgpu_scratch(c, 15, std::max<size_t>(std::max(n_out, kernel_out), 16), (void**)&d_out))) return st;
     if ((st = dabgpu_scratch(c, 16, sizeof(dabgpu_codeword_result), (void**)&d_res))) return st;
     if ((st = dabgpu_scratch(c, 10, sizeof(dabgpu_cw_desc), (void**)&d_desc))) return st;
     hipStream_t s = c->stream;
@@ -540,8 +550,8 @@ static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src,
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
     if (h_src) CK(hipMemcpyAsync(d_src, h_src, n_src, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, s));
-    if ((st = run_viterbi(c, d_desc, 1, D.n_steps, (D.n_steps - 6) / 8, tie_rule, d_res, s))) return st;
-    CK(hipMemcpyAsync(h_out, d_out, n_out, hipMemcpyDeviceToHost, s));
+    if ((st = run_viterbi(c, d_desc, 1, D.n_steps, D.n_steps > 6 ? (D.n_steps - 6) / 8 : 0, tie_rule, d_res, s))) return st;
+    if (n_out) CK(hipMemcpyAsync(h_out, d_out, n_out, hipMemcpyDeviceToHost, s));
     CK(hipMemcpyAsync(h_res, d_res, sizeof(*h_res), hipMemcpyDeviceToHost, s));
     CK(hipStreamSynchronize(s));
 #undef CK
@@ -589,6 +599,32 @@ extern "C" int dabgpu_viterbi_decode_host_sync(dabgpu_ctx* c, const int8_t* h_sr
     if (st) return st;
     if (path_error) *path_error = R.path_error;
     return DABGPU_OK;
+}
+
+extern "C" int dabgpu_viterbi_decode_depunctured_host_sync(dabgpu_ctx* c, const int8_t* h_mother, size_t n_steps, uint32_t start_state,
+                                                           uint32_t end_state, uint8_t* h_out, size_t n_out_bytes, uint64_t* path_error, int tie_rule) {
+    if (!c || !h_mother || (!h_out && n_out_bytes)) { dabgpu_set_error("viterbi_decode_depunctured_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (n_steps < 1 || n_steps > ((size_t)1 << 24)) { dabgpu_set_error("viterbi_decode_depunctured_host_sync: n_steps %zu out of range", n_steps); return DABGPU_ERR_INVALID_ARG; }
+    if (n_out_bytes && n_out_bytes * 8 + 6 > n_steps) {
+        dabgpu_set_error("viterbi_decode_depunctured_host_sync: a trace-back of %zu bytes starts at decision word %zu, only %zu steps were decoded",
+                         n_out_bytes, n_out_bytes * 8 + 5, n_steps);
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    DABGPU_HOST_LOCK(c);
+    dabgpu_cw_desc D = {};
+    D.start_state = start_state; D.end_state = end_state; D.flags = DABGPU_CW_RAW | DABGPU_CW_DEPUNCTURED;
+    D.d_src = 1;
+    dabgpu_codeword_result R;
+    // whole length: the path error (and the bytes, when the trace-back starts at the last step)
+    const bool same = n_out_bytes * 8 + 6 == n_steps;
+    D.n_steps = (uint32_t)n_steps;
+    int st = decode_one_sync(c, D, h_mother, 4 * n_steps, h_out, same ? n_out_bytes : 0, &R, tie_rule);
+    if (st) return st;
+    if (path_error) *path_error = R.path_error;
+    if (same || n_out_bytes == 0) return DABGPU_OK;
+    // the trace-back starts earlier: decode the prefix that ends there (same decisions for its steps), from the same end state
+    D.n_steps = (uint32_t)(n_out_bytes * 8 + 6);
+    return decode_one_sync(c, D, h_mother, 4 * (size_t)D.n_steps, h_out, n_out_bytes, &R, tie_rule);
 }
 
 struct dabgpu_msc_stream {

@@ -235,7 +235,10 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         const dabgpu_cw_desc D = descs[cw];
         const int n_steps = (int)D.n_steps;
         if (D.flags & DABGPU_CW_LANE_MAPPED) continue;        // decoded by vit_lanes_kernel in this call (hybrid MSC batches)
-        if (n_steps < 7) {                            // skipped work item (ring decode of an ensemble without a new frame)
+        // DABGPU_CW_DEPUNCTURED: the source holds all 4 mother symbols of every step (the caller de-punctured: any puncturing vectors, any
+        // lengths, dab_viterbi_decoder.cpp:131-181), the segment tables are not read and any n_steps >= 1 is a codeword
+        const bool full_rate = (D.flags & DABGPU_CW_DEPUNCTURED) != 0;
+        if (n_steps < (full_rate ? 1 : 7)) {          // skipped work item (ring decode of an ensemble without a new frame)
             if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; results[cw] = R; }
             continue;
         }
@@ -280,6 +283,10 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         int fidx[3], finc[3], frem[3], fkeep = 0;
         const int rbit = lane & 3;
         auto locate = [&](int q, int step) {
+            if (full_rate) {                              // symbol r of step `step` is byte 4 step + r; nothing is punctured, no segments
+                fidx[q] = 4 * step + rbit; finc[q] = 4 * VBLOCK; frem[q] = 0x40000000; fkeep |= 1 << q;
+                return;
+            }
             int k = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) k += (step >= seg_end[u]) ? 1 : 0;
@@ -345,7 +352,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         __syncthreads();
 
         // ---- write-out + optional FIB CRC16 ----
-        const int n_out = (n_steps - 6) >> 3;
+        const int n_out = n_steps > 6 ? (n_steps - 6) >> 3 : 0;
         unsigned char* out = reinterpret_cast<unsigned char*>(D.d_out);
         for (int k = lane; k < n_out; k += 64) out[k] = obytes[k];
         uint32_t crc_mask = 0;

@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames", "dabgpu_decode_frames_layout", "dabgpu_decode_ring_layout",
     "dabgpu_frame_session_create", "dabgpu_frame_session_destroy", "dabgpu_frame_session_set_subchannels", "dabgpu_frame_session_push_frame",
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
+    "dabgpu_viterbi_decode_depunctured_host_sync",
     "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]

@@ -2,12 +2,10 @@
 #include "./dab_viterbi_decoder.h"
 
 #include <cstdlib>
-#include <cstring>
 #include <stdexcept>
 #include <string>
 
 #include "dabgpu.h"
-#include "../constants/puncture_codes.h"
 #include "../dabgpu_shared_context.h"
 
 DAB_Viterbi_Decoder::DAB_Viterbi_Decoder() : m_ctx(dabgpu_shared_context()) {}
@@ -17,61 +15,43 @@ DAB_Viterbi_Decoder::~DAB_Viterbi_Decoder() = default;
 void DAB_Viterbi_Decoder::reset(const size_t starting_state) {
     m_start_state = starting_state;
     m_current_decoded_bit = 0;
-    m_symbols.clear();
-    m_nb_segments = 0;
-    m_has_tail = false;
-    m_is_bad = false;
-    for (int i = 0; i < 4; i++) { m_seg_pi[i] = 0; m_seg_steps[i] = 0; }
+    m_mother.clear();
 }
 
-// which PI_n is this kept-count vector? (the reference passes rows of PI_TABLE or PI_X, puncture_codes.h:42-72)
-static int identify_puncture_code(tcb::span<const uint8_t> code) {
-    if (code.size() == 6) {
-        for (size_t i = 0; i < 6; i++) if (code[i] != 2) return -1;
-        return 0;      // PI_X
-    }
-    if (code.size() != 8) return -1;
-    for (int pi = 1; pi <= 24; pi++)
-        if (std::memcmp(code.data(), dab_puncture_table().pi[pi - 1], 8) == 0) return pi;
-    return -1;
-}
-
-// :114-122 + depuncture bookkeeping of :131-181 (no symbols are expanded on the host)
+// :114-122 with depuncture_symbols (:131-181) run here, on the host: ANY puncture vector (kept counts 0..4 per group of four mother
+// symbols, applied cyclically), any requested_output_symbols (a multiple of the code rate), any number of calls.  The add-compare-select
+// the reference runs inside update() happens in chainback(), on the device, over everything recorded since reset().
 size_t DAB_Viterbi_Decoder::update(tcb::span<const viterbi_bit_t> punctured_symbols, tcb::span<const uint8_t> puncture_code,
                                    const size_t requested_output_symbols) {
-    if (requested_output_symbols == 0) return 0;
-    const int pi = identify_puncture_code(puncture_code);
-    size_t consumed = 0;
-    for (size_t g = 0, out = 0; out < requested_output_symbols; out += m_code_rate, g = (g + 1) % puncture_code.size())
-        consumed += puncture_code[g];
-    const bool is_tail = (pi == 0 && requested_output_symbols == 24);
-    const bool is_body = (pi >= 1 && requested_output_symbols % 128 == 0 && m_nb_segments < 4 && !m_has_tail);
-    if (consumed > punctured_symbols.size() || (!is_tail && !is_body) || (is_tail && m_has_tail)) {
-        m_is_bad = true;          // shape the device kernel does not implement: chainback() reports it
-        return 0;
+    if (requested_output_symbols == 0 || puncture_code.empty()) return 0;
+    const size_t before = m_mother.size();
+    size_t in = 0, code = 0, out = 0;
+    while (out < requested_output_symbols) {                          // :154-176
+        const size_t keep = puncture_code[code] < m_code_rate ? puncture_code[code] : m_code_rate;
+        if (punctured_symbols.size() - in < keep) {                   // :157-160: res comes back as initialised -- nothing decoded, nothing consumed
+            m_mother.resize(before);
+            return 0;
+        }
+        for (size_t i = 0; i < keep; i++) m_mother.push_back(punctured_symbols[in++]);
+        for (size_t i = keep; i < m_code_rate; i++) m_mother.push_back(0);          // SOFT_DECISION_VITERBI_PUNCTURED
+        out += m_code_rate;
+        code = (code + 1) % puncture_code.size();
     }
-    if (is_tail) {
-        m_has_tail = true;
-    } else {
-        m_seg_pi[m_nb_segments] = (uint32_t)pi;
-        m_seg_steps[m_nb_segments] = (uint32_t)(requested_output_symbols / m_code_rate);
-        m_nb_segments++;
-    }
-    m_symbols.insert(m_symbols.end(), punctured_symbols.begin(), punctured_symbols.begin() + (std::ptrdiff_t)consumed);
-    m_current_decoded_bit += requested_output_symbols / m_code_rate;
-    return consumed;
+    m_current_decoded_bit += out / m_code_rate;
+    return in;
 }
 
-// :124-129
+// :124-129.  bytes_out.size() * 8 bits are traced back from decision word bytes_out.size() * 8 + 5 downwards, starting in end_state;
+// the path error is the accumulated renormalisation + metric[end_state] after every step decoded since reset().
 uint64_t DAB_Viterbi_Decoder::chainback(tcb::span<uint8_t> bytes_out, const size_t end_state) {
-    if (m_is_bad || !m_has_tail)
-        throw std::runtime_error("DAB_Viterbi_Decoder: segment sequence not supported by the device decoder "
-                                 "(expected up to 4 PI_n segments of 128*L symbols, then the 24-symbol PI_X tail)");
+    if (m_current_decoded_bit == 0)
+        throw std::invalid_argument("DAB_Viterbi_Decoder::chainback: nothing was decoded since reset()");
     uint64_t path_error = 0;
     const int tie = std::getenv("DABGPU_TIE_RULE") ? std::atoi(std::getenv("DABGPU_TIE_RULE")) : 0;
-    const int st = dabgpu_viterbi_decode_host_sync(m_ctx, m_symbols.data(), m_symbols.size(), m_seg_pi, m_seg_steps,
-                                                   (uint32_t)m_start_state, (uint32_t)end_state, DABGPU_CW_RAW, bytes_out.data(),
-                                                   bytes_out.size(), &path_error, tie);
+    const int st = dabgpu_viterbi_decode_depunctured_host_sync(m_ctx, m_mother.data(), m_current_decoded_bit, (uint32_t)m_start_state,
+                                                               (uint32_t)end_state, bytes_out.data(), bytes_out.size(), &path_error, tie);
+    if (st == DABGPU_ERR_INVALID_ARG)           // a trace-back that starts beyond the decoded steps (the reference would read stale decision words)
+        throw std::invalid_argument(std::string("DAB_Viterbi_Decoder::chainback: ") + dabgpu_last_error());
     if (st != DABGPU_OK)
         throw std::runtime_error(std::string("DAB_Viterbi_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
     return path_error;

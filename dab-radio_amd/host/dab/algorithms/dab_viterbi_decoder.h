@@ -1,12 +1,12 @@
 // dab/algorithms/dab_viterbi_decoder.h -- DAB_Viterbi_Decoder with the reference's public interface
 // (src/dab/algorithms/dab_viterbi_decoder.h:12-33) over the MI355X C ABI.
 //
-// The reference runs the add-compare-select inside update() and the pointer chase inside chainback(); on the device
-// both live in one kernel, so update() only records (puncture vector, length) segments and gathers the punctured
-// symbols, and chainback() launches the decode of everything recorded since reset().  The values returned by
-// update() (symbols consumed), get_current_decoded_bit() and chainback() (path error) are the reference's.
-// Accepted segment shapes are the ones the reference's own callers use (FIC_Decoder, MSC_Decoder): up to four
-// PI_1..PI_24 segments of 128*L mother symbols followed by the 24-symbol PI_X tail.
+// The reference runs the add-compare-select inside update() and the pointer chase inside chainback(); on the device both live in one
+// kernel, so update() only de-punctures (exactly as depuncture_symbols does, :131-181) and records the mother code, and chainback()
+// launches the decode of everything recorded since reset().  The values returned by update() (symbols consumed),
+// get_current_decoded_bit() and chainback() (path error) are the reference's.  As general as the reference's class: any puncture
+// vector, any requested_output_symbols, any number of update() calls, any start and end state, a trace-back shorter than the decoded
+// length.  (FIC_Decoder / MSC_Decoder do not go through this class: they call the batch decoders, which de-puncture on the device.)
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -39,10 +39,5 @@ private:
     size_t m_traceback_length = 0;
     size_t m_current_decoded_bit = 0;
     size_t m_start_state = 0;
-    std::vector<viterbi_bit_t> m_symbols;     // punctured soft bits of all segments since reset()
-    uint32_t m_seg_pi[4] = {0, 0, 0, 0};
-    uint32_t m_seg_steps[4] = {0, 0, 0, 0};
-    int m_nb_segments = 0;
-    bool m_has_tail = false;
-    bool m_is_bad = false;
+    std::vector<viterbi_bit_t> m_mother;      // de-punctured mother code since reset(): 4 soft bits per trellis step, punctured ones 0
 };

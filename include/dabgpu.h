@@ -283,6 +283,10 @@ typedef struct {
     uint32_t flags;            /* DABGPU_CW_RAW: emit the decoder output without the energy-dispersal XOR */
 } dabgpu_codeword;
 #define DABGPU_CW_RAW 1u
+#define DABGPU_CW_DEPUNCTURED 8u  /* direct codewords only (n_slots == 0): d_src holds the MOTHER code, 4 soft bits per trellis step with the punctured
+                                  positions already 0 (the caller ran DAB_Viterbi_Decoder::depuncture_symbols, dab_viterbi_decoder.cpp:131-181,
+                                  for whatever puncture vectors and lengths it was given); seg_pi / seg_steps are ignored, n_steps may be any
+                                  value >= 1, (n_steps - 6) / 8 whole bytes are written.  Always decoded by the WAVE mapping. */
 #define DABGPU_CW_CLASSED 4u   /* ring codewords only: every ring row holds its cif_stride soft bits in time-interleaver class order;
                                   input bit i of a slot lives at d_src + slot offset + (i mod 16) * (cif_stride / 16) + i / 16, and
                                   d_src points at the sub-channel's first byte of class 0 (slot 0) */
@@ -417,6 +421,19 @@ int dabgpu_fic_decode_group_host_sync(dabgpu_ctx *ctx, const int8_t *h_bits /*[2
 int dabgpu_viterbi_decode_host_sync(dabgpu_ctx *ctx, const int8_t *h_src, size_t n_src, const uint32_t *seg_pi4,
                                     const uint32_t *seg_steps4, uint32_t start_state, uint32_t end_state, uint32_t flags,
                                     uint8_t *h_out, size_t n_out_bytes, uint64_t *path_error, int tie_rule);
+
+/* The general form of DAB_Viterbi_Decoder -- reset(start_state), update(...) any number of times with ANY puncture vector and ANY
+ * requested_output_symbols, chainback(bytes_out, end_state) (src/dab/algorithms/dab_viterbi_decoder.cpp:109-181) -- collapsed into one call:
+ * the caller de-punctures as it goes (kept symbols copied, punctured positions 0: :154-176) and hands over the mother code.
+ *   h_mother     [4 * n_steps] int8, n_steps >= 1 = trellis steps since reset()
+ *   n_out_bytes  bytes chainback() is asked for: its bits n_out_bytes * 8 - 1 .. 0 are traced back from decision word n_out_bytes * 8 + 5
+ *                downwards, starting in end_state (the core's chainback behind :126); n_out_bytes * 8 + 6 <= n_steps (a trace-back that
+ *                starts beyond the decoded steps reads decision words the reference never wrote in this run: DABGPU_ERR_INVALID_ARG)
+ *   path_error   accumulated renormalisation + metric[end_state] after ALL n_steps steps (:127-128), may be NULL
+ * When the trace-back does not start at the last decoded step the forward pass runs twice (whole length for the path error, the prefix
+ * for the bytes): the decisions of a prefix do not depend on what follows. */
+int dabgpu_viterbi_decode_depunctured_host_sync(dabgpu_ctx *ctx, const int8_t *h_mother, size_t n_steps, uint32_t start_state,
+                                                uint32_t end_state, uint8_t *h_out, size_t n_out_bytes, uint64_t *path_error, int tie_rule);
 
 /* per-sub-channel stream: a 16-slot device ring of the sub-channel's slice of every CIF + its protection plan.
  * Replaces MSC_Decoder + CIF_Deinterleaver state (src/dab/msc/msc_decoder.cpp:26-75, cif_deinterleaver.cpp:13-34). */

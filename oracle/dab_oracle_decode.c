@@ -163,7 +163,7 @@ size_t dab_viterbi_update(dab_viterbi *v, const int8_t *punctured, size_t n_punc
     size_t ip = 0, ic = 0, io = 0;
     while (io < requested) {
         const size_t keep = code[ic];
-        if (n_punctured - ip < keep) return ip;                    /* :158-160, res.total_output_symbols == 0 */
+        if (n_punctured - ip < keep) return 0;                     /* :157-160: res is returned as initialised, {0, 0}: no step runs, 0 consumed */
         for (size_t i = 0; i < keep; i++) v->depunctured[io++] = (int16_t)punctured[ip++];
         for (size_t i = keep; i < VR; i++) v->depunctured[io++] = 0;
         ic = (ic + 1) % n_code;
