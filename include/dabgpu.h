@@ -154,7 +154,7 @@ int dabgpu_ofdm_demod_phase_frames(dabgpu_ctx *ctx, const void *d_raw, int forma
  * n_frames frames (>= 512; smaller batches follow a fixed rule and return at once) on the caller's buffers -- ~40 ms of warm-up launches,
  * then three timed rounds over the candidates -- and records the fastest for (loader of `format`, bits_layout, with_phase_tail, size bucket
  * = ceil(log2(n_frames))).  BLOCKS the calling thread (hipEventSynchronize on `stream`; refused while the stream is capturing); d_bits
- * receives valid soft bits; with_phase_tail times the candidates with the phase tail of dabgpu_ofdm_demod_phase_frames (on context
+ * receives the frames' soft bits for a zero carrier offset; with_phase_tail times the candidates with the phase tail of dabgpu_ofdm_demod_phase_frames (on context
  * scratch, not on caller state).  *chosen (may be NULL) = the run length recorded.  Typical use: once at start-up per batch size.
  */
 int dabgpu_ofdm_tune(dabgpu_ctx *ctx, const void *d_raw, int format, size_t n_frames, int8_t *d_bits, size_t bits_frame_stride,

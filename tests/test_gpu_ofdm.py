@@ -264,7 +264,10 @@ def test_library_choice_of_symbols_per_block_is_invisible(oracle):
     scratch_bits = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")
     chosen = ctx2.ofdm_tune(raw, fmt, n, scratch_bits, with_phase_tail=True)
     assert chosen in (25, 38, 75)
-    assert torch.equal(scratch_bits, ref[0])                   # tuning leaves valid soft bits behind
+    plain = torch.zeros((n, 230400), dtype=torch.int8, device="cuda")           # tuning leaves valid soft bits behind: those of a zero carrier offset
+    ctx2.ofdm_demod_frames_history(raw, fmt, n, plain, symbols_per_block=25)
+    torch.cuda.synchronize()
+    assert torch.equal(scratch_bits, plain)
     assert ctx2.ofdm_auto_symbols_per_block(n) == chosen and ctx2.ofdm_auto_symbols_per_block(300) == 25
     assert ctx2.ofdm_tuned_symbols_per_block(fmt, n, with_phase_tail=True) == chosen
     assert ctx2.ofdm_tuned_symbols_per_block(fmt, 400 + 112, with_phase_tail=True) == chosen     # same bucket (257..512)
