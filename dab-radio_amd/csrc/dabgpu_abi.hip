@@ -12,14 +12,6 @@
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
 
-static thread_local std::string g_last_error;
-
-void dabgpu_set_error(const char* fmt, ...) {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-    g_last_error = buf;
-}
-
 int dabgpu_check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return DABGPU_OK;
     dabgpu_set_error("%s: %s", what, hipGetErrorString(e));
@@ -33,20 +25,6 @@ int dabgpu_bind_device(const dabgpu_ctx* c) {
 
 extern "C" {
 
-const char* dabgpu_strerror(int status) {
-    switch (status) {
-    case DABGPU_OK: return "ok";
-    case DABGPU_ERR_NO_DEVICE: return "no usable gfx950 device (this library has no CPU fallback)";
-    case DABGPU_ERR_INVALID_ARG: return "invalid argument";
-    case DABGPU_ERR_HIP: return "HIP runtime error";
-    case DABGPU_ERR_NOT_READY: return "not ready";
-    case DABGPU_ERR_UNSUPPORTED: return "unsupported transmission mode";
-    default: return "unknown status";
-    }
-}
-const char* dabgpu_last_error(void) { return g_last_error.c_str(); }
-int dabgpu_abi_version(void) { return DABGPU_ABI_VERSION; }
-
 int dabgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -56,74 +34,6 @@ int dabgpu_device_count(void) {
         if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) usable++;
     }
     return usable;
-}
-
-// ---- built-in tables ----
-// ETSI EN 300 401 14.3.2 tables 23/24 (mode I) and the mode II-IV tables of docs/DAB_implementation_in_SDR_detailed.pdf
-// appendix B, as (row of the h table, offset n) per block of 32 carriers, lowest carrier first
-// (replaces get_DAB_PRS_reference, src/ofdm/dab_prs_ref.cpp:25-195)
-static const signed char PRS_ROW_I[4][48] = {
-    { 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1, 0,3,2,1 },
-    { 0,1,2,3,0,1,  2,1,0,3,2,1 },
-    { 0,1,2,  3,2,1 },
-    { 0,1,2,3, 0,1,2,3, 0,1,2,3,  0,3,2,1, 0,3,2,1, 0,3,2,1 },
-};
-static const signed char PRS_ROW_N[4][48] = {
-    { 1,2,0,1, 3,2,2,3, 2,1,2,3, 1,2,3,3, 2,2,2,1, 1,3,1,2,  3,1,1,1, 2,2,1,0, 2,2,3,3, 0,2,1,3, 3,3,3,0, 3,0,1,1 },
-    { 2,3,2,2,1,2,  0,2,2,1,0,3 },
-    { 2,3,0,  2,2,2 },
-    { 0,1,1,2, 2,2,0,3, 3,1,3,2,  0,1,0,2, 0,1,2,2, 2,1,3,0 },
-};
-static const signed char PRS_H_TABLE[4][32] = {
-    {0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1,0,2,0,0,0,0,1,1,2,0,0,0,2,2,1,1},
-    {0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0,0,3,2,3,0,1,3,0,2,1,2,3,2,3,3,0},
-    {0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3,0,0,0,2,0,2,1,3,2,2,0,2,2,0,1,3},
-    {0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2,0,1,2,1,0,3,3,2,2,3,2,1,2,1,3,2},
-};
-
-int dabgpu_get_prs_fft_ref(int mode, float* out) {
-    if (!out) return DABGPU_ERR_INVALID_ARG;
-    int geom[9];
-    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
-    const int N = geom[3], nb = geom[5], rows = nb / 32, half = rows / 2;
-    memset(out, 0, sizeof(float) * 2 * (size_t)N);
-    for (int row = 0; row < rows; row++) {
-        const int k_min = (row < half) ? (-nb / 2 + 32 * row) : (1 + 32 * (row - half));
-        for (int j = 0; j < 32; j++) {
-            const int k = k_min + j;
-            const int h = PRS_H_TABLE[(int)PRS_ROW_I[mode - 1][row]][j];
-            const float phi = (float)M_PI / 2.0f * (float)(h + PRS_ROW_N[mode - 1][row]);
-            const int bin = (k < 0) ? (N + k) : k;
-            out[2 * bin] = cosf(phi);
-            out[2 * bin + 1] = sinf(phi);
-        }
-    }
-    return DABGPU_OK;
-}
-
-// ETSI EN 300 401 14.6.1 (replaces get_DAB_mapper_ref, src/ofdm/dab_mapper_ref.cpp:10-51)
-int dabgpu_get_carrier_mapper(int mode, int* out) {
-    if (!out) return DABGPU_ERR_INVALID_ARG;
-    int geom[9];
-    if (dabgpu_get_ofdm_params(mode, geom)) return DABGPU_ERR_INVALID_ARG;
-    const int N = geom[3], nb = geom[5], dc = N / 2, lo = dc - nb / 2, hi = dc + nb / 2;
-    int v = 0, n = 0;
-    for (int i = 0; i < N; i++) {
-        if (i > 0) v = (13 * v + N / 4 - 1) % N;
-        if (v < lo || v > hi || v == dc) continue;
-        out[n++] = (v < dc) ? (v - lo) : (v - lo - 1);
-    }
-    return DABGPU_OK;
-}
-
-int dabgpu_get_fft_twiddles(float* out) {
-    if (!out) return DABGPU_ERR_INVALID_ARG;
-    for (int m = 0; m < DABGPU_NB_FFT; m++) {
-        const double a = 2.0 * M_PI * (double)m / (double)DABGPU_NB_FFT;
-        out[2 * m] = (float)cos(a);
-        out[2 * m + 1] = (float)(-sin(a));
-    }
-    return DABGPU_OK;
 }
 
 // ---- context ----
@@ -278,28 +188,10 @@ int dabgpu_synchronize(dabgpu_ctx* c, void* stream) {
 // runs per frame let the dispatcher rebalance but transform two halo symbols more).  The data path never measures: it takes what
 // dabgpu_ofdm_tune has recorded for the kernel variant and the batch's size bucket (nearest recorded bucket of that variant), else 25;
 // small batches take shorter runs.
-// batches too small to fill the chip with three workgroups per frame: more, shorter runs -- a single frame in three runs of 25 symbols is
-// three workgroups 25 symbols long (130 us); in 25 runs of 3 symbols (4 transforms each, one of them the halo) it is 25 workgroups 20 us
-// long.  Aim at ~256 workgroups, at most 25 runs per frame; from 86 frames on the usual three runs.
-static int small_batch_spb(size_t n_frames) {
-    if (n_frames >= 86) return 25;
-    const size_t chunks = std::min<size_t>(25, (256 + n_frames - 1) / n_frames);
-    return (int)((75 + chunks - 1) / chunks);
-}
-
-// size bucket of a batch: ceil(log2(n_frames)) -- 513..1024 frames share a bucket, 1025..2048 the next
-static int spb_bucket(size_t n_frames) {
-    int b = 0;
-    while (((size_t)1 << b) < n_frames && b < 40) b++;
-    return b;
-}
-// kernel variant of a call: loader (0..3), soft-bit layout, whether the phase tail runs with it (fused at 75, a second launch otherwise)
-static int spb_variant(int src, int bits_layout, bool tail) { return src * 4 + (bits_layout == DABGPU_BITS_MSC_CLASSED ? 2 : 0) + (tail ? 1 : 0); }
-
 // what symbols_per_block = 0 resolves to; never blocks, never launches
 static int demod_cached_spb(dabgpu_ctx* c, size_t n_frames, int variant) {
-    if (n_frames < 512) return small_batch_spb(n_frames);
-    const int want = spb_bucket(n_frames);
+    if (n_frames < 512) return dabgpu_host_small_batch_spb(n_frames);
+    const int want = dabgpu_host_spb_bucket(n_frames);
     DABGPU_HOST_LOCK(c);
     int best = 25, best_d = 1 << 30;
     for (const auto& e : c->spb_cache) {
@@ -312,8 +204,8 @@ static int demod_cached_spb(dabgpu_ctx* c, size_t n_frames, int variant) {
 
 extern "C" int dabgpu_ofdm_auto_symbols_per_block(dabgpu_ctx* c, size_t n_frames) {
     if (!c) return 0;
-    if (n_frames < 512) return small_batch_spb(n_frames);
-    const int want = spb_bucket(n_frames);
+    if (n_frames < 512) return dabgpu_host_small_batch_spb(n_frames);
+    const int want = dabgpu_host_spb_bucket(n_frames);
     DABGPU_HOST_LOCK(c);
     for (auto e = c->spb_cache.rbegin(); e != c->spb_cache.rend(); ++e) if (e->bucket == want) return e->spb;      // the latest of any variant
     return 0;
@@ -340,8 +232,8 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
         if (st) return st;
     }
     if (symbols_per_block <= 0)
-        symbols_per_block = (d_fft || d_dqpsk) ? small_batch_spb(n_frames)      /* display views: three workgroups per CU, not tuned */
-                                               : demod_cached_spb(c, n_frames, spb_variant(src, bits_layout, d_total_phase || d_fine_freq));
+        symbols_per_block = (d_fft || d_dqpsk) ? dabgpu_host_small_batch_spb(n_frames)      /* display views: three workgroups per CU, not tuned */
+                                               : demod_cached_spb(c, n_frames, dabgpu_host_spb_variant(src, bits_layout, d_total_phase || d_fine_freq));
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, src, d_freq, d_bits, corr, d_fft, d_dqpsk, c->d_tw, c->d_inv_map,
                                                      (int)n_frames, symbols_per_block, bits_frame_stride, nullptr, nullptr, 0,
                                                      bits_layout == DABGPU_BITS_MSC_CLASSED, s, d_total_phase, d_fine_freq, beta),
@@ -412,7 +304,7 @@ int dabgpu_ofdm_tune(dabgpu_ctx* c, const void* d_raw, int format, size_t n_fram
         dabgpu_set_error("ofdm_tune: bits_frame_stride must be 0 or a multiple of 16 >= 230400"); return DABGPU_ERR_INVALID_ARG;
     }
     if (((uintptr_t)d_raw & 15) || ((uintptr_t)d_bits & 15)) { dabgpu_set_error("ofdm_tune: d_raw and d_bits must be 16-byte aligned"); return DABGPU_ERR_INVALID_ARG; }
-    if (n_frames < 512) { if (chosen) *chosen = small_batch_spb(n_frames); return DABGPU_OK; }      // nothing to measure: the small-batch rule
+    if (n_frames < 512) { if (chosen) *chosen = dabgpu_host_small_batch_spb(n_frames); return DABGPU_OK; }      // nothing to measure: the small-batch rule
     DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -453,7 +345,7 @@ int dabgpu_ofdm_tune(dabgpu_ctx* c, const void* d_raw, int format, size_t n_fram
     if (err != hipSuccess) return dabgpu_check_hip(err, "ofdm_tune");
     int best = 0;
     for (int k = 1; k < 3; k++) if (sum_ms[k] < sum_ms[best]) best = k;
-    const int bucket = spb_bucket(n_frames), variant = spb_variant(src, bits_layout, with_phase_tail != 0);
+    const int bucket = dabgpu_host_spb_bucket(n_frames), variant = dabgpu_host_spb_variant(src, bits_layout, with_phase_tail != 0);
     {
         DABGPU_HOST_LOCK(c);
         bool found = false;
@@ -467,7 +359,7 @@ int dabgpu_ofdm_tune(dabgpu_ctx* c, const void* d_raw, int format, size_t n_fram
 int dabgpu_ofdm_tuned_symbols_per_block(dabgpu_ctx* c, int format, size_t n_frames, int bits_layout, int with_phase_tail) {
     const int src = fused_loader_of(format);
     if (!c || src < 0 || n_frames == 0) return 0;
-    return demod_cached_spb(c, n_frames, spb_variant(src, bits_layout, with_phase_tail != 0));
+    return demod_cached_spb(c, n_frames, dabgpu_host_spb_variant(src, bits_layout, with_phase_tail != 0));
 }
 
 // One steady-state frame of n receivers: PRS synchronisation, then the demodulation it positions and corrects, then the fine-frequency
@@ -497,7 +389,7 @@ int dabgpu_ofdm_sync_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_str
     if (!corr && (st = dabgpu_scratch(c, 0, n_streams * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_sync(d_iq + 2 * prs_offset_samples, stream_stride_samples, (int)n_streams, cfg, d_states, nullptr, nullptr,
                                                  c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, 1, s), "ofdm_sync_kernel launch"))) return st;
-    if (symbols_per_block <= 0) symbols_per_block = demod_cached_spb(c, n_streams, spb_variant(0, bits_layout, true));
+    if (symbols_per_block <= 0) symbols_per_block = demod_cached_spb(c, n_streams, dabgpu_host_spb_variant(0, bits_layout, true));
     return dabgpu_check_hip(dabgpu_launch_ofdm_demod(d_iq, 0, nullptr, d_bits, corr, nullptr, nullptr, c->d_tw, c->d_inv_map, (int)n_streams, symbols_per_block,
                                                      bits_frame_stride, nullptr, nullptr, 0, bits_layout == DABGPU_BITS_MSC_CLASSED, s, d_total_phase, nullptr,
                                                      cfg->fine_freq_update_beta, nullptr, stream_stride_samples, d_states, (int)prs_offset_samples),
@@ -593,16 +485,6 @@ int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float 
 }
 
 // ---- sync ----
-void dabgpu_sync_cfg_default(dabgpu_sync_cfg* cfg) {          // ofdm_demodulator.h:34-44
-    if (!cfg) return;
-    cfg->fine_freq_update_beta = 0.9f;
-    cfg->is_coarse_freq_correction = 1;
-    cfg->max_coarse_freq_correction_norm = 0.5f;
-    cfg->coarse_freq_slow_beta = 0.1f;
-    cfg->impulse_peak_threshold_db = 20.0f;
-    cfg->impulse_peak_distance_probability = 0.15f;
-}
-
 int dabgpu_ofdm_sync(dabgpu_ctx* c, const float* d_prs_syms, size_t n_streams, size_t stride_samples, const dabgpu_sync_cfg* cfg,
                      dabgpu_sync_state* d_states, float* d_impulse, float* d_freq, void* stream) {
     if (!c || !d_prs_syms || !cfg || !d_states) { dabgpu_set_error("ofdm_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }

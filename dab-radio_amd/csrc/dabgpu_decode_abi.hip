@@ -10,63 +10,6 @@
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
 
-// ETSI EN 300 401 tables 8 + 15: {size CU, kbps, level, L1..L4, PI1..PI4, padding bits}; row order (and the two
-// exchanged size fields of rows 33/34) as the reference lists them, src/dab/constants/subchannel_protection_tables.h:21-86,
-// because FIG 0/1 short-form sub-channels index this table by position
-static const uint16_t UEP_ROWS[64][12] = {
-    {16,32,5,3,4,17,0,5,3,2,0,0},       {21,32,4,3,3,18,0,11,6,5,0,0},      {24,32,3,3,4,14,3,15,9,6,8,0},
-    {29,32,2,3,4,14,3,22,13,8,13,0},    {35,32,1,3,5,13,3,24,17,12,17,4},   {24,48,5,4,3,26,3,5,4,2,3,0},
-    {29,48,4,3,4,26,3,9,6,4,6,0},       {35,48,3,3,4,26,3,15,10,6,9,4},     {42,48,2,3,4,26,3,24,14,8,15,0},
-    {52,48,1,3,5,25,3,24,18,13,18,0},   {29,56,5,6,10,23,3,5,4,2,3,0},      {35,56,4,6,10,23,3,9,6,4,5,0},
-    {42,56,3,6,12,21,3,16,7,6,9,0},     {52,56,2,6,10,23,3,23,13,8,13,8},   {32,64,5,6,9,31,2,5,3,2,3,0},
-    {42,64,4,6,9,33,0,11,6,5,0,0},      {48,64,3,6,12,27,3,16,8,6,9,0},     {58,64,2,6,10,29,3,23,13,8,13,8},
-    {70,64,1,6,11,28,3,24,18,12,18,4},  {40,80,5,6,10,41,3,6,3,2,3,0},      {52,80,4,6,10,41,3,11,6,5,6,0},
-    {58,80,3,6,11,40,3,16,8,6,7,0},     {70,80,2,6,10,41,3,23,13,8,13,8},   {84,80,1,6,10,41,3,24,17,12,18,4},
-    {48,96,5,7,9,53,3,5,4,2,4,0},       {58,96,4,7,10,52,3,9,6,4,6,0},      {70,96,3,6,12,51,3,16,9,6,10,4},
-    {84,96,2,6,10,53,3,22,12,9,12,0},   {104,96,1,6,13,50,3,24,18,13,19,0}, {58,112,5,14,17,50,3,5,4,2,5,0},
-    {70,112,4,11,21,49,3,9,6,4,8,0},    {84,112,3,11,23,47,3,16,8,6,9,0},   {104,112,2,11,21,49,3,23,12,9,14,4},
-    {84,128,5,12,19,62,3,5,3,2,4,0},    {64,128,4,11,21,61,3,11,6,5,7,0},   {96,128,3,11,22,60,3,16,9,6,10,4},
-    {116,128,2,11,21,61,3,22,12,9,14,0},{140,128,1,11,20,62,3,24,17,13,19,8},{80,160,5,11,19,87,3,5,4,2,4,0},
-    {104,160,4,11,23,83,3,11,6,5,9,0},  {116,160,3,11,24,82,3,16,8,6,11,0}, {140,160,2,11,21,85,3,22,11,9,13,0},
-    {168,160,1,11,22,84,3,24,18,12,19,0},{96,192,5,11,20,110,3,6,4,2,5,0},  {116,192,4,11,22,108,3,10,6,4,9,0},
-    {140,192,3,11,24,106,3,16,10,6,11,0},{168,192,2,11,20,110,3,22,13,9,13,8},{208,192,1,11,21,109,3,24,20,13,24,0},
-    {116,224,5,12,22,131,3,8,6,2,6,4},  {140,224,4,12,26,127,3,12,8,4,11,0},{168,224,3,11,20,134,3,16,10,7,9,0},
-    {208,224,2,11,22,132,3,24,16,10,15,0},{232,224,1,11,24,130,3,24,20,12,20,4},{128,256,5,11,24,154,3,6,5,2,5,0},
-    {168,256,4,11,24,154,3,12,9,5,10,4},{192,256,3,11,27,151,3,16,10,7,10,0},{232,256,2,11,22,156,3,24,14,10,13,8},
-    {280,256,1,11,26,152,3,24,19,14,18,4},{160,320,5,11,26,200,3,8,5,2,6,4}, {208,320,4,11,25,201,3,13,9,5,10,8},
-    {280,320,2,11,26,200,3,24,17,9,17,0},{192,384,5,11,27,247,3,8,6,2,7,0}, {280,384,3,11,24,250,3,16,9,7,10,4},
-    {416,384,1,12,28,245,3,24,20,14,23,8},
-};
-// ETSI EN 300 401 tables 9/18 (EEP-A) and 10/20 (EEP-B): {CU multiple, m1, b1, m2, b2, PI1, PI2}, L = m*n + b;
-// same data as subchannel_protection_tables.h:121-139
-static const int EEP_A_ROWS[4][7] = { {12,6,-3,0,3,24,23}, {8,2,-3,4,3,14,13}, {6,6,-3,0,3,8,7}, {4,4,-3,2,3,3,2} };
-static const int EEP_2A_N1[7] = { 8,0,5,0,1,13,12 };
-static const int EEP_B_ROWS[4][7] = { {27,24,-3,0,3,10,9}, {21,24,-3,0,3,6,5}, {18,24,-3,0,3,4,3}, {15,24,-3,0,3,2,1} };
-
-extern "C" int dabgpu_subchannel_plan(const dabgpu_subchannel* sc, int* pi, int* lx, int* n_decoded_bytes) {
-    if (!sc || !pi || !lx) return -1;
-    int nseg, total = 0;
-    for (int i = 0; i < 4; i++) { pi[i] = 0; lx[i] = 0; }
-    if (!sc->is_uep) {
-        if (sc->eep_prot_level < 0 || sc->eep_prot_level > 3 || sc->length <= 0) return -1;
-        const int* d = (sc->eep_type == 0) ? ((sc->length == 8) ? EEP_2A_N1 : EEP_A_ROWS[sc->eep_prot_level])
-                                            : EEP_B_ROWS[sc->eep_prot_level];       // GetEEPDescriptor :145-154
-        const int n = sc->length / d[0];
-        pi[0] = d[5]; lx[0] = d[1] * n + d[2];
-        pi[1] = d[6]; lx[1] = d[3] * n + d[4];
-        if (lx[0] < 0 || lx[1] < 0) return -1;
-        nseg = 2;
-    } else {
-        if (sc->uep_prot_index < 0 || sc->uep_prot_index > 63) return -1;
-        const uint16_t* d = UEP_ROWS[sc->uep_prot_index];
-        for (int i = 0; i < 4; i++) { lx[i] = d[3 + i]; pi[i] = d[7 + i]; }
-        nseg = 4;
-    }
-    for (int i = 0; i < nseg; i++) total += lx[i];
-    if (n_decoded_bytes) *n_decoded_bytes = 4 * total;     // (32*sum(L) + 6 - 6) / 8, msc_decoder.cpp:99-103
-    return nseg;
-}
-
 static int device_waves(dabgpu_ctx* c) {
     if (c->n_cu <= 0) {
         hipDeviceProp_t p;
@@ -80,25 +23,7 @@ static int device_waves(dabgpu_ctx* c) {
 static int ensure_vit_tables(dabgpu_ctx* c) {
     if (c->d_vit_tables) return DABGPU_OK;
     dabgpu_vit_tables T;
-    memset(&T, 0, sizeof(T));
-    static const int order[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-    for (int pi = 1; pi <= 24; pi++) {
-        int cnt[8];
-        for (int g = 0; g < 8; g++) cnt[g] = 1;
-        for (int e = 0; e < pi; e++) cnt[order[e % 8]]++;
-        int pre = 0;
-        for (int g = 0; g < 8; g++) { T.pi_tab[pi * 8 + g] = (uint16_t)(cnt[g] | (pre << 8)); pre += cnt[g]; }
-    }
-    unsigned reg = 0xFFFFu;
-    for (int k = 0; k < 511; k++) {
-        unsigned b = 0;
-        for (int i = 0; i < 8; i++) {
-            const unsigned v = ((reg >> 8) ^ (reg >> 4)) & 1u;
-            b |= v << (7 - i);
-            reg = ((reg << 1) | v) & 0xFFFFu;
-        }
-        T.prbs[k] = (unsigned char)b;
-    }
+    dabgpu_host_fill_vit_tables(&T);
     int st = dabgpu_check_hip(hipMalloc((void**)&c->d_vit_tables, sizeof(T)), "hipMalloc(vit tables)");
     if (st) return st;
     return dabgpu_check_hip(hipMemcpy(c->d_vit_tables, &T, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(vit tables)");
@@ -137,16 +62,7 @@ extern "C" int dabgpu_viterbi_set_mapping(dabgpu_ctx* c, int mapping) {
 // n_cw codewords in n_groups groups; sums and maximum of their trellis steps.  Returns DABGPU_VIT_MAP_WAVE / _LANE / _OCTET
 static int choose_mapping(dabgpu_ctx* c, size_t n_cw, size_t n_groups, double sum_cw_steps, double sum_group_steps, double max_steps,
                           bool staged_gather) {
-    if (c->vit_mapping != DABGPU_VIT_MAP_AUTO) return c->vit_mapping;
-    if (n_groups == 0) return DABGPU_VIT_MAP_WAVE;
-    const double n_simd = (double)device_waves(c) / 8.0;
-    const double mean = sum_group_steps / (double)n_groups;
-    const double gather = (staged_gather ? 3.3e-6 : 8.5e-6) * sum_cw_steps;
-    const double t_wave = 0.0189e-3 * sum_cw_steps + 0.038 * (double)n_cw;
-    const double t_lane = 0.5 * std::max(max_steps, std::ceil((double)n_groups / n_simd) * mean) + gather;
-    const double t_oct = 0.095 * std::max(2.0 * max_steps, std::ceil(8.0 * (double)n_groups / n_simd) * mean) + gather;
-    if (t_wave <= t_lane && t_wave <= t_oct) return DABGPU_VIT_MAP_WAVE;
-    return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;
+    return dabgpu_host_choose_mapping(c->vit_mapping, (double)device_waves(c) / 8.0, n_cw, n_groups, sum_cw_steps, sum_group_steps, max_steps, staged_gather);
 }
 
 // lane-per-codeword decoder over prepared groups; the symbol / decision scratch of a launch is bounded (<= 768 bytes per decision
@@ -193,46 +109,13 @@ static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_
     return DABGPU_OK;
 }
 
-static int validate_codeword(const dabgpu_codeword& d, size_t i) {
-    if (d.flags & DABGPU_CW_DEPUNCTURED) {            // mother code handed over: no segment tables, any length, direct source only
-        if (d.n_steps < 1 || d.n_steps > (1u << 24) || d.n_slots != 0 || !d.d_src || !d.d_out) {
-            dabgpu_set_error("codeword %zu: DABGPU_CW_DEPUNCTURED needs 1 <= n_steps <= 2^24, n_slots = 0 and non-null addresses", i);
-            return DABGPU_ERR_INVALID_ARG;
-        }
-        return DABGPU_OK;
-    }
-    uint64_t steps = 0;
-    for (int k = 0; k < 4; k++) {
-        if (d.seg_steps[k] == 0) continue;
-        if (d.seg_pi[k] < 1 || d.seg_pi[k] > 24 || (d.seg_steps[k] & 7)) {
-            dabgpu_set_error("codeword %zu: segment %d has PI=%u steps=%u (PI must be 1..24, steps a multiple of 8)", i, k,
-                             d.seg_pi[k], d.seg_steps[k]);
-            return DABGPU_ERR_INVALID_ARG;
-        }
-        steps += d.seg_steps[k];
-    }
-    if (steps + 6 != d.n_steps || ((d.n_steps - 6) & 7) || !d.d_src || !d.d_out) {
-        dabgpu_set_error("codeword %zu: n_steps=%u does not equal sum(seg_steps)+6 with whole output bytes, or null address", i, d.n_steps);
-        return DABGPU_ERR_INVALID_ARG;
-    }
-    if ((d.flags & DABGPU_CW_CLASSED) && d.n_slots != 0 && (d.cif_stride == 0 || (d.cif_stride & 15))) {
-        dabgpu_set_error("codeword %zu: DABGPU_CW_CLASSED needs cif_stride = soft bits per ring row, a multiple of 16 (got %u)", i, d.cif_stride);
-        return DABGPU_ERR_INVALID_ARG;
-    }
-    if (d.n_slots != 0 && (d.n_slots < 16 || d.cifs_per_frame == 0 || d.newest_slot >= d.n_slots)) {
-        dabgpu_set_error("codeword %zu: bad CIF ring geometry (n_slots=%u newest=%u cifs_per_frame=%u)", i, d.n_slots, d.newest_slot, d.cifs_per_frame);
-        return DABGPU_ERR_INVALID_ARG;
-    }
-    return DABGPU_OK;
-}
-
 extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword* h_cw, size_t n, int tie_rule,
                                            dabgpu_codeword_result* d_results, void* stream) {
     if (!c || (!h_cw && n) || (!d_results && n)) { dabgpu_set_error("viterbi_decode_batch: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (n == 0) return DABGPU_OK;
     uint32_t max_steps = 0;
     for (size_t i = 0; i < n; i++) {
-        int st = validate_codeword(h_cw[i], i);
+        int st = dabgpu_host_validate_codeword(h_cw[i], i);
         if (st) return st;
         max_steps = std::max(max_steps, h_cw[i].n_steps);
     }
@@ -313,25 +196,11 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         dabgpu_set_error("msc_decode_frames: history_frames must be >= 5 (16 CIFs of delay + the 4 new ones) and 0 <= newest < history_frames");
         return DABGPU_ERR_INVALID_ARG;
     }
-    std::vector<dabgpu_msc_plan> plans((size_t)n_sub);
+    std::vector<dabgpu_msc_plan> plans;
     uint32_t off = 0, max_steps = 0, max_out = 0;
-    for (int s = 0; s < n_sub; s++) {
-        int pi[4], lx[4], nb = 0;
-        if (dabgpu_subchannel_plan(&h_sub[s], pi, lx, &nb) < 0 || h_sub[s].start_address < 0 ||
-            h_sub[s].start_address + h_sub[s].length > 864) {
-            dabgpu_set_error("msc_decode_frames: sub-channel %d has an invalid protection profile or exceeds 864 CU", s);
-            return DABGPU_ERR_INVALID_ARG;
-        }
-        dabgpu_msc_plan& P = plans[(size_t)s];
-        P.start_address = (uint32_t)h_sub[s].start_address;
-        uint32_t steps = 0;
-        for (int k = 0; k < 4; k++) { P.seg_pi[k] = lx[k] ? (uint32_t)pi[k] : 0u; P.seg_steps[k] = 32u * (uint32_t)lx[k]; steps += P.seg_steps[k]; }
-        P.n_steps = steps + 6;
-        P.out_offset = off;
-        P.n_out_bytes = (uint32_t)nb;
-        off += (uint32_t)nb;
-        max_steps = std::max(max_steps, P.n_steps);
-        max_out = std::max(max_out, (uint32_t)nb);
+    {
+        const int pst = dabgpu_host_build_msc_plans(h_sub, n_sub, plans, &off, &max_steps, &max_out);
+        if (pst) return pst;
     }
     if (out_ens_stride < (size_t)4 * off) { dabgpu_set_error("msc_decode_frames: out_ensemble_stride %zu < 4 x %u", out_ens_stride, off); return DABGPU_ERR_INVALID_ARG; }
     DABGPU_BIND(c);
@@ -546,7 +415,7 @@ static int decode_one_sync(dabgpu_ctx* c, dabgpu_cw_desc D, const int8_t* h_src,
     hipStream_t s = c->stream;
     if (h_src) D.d_src = (uint64_t)(uintptr_t)d_src;
     D.d_out = (uint64_t)(uintptr_t)d_out;
-    if ((st = validate_codeword(D, 0))) return st;
+    if ((st = dabgpu_host_validate_codeword(D, 0))) return st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
     if (h_src) CK(hipMemcpyAsync(d_src, h_src, n_src, hipMemcpyHostToDevice, s));
     CK(hipMemcpyAsync(d_desc, &D, sizeof(D), hipMemcpyHostToDevice, s));
@@ -643,6 +512,11 @@ extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* 
     if (!c || !sc || !out) return DABGPU_ERR_INVALID_ARG;
     *out = nullptr;
     int pi[4], lx[4], nb = 0;
+    {   // the same checks as the batch decoders': a valid profile, inside the CIF, consuming no more soft bits than the sub-channel holds
+        std::vector<dabgpu_msc_plan> one;
+        const int pst = dabgpu_host_build_msc_plans(sc, 1, one, nullptr, nullptr, nullptr);
+        if (pst) return pst;
+    }
     if (dabgpu_subchannel_plan(sc, pi, lx, &nb) < 0) { dabgpu_set_error("msc_stream_create: invalid protection profile"); return DABGPU_ERR_INVALID_ARG; }
     DABGPU_BIND(c);
     dabgpu_msc_stream* s = new dabgpu_msc_stream();

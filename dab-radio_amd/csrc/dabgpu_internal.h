@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "dabgpu.h"
+#include "dabgpu_host_logic.h"
 
 struct dabgpu_ctx {
     int device = 0;
@@ -46,7 +47,6 @@ struct dabgpu_ctx {
 // asynchronous host -> device copy on `s` that has consumed h_src when it returns (h_src may be freed or overwritten at once)
 extern "C" int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 
-void dabgpu_set_error(const char* fmt, ...);
 int dabgpu_check_hip(hipError_t e, const char* what);
 // Every entry point that launches, allocates or copies first makes the context's device current on the calling thread (a worker
 // thread of a one-process multi-GPU host starts on device 0) -- checked: a failed hipSetDevice is the call's status.
@@ -94,20 +94,7 @@ int dabgpu_launch_ofdm_demod_wave(dabgpu_ctx* c, int mode, const void* d_iq, int
 // ---- channel decode ----
 typedef dabgpu_codeword dabgpu_cw_desc;
 typedef dabgpu_codeword_result dabgpu_cw_result;
-struct dabgpu_msc_plan {            // device-side sub-channel plan (one per sub-channel of the multiplex)
-    uint32_t start_address;         // CUs
-    uint32_t n_steps;               // trellis steps incl. tail
-    uint32_t seg_pi[4];
-    uint32_t seg_steps[4];
-    uint32_t out_offset;            // byte offset of this sub-channel inside one CIF's output record
-    uint32_t n_out_bytes;
-    uint32_t lane_mapped;           // this call decodes the sub-channel with the lane-per-codeword kernel: viterbi_kernel skips it
-};
 #define DABGPU_CW_LANE_MAPPED 0x80000000u      // internal flag bit of dabgpu_codeword.flags (set by msc_build_descs_kernel)
-struct dabgpu_vit_tables {          // constant tables of the Viterbi kernels, built on the host at context creation
-    uint16_t pi_tab[25 * 8];        // [PI][group]: kept count | running prefix << 8 (puncture_codes.h:42-67)
-    unsigned char prbs[512];        // energy-dispersal bytes, period 511 (additive_scrambler.h:16-35)
-};
 // lane-per-codeword decoder (viterbi_lanes.hip): a GROUP = up to 64 codewords with one puncturing schedule.
 // Symbol area of a group: the codewords' KEPT soft bits only, transposed -- row j, lane L = input bytes 4 j .. 4 j + 3 of lane L's
 // codeword (after the time de-interleaver, -128 clamped to -127).  The trellis kernel de-punctures with wave-uniform selectors.
@@ -124,19 +111,6 @@ struct dabgpu_vit_group {
     int64_t res_delta;              // bytes added to &results[first + L * stride]: groups of ONE launch may report into different arrays
                                     // (the FIB groups of a frame decoded inside the MSC launch, dabgpu_decode_frames_layout)
 };
-// decisions are stored two steps per row pair; the chain-back reads whole 24-step chunks
-static inline __host__ __device__ uint32_t dabgpu_vit_alloc_steps(uint32_t n_steps) { return (n_steps + 6u + 63u) & ~63u; }
-#define DABGPU_VIT_SCHED_PREFETCH 6u          // entries past the last step the trellis loops may load (viterbi_lanes.hip, viterbi_octet.hip)
-static_assert(((0u + 6u + 63u) & ~63u) >= 0u + DABGPU_VIT_SCHED_PREFETCH && ((58u + 6u + 63u) & ~63u) >= 58u + DABGPU_VIT_SCHED_PREFETCH,
-              "dabgpu_vit_alloc_steps must leave room for the schedule prefetch");
-// soft bits a codeword consumes (dab_viterbi_decoder.cpp:131-181): 8 + PI per 8 steps, 12 for the tail
-static inline __host__ __device__ uint32_t dabgpu_vit_in_bytes(const uint32_t* seg_pi, const uint32_t* seg_steps) {
-    uint32_t n = 12;
-    for (int k = 0; k < 4; k++) n += (seg_steps[k] >> 3) * (8u + seg_pi[k]);
-    return n;
-}
-// symbol rows: 4 kept soft bits per row, + the row the last step's two-row window reaches into + one the prefetch may touch
-static inline __host__ __device__ uint32_t dabgpu_vit_in_rows(uint32_t n_in) { return (n_in + 3u) / 4u + 2u; }
 extern "C" hipError_t dabgpu_launch_vit_groups_uniform(dabgpu_vit_group* d_groups, size_t n_cw, uint32_t n_steps,
                                                        const uint32_t* seg_pi, const uint32_t* seg_steps, hipStream_t stream);
 // the same groups appended to another launch's: descriptor index, schedule entries, symbol / decision dwords and result bytes they start at

@@ -132,19 +132,6 @@ __global__ __launch_bounds__(256) void hard_to_soft_kernel(const uint8_t* __rest
 
 extern "C" {
 
-int dabgpu_iq_format_from_mode(const char* mode) {
-    static const char* const NAMES[14] = {"raw_u8", "raw_s8", "raw_s16l", "raw_s16b", "raw_u16l", "raw_u16b", "raw_s32l",
-                                          "raw_s32b", "raw_u32l", "raw_u32b", "raw_f32l", "raw_f32b", "raw_f64l", "raw_f64b"};
-    if (!mode) return -1;
-    for (int i = 0; i < 14; i++) if (strcmp(mode, NAMES[i]) == 0) return i;
-    return -1;
-}
-
-size_t dabgpu_iq_format_sample_bytes(int format) {
-    if (format < 0 || format >= DABGPU_IQ_NB_FORMATS) return 0;
-    return 2 * (size_t)FMT_TABLE[format].size;
-}
-
 int dabgpu_iq_convert(dabgpu_ctx* c, const void* d_raw, int format, size_t n_samples, float* d_iq, void* stream) {
     if (!c) { dabgpu_set_error("iq_convert: null context"); return DABGPU_ERR_INVALID_ARG; }
     if (format < 0 || format >= DABGPU_IQ_NB_FORMATS) { dabgpu_set_error("iq_convert: unknown format %d", format); return DABGPU_ERR_INVALID_ARG; }
@@ -242,106 +229,6 @@ int dabgpu_hard_bytes_to_soft_bits_host_sync(dabgpu_ctx* c, const uint8_t* h_byt
     return round_trip(c, h_bytes, n_bytes, h_bits, n_bytes * 8,
                       [](dabgpu_ctx* c, const void* i, void* o, size_t n, int, hipStream_t s) {
                           return dabgpu_hard_bytes_to_soft_bits(c, static_cast<const uint8_t*>(i), n, static_cast<int8_t*>(o), s); }, n_bytes, 0);
-}
-
-// ---- wav header (host only) ---------------------------------------------------------------------------------------
-namespace {
-struct byte_cursor {
-    const uint8_t* p; size_t n; size_t pos;
-    bool take(size_t k, const uint8_t** out) { if (n - pos < k) return false; *out = p + pos; pos += k; return true; }
-};
-inline uint32_t le32(const uint8_t* b) { return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24); }
-inline uint16_t le16(const uint8_t* b) { return (uint16_t)(b[0] | (b[1] << 8)); }
-static int map_wav_code(uint16_t code, uint16_t* out) {
-    switch (code) { case 1: case 3: case 6: case 7: case 0xFFFE: *out = code; return 1; default: return 0; }
-}
-}  // namespace
-
-int dabgpu_wav_parse_header(const uint8_t* bytes, size_t n_bytes, dabgpu_wav_header* out) {
-#define FAIL(...) do { dabgpu_set_error(__VA_ARGS__); return DABGPU_ERR_INVALID_ARG; } while (0)
-    if (!bytes || !out) FAIL("wav_parse_header: null argument");
-    byte_cursor cur{bytes, n_bytes, 0};
-    const uint8_t* b;
-    memset(out, 0, sizeof(*out));
-    if (!cur.take(12, &b)) FAIL("wav: insufficient bytes while reading RIFF chunk");
-    if (memcmp(b, "RIFF", 4) != 0) FAIL("wav: chunk id is not 'RIFF'");
-    if (memcmp(b + 8, "WAVE", 4) != 0) FAIL("wav: wave id is not 'WAVE'");
-    if (!cur.take(24, &b)) FAIL("wav: insufficient bytes while reading format chunk");
-    if (memcmp(b, "fmt ", 4) != 0) FAIL("wav: chunk id is not 'fmt '");
-    const uint32_t fmt_size = le32(b + 4);
-    if (fmt_size != 16 && fmt_size != 18 && fmt_size != 40) FAIL("wav: invalid format chunk size %u, expected 16, 18 or 40", fmt_size);
-    uint16_t code;
-    if (!map_wav_code(le16(b + 8), &code)) FAIL("wav: invalid audio format code %04X", le16(b + 8));
-    out->total_channels = le16(b + 10);
-    if (out->total_channels != 1 && out->total_channels != 2) FAIL("wav: expected mono or stereo but got %u channels", out->total_channels);
-    out->samples_per_second = le32(b + 12);
-    out->average_bytes_per_second = le32(b + 16);
-    out->data_block_align_bytes = le16(b + 20);
-    out->bits_per_sample = le16(b + 22);
-    if (fmt_size > 16) {
-        const size_t ext = fmt_size - 16;
-        if (!cur.take(ext, &b)) FAIL("wav: insufficient bytes while reading format chunk extension fields");
-        const uint16_t ext_size = le16(b);
-        if (ext_size != ext - 2) FAIL("wav: extension field size %u does not match actual size %zu", ext_size, ext - 2);
-        if (ext_size == 22) {
-            uint16_t sub;
-            if (!map_wav_code(le16(b + 8), &sub)) FAIL("wav: invalid audio format code %04X", le16(b + 8));
-            if (sub == 0xFFFE) FAIL("wav: extensible format again in sub-format");
-            static const uint8_t GUID[14] = {0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71};
-            if (memcmp(GUID, b + 10, 14) != 0) FAIL("wav: extensible format guid does not match");
-            code = sub;
-        }
-    }
-    if (code != 1) {                                   // fact chunk for non-PCM formats
-        if (!cur.take(8, &b)) FAIL("wav: insufficient bytes while reading fact chunk");
-        if (memcmp(b, "fact", 4) != 0) FAIL("wav: chunk id is not 'fact'");
-        const uint32_t fact_size = le32(b + 4);
-        if (fact_size < 4) FAIL("wav: fact chunk smaller than 4 bytes (%u)", fact_size);
-        if (!cur.take(fact_size, &b)) FAIL("wav: insufficient bytes while reading fact chunk data");
-    }
-    for (;;) {
-        if (!cur.take(8, &b)) FAIL("wav: insufficient bytes while reading possible data chunk");
-        const uint32_t size = le32(b + 4);
-        if (memcmp(b, "data", 4) != 0) {
-            // the reference fseek()s past the chunk and fails on the next header read when the file ends first
-            if (cur.n - cur.pos < size) FAIL("wav: insufficient bytes while reading possible data chunk");
-            cur.pos += size;
-            continue;
-        }
-        out->data_chunk_size = size;
-        out->data_chunk_offset = cur.pos;
-        break;
-    }
-    out->audio_format = code;
-    int f = -1;
-    switch (code) {
-    case 1:
-        switch (out->bits_per_sample) {
-        case 8: f = DABGPU_IQ_WAV_PCM8; break;
-        case 16: f = DABGPU_IQ_WAV_PCM16; break;
-        case 24: f = DABGPU_IQ_WAV_PCM24; break;
-        case 32: f = DABGPU_IQ_WAV_PCM32; break;
-        default: FAIL("wav: unhandled PCM format with %u bits per sample", out->bits_per_sample);
-        }
-        break;
-    case 3:
-        switch (out->bits_per_sample) {
-        case 32: f = DABGPU_IQ_WAV_F32; break;
-        case 64: f = DABGPU_IQ_WAV_F64; break;
-        default: FAIL("wav: unhandled IEEE754 format with %u bits per sample", out->bits_per_sample);
-        }
-        break;
-    case 6:
-        if (out->bits_per_sample != 8) FAIL("wav: unhandled G711 A law format with %u bits per sample", out->bits_per_sample);
-        f = DABGPU_IQ_WAV_ALAW; break;
-    case 7:
-        if (out->bits_per_sample != 8) FAIL("wav: unhandled G711 mu law format with %u bits per sample", out->bits_per_sample);
-        f = DABGPU_IQ_WAV_MULAW; break;
-    default: FAIL("wav: unhandled extensible wav audio format is not supported");
-    }
-    out->iq_format = f;
-    return DABGPU_OK;
-#undef FAIL
 }
 
 }  // extern "C"

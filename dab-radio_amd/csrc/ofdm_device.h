@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dabgpu_host_logic.h"
+
 namespace dabgpu {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -237,23 +239,6 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ---- transmission-mode geometry (src/ofdm/dab_ofdm_params_ref.cpp:11-60) ----
-struct ModeGeom { int n_sym, period, null_period, n_fft, n_cp, n_carriers, frame_samples, sym_bits, frame_bits; };
-
-__host__ __device__ inline bool mode_geometry(int mode, ModeGeom& g) {
-    switch (mode) {
-    case 1: g.n_sym = 76; g.period = 2552; g.null_period = 2656; g.n_fft = 2048; g.n_carriers = 1536; break;
-    case 2: g.n_sym = 76; g.period = 638; g.null_period = 664; g.n_fft = 512; g.n_carriers = 384; break;
-    case 3: g.n_sym = 153; g.period = 319; g.null_period = 345; g.n_fft = 256; g.n_carriers = 192; break;
-    case 4: g.n_sym = 76; g.period = 1276; g.null_period = 1328; g.n_fft = 1024; g.n_carriers = 768; break;
-    default: return false;
-    }
-    g.n_cp = g.period - g.n_fft;
-    g.frame_samples = g.n_sym * g.period + g.null_period;
-    g.sym_bits = 2 * g.n_carriers;
-    g.frame_bits = (g.n_sym - 1) * g.sym_bits;
-    return true;
-}
-
 // ---- size-generic Stockham autosort passes through LDS (modes II-IV; same butterflies and twiddle rule as mode I) ----
 template <int R>
 __device__ __forceinline__ void butterfly(f2 (&a)[8]) {

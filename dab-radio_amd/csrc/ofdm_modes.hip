@@ -211,14 +211,6 @@ int dabgpu_launch_ofdm_demod_mode(dabgpu_ctx* c, int mode, const void* d_iq, int
 
 extern "C" {
 
-int dabgpu_get_ofdm_params(int mode, int* out9) {
-    ModeGeom g;
-    if (!out9 || !mode_geometry(mode, g)) { dabgpu_set_error("get_ofdm_params: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
-    out9[0] = g.n_sym; out9[1] = g.period; out9[2] = g.null_period; out9[3] = g.n_fft; out9[4] = g.n_cp; out9[5] = g.n_carriers;
-    out9[6] = g.frame_samples; out9[7] = g.sym_bits; out9[8] = g.frame_bits;
-    return DABGPU_OK;
-}
-
 int dabgpu_ofdm_demod_frames_mode(dabgpu_ctx* c, int mode, const float* d_iq, size_t n_frames, const float* d_freq, int8_t* d_bits,
                                   float* d_cp_corr, float* d_fft, int symbols_per_block, void* stream) {
     ModeGeom g;

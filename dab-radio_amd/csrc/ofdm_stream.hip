@@ -415,13 +415,6 @@ struct dabgpu_stream_bank {
 
 extern "C" {
 
-void dabgpu_stream_cfg_default(dabgpu_stream_cfg* c) {
-    if (!c) return;
-    c->signal_l1_update_beta = 0.95f; c->signal_l1_nb_samples = 100; c->signal_l1_nb_decimate = 5;      // ofdm_demodulator.h:25-29
-    c->thresh_null_start = 0.35f; c->thresh_null_end = 0.75f;                                            // :30-33
-    dabgpu_sync_cfg_default(&c->sync);
-}
-
 void dabgpu_stream_bank_destroy(dabgpu_stream_bank* b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);

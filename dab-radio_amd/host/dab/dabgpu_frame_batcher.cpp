@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -12,23 +13,40 @@ namespace dabgpu_frame_batcher {
 namespace {
 
 constexpr int KEEP = 8;                                    // frames whose soft bits and results stay available (= the session's)
+constexpr int MAX_PRODUCERS = 8;                           // demodulators with a session of their own; further ones are not batched
+constexpr int RETRY_AFTER = 64;                            // frames a producer whose session failed waits before it tries again
 constexpr size_t FRAME_BITS = DABGPU_NB_FRAME_BITS, FIC_BITS = 9216, CIF_BITS = 55296, GROUP_BITS = 2304;
 
-struct State {
-    std::mutex mu;
+// one demodulator's frames: a device session + the host copy of its last KEEP frames (what the decoders' buffers are matched against)
+struct Producer {
+    const void* id = nullptr;
     dabgpu_frame_session* session = nullptr;
-    bool failed = false;                                   // the session could not be created / a push failed: stay out of the way
-    int fic_refs = 0;
-    struct Sub { dabgpu_subchannel sc; int refs; };
-    std::vector<Sub> subs;
-    bool subs_dirty = false;
+    int cool_down = 0;                                     // > 0: the session failed; frames to let pass before the next attempt
+    uint64_t subs_version = ~0ull;                         // version of the sub-channel list the session was last given
     struct Frame { uint64_t gen = ~0ull; std::vector<int8_t> bits; };
     Frame frames[KEEP];
     uint64_t next_gen = 0;
 };
+
+struct State {
+    std::mutex mu;
+    int fic_refs = 0;
+    struct Sub { dabgpu_subchannel sc; int refs; };
+    std::vector<Sub> subs;
+    uint64_t subs_version = 0;
+    std::vector<std::unique_ptr<Producer>> producers;      // index = cif_id::src
+};
 State& S() { static State s; return s; }
 
 bool same(const dabgpu_subchannel& a, const dabgpu_subchannel& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+
+void drop_session(Producer& p) {
+    if (p.session) dabgpu_frame_session_destroy(p.session);
+    p.session = nullptr;
+    for (auto& f : p.frames) f.gen = ~0ull;
+    p.next_gen = 0;
+    p.subs_version = ~0ull;
+}
 
 }  // namespace
 
@@ -47,7 +65,7 @@ void add_subchannel(const dabgpu_subchannel& sc) {
     for (auto& e : s.subs) if (same(e.sc, sc)) { e.refs++; return; }
     if (s.subs.size() >= 64) return;                       // more than the session takes: the extra decoders decode on their own
     s.subs.push_back({sc, 1});
-    s.subs_dirty = true;
+    s.subs_version++;
 }
 
 void remove_subchannel(const dabgpu_subchannel& sc) {
@@ -56,51 +74,71 @@ void remove_subchannel(const dabgpu_subchannel& sc) {
     std::lock_guard<std::mutex> g(s.mu);
     for (size_t k = 0; k < s.subs.size(); k++)
         if (same(s.subs[k].sc, sc)) {
-            if (--s.subs[k].refs == 0) { s.subs.erase(s.subs.begin() + (std::ptrdiff_t)k); s.subs_dirty = true; }
+            if (--s.subs[k].refs == 0) { s.subs.erase(s.subs.begin() + (std::ptrdiff_t)k); s.subs_version++; }
             return;
         }
 }
 
-void on_frame(const int8_t* frame_bits) {
+void remove_producer(const void* producer) {
     if (!enabled()) return;
     State& s = S();
     std::lock_guard<std::mutex> g(s.mu);
-    if (s.failed || (s.fic_refs == 0 && s.subs.empty())) return;         // nobody is listening
-    if (!s.session) {
-        const char* dev = std::getenv("DABGPU_DEVICE");
-        if (dabgpu_frame_session_create(&s.session, dev ? std::atoi(dev) : 0) != DABGPU_OK) { s.failed = true; return; }
-        s.subs_dirty = true;
+    for (auto& p : s.producers)
+        if (p && p->id == producer) { drop_session(*p); p->id = nullptr; p->cool_down = 0; }     // the slot stays (cif_id::src of others must not move)
+}
+
+void on_frame(const void* producer, const int8_t* frame_bits) {
+    if (!enabled()) return;
+    State& s = S();
+    std::lock_guard<std::mutex> g(s.mu);
+    if (s.fic_refs == 0 && s.subs.empty()) return;                       // nobody is listening
+    Producer* p = nullptr;
+    for (auto& q : s.producers) if (q && q->id == producer) { p = q.get(); break; }
+    if (!p) {
+        for (auto& q : s.producers) if (q && q->id == nullptr) { p = q.get(); break; }      // a slot a destroyed demodulator left
+        if (!p) {
+            if ((int)s.producers.size() >= MAX_PRODUCERS) return;        // this demodulator's decoders decode call by call
+            s.producers.emplace_back(new Producer());
+            p = s.producers.back().get();
+        }
+        p->id = producer;
     }
-    if (s.subs_dirty) {
+    if (p->cool_down > 0) { p->cool_down--; return; }
+    auto failed = [&] { drop_session(*p); p->cool_down = RETRY_AFTER; };  // stay out of the way for a while, then try again
+    if (!p->session) {
+        const char* dev = std::getenv("DABGPU_DEVICE");
+        if (dabgpu_frame_session_create(&p->session, dev ? std::atoi(dev) : 0) != DABGPU_OK) { p->session = nullptr; failed(); return; }
+    }
+    if (p->subs_version != s.subs_version) {
         std::vector<dabgpu_subchannel> list;
         for (const auto& e : s.subs) list.push_back(e.sc);
-        if (dabgpu_frame_session_set_subchannels(s.session, list.data(), (int)list.size()) != DABGPU_OK) { s.failed = true; return; }
-        s.subs_dirty = false;
+        if (dabgpu_frame_session_set_subchannels(p->session, list.data(), (int)list.size()) != DABGPU_OK) { failed(); return; }
+        p->subs_version = s.subs_version;
     }
     uint64_t gen = 0;
-    if (dabgpu_frame_session_push_frame(s.session, frame_bits, s.fic_refs > 0, dabgpu_tie_rule_from_env(), &gen) != DABGPU_OK) { s.failed = true; return; }
-    State::Frame& f = s.frames[gen % KEEP];
+    if (dabgpu_frame_session_push_frame(p->session, frame_bits, s.fic_refs > 0, dabgpu_tie_rule_from_env(), &gen) != DABGPU_OK) { failed(); return; }
+    Producer::Frame& f = p->frames[gen % KEEP];
     f.gen = ~0ull;
     f.bits.assign(frame_bits, frame_bits + FRAME_BITS);
     f.gen = gen;
-    s.next_gen = gen + 1;
+    p->next_gen = gen + 1;
 }
 
 bool fetch_fib_group(const int8_t* group_bits, int group, uint8_t* bytes96, uint32_t* crc_mask, uint64_t* path_error) {
     if (!enabled() || group < 0 || group > 3) return false;
     State& s = S();
-    uint64_t gen = ~0ull;
-    {
-        std::lock_guard<std::mutex> g(s.mu);
-        if (!s.session || s.failed) return false;
-        for (uint64_t back = 0; back < KEEP && back < s.next_gen; back++) {          // newest first
-            const State::Frame& f = s.frames[(s.next_gen - 1 - back) % KEEP];
-            if (f.gen != s.next_gen - 1 - back) continue;
-            if (std::memcmp(f.bits.data() + (size_t)group * GROUP_BITS, group_bits, GROUP_BITS) == 0) { gen = f.gen; break; }
+    std::lock_guard<std::mutex> g(s.mu);                                  // (held over the fetch: remove_producer destroys sessions)
+    for (auto& q : s.producers) {
+        if (!q || !q->session) continue;
+        const Producer& p = *q;
+        for (uint64_t back = 0; back < KEEP && back < p.next_gen; back++) {          // newest first
+            const Producer::Frame& f = p.frames[(p.next_gen - 1 - back) % KEEP];
+            if (f.gen != p.next_gen - 1 - back) continue;
+            if (std::memcmp(f.bits.data() + (size_t)group * GROUP_BITS, group_bits, GROUP_BITS) == 0)
+                return dabgpu_frame_session_fetch_fib_group(p.session, f.gen, group, bytes96, crc_mask, path_error) == DABGPU_OK;
         }
     }
-    if (gen == ~0ull) return false;
-    return dabgpu_frame_session_fetch_fib_group(s.session, gen, group, bytes96, crc_mask, path_error) == DABGPU_OK;
+    return false;
 }
 
 cif_id match_cif(const int8_t* slice_bits, size_t start_bit, size_t n_bits, cif_id after) {
@@ -108,25 +146,32 @@ cif_id match_cif(const int8_t* slice_bits, size_t start_bit, size_t n_bits, cif_
     if (!enabled() || start_bit + n_bits > CIF_BITS) return none;
     State& s = S();
     std::lock_guard<std::mutex> g(s.mu);
-    if (!s.session || s.failed || s.next_gen == 0) return none;
     auto holds = [&](cif_id id) {
-        if (id.gen >= s.next_gen || s.next_gen - id.gen > KEEP) return false;
-        const State::Frame& f = s.frames[id.gen % KEEP];
+        if (id.src < 0 || id.src >= (int)s.producers.size() || !s.producers[(size_t)id.src] || !s.producers[(size_t)id.src]->session) return false;
+        const Producer& p = *s.producers[(size_t)id.src];
+        if (id.gen >= p.next_gen || p.next_gen - id.gen > KEEP) return false;
+        const Producer::Frame& f = p.frames[id.gen % KEEP];
         return f.gen == id.gen && std::memcmp(f.bits.data() + FIC_BITS + (size_t)id.cif * CIF_BITS + start_bit, slice_bits, n_bits) == 0;
     };
+    // a decoder follows one demodulator: the successor of the CIF it consumed last is tried first (one memcmp in the steady state) ...
     if (after.valid()) { const cif_id nx = successor(after); if (holds(nx)) return nx; }
-    for (uint64_t back = 0; back < KEEP && back < s.next_gen; back++)
-        for (int c = 0; c < 4; c++) { cif_id id; id.gen = s.next_gen - 1 - back; id.cif = c; if (holds(id)) return id; }
+    // ... then the frames of the demodulator it followed, then everybody else's
+    for (int pass = 0; pass < 2; pass++)
+        for (int src = 0; src < (int)s.producers.size(); src++) {
+            if ((pass == 0) != (after.valid() && src == after.src)) continue;
+            const Producer* p = s.producers[(size_t)src].get();
+            if (!p || !p->session) continue;
+            for (uint64_t back = 0; back < KEEP && back < p->next_gen; back++)
+                for (int c = 0; c < 4; c++) { cif_id id; id.src = src; id.gen = p->next_gen - 1 - back; id.cif = c; if (holds(id)) return id; }
+        }
     return none;
 }
 
 bool fetch_cif(cif_id id, const dabgpu_subchannel& sc, uint8_t* bytes, size_t capacity, size_t* n_bytes, uint64_t* path_error) {
     State& s = S();
-    {
-        std::lock_guard<std::mutex> g(s.mu);
-        if (!s.session || s.failed) return false;
-    }
-    return dabgpu_frame_session_fetch_cif(s.session, id.gen, &sc, id.cif, bytes, capacity, n_bytes, path_error) == DABGPU_OK;
+    std::lock_guard<std::mutex> g(s.mu);
+    if (id.src < 0 || id.src >= (int)s.producers.size() || !s.producers[(size_t)id.src] || !s.producers[(size_t)id.src]->session) return false;
+    return dabgpu_frame_session_fetch_cif(s.producers[(size_t)id.src]->session, id.gen, &sc, id.cif, bytes, capacity, n_bytes, path_error) == DABGPU_OK;
 }
 
 }  // namespace dabgpu_frame_batcher

@@ -2,9 +2,11 @@
 //
 // The reference fans a frame out to a FIC runner and one MSC runner per sub-channel (src/basic_radio/basic_radio.cpp:41-65); behind
 // the mirror classes every DecodeFIBGroup / DecodeCIF used to be its own synchronous launch + two copies: 4 + 72 round trips per frame
-// for 18 sub-channels.  The batcher is a process-wide object that OFDM_Demod feeds every frame it completes (mode I) and every
+// for 18 sub-channels.  The batcher is a process-wide object that every OFDM_Demod feeds the frames it completes (mode I) and every
 // FIC_Decoder / MSC_Decoder registers with: the frame is decoded ONCE on the device (dabgpu_frame_session, include/dabgpu.h) -- the
-// FIC and all registered sub-channels -- and the classes pick their bytes up.
+// FIC and all registered sub-channels -- and the classes pick their bytes up.  Every demodulator has a session and an 8-frame history
+// of its own (up to 8 demodulators per process; a further one is simply not batched), so the frames of several receivers in one process
+// do not push each other out of the history; a session that fails is dropped and tried again 64 frames later.
 //
 // A class may take a batcher result only when it is the result the class itself would compute:
 //   * the soft bits it is handed are, byte for byte, the slice of a frame the batcher has decoded (compared with memcmp against the
@@ -24,20 +26,22 @@
 namespace dabgpu_frame_batcher {
 
 bool enabled();
-// OFDM_Demod: a completed mode-I frame (230400 soft bits)
-void on_frame(const int8_t* frame_bits);
+// OFDM_Demod `producer` (any address that identifies the demodulator): a completed mode-I frame (230400 soft bits); its destructor
+// gives the demodulator's session back
+void on_frame(const void* producer, const int8_t* frame_bits);
+void remove_producer(const void* producer);
 // decoders: registration (reference-counted per distinct sub-channel) -- the FIC counts as a registration of its own
 void add_fic();
 void remove_fic();
 void add_subchannel(const dabgpu_subchannel& sc);
 void remove_subchannel(const dabgpu_subchannel& sc);
 
-struct cif_id { uint64_t gen = ~0ull; int cif = -1; bool valid() const { return cif >= 0; } };
+struct cif_id { int src = -1; uint64_t gen = ~0ull; int cif = -1; bool valid() const { return cif >= 0 && src >= 0; } };     // (demodulator, frame, CIF)
 // which decoded frame (newest first) holds these 2304 soft bits as FIB group `group`?  On a hit the decoded bytes are copied out.
 bool fetch_fib_group(const int8_t* group_bits, int group, uint8_t* bytes96, uint32_t* crc_mask, uint64_t* path_error);
 // which (frame, CIF) holds these soft bits as the sub-channel's slice?  `after`: the CIF this decoder consumed last (tried first)
 cif_id match_cif(const int8_t* slice_bits, size_t start_bit, size_t n_bits, cif_id after);
 bool fetch_cif(cif_id id, const dabgpu_subchannel& sc, uint8_t* bytes, size_t capacity, size_t* n_bytes, uint64_t* path_error);
-inline cif_id successor(cif_id a) { cif_id b; b.gen = a.cif == 3 ? a.gen + 1 : a.gen; b.cif = a.cif == 3 ? 0 : a.cif + 1; return b; }
+inline cif_id successor(cif_id a) { cif_id b; b.src = a.src; b.gen = a.cif == 3 ? a.gen + 1 : a.gen; b.cif = a.cif == 3 ? 0 : a.cif + 1; return b; }
 
 }  // namespace dabgpu_frame_batcher

@@ -55,7 +55,7 @@ tcb::span<uint8_t> MSC_Decoder::DecodeCIF(tcb::span<const viterbi_bit_t> buf) {
     {
         const auto id = dabgpu_frame_batcher::match_cif(buf.data() + start_bit, start_bit, n_bits, B.last);
         const auto next = dabgpu_frame_batcher::successor(B.last);
-        B.run = !id.valid() ? 0 : ((B.last.valid() && next.gen == id.gen && next.cif == id.cif) ? B.run + 1 : 1);
+        B.run = !id.valid() ? 0 : ((B.last.valid() && next.src == id.src && next.gen == id.gen && next.cif == id.cif) ? B.run + 1 : 1);
         if (B.run > 16) B.run = 16;
         B.last = id;
         if (id.valid() && B.run >= 16 && B.cifs_seen >= 16 &&

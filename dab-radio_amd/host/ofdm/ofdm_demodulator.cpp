@@ -60,6 +60,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
 }
 
 OFDM_Demod::~OFDM_Demod() {
+    dabgpu_frame_batcher::remove_producer(this);
     if (m_pinned_frame) (void)dabgpu_host_unpin(m_frame.data());
     if (m_pinned_bits) (void)dabgpu_host_unpin(m_frame_bits.data());
     dabgpu_destroy(m_ctx);
@@ -218,6 +219,6 @@ void OFDM_Demod::DemodulateFrame() {
     m_freq_fine = fine;
     m_total_frames_read++;
     // the decoders of this process get the whole frame decoded in one go (mode I: the DAB layer above the soft bits is mode I only)
-    if (m_mode == 1) dabgpu_frame_batcher::on_frame(m_frame_bits.data());
+    if (m_mode == 1) dabgpu_frame_batcher::on_frame(this, m_frame_bits.data());
     m_on_frame.Notify(tcb::span<const viterbi_bit_t>(m_frame_bits.data(), m_frame_bits.size()));
 }

@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_ORACLE_SO = os.path.join(_HERE, "libdab_oracle.so")
+# DAB_ORACLE_SO: another build of the oracle (tests/test_host_sanitizers.py: the ASan + UBSan build, oracle/Makefile SAN=1)
+_ORACLE_SO = os.environ.get("DAB_ORACLE_SO") or os.path.join(_HERE, "libdab_oracle.so")
 _REF_SO = os.path.join(_HERE, "_ref", "libdab_ref.so")
 
 NB_FRAME_SYMBOLS = 76
@@ -30,7 +31,10 @@ NB_CIF_BITS = 55296
 
 def build(force=False):
     """Compile the oracle (and _ref when /root/reference exists). Building the checker is not using it."""
-    if force or not os.path.exists(_ORACLE_SO) or any(
+    if os.environ.get("DAB_ORACLE_SO"):
+        if not os.path.exists(_ORACLE_SO):
+            raise FileNotFoundError(_ORACLE_SO)
+    elif force or not os.path.exists(_ORACLE_SO) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_ORACLE_SO)
         for f in ("dab_oracle_ofdm.c", "dab_oracle_decode.c", "dab_oracle_io.c", "dab_oracle_dabplus.c", "dab_oracle_chain.c", "dab_oracle.h")
     ):

@@ -1,0 +1,216 @@
+// fake_dabgpu_oracle.cpp -- TEST INFRASTRUCTURE ONLY, never linked into the product: the entry points of include/dabgpu.h that the
+// C++ mirror classes call (dab-radio_amd/host/**), implemented on the CPU oracle (oracle/*.c), so that the classes' own host logic --
+// the framing state machine, the process-wide frame batcher with its per-demodulator sessions, the shared context, the decoders'
+// bookkeeping -- can run under ThreadSanitizer / AddressSanitizer on a machine without a GPU (tests/test_host_sanitizers.py).
+// Results are the oracle's, i.e. the ones the device produces (that equality is what the -m gpu tests establish); here only the
+// threading and memory behaviour of the host code is under test.
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "dabgpu.h"
+extern "C" {
+#include "dab_oracle.h"
+}
+
+struct dabgpu_ctx { std::vector<int> mapper; };
+
+extern "C" {
+
+int dabgpu_device_count(void) { return 1; }
+int dabgpu_create(dabgpu_ctx** out, int, const float*, const int* h_mapper) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    dabgpu_ctx* c = new dabgpu_ctx();
+    c->mapper.resize(DAB_NB_DATA_CARRIERS);
+    if (h_mapper) std::memcpy(c->mapper.data(), h_mapper, sizeof(int) * DAB_NB_DATA_CARRIERS); else dab_get_mapper(c->mapper.data());
+    *out = c;
+    return DABGPU_OK;
+}
+void dabgpu_destroy(dabgpu_ctx* c) { delete c; }
+int dabgpu_host_pin(void*, size_t) { return DABGPU_OK; }
+int dabgpu_host_unpin(void*) { return DABGPU_OK; }
+
+int dabgpu_ofdm_sync_host_sync_mode(dabgpu_ctx* c, int mode, const float* h_prs_sym, const dabgpu_sync_cfg* cfg, dabgpu_sync_state* st, float* imp, float* frq) {
+    if (!c || !h_prs_sym || !cfg || !st) return DABGPU_ERR_INVALID_ARG;
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return DABGPU_ERR_INVALID_ARG;
+    std::vector<dab_cf32> prs((size_t)g.nb_fft), conj_ref((size_t)g.nb_fft), time_ref((size_t)g.nb_fft);
+    dab_get_prs_fft_mode(mode, prs.data());
+    dab_sync_refs_mode(mode, prs.data(), conj_ref.data(), time_ref.data());
+    dab_sync_cfg oc;
+    oc.fine_freq_update_beta = cfg->fine_freq_update_beta; oc.is_coarse_freq_correction = cfg->is_coarse_freq_correction;
+    oc.max_coarse_freq_correction_norm = cfg->max_coarse_freq_correction_norm; oc.coarse_freq_slow_beta = cfg->coarse_freq_slow_beta;
+    oc.impulse_peak_threshold_db = cfg->impulse_peak_threshold_db; oc.impulse_peak_distance_probability = cfg->impulse_peak_distance_probability;
+    dab_sync_state os = {st->freq_coarse, st->freq_fine, st->is_found_coarse, 0, 0, 0};
+    const dab_cf32* sym = reinterpret_cast<const dab_cf32*>(h_prs_sym);
+    dab_coarse_freq_sync_mode(mode, sym, time_ref.data(), &oc, &os, frq);
+    int off = 0;
+    const int ok = dab_fine_time_sync_mode(mode, sym, conj_ref.data(), &oc, os.freq_coarse + os.freq_fine, &off, imp);
+    st->freq_coarse = os.freq_coarse; st->freq_fine = os.freq_fine; st->is_found_coarse = os.is_found_coarse;
+    st->sync_valid = ok; if (ok) st->fine_time_offset = off;
+    return DABGPU_OK;
+}
+
+int dabgpu_ofdm_demod_stream_frame_sync(dabgpu_ctx* c, const float* h_iq, float coarse, float* fine, float beta, int8_t* h_bits, float* h_total, float* h_fft, float*) {
+    if (!c || !h_iq || !fine || !h_bits) return DABGPU_ERR_INVALID_ARG;
+    const float total = dab_demod_frame(reinterpret_cast<const dab_cf32*>(h_iq), coarse + *fine, c->mapper.data(), h_bits, nullptr, nullptr, reinterpret_cast<dab_cf32*>(h_fft));
+    *fine = dab_update_fine_freq_mode(1, *fine, total, beta);
+    if (h_total) *h_total = total;
+    return DABGPU_OK;
+}
+int dabgpu_ofdm_demod_stream_frame_sync_mode(dabgpu_ctx* c, int mode, const float* h_iq, float coarse, float* fine, float beta, int8_t* h_bits, float* h_total, float* h_fft) {
+    if (!c || !h_iq || !fine || !h_bits) return DABGPU_ERR_INVALID_ARG;
+    dab_ofdm_geometry g;
+    if (dab_ofdm_geometry_get(mode, &g)) return DABGPU_ERR_INVALID_ARG;
+    std::vector<int> map((size_t)g.nb_carriers);
+    dab_mapper_n(g.nb_fft, g.nb_carriers, map.data());
+    const float total = dab_demod_frame_mode(mode, reinterpret_cast<const dab_cf32*>(h_iq), coarse + *fine, map.data(), h_bits, nullptr, nullptr, reinterpret_cast<dab_cf32*>(h_fft));
+    *fine = dab_update_fine_freq_mode(mode, *fine, total, beta);
+    if (h_total) *h_total = total;
+    return DABGPU_OK;
+}
+
+int dabgpu_fic_decode_group_host_sync(dabgpu_ctx* c, const int8_t* h_bits, uint8_t* h_bytes, uint32_t* mask, uint64_t* err, int tie) {
+    if (!c || !h_bits || !h_bytes) return DABGPU_ERR_INVALID_ARG;
+    uint32_t m = 0;
+    const uint64_t e = dab_fic_decode_group(h_bits, tie, h_bytes, &m);
+    if (mask) *mask = m;
+    if (err) *err = e;
+    return DABGPU_OK;
+}
+
+int dabgpu_viterbi_decode_depunctured_host_sync(dabgpu_ctx* c, const int8_t* h_mother, size_t n_steps, uint32_t start, uint32_t end, uint8_t* h_out, size_t n_out,
+                                                uint64_t* err, int tie) {
+    if (!c || !h_mother || n_steps < 1 || (n_out && n_out * 8 + 6 > n_steps)) return DABGPU_ERR_INVALID_ARG;
+    dab_viterbi* v = dab_viterbi_create(n_steps + 8, tie);
+    dab_viterbi_reset(v, start);
+    const uint8_t all[1] = {4};
+    dab_viterbi_update(v, h_mother, 4 * n_steps, all, 1, 4 * n_steps);
+    const uint64_t e = dab_viterbi_chainback(v, h_out, n_out, end);
+    if (err) *err = e;
+    dab_viterbi_destroy(v);
+    return DABGPU_OK;
+}
+
+// ---- per-sub-channel stream (MSC_Decoder, CIF_Deinterleaver) ----
+struct dabgpu_msc_stream { dab_subchannel sc; dab_deinterleaver* d; int nbits; std::vector<int8_t> logical; bool ready; };
+static dab_subchannel to_oracle(const dabgpu_subchannel& s) { return dab_subchannel{s.start_address, s.length, s.is_uep, s.uep_prot_index, s.eep_prot_level, s.eep_type}; }
+int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* sc, dabgpu_msc_stream** out) {
+    if (!c || !sc || !out) return DABGPU_ERR_INVALID_ARG;
+    int pi[4], lx[4], nb;
+    dab_subchannel o = to_oracle(*sc);
+    if (sc->length <= 0 || sc->length > 864 || dab_subchannel_plan(&o, pi, lx, &nb) < 0) return DABGPU_ERR_INVALID_ARG;
+    dabgpu_msc_stream* s = new dabgpu_msc_stream();
+    s->sc = o; s->nbits = sc->length * 64; s->d = dab_deinterleaver_create(sc->length * 8); s->logical.resize((size_t)s->nbits); s->ready = false;
+    *out = s;
+    return DABGPU_OK;
+}
+void dabgpu_msc_stream_destroy(dabgpu_msc_stream* s) { if (!s) return; dab_deinterleaver_destroy(s->d); delete s; }
+int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_bits) {
+    if (!s || !h_bits) return DABGPU_ERR_INVALID_ARG;
+    dab_deinterleaver_consume(s->d, h_bits);
+    s->ready = dab_deinterleaver_deinterleave(s->d, s->logical.data()) != 0;
+    return DABGPU_OK;
+}
+int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t* h_out) {
+    if (!s || !h_out) return DABGPU_ERR_INVALID_ARG;
+    if (!s->ready) return DABGPU_ERR_NOT_READY;
+    std::memcpy(h_out, s->logical.data(), (size_t)s->nbits);
+    return DABGPU_OK;
+}
+int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_out, size_t* n_out, uint64_t* err, int tie) {
+    if (!s || !h_out || !n_out) return DABGPU_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (!s->ready) return DABGPU_ERR_NOT_READY;
+    int nb = 0;
+    const uint64_t e = dab_msc_decode_logical(&s->sc, s->logical.data(), tie, h_out, &nb);
+    *n_out = (size_t)nb;
+    if (err) *err = e;
+    return DABGPU_OK;
+}
+
+// ---- frame session: one decode per pushed frame, results of the last 8 frames ----
+struct dabgpu_frame_session {
+    static constexpr int R = 8;
+    std::mutex mu;
+    struct Sub { dabgpu_subchannel sc; dab_deinterleaver* d; int cifs; };
+    std::vector<Sub> subs;
+    struct Slot {
+        uint64_t gen = ~0ull; bool fic = false;
+        uint8_t fib[4][96]; uint32_t mask[4]; uint64_t ferr[4];
+        struct Out { dabgpu_subchannel sc; std::vector<uint8_t> bytes[4]; uint64_t err[4]; bool ok[4]; };
+        std::vector<Out> outs;
+    } slots[R];
+    uint64_t next = 0;
+};
+int dabgpu_frame_session_create(dabgpu_frame_session** out, int) { if (!out) return DABGPU_ERR_INVALID_ARG; *out = new dabgpu_frame_session(); return DABGPU_OK; }
+void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
+    if (!s) return;
+    for (auto& e : s->subs) dab_deinterleaver_destroy(e.d);
+    delete s;
+}
+int dabgpu_frame_session_set_subchannels(dabgpu_frame_session* s, const dabgpu_subchannel* subs, int n) {
+    if (!s || n < 0 || n > 64 || (n && !subs)) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    std::vector<dabgpu_frame_session::Sub> keep;
+    for (int k = 0; k < n; k++) {
+        bool found = false;
+        for (auto& e : s->subs) if (e.d && !std::memcmp(&e.sc, &subs[k], sizeof(subs[k]))) { keep.push_back(e); e.d = nullptr; found = true; break; }
+        if (!found) keep.push_back({subs[k], dab_deinterleaver_create(subs[k].length * 8), 0});
+    }
+    for (auto& e : s->subs) if (e.d) dab_deinterleaver_destroy(e.d);
+    s->subs = keep;
+    return DABGPU_OK;
+}
+int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const int8_t* bits, int decode_fic, int tie, uint64_t* generation) {
+    if (!s || !bits) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    const uint64_t gen = s->next++;
+    auto& sl = s->slots[gen % dabgpu_frame_session::R];
+    sl.gen = gen; sl.fic = decode_fic != 0; sl.outs.clear();
+    if (decode_fic) for (int k = 0; k < 4; k++) sl.ferr[k] = dab_fic_decode_group(bits + k * 2304, tie, sl.fib[k], &sl.mask[k]);
+    for (auto& e : s->subs) {
+        dabgpu_frame_session::Slot::Out o;
+        o.sc = e.sc;
+        dab_subchannel osc = to_oracle(e.sc);
+        std::vector<int8_t> logical((size_t)e.sc.length * 64);
+        for (int c = 0; c < 4; c++) {
+            dab_deinterleaver_consume(e.d, bits + 9216 + (size_t)c * 55296 + (size_t)e.sc.start_address * 64);
+            o.ok[c] = dab_deinterleaver_deinterleave(e.d, logical.data()) != 0;
+            o.err[c] = 0;
+            if (o.ok[c]) { o.bytes[c].resize((size_t)e.sc.length * 8); int nb = 0; o.err[c] = dab_msc_decode_logical(&osc, logical.data(), tie, o.bytes[c].data(), &nb); o.bytes[c].resize((size_t)nb); }
+        }
+        sl.outs.push_back(std::move(o));
+    }
+    if (generation) *generation = gen;
+    return DABGPU_OK;
+}
+int dabgpu_frame_session_fetch_fib_group(dabgpu_frame_session* s, uint64_t gen, int group, uint8_t* bytes, uint32_t* mask, uint64_t* err) {
+    if (!s || group < 0 || group > 3 || !bytes) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    auto& sl = s->slots[gen % dabgpu_frame_session::R];
+    if (sl.gen != gen || !sl.fic) return DABGPU_ERR_NOT_READY;
+    std::memcpy(bytes, sl.fib[group], 96);
+    if (mask) *mask = sl.mask[group];
+    if (err) *err = sl.ferr[group];
+    return DABGPU_OK;
+}
+int dabgpu_frame_session_fetch_cif(dabgpu_frame_session* s, uint64_t gen, const dabgpu_subchannel* sc, int cif, uint8_t* bytes, size_t cap, size_t* n, uint64_t* err) {
+    if (!s || !sc || cif < 0 || cif > 3 || !bytes || !n) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(s->mu);
+    auto& sl = s->slots[gen % dabgpu_frame_session::R];
+    if (sl.gen != gen) return DABGPU_ERR_NOT_READY;
+    for (auto& o : sl.outs)
+        if (!std::memcmp(&o.sc, sc, sizeof(*sc))) {
+            if (!o.ok[cif] || o.bytes[cif].size() > cap) return DABGPU_ERR_NOT_READY;
+            std::memcpy(bytes, o.bytes[cif].data(), o.bytes[cif].size());
+            *n = o.bytes[cif].size();
+            if (err) *err = o.err[cif];
+            return DABGPU_OK;
+        }
+    return DABGPU_ERR_NOT_READY;
+}
+
+}  // extern "C"

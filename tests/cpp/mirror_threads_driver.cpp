@@ -1,0 +1,156 @@
+// mirror_threads_driver.cpp -- the C++ mirror classes (dab-radio_amd/host/**) driven the way basic_radio drives the reference's, with
+// SEVERAL receivers in one process and the decoders on their own threads, for ThreadSanitizer / AddressSanitizer runs on a machine
+// without a GPU: linked against tests/cpp/fake_dabgpu_oracle.cpp (the C ABI on the CPU oracle, test infrastructure) instead of
+// libdabgpu.so.  What is under test is the host code's threading: the process-wide frame batcher with one session per demodulator, the
+// shared context, the decoders' registration / matching / fall-back logic.
+//
+//   mirror_threads_driver <block> <start_cu> <len_cu> <eep_level> <eep_type_b> [more sub-channels ...] -- <iq0.c32> <iq1.c32> ...
+// Phase 1: every receiver alone, everything on one thread.  Phase 2: all receivers at once -- per receiver one reader thread
+// (OFDM_Demod::Process) and one radio thread that takes the frames from a queue (the reference's ring buffer between its OFDM and radio
+// threads, examples/app_helpers/app_ofdm_blocks.h:32-35) and decodes the FIC on itself and the sub-channels on two workers.  The bytes
+// of phase 2 must equal those of phase 1, receiver by receiver; prints one JSON line; exit status 0 only then.
+#include <atomic>
+#include <complex>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dab/constants/dab_parameters.h"
+#include "dab/fic/fic_decoder.h"
+#include "dab/msc/msc_decoder.h"
+#include "ofdm/ofdm_helpers.h"
+
+namespace {
+
+struct Output { std::vector<uint8_t> fibs, msc; int frames = 0; int cifs_out = 0; };
+
+uint64_t fnv(const std::vector<uint8_t>& v, uint64_t h = 0xCBF29CE484222325ull) { for (uint8_t b : v) { h ^= b; h *= 0x100000001B3ull; } return h; }
+
+std::vector<std::complex<float>> load(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+    const size_t n = (size_t)f.tellg() / sizeof(std::complex<float>);
+    std::vector<std::complex<float>> v(n);
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(n * sizeof(std::complex<float>)));
+    return v;
+}
+
+// the radio side of one receiver: FIC decoder + one MSC decoder per sub-channel
+struct Radio {
+    DAB_Parameters dab = get_dab_parameters(1);
+    FIC_Decoder fic;
+    std::vector<std::unique_ptr<MSC_Decoder>> msc;
+    Output* out;
+    Radio(const std::vector<Subchannel>& subs, Output* o) : fic((size_t)dab.nb_fib_cif_bits, (size_t)dab.nb_fibs_per_cif), out(o) {
+        for (const auto& s : subs) msc.push_back(std::make_unique<MSC_Decoder>(s));
+        fic.OnFIB().Attach([this](tcb::span<const uint8_t> fib) { out->fibs.insert(out->fibs.end(), fib.begin(), fib.end()); });
+    }
+    void frame(const std::vector<viterbi_bit_t>& bits, bool workers) {
+        out->frames++;
+        tcb::span<const viterbi_bit_t> all(bits.data(), bits.size());
+        auto fic_bits = all.subspan(0, (size_t)dab.nb_fic_bits);
+        auto msc_bits = all.subspan((size_t)dab.nb_fic_bits, (size_t)dab.nb_msc_bits);
+        for (int c = 0; c < dab.nb_cifs; c++) fic.DecodeFIBGroup(fic_bits.subspan((size_t)c * dab.nb_fib_cif_bits, (size_t)dab.nb_fib_cif_bits), (size_t)c);
+        for (int c = 0; c < dab.nb_cifs; c++) {
+            auto cif = msc_bits.subspan((size_t)c * dab.nb_cif_bits, (size_t)dab.nb_cif_bits);
+            std::vector<std::vector<uint8_t>> got(msc.size());
+            auto work = [&](size_t first, size_t step) {
+                for (size_t s = first; s < msc.size(); s += step) { auto r = msc[s]->DecodeCIF(cif); got[s].assign(r.begin(), r.end()); }
+            };
+            if (workers && msc.size() > 1) { std::thread a(work, 0, 2), b(work, 1, 2); a.join(); b.join(); }
+            else work(0, 1);
+            for (auto& g : got) { if (!g.empty()) out->cifs_out++; out->msc.insert(out->msc.end(), g.begin(), g.end()); }
+        }
+    }
+};
+
+struct FrameQueue {
+    std::mutex mu; std::condition_variable cv; std::deque<std::vector<viterbi_bit_t>> q; bool done = false;
+    void push(tcb::span<const viterbi_bit_t> b) { { std::lock_guard<std::mutex> g(mu); q.emplace_back(b.begin(), b.end()); } cv.notify_one(); }
+    bool pop(std::vector<viterbi_bit_t>& out) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done || !q.empty(); });
+        if (q.empty()) return false;
+        out = std::move(q.front()); q.pop_front();
+        return true;
+    }
+    void finish() { { std::lock_guard<std::mutex> g(mu); done = true; } cv.notify_all(); }
+};
+
+void feed(OFDM_Demod& demod, const std::vector<std::complex<float>>& iq, size_t block) {
+    for (size_t k = 0; k < iq.size(); k += block)
+        demod.Process(tcb::span<const std::complex<float>>(iq.data() + k, std::min(block, iq.size() - k)));
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 8) { std::fprintf(stderr, "usage: %s block start len level type_b [...] -- iq0.c32 [iq1.c32 ...]\n", argv[0]); return 2; }
+    const size_t block = (size_t)std::atol(argv[1]);
+    std::vector<Subchannel> subs;
+    int a = 2;
+    for (; a + 3 < argc && std::strcmp(argv[a], "--") != 0; a += 4) {
+        Subchannel sc((subchannel_id_t)subs.size());
+        sc.start_address = (subchannel_addr_t)std::atoi(argv[a]);
+        sc.length = (subchannel_size_t)std::atoi(argv[a + 1]);
+        sc.eep_prot_level = (eep_protection_level_t)std::atoi(argv[a + 2]);
+        sc.eep_type = std::atoi(argv[a + 3]) ? EEP_Type::TYPE_B : EEP_Type::TYPE_A;
+        sc.is_complete = true;
+        subs.push_back(sc);
+    }
+    if (a >= argc || std::strcmp(argv[a], "--") != 0) { std::fprintf(stderr, "missing --\n"); return 2; }
+    std::vector<std::vector<std::complex<float>>> iq;
+    for (a++; a < argc; a++) iq.push_back(load(argv[a]));
+    const size_t R = iq.size();
+
+    // ---- phase 1: one receiver at a time, one thread ----
+    std::vector<Output> serial(R);
+    for (size_t r = 0; r < R; r++) {
+        auto demod = Create_OFDM_Demodulator(1);
+        Radio radio(subs, &serial[r]);
+        demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { radio.frame(std::vector<viterbi_bit_t>(bits.begin(), bits.end()), false); });
+        feed(*demod, iq[r], block);
+    }
+
+    // ---- phase 2: all receivers at once; reader thread + radio thread (+ two decode workers) per receiver ----
+    std::vector<Output> threaded(R);
+    {
+        std::vector<std::unique_ptr<FrameQueue>> queues;
+        std::vector<std::thread> threads;
+        for (size_t r = 0; r < R; r++) queues.push_back(std::make_unique<FrameQueue>());
+        for (size_t r = 0; r < R; r++) {
+            threads.emplace_back([&, r] {                                   // radio thread: owns the decoders of receiver r
+                Radio radio(subs, &threaded[r]);
+                std::vector<viterbi_bit_t> bits;
+                while (queues[r]->pop(bits)) radio.frame(bits, true);
+            });
+            threads.emplace_back([&, r] {                                   // reader thread: owns the demodulator of receiver r
+                auto demod = Create_OFDM_Demodulator(1);
+                demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { queues[r]->push(bits); });
+                feed(*demod, iq[r], block);
+                queues[r]->finish();
+            });
+        }
+        for (auto& t : threads) t.join();
+    }
+
+    bool ok = true;
+    std::printf("{\"receivers\": %zu, \"sub_channels\": %zu, \"per_receiver\": [", R, subs.size());
+    for (size_t r = 0; r < R; r++) {
+        const bool same = serial[r].fibs == threaded[r].fibs && serial[r].msc == threaded[r].msc && serial[r].frames == threaded[r].frames;
+        ok = ok && same && serial[r].frames > 0;
+        std::printf("%s{\"frames\": %d, \"fib_bytes\": %zu, \"msc_bytes\": %zu, \"cifs_with_output\": %d, \"digest\": \"%016llx\", \"threaded_equals_serial\": %s}", r ? ", " : "",
+                    serial[r].frames, serial[r].fibs.size(), serial[r].msc.size(), serial[r].cifs_out, (unsigned long long)fnv(serial[r].msc, fnv(serial[r].fibs)), same ? "true" : "false");
+    }
+    std::printf("], \"ok\": %s}\n", ok ? "true" : "false");
+    return ok ? 0 : 1;
+}
