@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="demod, N = 1: skip extra.chain (the unsynchronised-stream chain at --extra-ensembles)")
+    ap.add_argument("--lanes", choices=("alternate", "split"), default="alternate",
+                    help="full / extras with two frames in flight: frame j wholly on stream j mod 2, or all demodulations on one (high-priority) stream and all decodes on the other")
     ap.add_argument("--aligned", action="store_true",
                     help="full / extras: frame-aligned input with synchronisation bypassed (what rounds 1-3 timed) instead of the sync-enabled path")
     ap.add_argument("--no-check", action="store_true")
@@ -252,9 +254,12 @@ class Pipeline:
     demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it; synced: the synchroniser of
     frame j reads the fine-frequency word frame j-1's phase tail wrote -> demod(j) waits for demod(j-1)."""
 
-    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1, synced=True, noise=0.05):
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1, synced=True, noise=0.05, lanes="alternate"):
         import dabsynth
         self.torch, self.E, self.inflight, self.synced, self.dabgpu = torch, E, inflight, synced, dabgpu
+        # lanes = "alternate": frame j entirely on stream j mod inflight; "split" (inflight = 2): every demodulation on stream 0 (high
+        # priority), every decode on stream 1 -- the front end of frame j + 1 is enqueued behind that of frame j, not behind j's decode
+        self.lanes = lanes if inflight == 2 else "alternate"
         # layout of the MSC soft bits in the history ring: 1 = time-interleaver class order (DABGPU_BITS_MSC_CLASSED: the demodulator
         # writes it for free and the decoder's gather then reads ~1.3 instead of 4.75 history bytes per soft bit), 0 = On_OFDM_Frame()
         self.layout, self.fmt_f32 = layout, dabgpu.IQ_FORMATS.index("raw_f32l")
@@ -276,7 +281,10 @@ class Pipeline:
         self.n_sub = dabsynth.N_SUB
         self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
         self.ctxs = [ctx] + [dabgpu.Context(device.index) for _ in range(inflight - 1)]
-        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
+        if self.lanes == "split":
+            self.streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)]
+        else:
+            self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(inflight - 1)]
         mk = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=device) for _ in range(inflight)]     # noqa: E731
         self.corr = mk((E, 76, 2), torch.float32)
         self.fic_out, self.fic_res = mk((E, 4, 96), torch.uint8), mk((E * 4, 16), torch.uint8)
@@ -351,6 +359,22 @@ class Pipeline:
                 self.demod(slot, 0, j)
             decode(slot)
             return
+        if self.lanes == "split":
+            sd, stt = self.streams
+            self.last_frame_of_lane = {1: j}
+            w = self.ev_msc.pop(j - self.H + 4, None)                # the last reader of the slot this frame overwrites
+            if w is not None:
+                sd.wait_event(w)
+            if on_demod:
+                on_demod(lambda: self.demod(slot, 0, j))
+            else:
+                self.demod(slot, 0, j)
+            ev = torch.cuda.Event(); ev.record(sd)
+            stt.wait_event(ev)
+            decode(slot, 1)
+            ev = torch.cuda.Event(); ev.record(stt)
+            self.ev_msc[j] = ev
+            return
         w = self.ev_msc.pop(j - self.H + 4, None)                    # the last reader of the slot this frame overwrites
         if w is not None:
             st.wait_event(w)
@@ -381,10 +405,11 @@ class Pipeline:
     def timed(self, fn, reps):
         torch = self.torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        torch.cuda.synchronize()
+        e0.record(self.streams[0])                   # (the stage functions launch on lane 0's stream)
         for k in range(reps):
             fn(k % self.H)
-        e1.record()
+        e1.record(self.streams[0])
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
@@ -394,11 +419,11 @@ class Pipeline:
         the wrong order cannot pass.  synced: plus what the synchroniser tracked, against what the generator put in."""
         import numpy as np
         torch, E, nd, P = self.torch, self.E, self.mux.n, self.mux.period
-        out = {"fib_crc_pass": 0, "fib_crc_expected": E * 12 * self.inflight, "fib_bytes_equal_transmitted": True,
+        out = {"fib_crc_pass": 0, "fib_crc_expected": E * 12 * len(self.last_frame_of_lane), "fib_bytes_equal_transmitted": True,
                "msc_bytes_equal_transmitted": True, "ensembles_checked": E, "distinct_multiplexes": nd, "frames_in_flight": self.inflight,
                "payload_period_cifs": P, "frames_checked": []}
         idx = torch.arange(E, device=self.hist.device) % nd
-        for k in range(self.inflight):                               # the outputs of the last frame of every lane
+        for k in sorted(self.last_frame_of_lane):                    # the outputs of the last frame of every lane
             j = self.last_frame_of_lane[k]
             out["frames_checked"].append(int(j))
             cifs = [(4 * j + c - 15) % P for c in range(4)]
@@ -422,9 +447,9 @@ class Pipeline:
         return out
 
 
-def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1, synced=True):
+def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1, synced=True, lanes="alternate"):
     """BASELINE configs[2] (full demod incl. sync + FIC Viterbi) and configs[3] (full FIC + MSC, E concurrent ensembles) on this GPU"""
-    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2, layout=layout, synced=synced)
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=7, inflight=2, layout=layout, synced=synced, lanes=lanes)
     chosen = p.tune()
     p.fill()
     torch.cuda.synchronize()
@@ -432,12 +457,12 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     t_sync = p.timed(p.sync_only, reps) if synced else None
     t_dec = p.timed(p.decode, reps)                                            # FIC + MSC as one call (what the pipeline runs)
     # configs[2]: (sync ->) demod -> FIC, one frame at a time on one stream ...
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for k in range(reps):
         p.demod(k % p.H); p.fic(k % p.H)
-    e1.record(); torch.cuda.synchronize()
-    t_c2_seq = e0.elapsed_time(e1) / reps
+    torch.cuda.synchronize()
+    t_c2_seq = (time.perf_counter() - t0) / reps * 1e3
     # ... and with two frames in flight like configs[3]: frame j on lane j mod 2, the FIC trellis of frame j beside the demodulation of j + 1
     p.fill()
     torch.cuda.synchronize()
@@ -655,14 +680,14 @@ def main():
         first_unit, n_units = shard.shard_range(E * world, rank, world)
         assert n_units == E
         pipe = Pipeline(ctx, dabgpu, torch, device, E, args.distinct, seed=5000 + first_unit, inflight=args.inflight,
-                        layout=int(args.hist_layout == "classed"), synced=not args.aligned)
+                        layout=int(args.hist_layout == "classed"), synced=not args.aligned, lanes=args.lanes)
         pipe_spb = pipe.tune()
         pipe.fill()
         units = E
 
         def timed_demod(launch):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st = pipe.streams[(pipe.j - 1) % pipe.inflight]
+            st = pipe.streams[0] if pipe.lanes == "split" else pipe.streams[(pipe.j - 1) % pipe.inflight]
             a.record(st); launch(); b.record(st)
             evs.append((a, b))
 
@@ -780,7 +805,7 @@ def main():
             del iq, iq_f, tx_bits, d_bits
             torch.cuda.empty_cache()
             c2, c3, host_sample = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"),
-                                                   synced=not args.aligned)
+                                                   synced=not args.aligned, lanes=args.lanes)
             line["extra"] = {"configs2": c2, "configs3": c3}
             if not args.no_chain:
                 import bench_chain

@@ -37,7 +37,7 @@ def counter_average(path, counter, kernel="ofdm_demod_kernel"):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
-    rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+    rnd = sys.argv[3] if len(sys.argv) > 3 else "r04"
     out = os.path.join(root, f"summary_{tag}")
     os.makedirs(out, exist_ok=True)
     stats = find(os.path.join(root, "prof"), "*kernel_stats.csv")

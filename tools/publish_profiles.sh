@@ -11,9 +11,9 @@ cp $S/kernel_stats_$TAG.csv $S/pmc_fetch_size_$TAG.csv $S/pmc_write_size_$TAG.cs
 [ -f $S/hbm_traffic_decode_$TAG.json ] && cp $S/hbm_traffic_decode_$TAG.json $D/
 cp $S/hbm_traffic.json $D/hbm_traffic_$TAG.json
 cp $S/hbm_traffic.json profiles/hbm_traffic.json
-for f in counters kernel_stats_decode4096; do for e in json csv; do [ -f gpurun_out/${f}_$TAG.$e ] && cp gpurun_out/${f}_$TAG.$e $D/; done; done
+for f in counters kernel_stats_decode4096 kernel_stats_synced4096 kernel_stats_chain4096; do for e in json csv; do [ -f gpurun_out/${f}_$TAG.$e ] && cp gpurun_out/${f}_$TAG.$e $D/; done; done
 for f in bench_n1 bench_decode bench_decode_4096 bench_decode_4096_natural bench_full bench_ingest bench_mirror bench_stream bench_stream_1024x4 bench_stream_retained bench_io bench_fic \
-         bench_cpp_host bench_dabplus; do
+         bench_cpp_host bench_dabplus bench_chain bench_chain_profiled bench_sync; do
   [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json $D/
 done
 ls $D | grep "_$TAG" | wc -l
