@@ -125,13 +125,25 @@ void stream_advance_kernel(BankView B, int s0, int n_streams, const uint8_t* __r
     if (first_round) {
         if (t == 0) {
             S.pos = 0; S.n_out = 0; S.avg_done = 0;
-            // what the previous call left in its block instead of copying it (retained mode) is this call's carry
+            // what the previous call left in its block instead of copying it (retained mode) is this call's carry -- unless the frame
+            // cannot complete inside this block (it began in the last samples of the previous block and this block is shorter than a
+            // frame: the ring form's blocks are): a frame may lie in the frame buffer, the previous block and this block, not in a
+            // third block, so those few samples are copied into the frame buffer now
             const int left = B.copy_cnt[s];
-            if (prev_block != nullptr && left > 0) { S.carry_dst = B.copy_dst[s]; S.carry_end = B.copy_dst[s] + left; S.carry_src = B.copy_src[s]; }
-            else { S.carry_dst = 0; S.carry_end = 0; S.carry_src = 0; }
+            sh_i[0] = 0;
+            if (prev_block != nullptr && left > 0) {
+                S.carry_dst = B.copy_dst[s]; S.carry_end = B.copy_dst[s] + left; S.carry_src = B.copy_src[s];
+                if ((long long)NB_FRAME_SAMPLES - (long long)S.frame_length > n_samples) sh_i[0] = 1;
+            } else { S.carry_dst = 0; S.carry_end = 0; S.carry_src = 0; }
             B.copy_cnt[s] = 0;
         }
         __syncthreads();
+        if (sh_i[0]) {
+            copy_block_samples<SRC>(frame + S.carry_dst, prev_block, S.carry_src, (long long)(S.carry_end - S.carry_dst), t);
+            __syncthreads();
+            if (t == 0) { S.carry_dst = 0; S.carry_end = 0; S.carry_src = 0; }
+            __syncthreads();
+        }
     }
 
     // ---- what the previous round's sync / demod kernels produced ----
@@ -527,11 +539,13 @@ static int bank_process_impl(dabgpu_stream_bank* b, const void* d_iq, size_t str
     const int n = (int)b->n;
     int st;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
-    // Retained blocks (mode I, not the ring form): the unfinished frame at the end of a block is not copied into the stream's frame
-    // buffer -- the next call reads it where it is.  That needs every pending frame to complete inside the next block (a frame then
-    // spans two blocks at most); a shorter block copies the carried samples out of the previous block first, like a release.
-    const bool use_retain = retain && G.mode == 1 && !ring_mode;
-    const bool prev_valid = b->carry_pending && n_samples >= (size_t)NB_FRAME_SAMPLES;
+    // Retained blocks (mode I): the unfinished frame at the end of a block is not copied into the stream's frame buffer -- the next
+    // call reads it where it is.  A frame may then lie in the frame buffer, the previous block and the current block.  With blocks of
+    // a frame's length or more every pending frame completes inside the next block; with the ring form's blocks (at most a frame
+    // minus a correlation window) the few streams whose frame began in the last samples of the previous block copy those samples
+    // themselves at the start of the call (stream_advance_kernel); a shorter block copies all carried samples first, like a release.
+    const bool use_retain = retain && G.mode == 1;
+    const bool prev_valid = b->carry_pending && n_samples >= (size_t)(NB_FRAME_SAMPLES - NB_CORR);
     if (b->carry_pending && !prev_valid) {
         hipLaunchKernelGGL(stream_copy_kernel<SRC>, dim3(COPY_WGS, (unsigned)n), dim3(256), 0, s, b->view, 0, static_cast<const uint8_t*>(d_prev),
                            stream_stride_samples);
@@ -737,8 +751,8 @@ int dabgpu_stream_bank_process_raw(dabgpu_stream_bank* b, const void* d_raw, int
 }
 
 // frames go straight into per-stream frame-history rings (the layout dabgpu_fic_decode_ring / dabgpu_msc_decode_ring read)
-int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
-                                           int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, int bits_layout, void* stream) {
+static int bank_process_ring_any(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                 int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, int bits_layout, void* stream, const void* d_prev, int retain) {
     if (!b || !d_raw || !d_hist || !d_newest_slot) { dabgpu_set_error("stream_bank_process_ring: null argument"); return DABGPU_ERR_INVALID_ARG; }
     if (hist_frames < 5) { dabgpu_set_error("stream_bank_process_ring: the ring needs at least 5 frames"); return DABGPU_ERR_INVALID_ARG; }
     if (bits_layout != DABGPU_BITS_NATURAL && bits_layout != DABGPU_BITS_MSC_CLASSED) {
@@ -751,17 +765,28 @@ int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank* b, const void* d_
     }
     switch (format) {
     case DABGPU_IQ_RAW_F32L: case DABGPU_IQ_WAV_F32:
-        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
+        return bank_process_impl<0>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed, d_prev, retain);
     case DABGPU_IQ_RAW_U8: case DABGPU_IQ_WAV_PCM8:
-        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
+        return bank_process_impl<1>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed, d_prev, retain);
     case DABGPU_IQ_RAW_S8:
-        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
+        return bank_process_impl<2>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed, d_prev, retain);
     case DABGPU_IQ_RAW_S16L: case DABGPU_IQ_WAV_PCM16:
-        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed);
+        return bank_process_impl<3>(b, d_raw, stream_stride_samples, n_samples, d_hist, (size_t)hist_frames, d_newest_slot, stream, 1, classed, d_prev, retain);
     default:
         dabgpu_set_error("stream_bank_process_ring: format %d is not read directly (use raw_f32l, raw_u8, raw_s8 or raw_s16l)", format);
         return DABGPU_ERR_UNSUPPORTED;
     }
+}
+
+int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                           int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, int bits_layout, void* stream) {
+    return bank_process_ring_any(b, d_raw, format, stream_stride_samples, n_samples, d_hist, hist_frames, d_newest_slot, bits_layout, stream, nullptr, 0);
+}
+
+int dabgpu_stream_bank_process_ring_retained(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,
+                                             const void* d_prev_raw, int8_t* d_hist, int hist_frames, int32_t* d_newest_slot, int bits_layout,
+                                             void* stream) {
+    return bank_process_ring_any(b, d_raw, format, stream_stride_samples, n_samples, d_hist, hist_frames, d_newest_slot, bits_layout, stream, d_prev_raw, 1);
 }
 
 int dabgpu_stream_bank_process_ring(dabgpu_stream_bank* b, const void* d_raw, int format, size_t stream_stride_samples, size_t n_samples,

@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "dabgpu_msc_decode_ring_layout", "dabgpu_ofdm_demod_phase_frames", "dabgpu_decode_frames_layout", "dabgpu_decode_ring_layout",
     "dabgpu_frame_session_create", "dabgpu_frame_session_destroy", "dabgpu_frame_session_set_subchannels", "dabgpu_frame_session_push_frame",
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
-    "dabgpu_viterbi_decode_depunctured_host_sync",
+    "dabgpu_viterbi_decode_depunctured_host_sync", "dabgpu_stream_bank_process_ring_retained",
     "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
@@ -224,6 +224,8 @@ def lib():
                                                       C.c_void_p, C.c_void_p]
         L.dabgpu_stream_bank_process_ring_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
                                                              C.c_void_p, C.c_int, C.c_void_p]
+        L.dabgpu_stream_bank_process_ring_retained.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                                               C.c_void_p, C.c_int, C.c_void_p]
         L.dabgpu_msc_decode_ring_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dabgpu_fic_decode_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -595,6 +597,13 @@ class StreamBank:
             return
         check(lib().dabgpu_stream_bank_process_ring(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(hist), hist_frames,
                                                     _ptr(newest_slot), Context._stream(stream)), "dabgpu_stream_bank_process_ring")
+
+    def process_ring_retained(self, raw, fmt, stream_stride_samples, n_samples, prev_raw, hist, hist_frames, newest_slot, stream=None, bits_layout=BITS_NATURAL):
+        """process_ring for callers that keep `raw` valid and unchanged until the NEXT call has returned (no carry-over copy);
+        prev_raw = the block of the previous retained call (None at the first)"""
+        check(lib().dabgpu_stream_bank_process_ring_retained(self._h, _ptr(raw), int(fmt), stream_stride_samples, n_samples, _ptr(prev_raw), _ptr(hist),
+                                                             hist_frames, _ptr(newest_slot), int(bits_layout), Context._stream(stream)),
+              "dabgpu_stream_bank_process_ring_retained")
 
     def status(self, stream=None):
         import numpy as np

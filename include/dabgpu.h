@@ -585,6 +585,14 @@ int dabgpu_stream_bank_process_ring(dabgpu_stream_bank *bank, const void *d_raw,
 int dabgpu_stream_bank_process_ring_layout(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
                                            size_t n_samples, int8_t *d_hist, int hist_frames, int32_t *d_newest_slot,
                                            int bits_layout, void *stream);
+/* The ring form with retained blocks (dabgpu_stream_bank_process_retained's contract: d_raw stays valid and unchanged until the NEXT call has
+ * returned; d_prev_raw = the previous call's block, NULL at the first call / after a release or reset): the unfinished frame at the end of a
+ * block stays where it is and the next call's demodulator reads it there -- in the ring form, whose blocks are shorter than a frame, the copy
+ * it saves is half a frame per stream and call on average (and a u8 -> complex float expansion).  A frame that began in the last samples of a
+ * block and cannot complete in the next one has those few samples copied at the start of the next call.  Same frames, same state, bit for bit. */
+int dabgpu_stream_bank_process_ring_retained(dabgpu_stream_bank *bank, const void *d_raw, int format, size_t stream_stride_samples,
+                                             size_t n_samples, const void *d_prev_raw, int8_t *d_hist, int hist_frames,
+                                             int32_t *d_newest_slot, int bits_layout, void *stream);
 /* snapshot of every stream's getters (GetState, GetSignalAverage, Get*FrequencyOffset, ...) into host memory; synchronous */
 int dabgpu_stream_bank_status(dabgpu_stream_bank *bank, dabgpu_stream_status *h_status, void *stream);
 

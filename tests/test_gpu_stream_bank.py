@@ -413,3 +413,53 @@ def test_retained_blocks_in_two_lanes(oracle):
     assert frames >= 10
     for bk in banks:
         bk.close()
+
+
+@pytest.mark.parametrize("block,layout", [(191400, 1), (191399, 0), (150001, 1), (60000, 0)])
+@pytest.mark.parametrize("name", ["raw_u8", "raw_f32l", "raw_s16l"])
+def test_ring_form_with_retained_blocks_equals_the_copying_ring_form(oracle, name, block, layout):
+    """dabgpu_stream_bank_process_ring_retained against dabgpu_stream_bank_process_ring_layout on the same blocks: the ring form's blocks
+    are shorter than a frame, so a frame regularly lies in three places -- frame buffer (the PRS head), previous block, current block --
+    and a frame that began in the last samples of a block cannot complete in the next one (those samples are copied at the start of the
+    next call).  Ring contents, slots and every status field after every call; the largest block the ring form takes, an odd one (pair
+    boundaries), a shorter one and one that takes the bulk-copy path; drop-outs (re-acquisition) and a noise-only stream."""
+    import dabgpu
+    import torch
+    ctx = dabgpu.Context(0)
+    base = [make_stream(oracle, 41, 5, 1.8e-3, 1235, 3.0), make_stream(oracle, 42, 5, -7.3e-3, 78, 6.0),
+            make_stream(oracle, 43, 5, 2.0e-4, 191400 - 2656 - 20000 - 3000, 1.0),      # its first frame begins in the last 3000 samples of a 191400-sample block
+            make_stream(oracle, 44, 5, 3.1e-3, 2551, 1.0, dropout=(415000, 435000)), noise_with_dips(45, streams_len=1000000)]
+    n = min(s.size for s in base)
+    E, H = len(base), 6
+    fmt = dabgpu.IQ_FORMATS.index(name)
+    if name == "raw_f32l":
+        q = np.stack([np.stack([s[:n].real, s[:n].imag], axis=-1).astype(np.float32) for s in base])
+    elif name == "raw_u8":
+        q = np.stack([np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 127.0 + 127.5), 0, 255).astype(np.uint8) for s in base])
+    else:
+        q = np.stack([np.clip(np.rint(np.stack([s[:n].real, s[:n].imag], axis=-1) / np.abs(s[:n]).max() * 30000.0), -32768, 32767).astype(np.int16) for s in base])
+    banks = [dabgpu.StreamBank(ctx, E), dabgpu.StreamBank(ctx, E)]                 # [0] copies, [1] retained
+    bufs = [torch.zeros((E, block, 2), dtype=torch.from_numpy(q[:1, :1]).dtype, device="cuda") for _ in range(3)]
+    hist = [torch.zeros((E, H, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device="cuda") for _ in range(2)]
+    slot = [torch.full((E,), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
+    prev, call, frames = None, 0, 0
+    for k in range(0, n, block):
+        m = min(block, n - k)
+        cur = bufs[1 + call % 2]
+        cur[:, :m] = torch.from_numpy(q[:, k:k + m]).cuda()
+        bufs[0][:, :m] = cur[:, :m]
+        banks[0].process_ring(bufs[0], fmt, block, m, hist[0], H, slot[0], bits_layout=layout)
+        banks[1].process_ring_retained(cur, fmt, block, m, prev, hist[1], H, slot[1], bits_layout=layout)
+        torch.cuda.synchronize()
+        bufs[0].fill_(0 if name != "raw_u8" else 9)                              # the copying bank's block is free to go
+        assert torch.equal(slot[0], slot[1]), (k, slot[0].tolist(), slot[1].tolist())
+        assert torch.equal(hist[0], hist[1]), k
+        s0, s1 = banks[0].status(), banks[1].status()
+        for f in s0.dtype.names:
+            a, b = (x[f].view(np.uint32) if x[f].dtype == np.float32 else x[f] for x in (s0, s1))
+            assert np.array_equal(a, b), (k, f)
+        frames += int((slot[0] >= 0).sum().item())
+        prev, call = cur, call + 1
+    assert frames >= 12 and hist[0].abs().sum().item() > 0
+    for bk in banks:
+        bk.close()

@@ -30,7 +30,7 @@ REALTIME_FRAMES_PER_S = 2.048e6 / 196608
 
 
 def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8, seed=31, layout=1, rs_errors=1, with_dabplus=True, noise=0.05,
-              sequential_steps=4):
+              sequential_steps=4, retained=True):
     import numpy as np
     import dabsynth
     prs, mapper, _ = dabgpu.host_tables()
@@ -66,13 +66,20 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
     d_nb = torch.full((S,), nb, dtype=torch.int32, device=device)
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
     pos = [0]
+    prev = [None]
     ev_dec = [None, None]
 
     def front(j, stream):
-        """block j of every receiver through the stream bank (synchronises with `stream`: the number of rounds depends on the data)"""
+        """block j of every receiver through the stream bank (synchronises with `stream`: the number of rounds depends on the data).
+        retained: the capture buffer outlives every call (a ring of device buffers does, dabgpu_ingest_*), so the bank leaves the
+        unfinished frame at a block's end where it is (dabgpu_stream_bank_process_ring_retained)"""
         p = pos[0]
         pos[0] = (p + BLOCK) % rep
-        bank.process_ring(raw.data_ptr() + 2 * p, fmt_u8, stride, BLOCK, hist, H, slots[j % 2], stream=stream.cuda_stream, bits_layout=layout)
+        if retained:
+            bank.process_ring_retained(raw.data_ptr() + 2 * p, fmt_u8, stride, BLOCK, prev[0], hist, H, slots[j % 2], stream=stream.cuda_stream, bits_layout=layout)
+            prev[0] = raw.data_ptr() + 2 * p
+        else:
+            bank.process_ring(raw.data_ptr() + 2 * p, fmt_u8, stride, BLOCK, hist, H, slots[j % 2], stream=stream.cuda_stream, bits_layout=layout)
 
     def back(j, stream):
         c = ctx2
@@ -185,6 +192,7 @@ def run_chain(ctx, dabgpu, torch, device, E, n_distinct, steps=12, warm_steps=8,
            "frames_per_s_one_stream": (f2 - f1) / dt_seq, "ms_per_step_one_stream": dt_seq / sequential_steps * 1e3,
            "stage_ms_one_at_a_time": {"stream_bank_process_ring": t_front, "decode_ring_fic_and_msc": t_dec},
            "history_layout": "time-interleaver class order" if layout else "natural",
+           "blocks": "retained (dabgpu_stream_bank_process_ring_retained: no carry-over copy)" if retained else "copied (dabgpu_stream_bank_process_ring_layout)",
            "input_bytes_per_frame": 2 * dabsynth.NB_FRAME_SAMPLES, "generation_s_untimed": t_gen, "check": chk}
     bank.close()
     if dp is not None:
@@ -203,6 +211,7 @@ def main():
     ap.add_argument("--hist-layout", choices=("classed", "natural"), default="classed")
     ap.add_argument("--rs-errors", type=int, default=1)
     ap.add_argument("--no-dabplus", action="store_true")
+    ap.add_argument("--copying", action="store_true", help="the ring form that copies the unfinished frame at a block's end (blocks need not outlive the call)")
     a = ap.parse_args()
     import torch
     import dabgpu
@@ -210,7 +219,7 @@ def main():
     torch.cuda.set_device(0)
     ctx = dabgpu.Context(0)
     out = run_chain(ctx, dabgpu, torch, device, a.ensembles, a.distinct, steps=a.steps, layout=int(a.hist_layout == "classed"),
-                    rs_errors=a.rs_errors, with_dabplus=not a.no_dabplus)
+                    rs_errors=a.rs_errors, with_dabplus=not a.no_dabplus, retained=not a.copying)
     print(json.dumps(out))
 
 
