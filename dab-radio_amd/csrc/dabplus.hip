@@ -216,15 +216,42 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         for (int k = lane; k < sf_bytes; k += 64) L.sf[k] = acc[k];
         if (lane == 0) { L.flags[1] = -1; L.flags[2] = 0; }
         __syncthreads();
-        // syndromes: work item = (codeword i, root r)
-        for (int w = lane; w < n_rs * RS_ROOTS; w += 64) {
-            const int i = w / RS_ROOTS, r = w - i * RS_ROOTS;
-            uint8_t sy = 0;
-            for (int j = 0; j < RS_N; j++) {
-                const uint8_t m = sy ? L.exp[L.log[sy] + r] : (uint8_t)0;
-                sy = (uint8_t)(m ^ L.sf[i + j * n_rs]);
+        // syndromes S_r(i) = sum_j c_j alpha^(r (119 - j)) -- what Horner's rule over the codeword (sy = sy alpha^r + c_j) evaluates.
+        // When the codewords divide the wavefront (n_rs = 1, 2, 4, ... 64: every frame size of 24 x 2^k bytes, 192 among them) lane
+        // (i, q) adds the terms of symbols j = q, q + 64 / n_rs, ... of codeword i for all ten roots -- independent table look-ups
+        // instead of Horner's chain of 120 dependent ones -- and the partial sums of a codeword's lanes are folded by XOR shuffles
+        // (GF(2^8) addition: exact, order-free).  Other sizes keep the (codeword, root) Horner form.
+        if ((64 % n_rs) == 0) {
+            const int per = 64 / n_rs, i = lane % n_rs, q = lane / n_rs;
+            uint32_t w0 = 0, w1 = 0, w2 = 0;                               // roots 0-3, 4-7, 8-9: one byte each
+            for (int j = q; j < RS_N; j += per) {
+                const uint8_t cj = L.sf[i + j * n_rs];
+                if (cj) {
+                    const int lc = L.log[cj], e = RS_N - 1 - j;
+                    int t = 0;                                             // (r e) mod 255
+#pragma unroll
+                    for (int r = 0; r < RS_ROOTS; r++) {
+                        const uint32_t term = L.exp[lc + t];
+                        if (r < 4) w0 ^= term << (8 * r); else if (r < 8) w1 ^= term << (8 * (r - 4)); else w2 ^= term << (8 * (r - 8));
+                        t += e; if (t >= 255) t -= 255;
+                    }
+                }
             }
-            L.syn[w] = sy;
+            for (int sft = 32; sft >= n_rs; sft >>= 1) { w0 ^= (uint32_t)__shfl_xor((int)w0, sft); w1 ^= (uint32_t)__shfl_xor((int)w1, sft); w2 ^= (uint32_t)__shfl_xor((int)w2, sft); }
+            if (q == 0) {
+#pragma unroll
+                for (int r = 0; r < RS_ROOTS; r++) L.syn[i * RS_ROOTS + r] = (uint8_t)(((r < 4) ? (w0 >> (8 * r)) : (r < 8) ? (w1 >> (8 * (r - 4))) : (w2 >> (8 * (r - 8)))) & 0xFFu);
+            }
+        } else {
+            for (int w = lane; w < n_rs * RS_ROOTS; w += 64) {             // work item = (codeword i, root r)
+                const int i = w / RS_ROOTS, r = w - i * RS_ROOTS;
+                uint8_t sy = 0;
+                for (int j = 0; j < RS_N; j++) {
+                    const uint8_t m = sy ? L.exp[L.log[sy] + r] : (uint8_t)0;
+                    sy = (uint8_t)(m ^ L.sf[i + j * n_rs]);
+                }
+                L.syn[w] = sy;
+            }
         }
         __syncthreads();
         int my_cnt = 0;
