@@ -39,6 +39,20 @@ constexpr GfTables make_gf() {
 }
 __constant__ GfTables GF_TABLES = make_gf();
 
+// fire code x^16+x^14+x^13+x^12+x^11+x^5+x^3+x^2+x+1 over the 72 bits after the check word, zero start value: message bit b (0 = MSB of
+// the first byte) contributes x^(16 + 71 - b) mod p(x); the check word is the XOR of the contributions of the set bits
+struct FireTab { uint16_t w[72]; };
+constexpr FireTab make_fire_tab() {
+    FireTab t{};
+    unsigned c = 0x782Fu;                                    // x^16 mod p
+    for (int p = 0; p < 72; p++) {
+        t.w[71 - p] = (uint16_t)c;
+        c = (c & 0x8000u) ? (((c << 1) ^ 0x782Fu) & 0xFFFFu) : ((c << 1) & 0xFFFFu);
+    }
+    return t;
+}
+__constant__ FireTab FIRE_TAB = make_fire_tab();
+
 struct DpLds {
     uint8_t exp[512];
     uint8_t log[256];
@@ -46,6 +60,7 @@ struct DpLds {
     uint8_t sf[DP_MAX_SF];
     uint8_t syn[64 * RS_ROOTS];
     int flags[4];
+    int au[8];                       // access-unit start offsets of the super frame being checked
 };
 
 struct DpState {                     // per stream, persistent
@@ -139,17 +154,30 @@ __device__ int rs_decode_lane(DpLds& L, int i, int n_rs) {
     return count;
 }
 
-__device__ __forceinline__ uint16_t crc16_bits(const uint8_t* x, int n, uint16_t poly, uint16_t init) {
-    uint16_t crc = init;
-    for (int i = 0; i < n; i++) {
-        crc ^= (uint16_t)((uint16_t)x[i] << 8);
+// fire code of the 9 bytes at x, by the whole wavefront: lane l takes message bits l and l + 64; every lane returns the check word
+__device__ __forceinline__ uint16_t firecode_wave(const uint8_t* x, int lane) {
+    uint32_t v = ((x[lane >> 3] >> (7 - (lane & 7))) & 1) ? FIRE_TAB.w[lane] : 0u;
+    if (lane < 8 && ((x[8] >> (7 - lane)) & 1)) v ^= FIRE_TAB.w[64 + lane];
 #pragma unroll
-        for (int j = 0; j < 8; j++) crc = (crc & 0x8000u) ? (uint16_t)((crc << 1) ^ poly) : (uint16_t)(crc << 1);
-    }
-    return crc;
+    for (int sft = 32; sft > 0; sft >>= 1) v ^= (uint32_t)__shfl_xor((int)v, sft);
+    return (uint16_t)v;
 }
 
-__global__ __launch_bounds__(64)
+// a(x) b(x) mod x^16+x^12+x^5+1 (16-bit residues)
+__device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        r ^= (0u - ((b >> i) & 1u)) & a;
+        a = (a << 1) ^ ((0u - ((a >> 15) & 1u)) & 0x11021u);
+    }
+    return r;
+}
+
+// 9.6 KB of LDS per workgroup lets 16 single-wave workgroups share a CU = 4 per SIMD: hold the kernel to the 128 VGPRs that allows (the
+// spilled values belong to the per-lane Berlekamp-Massey / Chien / Forney path; measured 0.224 / 0.169 / 0.153 ms per 18,432 clean super
+// frames at 2 / 3 / 4 waves per SIMD, profiles/r04/ab_notes.md)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ frames, const unsigned long long* __restrict__ stream_offsets,
                     size_t frame_stride, const uint32_t* __restrict__ frame_bytes, int n_frames, uint8_t* __restrict__ sf_acc,
                     uint8_t* __restrict__ sf_out, size_t sf_out_stride, dabgpu_superframe_result* __restrict__ results, int max_sf,
@@ -190,16 +218,10 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         if (st.desync_count >= 10) { st.desync_count = 0; st.synced = 0; }                           // :151-154
         if (st.synced) st.wait_frame_start = 0;                                                       // :158-160
         if (st.wait_frame_start) {                                                                    // :162-166
-            if (lane == 0) {
-                const uint16_t rx = (uint16_t)((frame[0] << 8) | frame[1]);
-                const uint16_t calc = crc16_bits(frame + 2, 9, 0x782Fu, 0);
-                L.flags[0] = (rx == calc) ? 1 : 0;
-                L.flags[1] = (int)(((uint32_t)rx << 16) | calc);
-            }
-            __syncthreads();
-            const int ok = L.flags[0];
-            if (!ok) last_wait_crc = L.flags[1];
-            __syncthreads();
+            const uint16_t rx = (uint16_t)((frame[0] << 8) | frame[1]);
+            const uint16_t calc = firecode_wave(frame + 2, lane);
+            const int ok = (rx == calc);
+            if (!ok) last_wait_crc = (int)(((uint32_t)rx << 16) | calc);
             if (!ok) { n_wait_failed++; continue; }
             st.wait_frame_start = 0;
         }
@@ -285,16 +307,11 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         }
         res.rs_corrected = L.flags[2];
         if (good) {
-            if (lane == 0) {
-                const uint16_t rx = (uint16_t)((L.sf[0] << 8) | L.sf[1]);
-                const uint16_t calc = crc16_bits(L.sf + 2, 9, 0x782Fu, 0);
-                L.flags[0] = (rx == calc) ? 1 : 0;
-                L.flags[1] = (int)(((uint32_t)rx << 16) | calc);
-            }
-            __syncthreads();
-            good = L.flags[0] != 0;
+            const uint16_t rx = (uint16_t)((L.sf[0] << 8) | L.sf[1]);
+            const uint16_t calc = firecode_wave(L.sf + 2, lane);
+            good = (rx == calc);
             res.firecode_ok = good ? 1 : 0;
-            res.firecode_rx_calc = (uint32_t)L.flags[1];
+            res.firecode_rx_calc = ((uint32_t)rx << 16) | calc;
         }
         if (!good) {
             st.desync_count++;
@@ -308,35 +325,72 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
             const int num_aus = dac_rate ? (sbr ? 3 : 6) : (sbr ? 2 : 4);
             res.num_aus = num_aus;
             int bit = 0;
-            for (int a = 1; a < num_aus; a++) {
-                int v = 0;
-                for (int b = 0; b < 12; b++, bit++) v = (v << 1) | ((L.sf[3 + (bit >> 3)] >> (7 - (bit & 7))) & 1);
-                res.au_start[a] = v;
+#pragma unroll
+            for (int a = 1; a < 6; a++) {
+                if (a < num_aus) {
+                    int v = 0;
+                    for (int b = 0; b < 12; b++, bit++) v = (v << 1) | ((L.sf[3 + (bit >> 3)] >> (7 - (bit & 7))) & 1);
+                    res.au_start[a] = v;
+                }
             }
             res.au_start[0] = 3 + ((bit + 7) >> 3);
-            res.au_start[num_aus] = 110 * n_rs;
+#pragma unroll
+            for (int a = 2; a <= 6; a++) if (a == num_aus) res.au_start[a] = 110 * n_rs;
             // the walk stops at the first access unit that fails the bounds test (:291-297)
             int stop = -1;
-            for (int a = 0; a < num_aus; a++) {
-                const int nb_data = res.au_start[a + 1] - res.au_start[a] - 2;
-                if (nb_data < 0 || res.au_start[a + 1] >= sf_bytes) { stop = a; break; }
+#pragma unroll
+            for (int a = 5; a >= 0; a--) {
+                if (a < num_aus) {
+                    const int nb_data = res.au_start[a + 1] - res.au_start[a] - 2;
+                    if (nb_data < 0 || res.au_start[a + 1] >= sf_bytes) stop = a;
+                }
             }
             res.au_walk_stopped_at = stop;
             const int walked = (stop < 0) ? num_aus : stop;
+            // access-unit CRCs (x^16+x^12+x^5+1, start value 0xFFFF, inverted).  An access unit is shared by `per` lanes: with the
+            // start value folded into its first two bytes the register is linear in the message, so the unit is padded at the FRONT
+            // with zero bytes to per x c, lane q runs chunk q from a zero register (and x^(8c) beside it, on the same table), and the
+            // chunks are joined pairwise -- left x^(8 c 2^k) + right -- in log2(per) rounds of shuffles.
             if (lane == 0) L.flags[0] = 0;
+            if (lane == 0) {
+#pragma unroll
+                for (int a = 0; a <= 6; a++) L.au[a] = res.au_start[a];
+            }
             __syncthreads();
-            if (lane < walked) {
-                const int a0 = res.au_start[lane], nb_data = res.au_start[lane + 1] - a0 - 2;
-                uint16_t crc = 0xFFFF;
-                for (int k = 0; k < nb_data; k++) crc = (uint16_t)((crc << 8) ^ L.crc_tab[((crc >> 8) ^ L.sf[a0 + k]) & 0xFF]);
-                crc ^= 0xFFFF;
-                const uint16_t rx = (uint16_t)((L.sf[a0 + nb_data] << 8) | L.sf[a0 + nb_data + 1]);
-                if (rx == crc) atomicOr(&L.flags[0], 1 << lane);
-                L.syn[2 * lane] = (uint8_t)(crc >> 8); L.syn[2 * lane + 1] = (uint8_t)(crc & 0xFF);     // syndromes are done with
+            {
+                const int lg = (num_aus <= 2) ? 5 : (num_aus <= 4) ? 4 : 3, per = 1 << lg;
+                const int a = lane >> lg, q = lane & (per - 1);
+                const bool mine = a < walked;
+                const int a0 = mine ? L.au[a] : 0, nb_data = mine ? (L.au[a + 1] - a0 - 2) : 0;
+                uint32_t state = 0, m = 1;
+                if (nb_data >= 2) {
+                    const int c = (nb_data + per - 1) >> lg, z = per * c - nb_data;
+                    for (int t = 0, k = q * c - z; t < c; t++, k++) {
+                        uint32_t byte = (k >= 0) ? L.sf[a0 + k] : 0u;
+                        if (k == 0 || k == 1) byte ^= 0xFFu;
+                        state = ((state << 8) ^ L.crc_tab[((state >> 8) ^ byte) & 0xFFu]) & 0xFFFFu;
+                        m = ((m << 8) ^ L.crc_tab[(m >> 8) & 0xFFu]) & 0xFFFFu;
+                    }
+                } else if (nb_data == 1 && q == per - 1) {
+                    state = 0xFFFFu;
+                    state = ((state << 8) ^ L.crc_tab[((state >> 8) ^ L.sf[a0]) & 0xFFu]) & 0xFFFFu;
+                } else if (q == per - 1) state = 0xFFFFu;
+                for (int d = 1; d < per; d <<= 1) {
+                    const uint32_t left = (uint32_t)__shfl_xor((int)state, d);
+                    if (q & d) state ^= crc_mulmod(left, m);
+                    m = crc_mulmod(m, m);
+                }
+                if (mine && q == per - 1) {
+                    const uint16_t crc = (uint16_t)(state ^ 0xFFFFu);
+                    const uint16_t rx = (uint16_t)((L.sf[a0 + nb_data] << 8) | L.sf[a0 + nb_data + 1]);
+                    if (rx == crc) atomicOr(&L.flags[0], 1 << a);
+                    L.syn[2 * a] = (uint8_t)(crc >> 8); L.syn[2 * a + 1] = (uint8_t)(crc & 0xFF);       // syndromes are done with
+                }
             }
             __syncthreads();
             res.au_crc_ok_mask = (uint32_t)L.flags[0];
-            for (int a = 0; a < walked; a++) res.au_crc_calc[a] = (uint16_t)((L.syn[2 * a] << 8) | L.syn[2 * a + 1]);
+#pragma unroll
+            for (int a = 0; a < 6; a++) if (a < walked) res.au_crc_calc[a] = (uint16_t)((L.syn[2 * a] << 8) | L.syn[2 * a + 1]);
         }
         // hand the (corrected) super frame and its record to the caller
         if (n_sf < max_sf) {
