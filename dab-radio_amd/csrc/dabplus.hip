@@ -6,8 +6,10 @@
 //   fire code of the corrected super frame (:206-209), header walk (:215-283) and access-unit CRCs (:286-317),
 //   re-acquisition after 10 failed super frames (:151-154).
 // One wavefront per stream (an (ensemble, sub-channel) pair); its acquisition state and the super frame being collected
-// live in HBM between calls.  Syndromes are computed 64 (codeword, root) pairs at a time from an LDS copy of the super
-// frame; a codeword with a non-zero syndrome is decoded by one lane (all codewords of a super frame in parallel).
+// live in HBM between calls.  Syndromes: every lane adds the terms of a share of one codeword's symbols for all ten roots
+// (XOR shuffles fold the shares); a codeword with a non-zero syndrome gets its error locator from ONE lane (Berlekamp-Massey,
+// all codewords of the super frame in parallel), the Chien search and Forney's corrections are dealt over all 64 lanes; the
+// access-unit CRCs are shared by 8-32 lanes each.  LDS table look-ups throughout (GF(2^8) log / exp, CRC-16).
 // Integer / byte work, bit-exact by construction; checked against the oracle and the reference-generated vectors.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,7 +58,12 @@ __constant__ FireTab FIRE_TAB = make_fire_tab();
 struct DpLds {
     uint8_t exp[512];
     uint8_t log[256];
-    uint16_t crc_tab[256];           // CRC-16 x^16+x^12+x^5+1, MSB first (access units)
+    // CRC-16 x^16+x^12+x^5+1 table, MSB first (access units) -- or, while a super frame's codewords are being corrected, one record per
+    // codeword: error-locator coefficients C_1..C_10, then (word at +12) degree | roots found << 8.  The table is rebuilt afterwards.
+    union {
+        uint16_t crc_tab[256];
+        uint8_t rs_rec[64 * 16];
+    };
     uint8_t sf[DP_MAX_SF];
     uint8_t syn[64 * RS_ROOTS];
     int flags[4];
@@ -71,9 +78,15 @@ __device__ __forceinline__ uint8_t gmul(const DpLds& L, uint8_t a, uint8_t b) { 
 __device__ __forceinline__ uint8_t gdiv(const DpLds& L, uint8_t a, uint8_t b) { return a ? L.exp[L.log[a] + 255 - L.log[b]] : (uint8_t)0; }
 __device__ __forceinline__ uint8_t gpow(const DpLds& L, int e) { e %= 255; if (e < 0) e += 255; return L.exp[e]; }
 
-// one lane decodes codeword `i` of the super frame held in L.sf (columns interleaved with stride n_rs) from its syndromes;
-// returns the number of located errors or -1 (restates dab_rs120_decode of the oracle)
-__device__ int rs_decode_lane(DpLds& L, int i, int n_rs) {
+// RS(120,110) decoding of a super frame's codewords (restates dab_rs120_decode of the oracle), in two phases:
+// rs_locator: ONE lane per codeword with a non-zero syndrome runs Berlekamp-Massey and leaves the error locator (C_1..C_10, degree) in the
+// codeword's record and the evaluator omega = S C mod x^deg in place of the syndromes;
+// rs_search_and_correct: the Chien search over alpha^1..alpha^255 and Forney's formula are shared by ALL lanes -- the wavefront's lanes are
+// dealt to the codewords (64 / n_rs each), every lane scans its share of the 255 candidates and corrects the symbol of each root it
+// finds, counting it in the record.  A locator of degree d has at most d roots, so scanning all candidates finds what the reference's scan
+// (which stops after d) finds; corrections made for a codeword that then turns out uncorrectable (roots != degree) are undone by the
+// caller from the received bytes.
+__device__ void rs_locator(DpLds& L, int i) {
     uint8_t S[RS_ROOTS];
 #pragma unroll
     for (int r = 0; r < RS_ROOTS; r++) S[r] = L.syn[i * RS_ROOTS + r];
@@ -109,41 +122,48 @@ __device__ int rs_decode_lane(DpLds& L, int i, int n_rs) {
     int deg = 0;
 #pragma unroll
     for (int k = 0; k <= RS_ROOTS; k++) if (C[k]) deg = k;
-    int root[RS_ROOTS], count = 0;
-    int reg[RS_ROOTS + 1];                                   // log C_k + x k (mod 255), advanced incrementally
-#pragma unroll
-    for (int k = 1; k <= RS_ROOTS; k++) reg[k] = L.log[C[k]];
-    for (int x = 1; x <= 255 && count < deg; x++) {
-        uint8_t q = 1;
-#pragma unroll
-        for (int k = 1; k <= RS_ROOTS; k++) {
-            if (k <= deg && C[k]) {
-                reg[k] += k;
-                if (reg[k] >= 255) reg[k] -= 255;
-                q ^= L.exp[reg[k]];
-            }
-        }
-        if (q) continue;
-#pragma unroll
-        for (int k = 0; k < RS_ROOTS; k++) if (k == count) root[k] = x;
-        count++;
-    }
-    if (count != deg) return -1;
-    uint8_t omega[RS_ROOTS];
 #pragma unroll
     for (int a = 0; a < RS_ROOTS; a++) {
         uint8_t t = 0;
 #pragma unroll
         for (int b = 0; b < RS_ROOTS; b++) if (b <= a) t ^= gmul(L, S[a - b < 0 ? 0 : a - b], C[b]);
-        omega[a] = t;
+        L.syn[i * RS_ROOTS + a] = t;                                    // omega_a (the syndromes are done with)
     }
-    for (int k = count - 1; k >= 0; k--) {
-        int rk = 0;
 #pragma unroll
-        for (int a = 0; a < RS_ROOTS; a++) if (a == k) rk = root[a];
+    for (int k = 1; k <= RS_ROOTS; k++) L.rs_rec[i * 16 + k - 1] = C[k];
+    *reinterpret_cast<int*>(&L.rs_rec[i * 16 + 12]) = deg;
+}
+
+__device__ void rs_search_and_correct(DpLds& L, int i, int q, int per, int n_rs) {
+    int* const rec = reinterpret_cast<int*>(&L.rs_rec[i * 16 + 12]);
+    const int deg = *rec & 0xFF;
+    if (deg == 0) return;
+    const int span = (255 + per - 1) / per, x0 = 1 + q * span, x1 = (x0 + span - 1 < 255) ? (x0 + span - 1) : 255;
+    uint8_t C[RS_ROOTS + 1];
+    int reg[RS_ROOTS + 1];                                   // log C_k + x k (mod 255), advanced incrementally
+    C[0] = 1;
+#pragma unroll
+    for (int k = 1; k <= RS_ROOTS; k++) {
+        C[k] = L.rs_rec[i * 16 + k - 1];
+        reg[k] = (L.log[C[k]] + k * (x0 - 1)) % 255;
+    }
+    for (int x = x0; x <= x1; x++) {
+        uint8_t v = 1;
+#pragma unroll
+        for (int k = 1; k <= RS_ROOTS; k++) {
+            if (k <= deg && C[k]) {
+                reg[k] += k;
+                if (reg[k] >= 255) reg[k] -= 255;
+                v ^= L.exp[reg[k]];
+            }
+        }
+        if (v) continue;
+        atomicAdd(rec, 0x100);
+        // Forney: e = omega(X^-1) X / C'(X^-1), first root alpha^0
+        const int rk = x;
         uint8_t num1 = 0, den = 0;
 #pragma unroll
-        for (int a = RS_ROOTS - 1; a >= 0; a--) if (a < deg) num1 ^= gmul(L, omega[a], gpow(L, a * rk));
+        for (int a = RS_ROOTS - 1; a >= 0; a--) if (a < deg) num1 ^= gmul(L, L.syn[i * RS_ROOTS + a], gpow(L, a * rk));
         const uint8_t num2 = gpow(L, -rk);
         const int top = ((deg < RS_ROOTS - 1) ? deg : (RS_ROOTS - 1)) & ~1;
 #pragma unroll
@@ -151,7 +171,6 @@ __device__ int rs_decode_lane(DpLds& L, int i, int n_rs) {
         const int loc = rk - 1;
         if (num1 != 0 && loc >= RS_PAD) L.sf[i + (loc - RS_PAD) * n_rs] ^= gdiv(L, gmul(L, num1, num2), den);
     }
-    return count;
 }
 
 // fire code of the 9 bytes at x, by the whole wavefront: lane l takes message bits l and l + 64; every lane returns the check word
@@ -276,12 +295,34 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
             }
         }
         __syncthreads();
-        int my_cnt = 0;
+        int any = 0;
         if (lane < n_rs) {
-            int any = 0;
 #pragma unroll
             for (int r = 0; r < RS_ROOTS; r++) any |= L.syn[lane * RS_ROOTS + r];
-            if (any) my_cnt = rs_decode_lane(L, lane, n_rs);
+        }
+        const bool decode = __any(any != 0);               // (clean super frames skip all of this and keep the CRC table)
+        int my_cnt = 0;
+        if (decode) {
+            __syncthreads();                                // every lane has read its syndromes; the records take the table's place
+            if (lane < n_rs) {
+                if (any) rs_locator(L, lane);
+                else *reinterpret_cast<int*>(&L.rs_rec[lane * 16 + 12]) = 0;
+            }
+            __syncthreads();
+            const int per = 64 / n_rs;                      // lanes per codeword (n_rs <= 64)
+            if (lane < per * n_rs) rs_search_and_correct(L, lane % n_rs, lane / n_rs, per, n_rs);
+            __syncthreads();
+            if (lane < n_rs) {
+                const int w = *reinterpret_cast<const int*>(&L.rs_rec[lane * 16 + 12]), deg = w & 0xFF, found = w >> 8;
+                my_cnt = (found == deg) ? deg : -1;
+            }
+            __syncthreads();
+            for (int k = lane; k < 256; k += 64) {          // the CRC table back in its place
+                uint16_t c = (uint16_t)(k << 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) c = (c & 0x8000u) ? (uint16_t)((c << 1) ^ 0x1021u) : (uint16_t)(c << 1);
+                L.crc_tab[k] = c;
+            }
         }
         __syncthreads();
         if (lane == 0) L.flags[3] = 0x7FFFFFFF;
@@ -299,7 +340,8 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         if (!good) {
             // the reference stops at the first uncorrectable codeword (:336-341): later codewords keep their received
             // symbols and the corrected-symbol count only covers the codewords before it
-            for (int k = lane; k < sf_bytes; k += 64) if ((k % n_rs) > first_fail) L.sf[k] = acc[k];
+            // (and the failed codeword itself: the shared search corrects as it finds roots, before their number is known)
+            for (int k = lane; k < sf_bytes; k += 64) if ((k % n_rs) >= first_fail) L.sf[k] = acc[k];
             if (lane == 0) L.flags[2] = 0;
             __syncthreads();
             if (my_cnt > 0 && lane < first_fail) atomicAdd(&L.flags[2], my_cnt);
