@@ -262,7 +262,7 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
         // (i, q) adds the terms of symbols j = q, q + 64 / n_rs, ... of codeword i for all ten roots -- independent table look-ups
         // instead of Horner's chain of 120 dependent ones -- and the partial sums of a codeword's lanes are folded by XOR shuffles
         // (GF(2^8) addition: exact, order-free).  Other sizes keep the (codeword, root) Horner form.
-        if ((64 % n_rs) == 0) {
+        if (n_rs > 0 && (64 % n_rs) == 0) {              // (frames below 24 bytes hold no codeword at all: n_rs = 0, nothing to correct)
             const int per = 64 / n_rs, i = lane % n_rs, q = lane / n_rs;
             uint32_t w0 = 0, w1 = 0, w2 = 0;                               // roots 0-3, 4-7, 8-9: one byte each
             for (int j = q; j < RS_N; j += per) {
@@ -309,7 +309,7 @@ void dabplus_kernel(DpState* __restrict__ states, const uint8_t* __restrict__ fr
                 else *reinterpret_cast<int*>(&L.rs_rec[lane * 16 + 12]) = 0;
             }
             __syncthreads();
-            const int per = 64 / n_rs;                      // lanes per codeword (n_rs <= 64)
+            const int per = 64 / n_rs;                      // lanes per codeword (1 <= n_rs <= 64 here: a non-zero syndrome exists)
             if (lane < per * n_rs) rs_search_and_correct(L, lane % n_rs, lane / n_rs, per, n_rs);
             __syncthreads();
             if (lane < n_rs) {

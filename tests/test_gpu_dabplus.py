@@ -200,3 +200,49 @@ def test_unsupported_frame_sizes_are_reported_per_stream(ctx):
     assert c[0, 0] == 0 and c[0, 1] == -1                            # 1600-byte frames: not supported by the bank kernel
     assert c[2, 0] == 0 and c[2, 1] == -2                            # 5 x 400 bytes do not fit the 960-byte slot
     assert c[1, 1] >= 0 and c[1, 0] + c[1, 1] >= 1                  # the 192-byte stream was processed (a super frame attempted or frames dropped)
+
+
+def test_frame_sizes_that_are_not_whole_codewords(ctx, oracle):
+    """the reference accepts any logical frame of at least 11 bytes (aac_frame_processor.cpp:129-137): below 24 bytes a super frame holds
+    NO RS codeword (nothing is corrected, the fire code and the header walk still run), sizes that are not multiples of 24 leave bytes
+    outside the codewords -- records and super-frame bytes must equal the oracle's for all of them"""
+    import dabgpu
+    import torch
+    rng = np.random.default_rng(17)
+    sizes = [11, 12, 23, 24, 25, 47, 100]
+    E, F = len(sizes), 10
+    max_n = max(sizes)
+    streams = np.zeros((E, F, max_n), np.uint8)
+    for e, n in enumerate(sizes):
+        for k in range(F // 5):
+            sf = rng.integers(0, 256, 5 * n, dtype=np.uint8)
+            fc = oracle.firecode_crc(sf[2:11])
+            sf[0], sf[1] = fc >> 8, fc & 0xFF
+            streams[e, 5 * k:5 * k + 5, :n] = sf.reshape(5, n)
+    bank = dabgpu.DabPlusBank(ctx, E)
+    d_off = torch.from_numpy((np.arange(E, dtype=np.int64) * (F * max_n))).cuda()
+    d_n = torch.from_numpy(np.array(sizes, np.int32)).cuda()
+    max_sf = 2
+    d_sf = torch.zeros((E, max_sf, 5 * max_n), dtype=torch.uint8, device="cuda")
+    rec = np.dtype(dabgpu.SUPERFRAME_RESULT_DTYPE)
+    d_res = torch.zeros((E, max_sf, rec.itemsize), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((E, 4), dtype=torch.int32, device="cuda")
+    bank.process(torch.from_numpy(streams).cuda(), d_off, max_n, d_n, F, d_sf, 5 * max_n, d_res, max_sf, d_cnt)
+    torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(rec).reshape(E, max_sf)
+    sfs, cnt = d_sf.cpu().numpy(), d_cnt.cpu().numpy()
+    done = 0
+    for e, n in enumerate(sizes):
+        proc = oracle.AacFrameProcessor()
+        k_sf = 0
+        for f in range(F):
+            _, o, sf_o = proc.process(streams[e, f, :n])
+            if o["superframe_done"]:
+                ok, field = same_record(res[e, k_sf], o)
+                assert ok, (n, f, field, res[e, k_sf], o)
+                assert np.array_equal(sfs[e, k_sf, :5 * n], sf_o), (n, f)
+                k_sf += 1
+        assert cnt[e, 0] == k_sf, (n, cnt[e], k_sf)
+        done += k_sf
+    assert done >= 2 * len(sizes) - 2
+    bank.close()
