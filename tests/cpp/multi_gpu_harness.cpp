@@ -1,10 +1,12 @@
 // multi_gpu_harness.cpp -- the C++ multi-device host of the batch path: one std::thread per listed device, each with its own
-// dabgpu contexts, streams and block of ensembles, running BASELINE configs[4]'s step (OFDM demodulation into the frame-history ring
-// -> FIC Viterbi -> MSC time de-interleave + Viterbi + descramble for 18 x 48 CU EEP 3-A) with two transmission frames in flight.
+// dabgpu contexts, streams and block of ensembles, running BASELINE configs[4]'s step (PRS synchronisation -> OFDM demodulation at the
+// position and with the carrier offset it found, into the frame-history ring -> fine-frequency update -> FIC Viterbi -> MSC time
+// de-interleave + Viterbi + descramble for 18 x 48 CU EEP 3-A) with two transmission frames in flight.  Every multiplex has its own
+// carrier offset (+-5 kHz) and timing offset (+-100 samples); `--aligned` = frame-aligned input, synchronisation bypassed (rounds 1-3).
 // Ensembles are independent, so there is no collective: this is the one-process form of what `bench.py --gpus N` does with one
 // process per GPU (replaces the per-frame fan-out of src/basic_radio/basic_radio.cpp:51-62 across a node).
 //
-//   multi_gpu_harness --devices 0,1,2,3 [--ensembles 8192] [--steps 10] [--distinct 8] [--inflight 2] [--identical]
+//   multi_gpu_harness --devices 0,1,2,3 [--ensembles 8192] [--steps 10] [--distinct 8] [--inflight 2] [--identical] [--aligned]
 // `--devices 0,0` runs two workers on ONE GPU (the -m gpu test: tests/test_gpu_multi_device.py).  Every worker generates its
 // multiplexes itself (seeded: energy dispersal, convolutional code, puncturing, FIB CRCs, QPSK / differential modulation / IFFT /
 // cyclic prefix -- the transmit side, written independently of the path under test), checks every decoded FIB and sub-channel byte of
@@ -31,6 +33,9 @@
 namespace {
 
 constexpr int N_SUB = 18, SUB_BYTES = 192, SUB_CU = 48, FRAME_BITS = 230400, FRAME_SAMPLES = 196608;
+// synchronised path: a receiver's slice = SLICE_LEAD samples before the expected PRS position, then room for the latest frame start the
+// synchroniser can report (dabgpu_ofdm_sync_demod_frames: stride >= offset + 1544 + 76 x 2552)
+constexpr int SLICE_LEAD = 1024, SLICE_SAMPLES = SLICE_LEAD + 1544 + FRAME_SAMPLES, FRAME_BODY = 76 * 2552;
 typedef std::complex<float> c32;
 
 struct Rng {                                                   // xorshift64*
@@ -195,7 +200,7 @@ struct Result {
 
 uint64_t fnv1a(uint64_t h, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001B3ull; } return h; }
 
-bool worker(int rank, int device, size_t E, int steps, int n_distinct, int inflight, int probe_step, Barrier* bar, Result* R) {
+bool worker(int rank, int device, size_t E, int steps, int n_distinct, int inflight, int probe_step, bool synced, Barrier* bar, Result* R) {
     // rank < 0 (--identical): every worker carries the same ensembles (equal digests), else worker r starts at multiplex r
     if (rank < 0) rank = 0;
     R->device = device;
@@ -212,19 +217,44 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
     std::vector<dabgpu_ctx*> ctx((size_t)inflight, nullptr);
     std::vector<hipStream_t> st((size_t)inflight, nullptr);
     for (int k = 0; k < inflight; k++) { DABCK(dabgpu_create(&ctx[(size_t)k], device, nullptr, nullptr)); HIPCK(hipStreamCreateWithFlags(&st[(size_t)k], hipStreamNonBlocking)); }
-    c32* d_iq = nullptr; int8_t* d_hist = nullptr;
-    HIPCK(hipMalloc((void**)&d_iq, E * FRAME_SAMPLES * sizeof(c32)));
+    // what a receiver is handed per transmission frame: the frame itself (aligned), or a slice around where it expects the frame, in
+    // which the frame begins toff samples off and carries the multiplex's carrier offset
+    const size_t in_samples = synced ? (size_t)SLICE_SAMPLES : (size_t)FRAME_SAMPLES;
+    c32* d_iq = nullptr; int8_t* d_hist = nullptr; dabgpu_sync_state* d_states = nullptr;
+    HIPCK(hipMalloc((void**)&d_iq, E * in_samples * sizeof(c32)));
     HIPCK(hipMalloc((void**)&d_hist, E * stride));
     HIPCK(hipMemset(d_hist, 0, E * stride));
+    HIPCK(hipMalloc((void**)&d_states, E * sizeof(dabgpu_sync_state)));
+    HIPCK(hipMemset(d_states, 0, E * sizeof(dabgpu_sync_state)));       // OFDM_Demod's constructed state: nothing found yet
     {
         c32* d_base = nullptr;
-        HIPCK(hipMalloc((void**)&d_base, (size_t)n_distinct * FRAME_SAMPLES * sizeof(c32)));
-        for (int d = 0; d < n_distinct; d++) HIPCK(hipMemcpy(d_base + (size_t)d * FRAME_SAMPLES, mux[(size_t)d].iq.data(), FRAME_SAMPLES * sizeof(c32), hipMemcpyHostToDevice));
+        HIPCK(hipMalloc((void**)&d_base, (size_t)n_distinct * in_samples * sizeof(c32)));
+        std::vector<c32> slice;
+        for (int d = 0; d < n_distinct; d++) {
+            const c32* src = mux[(size_t)d].iq.data();
+            if (synced) {
+                Rng rng(777u + (uint64_t)d);
+                const double cfo = ((double)rng.next() / 4294967296.0 * 2.0 - 1.0) * (5000.0 / 2.048e6);       // cycles per sample
+                const int toff = (int)(rng.next() % 201u) - 100;
+                slice.assign((size_t)SLICE_SAMPLES, c32(0.0f, 0.0f));
+                for (int n = 0; n < FRAME_BODY; n++) {
+                    const int at = SLICE_LEAD + toff + n;
+                    if (at < 0 || at >= SLICE_SAMPLES) continue;
+                    const double ph = 2.0 * 3.14159265358979323846 * cfo * (double)n;
+                    const std::complex<double> v = std::complex<double>(src[n].real(), src[n].imag()) * std::complex<double>(std::cos(ph), std::sin(ph));
+                    slice[(size_t)at] = c32((float)v.real(), (float)v.imag());
+                }
+                src = slice.data();
+            }
+            HIPCK(hipMemcpy(d_base + (size_t)d * in_samples, src, in_samples * sizeof(c32), hipMemcpyHostToDevice));
+        }
         for (size_t e = 0; e < E; e++)                                  // ensemble e of worker `rank` carries multiplex (e + rank) mod distinct
-            HIPCK(hipMemcpyAsync(d_iq + e * FRAME_SAMPLES, d_base + ((e + (size_t)rank) % (size_t)n_distinct) * FRAME_SAMPLES, FRAME_SAMPLES * sizeof(c32), hipMemcpyDeviceToDevice, st[0]));
+            HIPCK(hipMemcpyAsync(d_iq + e * in_samples, d_base + ((e + (size_t)rank) % (size_t)n_distinct) * in_samples, in_samples * sizeof(c32), hipMemcpyDeviceToDevice, st[0]));
         HIPCK(hipStreamSynchronize(st[0]));
         HIPCK(hipFree(d_base));
     }
+    dabgpu_sync_cfg sync_cfg;
+    dabgpu_sync_cfg_default(&sync_cfg);
     std::vector<float*> d_corr((size_t)inflight); std::vector<uint8_t*> d_fib((size_t)inflight), d_msc((size_t)inflight);
     std::vector<dabgpu_codeword_result*> d_fres((size_t)inflight), d_mres((size_t)inflight);
     for (int k = 0; k < inflight; k++) {
@@ -247,8 +277,15 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
         const int k = (int)(j % inflight), slot = (int)(j % H);
         hipStream_t s = st[(size_t)k];
         if (inflight > 1 && j - H + 4 >= 0) HIPCK(hipStreamWaitEvent(s, ev_msc[(size_t)((j - H + 4) % NEV)], 0));
-        DABCK(dabgpu_ofdm_demod_frames_history(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, nullptr, d_hist + (size_t)slot * FRAME_BITS, d_corr[(size_t)k], 0, stride,
-                                               DABGPU_BITS_MSC_CLASSED, s));
+        if (synced) {
+            // frame j's synchroniser starts from the records frame j - 1's fine-frequency update left (one receiver's frames are a serial chain)
+            if (inflight > 1 && j >= 1) HIPCK(hipStreamWaitEvent(s, ev_demod[(size_t)((j - 1) % NEV)], 0));
+            DABCK(dabgpu_ofdm_sync_demod_frames(ctx[(size_t)k], reinterpret_cast<const float*>(d_iq), E, (size_t)SLICE_SAMPLES, (size_t)SLICE_LEAD, &sync_cfg, d_states,
+                                                d_hist + (size_t)slot * FRAME_BITS, d_corr[(size_t)k], 0, stride, DABGPU_BITS_MSC_CLASSED, nullptr, s));
+        } else {
+            DABCK(dabgpu_ofdm_demod_frames_history(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, nullptr, d_hist + (size_t)slot * FRAME_BITS, d_corr[(size_t)k], 0, stride,
+                                                   DABGPU_BITS_MSC_CLASSED, s));
+        }
         HIPCK(hipEventRecord(ev_demod[(size_t)(j % NEV)], s));
         for (int d = 1; d < inflight; d++) if (j - d >= 0) HIPCK(hipStreamWaitEvent(s, ev_demod[(size_t)((j - d) % NEV)], 0));
         // FIC + MSC of the frame in one call: the FIB groups are decoded inside the MSC launch
@@ -260,7 +297,7 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
     };
     // explicit calibration of the demodulator's run length for this batch size, once per context, before anything is timed
     // (symbols_per_block = 0 in step() resolves to what is recorded here; the data path never measures)
-    for (int k = 0; k < inflight; k++) DABCK(dabgpu_ofdm_tune(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, d_hist, stride, DABGPU_BITS_MSC_CLASSED, 0, st[(size_t)k], &R->spb));
+    for (int k = 0; k < inflight; k++) DABCK(dabgpu_ofdm_tune(ctx[(size_t)k], d_iq, DABGPU_IQ_RAW_F32L, E, d_hist, stride, DABGPU_BITS_MSC_CLASSED, synced ? 1 : 0, st[(size_t)k], &R->spb));
     for (int i = 0; i < H + inflight; i++) if (!step()) return false;   // fill the history ring: the time de-interleaver needs 16 CIFs
     HIPCK(hipDeviceSynchronize());
     bar->wait();                                                       // all workers start their timed steps together
@@ -304,7 +341,7 @@ bool worker(int rank, int device, size_t E, int steps, int n_distinct, int infli
         dabgpu_destroy(ctx[(size_t)k]); (void)hipStreamDestroy(st[(size_t)k]);
     }
     for (int i = 0; i < NEV; i++) { (void)hipEventDestroy(ev_demod[(size_t)i]); (void)hipEventDestroy(ev_msc[(size_t)i]); }
-    (void)hipFree(d_iq); (void)hipFree(d_hist);
+    (void)hipFree(d_iq); (void)hipFree(d_hist); (void)hipFree(d_states);
     R->ok = true;
     return true;
 }
@@ -315,7 +352,7 @@ int main(int argc, char** argv) {
     std::vector<int> devices;
     size_t E = 8192;
     int steps = 10, distinct = 8, inflight = 2, probe_step = 0;
-    bool identical = false;
+    bool identical = false, synced = true;
     for (int a = 1; a < argc; a++) {
         const std::string k = argv[a];
         auto val = [&]() -> const char* { if (a + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", k.c_str()); std::exit(2); } return argv[++a]; };
@@ -325,8 +362,9 @@ int main(int argc, char** argv) {
         else if (k == "--distinct") distinct = std::atoi(val());
         else if (k == "--inflight") inflight = std::atoi(val());
         else if (k == "--identical") identical = true;
+        else if (k == "--aligned") synced = false;
         else if (k == "--mem-probe-step") probe_step = std::atoi(val());      // soak: device memory free after this step and after the last one
-        else { std::fprintf(stderr, "usage: %s --devices 0,1,... [--ensembles E] [--steps K] [--distinct D] [--inflight 1|2]\n", argv[0]); return 2; }
+        else { std::fprintf(stderr, "usage: %s --devices 0,1,... [--ensembles E] [--steps K] [--distinct D] [--inflight 1|2] [--identical] [--aligned]\n", argv[0]); return 2; }
     }
     if (devices.empty()) devices.push_back(0);
     if (E == 0 || steps < 1 || distinct < 1 || inflight < 1 || inflight > 4 || probe_step < 0 || probe_step >= steps) { std::fprintf(stderr, "bad arguments\n"); return 2; }
@@ -337,7 +375,7 @@ int main(int argc, char** argv) {
     std::atomic<int> failed{0};
     for (size_t r = 0; r < devices.size(); r++)
         th.emplace_back([&, r] {
-            if (!worker(identical ? -1 : (int)r, devices[r], E, steps, distinct, inflight, probe_step, &bar, &res[r])) {
+            if (!worker(identical ? -1 : (int)r, devices[r], E, steps, distinct, inflight, probe_step, synced, &bar, &res[r])) {
                 failed++;
                 // a worker that failed before the start line must not leave the others waiting at it
                 std::unique_lock<std::mutex> lk(bar.mu);
@@ -348,10 +386,11 @@ int main(int argc, char** argv) {
     double worst = 0.0;
     bool all_ok = failed == 0;
     for (const auto& r : res) { worst = std::max(worst, r.ms_per_step); all_ok = all_ok && r.ok && r.fib_mismatch == 0 && r.msc_mismatch == 0 && r.crc_pass == r.crc_expected; }
-    std::printf("{\"program\": \"multi_gpu_harness\", \"workload\": \"BASELINE configs[4] per device: OFDM demod + FIC Viterbi + 18 x 48 CU EEP 3-A MSC per transmission frame\", "
+    std::printf("{\"program\": \"multi_gpu_harness\", \"workload\": \"BASELINE configs[4] per device: %s + FIC Viterbi + 18 x 48 CU EEP 3-A MSC per transmission frame\", "
                 "\"workers\": %zu, \"ensembles_per_worker\": %zu, \"steps\": %d, \"frames_in_flight\": %d, \"distinct_multiplexes\": %d, "
                 "\"scaling\": \"weak: independent ensembles per device, one host thread + contexts + streams per device, no collective\", "
                 "\"frames_per_s\": %.1f, \"ms_per_step_slowest_worker\": %.4f, \"all_outputs_equal_transmitted\": %s, \"mem_probe_step\": %d, \"per_worker\": [",
+                synced ? "PRS synchronisation + OFDM demod at the tracked offsets + fine-frequency update (per-multiplex carrier and timing offsets)" : "OFDM demod of frame-aligned input (synchronisation bypassed)",
                 devices.size(), E, steps, inflight, distinct, all_ok && worst > 0.0 ? (double)devices.size() * (double)E / worst * 1e3 : 0.0, worst, all_ok ? "true" : "false", probe_step);
     for (size_t r = 0; r < res.size(); r++)
         std::printf("%s{\"device\": %d, \"ok\": %s, \"ms_per_step\": %.4f, \"fib_groups_wrong\": %ld, \"msc_cifs_wrong\": %ld, \"fib_crc_pass\": %ld, \"fib_crc_expected\": %ld, \"digest\": \"%016llx\", "

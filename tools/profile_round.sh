@@ -31,6 +31,7 @@ for F in 1024 4096 16384; do python3 tools/bench_fic.py --frames $F; done > $OUT
 python3 tools/bench_sync.py > $OUT/bench_sync_$TAG.json 2> $OUT/bench_sync_$TAG.err
 LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devices 0 --ensembles 8192 --steps 10 > $OUT/bench_cpp_host_$TAG.json 2> $OUT/bench_cpp_host_$TAG.err
 LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devices 0,0,0,0,0,0,0,0 --ensembles 1024 --steps 20 --distinct 16 >> $OUT/bench_cpp_host_$TAG.json 2>> $OUT/bench_cpp_host_$TAG.err
+LD_LIBRARY_PATH=dab-radio_amd:/opt/rocm/lib ./tests/cpp/multi_gpu_harness --devices 0 --ensembles 8192 --steps 10 --aligned >> $OUT/bench_cpp_host_$TAG.json 2>> $OUT/bench_cpp_host_$TAG.err
 python3 tools/bench_io.py > $OUT/bench_io_$TAG.json 2> $OUT/bench_io_$TAG.err
 python3 tools/bench_dabplus.py > $OUT/bench_dabplus_$TAG.json 2> $OUT/bench_dabplus_$TAG.err
 python3 tools/bench_ingest.py > $OUT/bench_ingest_$TAG.json 2> $OUT/bench_ingest_$TAG.err
