@@ -68,7 +68,19 @@ __device__ __forceinline__ float fine_freq_add(float fine, float delta, int n_ff
 // conj_io: inverse transform as conj(FFT(conj(x))), unnormalised like FFTW_BACKWARD
 // x, bufA and y may all be ONE array (in place): a thread writes bufA at exactly the eight positions it has read x at, and the results
 // are written behind a barrier
-__device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* __restrict__ tw, bool conj_io) {
+// the 20 twiddles a thread needs in a 2048-point transform depend on its index only: a kernel that runs several transforms loads them once
+struct Fft2048Tw { f2 p1[6], p2[7], p3[7]; };
+__device__ __forceinline__ Fft2048Tw fft2048_twiddles(const f2* __restrict__ tw) {
+    const int t = threadIdx.x, lane = t & 63, la = lane & 7;
+    Fft2048Tw w;
+#pragma unroll
+    for (int k = 1; k <= 3; k++) { w.p1[k - 1] = tw[(2 * t) * k]; w.p1[2 + k] = tw[(2 * t + 1) * k]; }
+#pragma unroll
+    for (int k = 1; k < 8; k++) { w.p2[k - 1] = tw[4 * lane * k]; w.p3[k - 1] = tw[32 * la * k]; }
+    return w;
+}
+
+__device__ __forceinline__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const Fft2048Tw& w, bool conj_io) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int la = lane & 7, lb = lane >> 3;
     f2* patch = patch0 + wave * WAVE_PATCH;
@@ -83,8 +95,8 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
         f2 b0, b1, b2, b3, c0, c1, c2, c3;
         dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
         dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
-        b1 = cmul(b1, tw[(2 * t) * 1]); b2 = cmul(b2, tw[(2 * t) * 2]); b3 = cmul(b3, tw[(2 * t) * 3]);
-        c1 = cmul(c1, tw[(2 * t + 1) * 1]); c2 = cmul(c2, tw[(2 * t + 1) * 2]); c3 = cmul(c3, tw[(2 * t + 1) * 3]);
+        b1 = cmul(b1, w.p1[0]); b2 = cmul(b2, w.p1[1]); b3 = cmul(b3, w.p1[2]);
+        c1 = cmul(c1, w.p1[3]); c2 = cmul(c2, w.p1[4]); c3 = cmul(c3, w.p1[5]);
         bufA[2 * t] = b0;        bufA[2 * t + 1] = c0;
         bufA[2 * t + 512] = b1;  bufA[2 * t + 513] = c1;
         bufA[2 * t + 1024] = b2; bufA[2 * t + 1025] = c2;
@@ -96,7 +108,7 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
     dft8(a);
     patch[lane] = a[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) patch[lane + 72 * k] = cmul(a[k], tw[4 * lane * k]);
+    for (int k = 1; k < 8; k++) patch[lane + 72 * k] = cmul(a[k], w.p2[k - 1]);
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = patch[la + 72 * lb + 8 * j];
@@ -104,7 +116,7 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
     dft8(a);
     patch[la + 72 * lb] = a[0];
 #pragma unroll
-    for (int k = 1; k < 8; k++) patch[la + 72 * lb + 9 * k] = cmul(a[k], tw[32 * la * k]);
+    for (int k = 1; k < 8; k++) patch[la + 72 * lb + 9 * k] = cmul(a[k], w.p3[k - 1]);
     wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = patch[9 * la + 72 * lb + j];
@@ -124,8 +136,8 @@ __device__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const f2* 
 
 // transform of any supported length between natural-order LDS arrays: the register-resident 2048-point version above, or
 // Stockham passes r1 x 8 x 8 [x 8] alternating between `tmp` and `y` so that the last pass lands in `y`
-__device__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __restrict__ tw, bool conj_io) {
-    if (N == NB_FFT) { fft2048_lds(x, y, tmp, patch0, tw, conj_io); return; }
+__device__ __forceinline__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __restrict__ tw, const Fft2048Tw& w2048, bool conj_io) {
+    if (N == NB_FFT) { fft2048_lds(x, y, tmp, patch0, w2048, conj_io); return; }
     const int t = threadIdx.x;
     if (conj_io) { for (int i = t; i < N; i += 256) x[i].y = -x[i].y; __syncthreads(); }
     const int r1 = (N == 256) ? 4 : (N == 1024 ? 2 : 8);
@@ -189,10 +201,12 @@ void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2*
     extern __shared__ __attribute__((aligned(16))) char ssm[];
     SyncLds* S = reinterpret_cast<SyncLds*>(ssm);
     const int t = threadIdx.x;
+    Fft2048Tw w2048 = {};
+    if (N == NB_FFT) w2048 = fft2048_twiddles(tw);
     for (int i = t; i < N; i += 256)
         S->x()[i] = (i < N - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);         // CalculateRelativePhase :901-909
     __syncthreads();
-    fft_lds(N, S->x(), S->y(N), S->tmp(N), S->P, tw, true);
+    fft_lds(N, S->x(), S->y(N), S->tmp(N), S->P, tw, w2048, true);
     for (int i = t; i < N; i += 256) prs_time_ref[i] = mk2(S->y(N)[i].x, -S->y(N)[i].y);
 }
 
@@ -211,6 +225,8 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     const f2* prs_sym = prs_syms + (size_t)sidx * stride_samples;
     dabgpu_sync_state st = states[sidx];
     const int N = g.n_fft, M = N / 2;
+    Fft2048Tw w2048 = {};                                    // (mode I: the five transforms share their twiddles)
+    if (N == NB_FFT) w2048 = fft2048_twiddles(tw);
 
     // ================= coarse frequency sync (:360-471) =================
     f2* const X = S->x();
@@ -220,7 +236,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     if (cfg.is_coarse_freq_correction) {
         for (int i = t; i < N; i += 256) X[i] = prs_sym[i];
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, false);                                               // :377
+        fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                               // :377
         {   // X[i] = Y[i + 1] * conj(Y[i]) (:380) -- X and Y may be one array: through registers, behind a barrier
             f2 q[NB_FFT / 256];
 #pragma unroll
@@ -233,7 +249,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
             for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
         }
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, true);                                                // :383
+        fft_lds(N, X, Y, T, S->P, tw, w2048, true);                                                // :383
         {   // (same index in and out; X and Y may be one array or two)
             f2 q[NB_FFT / 256];
 #pragma unroll
@@ -242,7 +258,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
             for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
         }
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, false);                                               // :392
+        fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                               // :392
         for (int i = t; i < N; i += 256) {                                                  // :911-920
             const float r = db20_det(cabs_det(Y[(i + M) % N]));
             R[i] = r;
@@ -306,7 +322,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
     }
     __syncthreads();
-    fft_lds(N, X, Y, T, S->P, tw, false);                                                   // :487
+    fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                                   // :487
     {
         f2 q[NB_FFT / 256];
 #pragma unroll
@@ -315,7 +331,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
     }
     __syncthreads();
-    fft_lds(N, X, Y, T, S->P, tw, true);                                                    // :493
+    fft_lds(N, X, Y, T, S->P, tw, w2048, true);                                                    // :493
     for (int i = t; i < N; i += 256) {                                                      // :494-498
         const float r = db20_det(cabs_det(Y[i]));
         R[i] = r;
