@@ -254,19 +254,28 @@ __device__ __forceinline__ void butterfly(f2 (&a)[8]) {
     }
 }
 
-// one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst`
+// one Stockham pass of radix R over `src` (current sub-transform length cur_n, stride s) into `dst` -- both in LDS: the callers ping-pong
+// between two LDS arrays chosen at run time, which leaves the compiler with generic pointers (flat_load / flat_store, slower than the
+// LDS path and counted on both memory counters); the casts say what they are
+typedef float lds_v2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lds_v2* lds_cf2;
+typedef __attribute__((address_space(3))) lds_v2* lds_f2;
+__device__ __forceinline__ f2 lds_get(lds_cf2 p, int i) { const lds_v2 v = p[i]; return mk2(v.x, v.y); }
+__device__ __forceinline__ void lds_put(lds_f2 p, int i, f2 v) { lds_v2 w; w.x = v.x; w.y = v.y; p[i] = w; }
 template <int R>
-__device__ __forceinline__ void stockham_pass(const f2* __restrict__ src, f2* __restrict__ dst, int n_total, int cur_n, int s, bool last,
+__device__ __forceinline__ void stockham_pass(const f2* src_, f2* dst_, int n_total, int cur_n, int s, bool last,
                                               const f2* __restrict__ tw, int t, int n_threads) {
+    const lds_cf2 src = (lds_cf2)src_;
+    const lds_f2 dst = (lds_f2)dst_;
     const int m = cur_n / R, tw_step = NB_FFT / cur_n;
     for (int u = t; u < n_total / R; u += n_threads) {
         const int q = u % s, p = u / s;
         f2 a[8];
 #pragma unroll
-        for (int j = 0; j < R; j++) a[j] = src[q + s * (p + m * j)];
+        for (int j = 0; j < R; j++) a[j] = lds_get(src, q + s * (p + m * j));
         butterfly<R>(a);
 #pragma unroll
-        for (int k = 0; k < R; k++) dst[q + s * (R * p + k)] = (k == 0 || last) ? a[k] : cmul(a[k], tw[tw_step * p * k]);
+        for (int k = 0; k < R; k++) lds_put(dst, q + s * (R * p + k), (k == 0 || last) ? a[k] : cmul(a[k], tw[tw_step * p * k]));
     }
 }
 

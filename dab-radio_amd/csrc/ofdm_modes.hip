@@ -137,7 +137,8 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
         }
         if (fft_out != nullptr) {
             f2* dst = fft_out + ((size_t)frame * (g.n_sym + 1) + i) * N;
-            for (int k = t; k < N; k += NT) dst[k] = W[cur][k];
+            const lds_cf2 wc = (lds_cf2)W[cur];
+            for (int k = t; k < N; k += NT) dst[k] = lds_get(wc, k);
         }
         if (i > out0 && i < g.n_sym) {
             // ---- DQPSK + frequency de-interleave + soft bits (ofdm_demodulator.cpp:842-889) ----
@@ -147,7 +148,7 @@ void ofdm_demod_mode_kernel(int mode, const f2* __restrict__ iq, const float* __
                 const int c = mapper[n];
                 const int k = (c < M) ? (c - M) : (c - M + 1);
                 const int bin = (N + k) % N;
-                const f2 d = conj_mul(W[prev][bin], W[cur][bin]);
+                const f2 d = conj_mul(lds_get((lds_cf2)W[prev], bin), lds_get((lds_cf2)W[cur], bin));   // (LDS: W is indexed at run time, the casts keep the ds_ path)
                 int bx, by;
                 soft_bit_pair(d, bx, by);
                 o[n] = (int8_t)bx;
