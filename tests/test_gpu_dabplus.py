@@ -47,10 +47,15 @@ def test_golden_sequences_one_stream_host_path(ctx, oracle):
 
 
 def test_batch_of_streams_matches_oracle(ctx, oracle):
+    run_batch_of_streams(ctx, oracle, 5)
+
+
+def run_batch_of_streams(ctx, oracle, seed, strict_mix=True):
+    """(also driven with many seeds by tools/fuzz_dabplus.py)"""
     import dabgpu
     import dabplus_model as M
     import torch
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
     sizes = [24, 48, 96, 120, 192, 264, 384, 576, 1536, 96, 192, 72]
     E, n_calls, F = len(sizes), 14, 7                  # 7 logical frames per call: super frames straddle calls
     total = n_calls * F
@@ -107,8 +112,10 @@ def test_batch_of_streams_matches_oracle(ctx, oracle):
                     k_sf += 1
             assert cnt[e, 0] == k_sf and cnt[e, 1] == waits, (c, e, cnt[e], k_sf, waits)
             seen["wait"] += waits
-    assert seen["ok"] > 20 and seen["rs_fail"] > 3 and seen["wait"] > 5, seen
+    if strict_mix:
+        assert seen["ok"] > 20 and seen["rs_fail"] > 3 and seen["wait"] > 5, seen
     bank.close()
+    return seen
 
 
 def test_behind_the_msc_viterbi_kernel(ctx, oracle):
