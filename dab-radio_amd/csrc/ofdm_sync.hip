@@ -80,31 +80,36 @@ __device__ __forceinline__ Fft2048Tw fft2048_twiddles(const f2* __restrict__ tw)
     return w;
 }
 
-__device__ __forceinline__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* patch0, const Fft2048Tw& w, bool conj_io) {
+// x, y and the exchange array are ONE array of 4 x WAVE_PATCH elements (in place): input and output in natural order in its first 2048
+// elements; between them the radix-4 outputs sit as four 512-element blocks WAVE_PATCH apart, one per wave's 512-point problem, and a
+// wave's transpose patch aliases its own block (the wave has read its 8 inputs per lane before it writes the patch; one wave's LDS
+// instructions execute in order) -- the layout of the symbol kernel (ofdm_demod.hip).  Barriers: inputs read / blocks written / results written.
+__device__ __forceinline__ void fft2048_lds(f2* A, const Fft2048Tw& w, bool conj_io) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int la = lane & 7, lb = lane >> 3;
-    f2* patch = patch0 + wave * WAVE_PATCH;
+    f2* patch = A + wave * WAVE_PATCH;
     f2 a[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { a[j] = x[2 * t + 512 * j]; a[4 + j] = x[2 * t + 1 + 512 * j]; }
+    for (int j = 0; j < 4; j++) { a[j] = A[2 * t + 512 * j]; a[4 + j] = A[2 * t + 1 + 512 * j]; }
     if (conj_io) {
 #pragma unroll
         for (int j = 0; j < 8; j++) a[j].y = -a[j].y;
     }
+    __syncthreads();                                       // (the blocks below do not sit where the inputs did)
     {
         f2 b0, b1, b2, b3, c0, c1, c2, c3;
         dft4(a[0], a[1], a[2], a[3], b0, b1, b2, b3);
         dft4(a[4], a[5], a[6], a[7], c0, c1, c2, c3);
         b1 = cmul(b1, w.p1[0]); b2 = cmul(b2, w.p1[1]); b3 = cmul(b3, w.p1[2]);
         c1 = cmul(c1, w.p1[3]); c2 = cmul(c2, w.p1[4]); c3 = cmul(c3, w.p1[5]);
-        bufA[2 * t] = b0;        bufA[2 * t + 1] = c0;
-        bufA[2 * t + 512] = b1;  bufA[2 * t + 513] = c1;
-        bufA[2 * t + 1024] = b2; bufA[2 * t + 1025] = c2;
-        bufA[2 * t + 1536] = b3; bufA[2 * t + 1537] = c3;
+        A[2 * t] = b0;                       A[2 * t + 1] = c0;
+        A[2 * t + WAVE_PATCH] = b1;          A[2 * t + 1 + WAVE_PATCH] = c1;
+        A[2 * t + 2 * WAVE_PATCH] = b2;      A[2 * t + 1 + 2 * WAVE_PATCH] = c2;
+        A[2 * t + 3 * WAVE_PATCH] = b3;      A[2 * t + 1 + 3 * WAVE_PATCH] = c3;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; j++) a[j] = bufA[lane + 512 * wave + 64 * j];
+    for (int j = 0; j < 8; j++) a[j] = patch[lane + 64 * j];
     dft8(a);
     patch[lane] = a[0];
 #pragma unroll
@@ -123,21 +128,20 @@ __device__ __forceinline__ void fft2048_lds(const f2* x, f2* y, f2* bufA, f2* pa
     wave_lds_fence();
     dft8(a);
     const int Kb = wave + 4 * lb + 32 * la;
-    // (y may be the array bufA lives in: every wave has taken its 512-point block out of it before anybody writes a result)
-    __syncthreads();
+    __syncthreads();                                       // every wave has taken its block out of the array before anybody writes a result
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         f2 v = a[k];
         if (conj_io) v.y = -v.y;
-        y[Kb + 256 * k] = v;
+        A[Kb + 256 * k] = v;
     }
     __syncthreads();
 }
 
 // transform of any supported length between natural-order LDS arrays: the register-resident 2048-point version above, or
 // Stockham passes r1 x 8 x 8 [x 8] alternating between `tmp` and `y` so that the last pass lands in `y`
-__device__ __forceinline__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0, const f2* __restrict__ tw, const Fft2048Tw& w2048, bool conj_io) {
-    if (N == NB_FFT) { fft2048_lds(x, y, tmp, patch0, w2048, conj_io); return; }
+__device__ __forceinline__ void fft_lds(int N, f2* x, f2* y, f2* tmp, const f2* __restrict__ tw, const Fft2048Tw& w2048, bool conj_io) {
+    if (N == NB_FFT) { fft2048_lds(x, w2048, conj_io); return; }      // (x == y == tmp: in place)
     const int t = threadIdx.x;
     if (conj_io) { for (int i = t; i < N; i += 256) x[i].y = -x[i].y; __syncthreads(); }
     const int r1 = (N == 256) ? 4 : (N == 1024 ? 2 : 8);
@@ -157,23 +161,24 @@ __device__ __forceinline__ void fft_lds(int N, f2* x, f2* y, f2* tmp, f2* patch0
     if (conj_io) { for (int i = t; i < N; i += 256) y[i].y = -y[i].y; __syncthreads(); }
 }
 
-// LDS of a synchroniser workgroup: 34.6 KB, so that four fit on a CU and one retiring demodulator workgroup (35.3 KB, stream-bank rounds)
-// makes room for one (it was 75.8 KB -- three natural-order arrays, the patches and the dB response side by side: two per CU, and a
-// synchroniser workgroup of a stream-bank round had to wait for TWO demodulator workgroups to retire).
-//   N = 2048 (mode I): every transform runs in place in A; the waves' transpose patches live in P during a transform, the dB response
-//                      R in P after it
+// LDS of a synchroniser workgroup.
+//   N = 2048 (mode I): ONE array A of 4 x WAVE_PATCH elements -- every transform runs in place in it (fft2048_lds), the element-wise steps
+//                      between transforms pass through registers, the dB response is written over its first 8 KB behind a barrier:
+//                      18.5 KB (dabgpu_sync_lds_bytes; P is not allocated), five to eight workgroups per CU.  (Round 3: 34.6 KB with the
+//                      patches and the response in a second region, four per CU; before: 75.8 KB, two per CU.)
 //   N <= 1024:         x = A, y = A + 1024 (Stockham passes ping-pong), tmp = P, R = P + 1024
 struct SyncLds {
-    f2 A[NB_FFT];
-    f2 P[4 * WAVE_PATCH];
+    f2 A[4 * WAVE_PATCH];
     float redv[4];
     int redi[4];
     float reds[4];
+    f2 P[NB_FFT];                    // modes II-IV only (last member: a mode I launch does not allocate it)
     __device__ f2* x() { return A; }
     __device__ f2* y(int N) { return N == NB_FFT ? A : A + 1024; }
     __device__ f2* tmp(int N) { return N == NB_FFT ? A : P; }
-    __device__ float* R(int N) { return reinterpret_cast<float*>(N == NB_FFT ? P : P + 1024); }
+    __device__ float* R(int N) { return reinterpret_cast<float*>(N == NB_FFT ? A : P + 1024); }
 };
+__host__ __device__ inline size_t dabgpu_sync_lds_bytes(int n_fft) { return n_fft == NB_FFT ? offsetof(SyncLds, P) : sizeof(SyncLds); }
 
 // (value, index) reduction with "largest value, ties -> lowest index" == first maximum of a sequential strict-> scan
 __device__ __forceinline__ void argmax_reduce(float& v, int& i, SyncLds* S) {
@@ -206,7 +211,7 @@ void sync_init_kernel(const f2* __restrict__ prs, const f2* __restrict__ tw, f2*
     for (int i = t; i < N; i += 256)
         S->x()[i] = (i < N - 1) ? conj_mul(prs[i + 1], prs[i]) : mk2(0.0f, 0.0f);         // CalculateRelativePhase :901-909
     __syncthreads();
-    fft_lds(N, S->x(), S->y(N), S->tmp(N), S->P, tw, w2048, true);
+    fft_lds(N, S->x(), S->y(N), S->tmp(N), tw, w2048, true);
     for (int i = t; i < N; i += 256) prs_time_ref[i] = mk2(S->y(N)[i].x, -S->y(N)[i].y);
 }
 
@@ -236,7 +241,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
     if (cfg.is_coarse_freq_correction) {
         for (int i = t; i < N; i += 256) X[i] = prs_sym[i];
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                               // :377
+        fft_lds(N, X, Y, T, tw, w2048, false);                                               // :377
         {   // X[i] = Y[i + 1] * conj(Y[i]) (:380) -- X and Y may be one array: through registers, behind a barrier
             f2 q[NB_FFT / 256];
 #pragma unroll
@@ -249,7 +254,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
             for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
         }
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, w2048, true);                                                // :383
+        fft_lds(N, X, Y, T, tw, w2048, true);                                                // :383
         {   // (same index in and out; X and Y may be one array or two)
             f2 q[NB_FFT / 256];
 #pragma unroll
@@ -258,11 +263,17 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
             for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
         }
         __syncthreads();
-        fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                               // :392
-        for (int i = t; i < N; i += 256) {                                                  // :911-920
-            const float r = db20_det(cabs_det(Y[(i + M) % N]));
-            R[i] = r;
-            if (freq_out) freq_out[(size_t)sidx * N + i] = r;
+        fft_lds(N, X, Y, T, tw, w2048, false);                                               // :392
+        {   // :911-920 -- R may lie over Y (mode I): through registers, behind a barrier
+            float r[NB_FFT / 256];
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; r[j] = (i < N) ? db20_det(cabs_det(Y[(i + M) % N])) : 0.0f; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NB_FFT / 256; j++) {
+                const int i = t + 256 * j;
+                if (i < N) { R[i] = r[j]; if (freq_out) freq_out[(size_t)sidx * N + i] = r[j]; }
+            }
         }
         __syncthreads();
         int max_off = (int)(cfg.max_coarse_freq_correction_norm * (float)N);                // :399-402
@@ -322,7 +333,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         X[i] = pll1(prs_sym[i], base, mk2(ss + 0.25f, ss));
     }
     __syncthreads();
-    fft_lds(N, X, Y, T, S->P, tw, w2048, false);                                                   // :487
+    fft_lds(N, X, Y, T, tw, w2048, false);                                                   // :487
     {
         f2 q[NB_FFT / 256];
 #pragma unroll
@@ -331,11 +342,17 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
         for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; if (i < N) X[i] = q[j]; }
     }
     __syncthreads();
-    fft_lds(N, X, Y, T, S->P, tw, w2048, true);                                                    // :493
-    for (int i = t; i < N; i += 256) {                                                      // :494-498
-        const float r = db20_det(cabs_det(Y[i]));
-        R[i] = r;
-        if (impulse_out) impulse_out[(size_t)sidx * N + i] = r;
+    fft_lds(N, X, Y, T, tw, w2048, true);                                                    // :493
+    {   // :494-498 (through registers, as above)
+        float r[NB_FFT / 256];
+#pragma unroll
+        for (int j = 0; j < NB_FFT / 256; j++) { const int i = t + 256 * j; r[j] = (i < N) ? db20_det(cabs_det(Y[i])) : 0.0f; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NB_FFT / 256; j++) {
+            const int i = t + 256 * j;
+            if (i < N) { R[i] = r[j]; if (impulse_out) impulse_out[(size_t)sidx * N + i] = r[j]; }
+        }
     }
     __syncthreads();
     // weighted arg-max (:505-524) and mean of the dB response with the contract's 256-leaf tree
@@ -373,7 +390,7 @@ void ofdm_sync_kernel(const f2* __restrict__ prs_syms, size_t stride_samples, in
 
 extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream) {
     using namespace dabgpu;
-    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(256), sizeof(SyncLds), stream,
+    hipLaunchKernelGGL(sync_init_kernel, dim3(1), dim3(256), dabgpu_sync_lds_bytes(n_fft), stream,
                        reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_tw), reinterpret_cast<f2*>(d_prs_time_ref), n_fft);
     return hipGetLastError();
 }
@@ -385,7 +402,7 @@ extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_
     using namespace dabgpu;
     ModeGeom g;
     if (!mode_geometry(mode, g)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ofdm_sync_kernel, dim3((unsigned)n_streams), dim3(256), sizeof(SyncLds), stream,
+    hipLaunchKernelGGL(ofdm_sync_kernel, dim3((unsigned)n_streams), dim3(256), dabgpu_sync_lds_bytes(g.n_fft), stream,
                        reinterpret_cast<const f2*>(d_prs_syms), stride_samples, n_streams, *cfg, d_states, d_impulse, d_freq,
                        reinterpret_cast<const f2*>(d_tw), reinterpret_cast<const f2*>(d_prs), reinterpret_cast<const f2*>(d_prs_time_ref), d_active, g);
     return hipGetLastError();
