@@ -165,6 +165,23 @@ int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes
     return DABGPU_OK;
 }
 
+int dabgpu_stage_h2d_cached(dabgpu_ctx* c, int which, void* d_dst, const void* h_src, size_t bytes, hipStream_t s) {
+    dabgpu_ctx::table_copy& T = c->tables[which];
+    std::lock_guard<std::mutex> g(c->tables_mu);
+    if (T.d == d_dst && T.s == s && T.bytes.size() == bytes && memcmp(T.bytes.data(), h_src, bytes) == 0) return DABGPU_OK;
+    T.d = nullptr;                                                     // (invalid until the copy below has been enqueued)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        dabgpu_set_error("this call uploads a table it has not uploaded before (first call with these sub-channels on this stream): run it once before capturing");
+        return DABGPU_ERR_INVALID_ARG;
+    }
+    const int st = dabgpu_stage_h2d(c, d_dst, h_src, bytes, s);
+    if (st) return st;
+    T.bytes.assign(static_cast<const unsigned char*>(h_src), static_cast<const unsigned char*>(h_src) + bytes);
+    T.d = d_dst; T.s = s;
+    return DABGPU_OK;
+}
+
 // host buffers a caller hands to the *_host_sync entry points again and again (the mirror classes' frame buffers): page-locked, their
 // copies run at PCIe speed instead of through the runtime's staging
 int dabgpu_host_pin(void* p, size_t bytes) {

@@ -254,7 +254,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     if (fic && !fic_inside && (st = fic_decode_any(c, fic_bits, n_ens, ens_stride, d_slots, fic->d_fib_bytes, fic->d_results, tie_rule, stream))) return st;
     // flag the lane-mapped sub-channels in the plans the descriptor builder reads, then stage the plans and build the descriptors
     for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
-    if ((st = dabgpu_stage_h2d(c, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
+    if ((st = dabgpu_stage_h2d_cached(c, 0, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
                                                        d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
     if (n_lane > 0) {
@@ -280,7 +280,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
         uint64_t* d_lane_subs = nullptr;
         if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs))) return st;
-        if ((st = dabgpu_stage_h2d(c, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
+        if ((st = dabgpu_stage_h2d_cached(c, 1, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
         // the schedule table of every lane-mapped sub-channel, once per call
         const uint32_t sched_stride = dabgpu_vit_alloc_steps(lane_max_steps);
         const uint32_t fic_pi[4] = {16, 15, 0, 0}, fic_steps[4] = {32 * 21, 32 * 3, 0, 0};

@@ -42,10 +42,19 @@ struct dabgpu_ctx {
     stage_slot stage[8];
     unsigned stage_next = 0;
     std::mutex stage_mu;
+    // small tables that are a function of the call's arguments only (the sub-channel plans of a multiplex): what was last uploaded where
+    // and on which stream -- a call that would upload the same bytes to the same place on the same stream uploads nothing
+    // (dabgpu_stage_h2d_cached).  Steady-state decode calls then contain kernel launches only, which is what lets a caller capture them
+    // in a HIP graph.
+    struct table_copy { void* d = nullptr; hipStream_t s = nullptr; std::vector<unsigned char> bytes; };
+    table_copy tables[2];
+    std::mutex tables_mu;
 };
 #define DABGPU_HOST_LOCK(ctx) std::lock_guard<std::recursive_mutex> dabgpu_host_lock_(ctx->host_mu)
 // asynchronous host -> device copy on `s` that has consumed h_src when it returns (h_src may be freed or overwritten at once)
 extern "C" int dabgpu_stage_h2d(dabgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
+// the same for table `which` (0: sub-channel plans, 1: lane table) of the context, skipped when nothing changed (see dabgpu_ctx::tables)
+extern "C" int dabgpu_stage_h2d_cached(dabgpu_ctx* c, int which, void* d_dst, const void* h_src, size_t bytes, hipStream_t s);
 
 int dabgpu_check_hip(hipError_t e, const char* what);
 // Every entry point that launches, allocates or copies first makes the context's device current on the calling thread (a worker

@@ -13,6 +13,12 @@
  * are asynchronous on that stream unless the function name ends in _sync (those use a private stream of the
  * context and return when the results are in host memory).
  *
+ * HIP graphs: the batch entry points (dabgpu_ofdm_demod_frames*, dabgpu_ofdm_sync_demod_frames, dabgpu_fic_decode_frames,
+ * dabgpu_msc_decode_frames*, dabgpu_decode_frames_layout) enqueue kernels only once they have run ONCE with the same shapes and the
+ * same sub-channel list on the stream (scratch is grow-only, tables that depend on the sub-channel list are uploaded when they change):
+ * such calls may be issued between hipStreamBeginCapture and hipStreamEndCapture.  A call that would have to upload a table during a
+ * capture returns DABGPU_ERR_INVALID_ARG instead of invalidating it.  (tests/test_gpu_graph_capture.py)
+ *
  * All functions fail with DABGPU_ERR_NO_DEVICE when no gfx950 device is usable: there is no CPU
  * fallback behind this ABI.
  */
