@@ -594,26 +594,7 @@ extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_ou
 // time de-interleave + Viterbi of every registered sub-channel for its 4 CIFs (the batch entry points above, one ensemble), the
 // results return to pinned host slots asynchronously, and the classes pick theirs up by (generation, group / CIF) -- see
 // dab-radio_amd/host/dab/dabgpu_frame_batcher.h for when a class may use them.
-struct dabgpu_frame_session {
-    static constexpr int H = 8, R = 8;
-    dabgpu_ctx* ctx = nullptr;
-    int8_t* d_hist = nullptr;                       // [H][230400]
-    uint8_t* d_fib = nullptr; dabgpu_codeword_result* d_fres = nullptr;
-    uint8_t* d_msc = nullptr; dabgpu_codeword_result* d_mres = nullptr;
-    std::vector<dabgpu_subchannel> subs;
-    std::vector<uint32_t> sub_off, sub_n;           // byte offset / size of a sub-channel inside one CIF's output record
-    uint32_t cif_out = 0;
-    uint64_t next_gen = 0;
-    struct slot {
-        uint64_t gen = ~0ull; bool fic = false, pending = false;
-        std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
-        uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // pinned: [4][96], [4]
-        uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // pinned: [4][cif_out], [4][n_sub]
-        size_t h_msc_cap = 0, h_mres_cap = 0;
-        hipEvent_t done = nullptr;
-    } slots[R];
-    std::mutex mu;
-};
+// (struct dabgpu_frame_session: dabgpu_internal.h -- the receiver pipeline, receiver.hip, pushes frames that are already on the device)
 
 extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int device) {
     if (!out) return DABGPU_ERR_INVALID_ARG;
@@ -645,6 +626,10 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
         if (sl.h_fres) (void)hipHostFree(sl.h_fres);
         if (sl.h_msc) (void)hipHostFree(sl.h_msc);
         if (sl.h_mres) (void)hipHostFree(sl.h_mres);
+        if (sl.h_bits) (void)hipHostFree(sl.h_bits);
+        if (sl.h_aux) (void)hipHostFree(sl.h_aux);
+        if (sl.h_fft) (void)hipHostFree(sl.h_fft);
+        if (sl.h_dq) (void)hipHostFree(sl.h_dq);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->d_hist) (void)hipFree(s->d_hist);
@@ -682,24 +667,15 @@ extern "C" int dabgpu_frame_session_set_subchannels(dabgpu_frame_session* s, con
     return DABGPU_OK;
 }
 
-extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const int8_t* h_bits, int decode_fic, int tie_rule, uint64_t* generation) {
-    if (!s || !h_bits) { dabgpu_set_error("frame_session_push_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
-    std::lock_guard<std::mutex> lock(s->mu);
+// The decode of generation `gen` on the session's stream: FIC of the frame in history slot gen % H, MSC of its 4 CIFs (the time
+// de-interleaver reaches 4 frames back), results to the slot's pinned buffers, the slot's done event.  s->mu held.
+static int session_decode(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot& sl, int decode_fic, int tie_rule) {
     dabgpu_ctx* c = s->ctx;
-    DABGPU_BIND(c);
     hipStream_t q = c->stream;
-    const uint64_t gen = s->next_gen;
     const int hs = (int)(gen % dabgpu_frame_session::H);
-    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
-    int st;
-    if (sl.pending) {                                                   // the slot's previous frame (R frames ago)
-        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)"))) return st;
-        sl.pending = false;
-    }
     int8_t* d_frame = s->d_hist + (size_t)hs * DABGPU_NB_FRAME_BITS;
-    if ((st = dabgpu_stage_h2d(c, d_frame, h_bits, DABGPU_NB_FRAME_BITS, q))) return st;
     const int n_sub = (int)s->subs.size();
-    sl.gen = ~0ull;
+    int st;
     sl.fic = decode_fic != 0;
     sl.subs = s->subs; sl.sub_off = s->sub_off; sl.sub_n = s->sub_n; sl.cif_out = s->cif_out;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
@@ -727,8 +703,29 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
         CK(hipMemcpyAsync(sl.h_msc, s->d_msc, need, hipMemcpyDeviceToHost, q));
         CK(hipMemcpyAsync(sl.h_mres, s->d_mres, need_r, hipMemcpyDeviceToHost, q));
     }
-    CK(hipEventRecord(sl.done, q));
 #undef CK
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const int8_t* h_bits, int decode_fic, int tie_rule, uint64_t* generation) {
+    if (!s || !h_bits) { dabgpu_set_error("frame_session_push_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lock(s->mu);
+    dabgpu_ctx* c = s->ctx;
+    DABGPU_BIND(c);
+    hipStream_t q = c->stream;
+    const uint64_t gen = s->next_gen;
+    const int hs = (int)(gen % dabgpu_frame_session::H);
+    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
+    int st;
+    if (sl.pending) {                                                   // the slot's previous frame (R frames ago)
+        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)"))) return st;
+        sl.pending = false;
+    }
+    int8_t* d_frame = s->d_hist + (size_t)hs * DABGPU_NB_FRAME_BITS;
+    if ((st = dabgpu_stage_h2d(c, d_frame, h_bits, DABGPU_NB_FRAME_BITS, q))) return st;
+    sl.gen = ~0ull;
+    if ((st = session_decode(s, gen, sl, decode_fic, tie_rule))) return st;
+    if ((st = dabgpu_check_hip(hipEventRecord(sl.done, q), "hipEventRecord(session)"))) return st;
     sl.pending = true;
     sl.gen = gen;
     s->next_gen = gen + 1;
@@ -736,7 +733,54 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
     return DABGPU_OK;
 }
 
-static int session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out) {
+int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64_t* gen_out, int8_t** d_frame_bits, dabgpu_frame_session::slot** slot_out) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    DABGPU_BIND(s->ctx);
+    const uint64_t gen = s->next_gen;
+    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
+    int st;
+    if (sl.pending) {
+        if ((st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)"))) return st;
+        sl.pending = false;
+    }
+    // history slot gen % H holds frame gen - H, which the decodes of the frames gen - H .. gen - 4 read (5 frames = 16 CIFs + the frame's own
+    // 4): the producer may overwrite it once the decode of frame gen - 4 has run (the decodes run in order on one stream)
+    if (gen >= 4) {
+        dabgpu_frame_session::slot& old = s->slots[(gen - 4) % dabgpu_frame_session::R];
+        if (old.pending && old.gen == gen - 4 &&
+            (st = dabgpu_check_hip(hipStreamWaitEvent(producer, old.done, 0), "hipStreamWaitEvent(session history)"))) return st;
+    }
+    sl.gen = ~0ull;
+    *gen_out = gen;
+    *d_frame_bits = s->d_hist + (size_t)(gen % dabgpu_frame_session::H) * DABGPU_NB_FRAME_BITS;
+    *slot_out = &sl;
+    return DABGPU_OK;
+}
+
+int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    dabgpu_ctx* c = s->ctx;
+    DABGPU_BIND(c);
+    if (gen != s->next_gen) { dabgpu_set_error("session_commit: generation %llu was not the one reserved", (unsigned long long)gen); return DABGPU_ERR_INVALID_ARG; }
+    hipStream_t q = c->stream;
+    dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
+    int st;
+    if ((st = dabgpu_check_hip(hipStreamWaitEvent(q, ready, 0), "hipStreamWaitEvent(session producer)"))) return st;
+    if (bits_bytes) {
+        if (!sl.h_bits && (st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_bits, DABGPU_NB_FRAME_BITS, hipHostMallocDefault), "hipHostMalloc(session bits)"))) return st;
+        if ((st = dabgpu_check_hip(hipMemcpyAsync(sl.h_bits, s->d_hist + (size_t)(gen % dabgpu_frame_session::H) * DABGPU_NB_FRAME_BITS, bits_bytes,
+                                                  hipMemcpyDeviceToHost, q), "hipMemcpyAsync(session bits)"))) return st;
+    }
+    sl.fic = false; sl.subs.clear(); sl.sub_off.clear(); sl.sub_n.clear(); sl.cif_out = 0;
+    if (decode && (st = session_decode(s, gen, sl, decode_fic, tie_rule))) return st;
+    if ((st = dabgpu_check_hip(hipEventRecord(sl.done, q), "hipEventRecord(session)"))) return st;
+    sl.pending = true;
+    sl.gen = gen;
+    s->next_gen = gen + 1;
+    return DABGPU_OK;
+}
+
+int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out) {
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
     if (sl.gen != gen) return DABGPU_ERR_NOT_READY;                     // never pushed, or overwritten by a later frame
     if (sl.pending) {
@@ -748,6 +792,7 @@ static int session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_sess
     *out = &sl;
     return DABGPU_OK;
 }
+static int session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out) { return dabgpu_session_slot(s, gen, out); }
 
 extern "C" int dabgpu_frame_session_fetch_fib_group(dabgpu_frame_session* s, uint64_t generation, int group, uint8_t* h_bytes,
                                                     uint32_t* crc_ok_mask, uint64_t* path_error) {

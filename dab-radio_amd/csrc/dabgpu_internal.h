@@ -165,6 +165,43 @@ extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
                                               int classed, hipStream_t stream);
 
+// ---- frame session (dabgpu_decode_abi.hip) ----
+// One receiver's decode state behind the single-stream classes: an 8-frame history of soft bits on the device, the FIC + MSC decode of
+// every frame pushed, result slots in pinned host memory (include/dabgpu.h, "Frame session").  Frames arrive either from host memory
+// (dabgpu_frame_session_push_frame) or -- the receiver pipeline, receiver.hip -- are demodulated straight into the history slot by a
+// producer stream: dabgpu_session_reserve hands the slot out, dabgpu_session_commit chains the decode behind the producer's event.
+struct dabgpu_frame_session {
+    static constexpr int H = 8, R = 8;
+    dabgpu_ctx* ctx = nullptr;
+    int8_t* d_hist = nullptr;                       // [H][230400]
+    uint8_t* d_fib = nullptr; dabgpu_codeword_result* d_fres = nullptr;
+    uint8_t* d_msc = nullptr; dabgpu_codeword_result* d_mres = nullptr;
+    std::vector<dabgpu_subchannel> subs;
+    std::vector<uint32_t> sub_off, sub_n;           // byte offset / size of a sub-channel inside one CIF's output record
+    uint32_t cif_out = 0;
+    uint64_t next_gen = 0;
+    struct slot {
+        uint64_t gen = ~0ull; bool fic = false, pending = false;
+        std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
+        uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // pinned: [4][96], [4]
+        uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // pinned: [4][cif_out], [4][n_sub]
+        size_t h_msc_cap = 0, h_mres_cap = 0;
+        hipEvent_t done = nullptr;
+        // receiver pipeline only (pinned, allocated at first use): the frame's soft bits, a few scalars of the producer, display views
+        int8_t* h_bits = nullptr; float* h_aux = nullptr; float* h_fft = nullptr; float* h_dq = nullptr;
+        size_t h_fft_cap = 0, h_dq_cap = 0;
+    } slots[R];
+    std::mutex mu;
+};
+// the history slot the next frame goes to (*d_frame_bits) and its result slot; waits (host) for the result slot's previous frame, makes
+// `producer` wait (device) for the decode that still reads the history slot.  No frame is pushed yet: dabgpu_session_commit does that.
+int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64_t* gen, int8_t** d_frame_bits, dabgpu_frame_session::slot** sl);
+// the frame reserved last is in its history slot once `ready` (recorded on the producer stream) has fired: the session's stream waits for
+// it, copies `bits_bytes` soft bits to the slot's h_bits (0 = no copy), decodes, records the slot's done event
+int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule);
+// result slot of a generation, waited for (DABGPU_ERR_NOT_READY: gone or never pushed); call with s->mu held
+int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out);
+
 // ---- sync ----
 extern "C" hipError_t dabgpu_launch_sync_init(const float* d_prs, const float* d_tw, float* d_prs_time_ref, int n_fft, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_sync(const float* d_prs_syms, size_t stride_samples, int n_streams, const dabgpu_sync_cfg* cfg,

@@ -1,0 +1,265 @@
+// receiver.hip -- the receiver pipeline of the C ABI (include/dabgpu.h, "Receiver pipeline"): one receiver's per-frame device work
+// enqueued without a host wait in between, SURVEY P2 behind the OFDM_Demod mirror class.
+//
+// The reference overlaps three things per frame (src/ofdm/ofdm_demodulator.cpp:550-577, :581-639): the reader thread buffers frame k + 1
+// and runs its PRS synchronisation while the pipeline threads demodulate frame k and the coordinator thread calls the observers, which
+// decode it (src/basic_radio/basic_radio.cpp:41-65).  Here the same overlap is two device streams and events:
+//   stream A (the receiver's context)   H2D PRS -> ofdm_sync_kernel -> D2H record           per frame, as soon as the PRS slot is buffered
+//                                       H2D frame -> ofdm_demod_kernel (soft bits straight into the frame session's history slot)
+//                                       -> ofdm_phase_kernel on the device-resident frequency state -> D2H scalars
+//   stream B (the frame session's)      waits for A's event -> D2H soft bits -> FIC + MSC decode of the frame -> D2H results -> done event
+// The frequency state (m_freq_coarse_offset, m_freq_fine_offset, m_is_found_coarse_freq_offset) lives on the device: the synchroniser of
+// frame k + 1 reads the fine-frequency word frame k's phase kernel wrote, in stream order, and never waits for frame k's decode.
+// The host learns two things per frame and both late: the synchroniser's record (before it must know where the frame ends) and the
+// frame's results (dabgpu_receiver_wait_frame, on whatever thread delivers frames).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "dabgpu.h"
+#include "dabgpu_internal.h"
+
+namespace {
+constexpr int STAGES = 3;
+
+__global__ void rx_net_freq_kernel(const dabgpu_sync_state* __restrict__ st, float* __restrict__ net) {
+    // :672 the PLL of a frame runs with m_freq_coarse_offset + m_freq_fine_offset
+    if (threadIdx.x == 0) net[0] = st->freq_coarse + st->freq_fine;
+}
+}  // namespace
+
+struct dabgpu_receiver {
+    dabgpu_ctx* ctx = nullptr;               // tables of the mode + stream A
+    dabgpu_frame_session* ses = nullptr;     // history ring, decode, result slots + stream B
+    int mode = 1;
+    int geom[9] = {0};
+    size_t stage_cap = 0;                    // samples
+    float* h_stage[STAGES] = {nullptr, nullptr, nullptr};
+    hipEvent_t stage_free[STAGES] = {nullptr, nullptr, nullptr};
+    bool stage_pending[STAGES] = {false, false, false};
+    int cur = 0;
+    float* d_prs = nullptr;                  // nb_fft samples of the PRS slot
+    float* d_iq = nullptr;                   // one frame, aligned
+    dabgpu_sync_state* d_state = nullptr;    // the receiver's frequency state + the last synchroniser record
+    float* d_small = nullptr;                // [0] net offset of the frame, [2] sum of the cyclic-prefix angles
+    float* d_corr = nullptr;
+    float* d_imp = nullptr;                  // impulse response | coarse frequency response, nb_fft floats each
+    float* d_fft = nullptr; float* d_dq = nullptr;
+    // pinned: the synchroniser's record and responses
+    dabgpu_sync_state* h_sync = nullptr; float* h_imp = nullptr;
+    hipEvent_t sync_done = nullptr; bool sync_pending = false; bool sync_coarse = false;
+    hipEvent_t ready = nullptr;              // frame demodulated (stream A) -> decode may start (stream B)
+    int decode_fic = 0;
+};
+
+#define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+
+extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
+    if (!rx) return;
+    if (rx->ctx) {
+        (void)hipSetDevice(rx->ctx->device);
+        (void)hipStreamSynchronize(rx->ctx->stream);
+    }
+    if (rx->ses) dabgpu_frame_session_destroy(rx->ses);          // (synchronises stream B)
+    for (int k = 0; k < STAGES; k++) {
+        if (rx->h_stage[k]) (void)hipHostFree(rx->h_stage[k]);
+        if (rx->stage_free[k]) (void)hipEventDestroy(rx->stage_free[k]);
+    }
+    if (rx->d_prs) (void)hipFree(rx->d_prs);
+    if (rx->d_iq) (void)hipFree(rx->d_iq);
+    if (rx->d_state) (void)hipFree(rx->d_state);
+    if (rx->d_small) (void)hipFree(rx->d_small);
+    if (rx->d_corr) (void)hipFree(rx->d_corr);
+    if (rx->d_imp) (void)hipFree(rx->d_imp);
+    if (rx->d_fft) (void)hipFree(rx->d_fft);
+    if (rx->d_dq) (void)hipFree(rx->d_dq);
+    if (rx->h_sync) (void)hipHostFree(rx->h_sync);
+    if (rx->h_imp) (void)hipHostFree(rx->h_imp);
+    if (rx->sync_done) (void)hipEventDestroy(rx->sync_done);
+    if (rx->ready) (void)hipEventDestroy(rx->ready);
+    if (rx->ctx) dabgpu_destroy(rx->ctx);
+    delete rx;
+}
+
+extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mode, const float* h_prs, const int* h_mapper) {
+    if (!out) { dabgpu_set_error("receiver_create: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int geom[9];
+    if (dabgpu_get_ofdm_params(mode, geom) != DABGPU_OK) { dabgpu_set_error("receiver_create: invalid transmission mode %d", mode); return DABGPU_ERR_INVALID_ARG; }
+    if (mode != 1 && (h_prs || h_mapper)) { dabgpu_set_error("receiver_create: custom PRS / carrier tables are only supported in transmission mode I"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_receiver* rx = new dabgpu_receiver();
+    rx->mode = mode;
+    memcpy(rx->geom, geom, sizeof(geom));
+    int st = dabgpu_create(&rx->ctx, device, h_prs, h_mapper);
+    if (!st) st = dabgpu_frame_session_create(&rx->ses, device);
+    const size_t n_fft = (size_t)geom[3], n_sym = (size_t)geom[0], frame_samples = (size_t)geom[6];
+    // NULL symbol | frame, the frame between nb_cyclic_prefix samples before and nb_fft - nb_cyclic_prefix - 1 after the expected position
+    rx->stage_cap = (size_t)geom[2] + (n_fft - (size_t)geom[4]) + frame_samples;
+    for (int k = 0; k < STAGES && !st; k++) {
+        st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_stage[k], rx->stage_cap * 2 * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver stage)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->stage_free[k], hipEventDisableTiming), "hipEventCreate(receiver)");
+    }
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_prs, n_fft * 2 * sizeof(float)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_iq, frame_samples * 2 * sizeof(float)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_state, sizeof(dabgpu_sync_state)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMemset(rx->d_state, 0, sizeof(dabgpu_sync_state)), "hipMemset(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_small, 4 * sizeof(float)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_corr, n_sym * 2 * sizeof(float)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_imp, 2 * n_fft * sizeof(float)), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_sync, sizeof(dabgpu_sync_state), hipHostMallocDefault), "hipHostMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_imp, 2 * n_fft * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, hipEventDisableTiming), "hipEventCreate(receiver)");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->ready, hipEventDisableTiming), "hipEventCreate(receiver)");
+    if (st) { dabgpu_receiver_destroy(rx); return st; }
+    *out = rx;
+    return DABGPU_OK;
+}
+
+extern "C" dabgpu_frame_session* dabgpu_receiver_session(dabgpu_receiver* rx) { return rx ? rx->ses : nullptr; }
+
+extern "C" int dabgpu_receiver_set_subchannels(dabgpu_receiver* rx, const dabgpu_subchannel* subs, int n, int decode_fic) {
+    if (!rx) { dabgpu_set_error("receiver_set_subchannels: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->mode != 1 && (n > 0 || decode_fic)) { dabgpu_set_error("receiver_set_subchannels: the DAB layer above the soft bits exists for transmission mode I only"); return DABGPU_ERR_UNSUPPORTED; }
+    const int st = dabgpu_frame_session_set_subchannels(rx->ses, subs, n);
+    if (st) return st;
+    rx->decode_fic = decode_fic ? 1 : 0;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_receiver_stage(dabgpu_receiver* rx, float** h_stage, size_t* capacity_samples) {
+    if (!rx || !h_stage) { dabgpu_set_error("receiver_stage: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    *h_stage = rx->h_stage[rx->cur];
+    if (capacity_samples) *capacity_samples = rx->stage_cap;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_receiver_reset(dabgpu_receiver* rx) {
+    if (!rx) { dabgpu_set_error("receiver_reset: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(rx->ctx);
+    // :277-289 coarse = fine = 0, no coarse offset found -- behind everything already enqueued (a frame in flight keeps its offsets)
+    return dabgpu_check_hip(hipMemsetAsync(rx->d_state, 0, sizeof(dabgpu_sync_state), rx->ctx->stream), "hipMemsetAsync(receiver state)");
+}
+
+extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_sync_cfg* cfg, size_t prs_sample) {
+    if (!rx || !cfg) { dabgpu_set_error("receiver_submit_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    const size_t n_fft = (size_t)rx->geom[3];
+    if (prs_sample + n_fft > rx->stage_cap) { dabgpu_set_error("receiver_submit_sync: the PRS slot lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->sync_pending) { dabgpu_set_error("receiver_submit_sync: the previous record has not been collected (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_ctx* c = rx->ctx;
+    DABGPU_BIND(c);
+    hipStream_t a = c->stream;
+    int st;
+    CK(hipMemcpyAsync(rx->d_prs, rx->h_stage[rx->cur] + 2 * prs_sample, n_fft * 2 * sizeof(float), hipMemcpyHostToDevice, a));
+    rx->sync_coarse = cfg->is_coarse_freq_correction != 0;
+    if ((st = dabgpu_ofdm_sync_mode(c, rx->mode, rx->d_prs, 1, n_fft, cfg, rx->d_state, rx->d_imp, rx->sync_coarse ? rx->d_imp + n_fft : nullptr, a))) return st;
+    CK(hipMemcpyAsync(rx->h_sync, rx->d_state, sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
+    CK(hipMemcpyAsync(rx->h_imp, rx->d_imp, (rx->sync_coarse ? 2 : 1) * n_fft * sizeof(float), hipMemcpyDeviceToHost, a));
+    CK(hipEventRecord(rx->sync_done, a));
+    rx->sync_pending = true;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state* out, float* h_impulse, float* h_freq_response) {
+    if (!rx || !out) { dabgpu_set_error("receiver_wait_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (!rx->sync_pending) { dabgpu_set_error("receiver_wait_sync: no synchronisation was submitted"); return DABGPU_ERR_NOT_READY; }
+    DABGPU_BIND(rx->ctx);
+    int st;
+    CK(hipEventSynchronize(rx->sync_done));
+    rx->sync_pending = false;
+    *out = *rx->h_sync;
+    const size_t n_fft = (size_t)rx->geom[3];
+    if (h_impulse) memcpy(h_impulse, rx->h_imp, n_fft * sizeof(float));
+    if (h_freq_response && rx->sync_coarse) memcpy(h_freq_response, rx->h_imp + n_fft, n_fft * sizeof(float));
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie_rule, uint64_t* generation) {
+    if (!rx) { dabgpu_set_error("receiver_submit_frame: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    const size_t frame_samples = (size_t)rx->geom[6], n_fft = (size_t)rx->geom[3], n_sym = (size_t)rx->geom[0], frame_bits = (size_t)rx->geom[8];
+    if (frame_sample + frame_samples > rx->stage_cap) { dabgpu_set_error("receiver_submit_frame: the frame lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->sync_pending) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_ctx* c = rx->ctx;
+    DABGPU_BIND(c);
+    hipStream_t a = c->stream;
+    int st;
+    uint64_t gen = 0;
+    int8_t* d_bits = nullptr;
+    dabgpu_frame_session::slot* sl = nullptr;
+    if ((st = dabgpu_session_reserve(rx->ses, a, &gen, &d_bits, &sl))) return st;
+    const size_t fft_bytes = (n_sym + 1) * n_fft * 2 * sizeof(float), dq_bytes = (n_sym - 1) * (size_t)rx->geom[5] * 2 * sizeof(float);
+    const bool want_dq = want_views && rx->mode == 1;
+    if (want_views) {
+        if (!rx->d_fft) CK(hipMalloc((void**)&rx->d_fft, fft_bytes));
+        if (want_dq && !rx->d_dq) CK(hipMalloc((void**)&rx->d_dq, dq_bytes));
+        if (sl->h_fft_cap < fft_bytes) {
+            if (sl->h_fft) (void)hipHostFree(sl->h_fft);
+            sl->h_fft = nullptr; sl->h_fft_cap = 0;
+            CK(hipHostMalloc((void**)&sl->h_fft, fft_bytes, hipHostMallocDefault));
+            sl->h_fft_cap = fft_bytes;
+        }
+        if (want_dq && sl->h_dq_cap < dq_bytes) {
+            if (sl->h_dq) (void)hipHostFree(sl->h_dq);
+            sl->h_dq = nullptr; sl->h_dq_cap = 0;
+            CK(hipHostMalloc((void**)&sl->h_dq, dq_bytes, hipHostMallocDefault));
+            sl->h_dq_cap = dq_bytes;
+        }
+    }
+    if (!sl->h_aux) CK(hipHostMalloc((void**)&sl->h_aux, 16 * sizeof(float), hipHostMallocDefault));
+    CK(hipMemcpyAsync(rx->d_iq, rx->h_stage[rx->cur] + 2 * frame_sample, frame_samples * 2 * sizeof(float), hipMemcpyHostToDevice, a));
+    CK(hipEventRecord(rx->stage_free[rx->cur], a));
+    rx->stage_pending[rx->cur] = true;
+    rx_net_freq_kernel<<<1, 64, 0, a>>>(rx->d_state, rx->d_small);
+    CK(hipGetLastError());
+    float* d_fine = &rx->d_state->freq_fine;
+    if (rx->mode == 1) {
+        if ((st = dabgpu_ofdm_demod_frames(c, rx->d_iq, 1, rx->d_small, d_bits, rx->d_corr, want_views ? rx->d_fft : nullptr, want_dq ? rx->d_dq : nullptr, 0, 0, a))) return st;
+        if ((st = dabgpu_ofdm_phase_update(c, rx->d_corr, 1, beta, rx->d_small + 2, d_fine, a))) return st;
+    } else {
+        if ((st = dabgpu_ofdm_demod_frames_mode(c, rx->mode, rx->d_iq, 1, rx->d_small, d_bits, rx->d_corr, want_views ? rx->d_fft : nullptr, 0, a))) return st;
+        if ((st = dabgpu_ofdm_phase_update_mode(c, rx->mode, rx->d_corr, 1, beta, rx->d_small + 2, d_fine, a))) return st;
+    }
+    // h_aux: [0] fine-frequency word after this frame's update, [1] sum of the cyclic-prefix angles
+    CK(hipMemcpyAsync(sl->h_aux, d_fine, sizeof(float), hipMemcpyDeviceToHost, a));
+    CK(hipMemcpyAsync(sl->h_aux + 1, rx->d_small + 2, sizeof(float), hipMemcpyDeviceToHost, a));
+    if (want_views) CK(hipMemcpyAsync(sl->h_fft, rx->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
+    if (want_dq) CK(hipMemcpyAsync(sl->h_dq, rx->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
+    CK(hipEventRecord(rx->ready, a));
+    const bool decode = rx->mode == 1 && (rx->decode_fic || !rx->ses->subs.empty());
+    if ((st = dabgpu_session_commit(rx->ses, gen, rx->ready, frame_bits, decode ? 1 : 0, rx->decode_fic, tie_rule))) return st;
+    // the next frame is assembled in the next staging buffer; its last upload (STAGES frames ago) has long finished
+    rx->cur = (rx->cur + 1) % STAGES;
+    if (rx->stage_pending[rx->cur]) {
+        CK(hipEventSynchronize(rx->stage_free[rx->cur]));
+        rx->stage_pending[rx->cur] = false;
+    }
+    if (generation) *generation = gen;
+    return DABGPU_OK;
+}
+
+extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generation, dabgpu_receiver_frame* out) {
+    if (!rx || !out) { dabgpu_set_error("receiver_wait_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_frame_session* s = rx->ses;
+    DABGPU_BIND(s->ctx);
+    dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];
+    hipEvent_t done = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (sl->gen != generation) { dabgpu_set_error("receiver_wait_frame: generation %llu is gone or was never submitted", (unsigned long long)generation); return DABGPU_ERR_NOT_READY; }
+        if (sl->pending) done = sl->done;
+    }
+    // waited for outside the session's lock: the producer thread submits the next frame meanwhile (the slot is not reused before
+    // R more frames were submitted -- the caller bounds the frames in flight)
+    if (done) {
+        int st = dabgpu_check_hip(hipEventSynchronize(done), "hipEventSynchronize(receiver frame)");
+        if (st) return st;
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (sl->gen == generation) sl->pending = false;
+    }
+    out->generation = generation;
+    out->bits = sl->h_bits;
+    out->n_bits = (size_t)rx->geom[8];
+    out->freq_fine = sl->h_aux[0];
+    out->total_phase = sl->h_aux[1];
+    out->fft = sl->h_fft;
+    out->dqpsk = sl->h_dq;
+    return DABGPU_OK;
+}

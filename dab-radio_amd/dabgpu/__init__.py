@@ -23,6 +23,7 @@ NB_FRAME_BITS = 230400
 NB_FIC_BITS = 9216
 NB_FIB_GROUP_BITS = 2304
 NB_CIF_BITS = 55296
+ABI_VERSION = 2                          # DABGPU_ABI_VERSION of include/dabgpu.h
 BITS_NATURAL, BITS_MSC_CLASSED = 0, 1     # dabgpu_ofdm_demod_frames_history / dabgpu_msc_decode_frames_layout
 
 
@@ -63,6 +64,8 @@ ABI_SYMBOLS = [
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
     "dabgpu_viterbi_decode_depunctured_host_sync", "dabgpu_stream_bank_process_ring_retained",
     "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
+    "dabgpu_receiver_create", "dabgpu_receiver_destroy", "dabgpu_receiver_session", "dabgpu_receiver_set_subchannels", "dabgpu_receiver_stage",
+    "dabgpu_receiver_reset", "dabgpu_receiver_submit_sync", "dabgpu_receiver_wait_sync", "dabgpu_receiver_submit_frame", "dabgpu_receiver_wait_frame",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 
@@ -153,6 +156,8 @@ def lib():
         except Exception:
             pass
         L = C.CDLL(LIB_PATH)
+        if L.dabgpu_abi_version() != ABI_VERSION:
+            raise DabGpuError(f"{LIB_PATH} implements ABI version {L.dabgpu_abi_version()}, this binding was written for {ABI_VERSION}: rebuild it")
         L.dabgpu_strerror.restype = C.c_char_p
         L.dabgpu_strerror.argtypes = [C.c_int]
         L.dabgpu_last_error.restype = C.c_char_p

@@ -226,6 +226,7 @@ static int run(const Args& args) {
             demod->Process(tcb::span<const std::complex<float>>(block.data(), length));
             if (length != block.size()) break;
         }
+        demod->Synchronize();
         fprintf(stderr, "ofdm: frames_read=%d frames_desync=%d coarse=%.6g fine=%.6g\n", demod->GetTotalFramesRead(),
                 demod->GetTotalFramesDesync(), demod->GetCoarseFrequencyOffset(), demod->GetFineFrequencyOffset());
     } else {

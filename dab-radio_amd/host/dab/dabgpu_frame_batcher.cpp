@@ -14,15 +14,13 @@ namespace {
 
 constexpr int KEEP = 8;                                    // frames whose soft bits and results stay available (= the session's)
 constexpr int MAX_PRODUCERS = 8;                           // demodulators with a session of their own; further ones are not batched
-constexpr int RETRY_AFTER = 64;                            // frames a producer whose session failed waits before it tries again
 constexpr size_t FRAME_BITS = DABGPU_NB_FRAME_BITS, FIC_BITS = 9216, CIF_BITS = 55296, GROUP_BITS = 2304;
 
-// one demodulator's frames: a device session + the host copy of its last KEEP frames (what the decoders' buffers are matched against)
+// one demodulator's frames: its receiver's frame session (owned by the demodulator) + the host copy of its last KEEP frames (what the
+// decoders' buffers are matched against)
 struct Producer {
     const void* id = nullptr;
     dabgpu_frame_session* session = nullptr;
-    int cool_down = 0;                                     // > 0: the session failed; frames to let pass before the next attempt
-    uint64_t subs_version = ~0ull;                         // version of the sub-channel list the session was last given
     struct Frame { uint64_t gen = ~0ull; std::vector<int8_t> bits; };
     Frame frames[KEEP];
     uint64_t next_gen = 0;
@@ -40,12 +38,10 @@ State& S() { static State s; return s; }
 
 bool same(const dabgpu_subchannel& a, const dabgpu_subchannel& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
-void drop_session(Producer& p) {
-    if (p.session) dabgpu_frame_session_destroy(p.session);
-    p.session = nullptr;
+void forget(Producer& p) {
+    p.session = nullptr;                                   // (the session is the demodulator's)
     for (auto& f : p.frames) f.gen = ~0ull;
     p.next_gen = 0;
-    p.subs_version = ~0ull;
 }
 
 }  // namespace
@@ -84,11 +80,22 @@ void remove_producer(const void* producer) {
     State& s = S();
     std::lock_guard<std::mutex> g(s.mu);
     for (auto& p : s.producers)
-        if (p && p->id == producer) { drop_session(*p); p->id = nullptr; p->cool_down = 0; }     // the slot stays (cif_id::src of others must not move)
+        if (p && p->id == producer) { forget(*p); p->id = nullptr; }     // the slot stays (cif_id::src of others must not move)
 }
 
-void on_frame(const void* producer, const int8_t* frame_bits) {
-    if (!enabled()) return;
+uint64_t subscription(std::vector<dabgpu_subchannel>& subs, bool& fic) {
+    subs.clear();
+    fic = false;
+    if (!enabled()) return 0;
+    State& s = S();
+    std::lock_guard<std::mutex> g(s.mu);
+    for (const auto& e : s.subs) subs.push_back(e.sc);
+    fic = s.fic_refs > 0;
+    return (s.subs_version << 1) | (fic ? 1u : 0u);
+}
+
+void on_frame_decoded(const void* producer, dabgpu_frame_session* session, uint64_t gen, const int8_t* frame_bits) {
+    if (!enabled() || !session) return;
     State& s = S();
     std::lock_guard<std::mutex> g(s.mu);
     if (s.fic_refs == 0 && s.subs.empty()) return;                       // nobody is listening
@@ -103,20 +110,7 @@ void on_frame(const void* producer, const int8_t* frame_bits) {
         }
         p->id = producer;
     }
-    if (p->cool_down > 0) { p->cool_down--; return; }
-    auto failed = [&] { drop_session(*p); p->cool_down = RETRY_AFTER; };  // stay out of the way for a while, then try again
-    if (!p->session) {
-        const char* dev = std::getenv("DABGPU_DEVICE");
-        if (dabgpu_frame_session_create(&p->session, dev ? std::atoi(dev) : 0) != DABGPU_OK) { p->session = nullptr; failed(); return; }
-    }
-    if (p->subs_version != s.subs_version) {
-        std::vector<dabgpu_subchannel> list;
-        for (const auto& e : s.subs) list.push_back(e.sc);
-        if (dabgpu_frame_session_set_subchannels(p->session, list.data(), (int)list.size()) != DABGPU_OK) { failed(); return; }
-        p->subs_version = s.subs_version;
-    }
-    uint64_t gen = 0;
-    if (dabgpu_frame_session_push_frame(p->session, frame_bits, s.fic_refs > 0, dabgpu_tie_rule_from_env(), &gen) != DABGPU_OK) { failed(); return; }
+    p->session = session;
     Producer::Frame& f = p->frames[gen % KEEP];
     f.gen = ~0ull;
     f.bits.assign(frame_bits, frame_bits + FRAME_BITS);
@@ -127,7 +121,7 @@ void on_frame(const void* producer, const int8_t* frame_bits) {
 bool fetch_fib_group(const int8_t* group_bits, int group, uint8_t* bytes96, uint32_t* crc_mask, uint64_t* path_error) {
     if (!enabled() || group < 0 || group > 3) return false;
     State& s = S();
-    std::lock_guard<std::mutex> g(s.mu);                                  // (held over the fetch: remove_producer destroys sessions)
+    std::lock_guard<std::mutex> g(s.mu);                                  // (held over the fetch -- a copy out of host memory, the frame was delivered complete: remove_producer forgets sessions)
     for (auto& q : s.producers) {
         if (!q || !q->session) continue;
         const Producer& p = *q;

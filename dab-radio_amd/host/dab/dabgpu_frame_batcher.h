@@ -2,11 +2,12 @@
 //
 // The reference fans a frame out to a FIC runner and one MSC runner per sub-channel (src/basic_radio/basic_radio.cpp:41-65); behind
 // the mirror classes every DecodeFIBGroup / DecodeCIF used to be its own synchronous launch + two copies: 4 + 72 round trips per frame
-// for 18 sub-channels.  The batcher is a process-wide object that every OFDM_Demod feeds the frames it completes (mode I) and every
-// FIC_Decoder / MSC_Decoder registers with: the frame is decoded ONCE on the device (dabgpu_frame_session, include/dabgpu.h) -- the
-// FIC and all registered sub-channels -- and the classes pick their bytes up.  Every demodulator has a session and an 8-frame history
-// of its own (up to 8 demodulators per process; a further one is simply not batched), so the frames of several receivers in one process
-// do not push each other out of the history; a session that fails is dropped and tried again 64 frames later.
+// for 18 sub-channels.  The batcher is a process-wide registry between the two sides: every FIC_Decoder / MSC_Decoder registers what
+// it decodes, every OFDM_Demod (mode I) asks it what to decode (`subscription`) and has its receiver pipeline decode exactly that with
+// the frame, ON THE DEVICE, chained behind the demodulation (dabgpu_receiver_*, include/dabgpu.h) -- the FIC and all registered
+// sub-channels in one batched decode; when the frame is delivered the demodulator reports it here (`on_frame_decoded`) and the classes
+// pick their bytes up from its frame session.  Every demodulator has a session and an 8-frame history of its own (up to 8 demodulators
+// per process; a further one is simply not batched), so the frames of several receivers in one process do not push each other out.
 //
 // A class may take a batcher result only when it is the result the class itself would compute:
 //   * the soft bits it is handed are, byte for byte, the slice of a frame the batcher has decoded (compared with memcmp against the
@@ -20,15 +21,19 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
 
 #include "dabgpu.h"
 
 namespace dabgpu_frame_batcher {
 
 bool enabled();
-// OFDM_Demod `producer` (any address that identifies the demodulator): a completed mode-I frame (230400 soft bits); its destructor
-// gives the demodulator's session back
-void on_frame(const void* producer, const int8_t* frame_bits);
+// what the demodulators' receivers decode with every frame: the sub-channels registered, whether a FIC_Decoder listens; the value
+// returned changes whenever the answer does
+uint64_t subscription(std::vector<dabgpu_subchannel>& subs, bool& fic);
+// OFDM_Demod `producer` (any address that identifies the demodulator): frame `gen` of its receiver's `session` (230400 soft bits) has been
+// delivered, decoded for the subscription as it was when the frame was submitted; its destructor takes the demodulator out
+void on_frame_decoded(const void* producer, dabgpu_frame_session* session, uint64_t gen, const int8_t* frame_bits);
 void remove_producer(const void* producer);
 // decoders: registration (reference-counted per distinct sub-channel) -- the FIC counts as a registration of its own
 void add_fic();

@@ -10,6 +10,7 @@
 
 #include "dabgpu.h"
 #include "dab/dabgpu_frame_batcher.h"
+#include "dab/dabgpu_shared_context.h"
 
 namespace {
 [[noreturn]] void fail(const char* what, int st) {
@@ -33,7 +34,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     const char* dev = std::getenv("DABGPU_DEVICE");
     int st;
     if (m_mode == 1) {
-        st = dabgpu_create(&m_ctx, dev ? std::atoi(dev) : 0, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+        st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
     } else {
         // modes II-IV run on the library's built-in tables of that mode: a caller-supplied table must be that table
         std::vector<float> prs(2 * params.nb_fft);
@@ -42,41 +43,93 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
             std::memcmp(prs.data(), prs_fft_ref.data(), prs.size() * sizeof(float)) != 0 ||
             std::memcmp(map.data(), carrier_mapper.data(), map.size() * sizeof(int)) != 0)
             throw std::runtime_error("OFDM_Demod: custom PRS / carrier tables are only supported in transmission mode I");
-        st = dabgpu_create(&m_ctx, dev ? std::atoi(dev) : 0, nullptr, nullptr);
+        st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, m_mode, nullptr, nullptr);
     }
-    if (st != DABGPU_OK) fail("dabgpu_create", st);       // no CPU fallback: a missing GPU is a construction error
+    if (st != DABGPU_OK) fail("dabgpu_receiver_create", st);       // no CPU fallback: a missing GPU is a construction error
+    float* stage = nullptr;
+    if ((st = dabgpu_receiver_stage(m_rx, &stage, &m_stage_capacity)) != DABGPU_OK) { dabgpu_receiver_destroy(m_rx); fail("dabgpu_receiver_stage", st); }
+    m_stage = reinterpret_cast<std::complex<float>*>(stage);
+    if (const char* d = std::getenv("DABGPU_MIRROR_DEPTH")) m_depth = std::min(6, std::max(1, std::atoi(d)));
     m_ring.assign(params.nb_null_period, {0.0f, 0.0f});
     m_corr.assign(params.nb_null_period + params.nb_symbol_period, {0.0f, 0.0f});
-    m_frame.assign(params.nb_frame_symbols * params.nb_symbol_period + params.nb_null_period, {0.0f, 0.0f});
     m_frame_bits.assign((params.nb_frame_symbols - 1) * params.nb_data_carriers * 2, 0);
+    m_bits_ptr = m_frame_bits.data();
+    m_bits_len = m_frame_bits.size();
     m_frame_fft.assign((params.nb_frame_symbols + 1) * params.nb_fft, {0.0f, 0.0f});
     m_frame_dqpsk.assign((params.nb_frame_symbols - 1) * params.nb_fft, {0.0f, 0.0f});
     m_impulse_response.assign(params.nb_fft, 0.0f);
     m_frequency_response.assign(params.nb_fft, 0.0f);
-    // the frame's samples go to the device and its soft bits come back once per frame: page-locked, the two copies run at PCIe speed
-    // (best effort: an unpinned buffer works too)
-    m_pinned_frame = dabgpu_host_pin(m_frame.data(), m_frame.size() * sizeof(m_frame[0])) == DABGPU_OK;
-    m_pinned_bits = dabgpu_host_pin(m_frame_bits.data(), m_frame_bits.size() * sizeof(m_frame_bits[0])) == DABGPU_OK;
+    m_thread = std::thread([this] { DeliveryThread(); });
 }
 
 OFDM_Demod::~OFDM_Demod() {
+    {
+        // every frame handed to the device is delivered before the object goes (the reference's destructor lets the coordinator finish too)
+        std::unique_lock<std::mutex> lock(m_mu);
+        m_cv_done.wait(lock, [this] { return m_items.empty() && !m_busy; });
+        m_stop = true;
+    }
+    m_cv_items.notify_all();
+    if (m_thread.joinable()) m_thread.join();
     dabgpu_frame_batcher::remove_producer(this);
-    if (m_pinned_frame) (void)dabgpu_host_unpin(m_frame.data());
-    if (m_pinned_bits) (void)dabgpu_host_unpin(m_frame_bits.data());
-    dabgpu_destroy(m_ctx);
+    dabgpu_receiver_destroy(m_rx);
+}
+
+void OFDM_Demod::RethrowDeliveryError() {
+    std::exception_ptr e;
+    { std::lock_guard<std::mutex> lock(m_mu); e = m_error; m_error = nullptr; }
+    if (e) std::rethrow_exception(e);
+}
+
+// not in the reference: the point at which everything Process() was handed has come out of the observers
+void OFDM_Demod::Synchronize() {
+    {
+        std::unique_lock<std::mutex> lock(m_mu);
+        m_cv_done.wait(lock, [this] { return m_items.empty() && !m_busy; });
+    }
+    RethrowDeliveryError();
 }
 
 // :235-275
 void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {
+    RethrowDeliveryError();
+    // A record still outstanding from the previous block is collected first.  If the impulse-peak test failed, the samples that were
+    // buffered behind the PRS slot meanwhile -- the rest of that block -- go through the NULL search they would have gone through
+    // (:529-532 Reset, then FindNullPowerDip on the remainder of the block, with that block's signal average)
+    if (m_sync_pending) {
+        const size_t buffered = m_stage_length;
+        if (!ResolveSync()) {
+            const std::vector<std::complex<float>> rest(m_stage + m_corr.size(), m_stage + buffered);
+            Run(rest);
+        }
+    }
     UpdateSignalAverage(buf);
+    Run(buf);
+}
+
+void OFDM_Demod::Run(tcb::span<const std::complex<float>> buf) {
     size_t pos = 0;
     while (pos < buf.size()) {
         auto rest = buf.subspan(pos);
         switch (m_state) {
         case FINDING_NULL_POWER_DIP: pos += FindNullPowerDip(rest); break;
-        case READING_NULL_AND_PRS: pos += ReadNullPRS(rest); break;
+        case READING_NULL_AND_PRS:
+            pos += ReadNullPRS(rest);
+            if (m_state == RUNNING_COARSE_FREQ_SYNC) { SubmitSync(); m_spec_pos = pos; }
+            break;
         case RUNNING_COARSE_FREQ_SYNC:
-        case RUNNING_FINE_TIME_SYNC: RunSync(); break;
+        case RUNNING_FINE_TIME_SYNC: {
+            // the synchroniser runs on the device; whatever it finds, the samples up to where the earliest possible frame ends belong
+            // to this frame if the impulse-peak test passes: buffer on instead of waiting
+            const size_t earliest_end = m_params.nb_null_period - m_params.nb_cyclic_prefix +
+                                        m_params.nb_frame_symbols * m_params.nb_symbol_period + m_params.nb_null_period;
+            const size_t take = std::min(earliest_end - m_stage_length, rest.size());
+            std::copy_n(rest.begin(), take, m_stage + m_stage_length);
+            m_stage_length += take;
+            pos += take;
+            if (m_stage_length == earliest_end && !ResolveSync()) { m_stage_length = 0; pos = m_spec_pos; }       // back to the sample after the PRS slot
+            break;
+        }
         case READING_SYMBOLS: pos += ReadSymbols(rest); break;
         }
     }
@@ -84,13 +137,25 @@ void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {
 
 // :277-289
 void OFDM_Demod::Reset() {
+    if (m_sync_pending) {                     // (a record in flight belongs to the state being abandoned)
+        dabgpu_sync_state st;
+        (void)dabgpu_receiver_wait_sync(m_rx, &st, nullptr, nullptr);
+        m_sync_pending = false;
+    }
+    ResetReader();
+}
+
+void OFDM_Demod::ResetReader() {
     m_state = FINDING_NULL_POWER_DIP;
     m_corr_length = 0;
-    m_total_frames_desync++;
-    m_is_found_coarse = false;
-    m_freq_coarse = 0.0f;
-    m_freq_fine = 0.0f;
-    m_fine_time_offset = 0;
+    m_stage_length = 0;
+    const int rc = dabgpu_receiver_reset(m_rx);       // coarse = fine = 0, no coarse offset found -- behind the frames already submitted
+    if (rc != DABGPU_OK) fail("dabgpu_receiver_reset", rc);
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        m_items.push_back(Item{Item::RESET, 0.0f, 0.0f, 0, 0, false, false});
+    }
+    m_cv_items.notify_one();
 }
 
 // :922-932
@@ -149,8 +214,8 @@ size_t OFDM_Demod::ReadNullPRS(tcb::span<const std::complex<float>> buf) {
     return take;
 }
 
-// :360-471 + :473-548, both on the device in one launch
-void OFDM_Demod::RunSync() {
+// :360-471 + :473-548 on the device, one launch, enqueued: the correlation window heads the staging buffer the frame is assembled in
+void OFDM_Demod::SubmitSync() {
     dabgpu_sync_cfg cfg;
     cfg.fine_freq_update_beta = m_cfg.sync.fine_freq_update_beta;
     cfg.is_coarse_freq_correction = m_cfg.sync.is_coarse_freq_correction ? 1 : 0;
@@ -158,67 +223,142 @@ void OFDM_Demod::RunSync() {
     cfg.coarse_freq_slow_beta = m_cfg.sync.coarse_freq_slow_beta;
     cfg.impulse_peak_threshold_db = m_cfg.sync.impulse_peak_threshold_db;
     cfg.impulse_peak_distance_probability = m_cfg.sync.impulse_peak_distance_probability;
-    dabgpu_sync_state st;
-    st.freq_coarse = m_freq_coarse;
-    st.freq_fine = m_freq_fine;
-    st.is_found_coarse = m_is_found_coarse ? 1 : 0;
-    st.fine_time_offset = 0;
-    st.sync_valid = 0;
-    st.reserved = 0;
+    std::copy(m_corr.begin(), m_corr.end(), m_stage);
+    m_stage_length = m_corr.size();
     m_state = RUNNING_FINE_TIME_SYNC;
-    const auto* prs_sym = &m_corr[m_params.nb_null_period];
-    const int rc = dabgpu_ofdm_sync_host_sync_mode(m_ctx, m_mode, reinterpret_cast<const float*>(prs_sym), &cfg, &st,
-                                                   m_impulse_response.data(),
-                                                   cfg.is_coarse_freq_correction ? m_frequency_response.data() : nullptr);
-    if (rc != DABGPU_OK) fail("dabgpu_ofdm_sync_host_sync_mode", rc);
-    m_freq_coarse = st.freq_coarse;
-    m_freq_fine = st.freq_fine;
-    m_is_found_coarse = st.is_found_coarse != 0;
-    if (!st.sync_valid) { Reset(); return; }                  // :529-532
-    // :536-546 the PRS starts `offset` samples after (or before) the expected position
-    const int offset = st.fine_time_offset;
-    const size_t start = (size_t)((int)m_params.nb_null_period + offset);
-    const size_t count = m_corr.size() - start;
-    std::copy_n(m_corr.begin() + (std::ptrdiff_t)start, count, m_frame.begin());
-    m_frame_length = count;
+    const int rc = dabgpu_receiver_submit_sync(m_rx, &cfg, m_params.nb_null_period);
+    if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_sync", rc);
+    m_sync_pending = true;
+}
+
+// the record of the synchroniser submitted last; false = the impulse-peak test failed and the receiver was reset (:529-532)
+bool OFDM_Demod::ResolveSync() {
+    dabgpu_sync_state st;
+    const int rc = dabgpu_receiver_wait_sync(m_rx, &st, m_impulse_response.data(),
+                                             m_cfg.sync.is_coarse_freq_correction ? m_frequency_response.data() : nullptr);
+    m_sync_pending = false;
+    if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_sync", rc);
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        m_items.push_back(Item{Item::SYNC, st.freq_coarse, st.freq_fine, st.sync_valid ? st.fine_time_offset : 0, 0, false, false});
+    }
+    m_cv_items.notify_one();
     m_corr_length = 0;
-    m_fine_time_offset = offset;
+    if (!st.sync_valid) { ResetReader(); return false; }
+    // :536-546 the PRS starts `offset` samples after (or before) the expected position
+    m_reader_time_offset = st.fine_time_offset;
+    m_frame_end = (size_t)((int)m_params.nb_null_period + st.fine_time_offset) + m_params.nb_frame_symbols * m_params.nb_symbol_period + m_params.nb_null_period;
     m_state = READING_SYMBOLS;
+    return true;
 }
 
 // :550-577
 size_t OFDM_Demod::ReadSymbols(tcb::span<const std::complex<float>> buf) {
-    const size_t want = m_frame.size() - m_frame_length;
+    const size_t want = m_frame_end - m_stage_length;
     const size_t take = std::min(want, buf.size());
-    std::copy_n(buf.begin(), take, m_frame.begin() + (std::ptrdiff_t)m_frame_length);
-    m_frame_length += take;
-    if (m_frame_length < m_frame.size()) return take;
+    std::copy_n(buf.begin(), take, m_stage + m_stage_length);
+    m_stage_length += take;
+    if (m_stage_length < m_frame_end) return take;
     // the NULL symbol at the end of this frame heads the next correlation window (:558-562)
-    const size_t null_at = m_params.nb_frame_symbols * m_params.nb_symbol_period;
-    std::copy_n(m_frame.begin() + (std::ptrdiff_t)null_at, m_params.nb_null_period, m_corr.begin());
+    std::copy_n(m_stage + (m_frame_end - m_params.nb_null_period), m_params.nb_null_period, m_corr.begin());
     m_corr_length = m_params.nb_null_period;
-    DemodulateFrame();
-    m_frame_length = 0;
+    SubmitFrame();
+    m_stage_length = 0;
     m_state = READING_NULL_AND_PRS;
     return take;
 }
 
-// :581-639 (coordinator) + :650-766 (pipelines) for one frame
-void OFDM_Demod::DemodulateFrame() {
-    float fine = m_freq_fine;
-    // mode I: the register-resident kernel (also fills GetFrameDataVec); modes II-IV: the size-generic kernel
-    const int rc = (m_mode == 1)
-        ? dabgpu_ofdm_demod_stream_frame_sync(
-              m_ctx, reinterpret_cast<const float*>(m_frame.data()), m_freq_coarse, &fine, m_cfg.sync.fine_freq_update_beta,
-              m_frame_bits.data(), nullptr, m_fetch_debug ? reinterpret_cast<float*>(m_frame_fft.data()) : nullptr,
-              m_fetch_debug ? reinterpret_cast<float*>(m_frame_dqpsk.data()) : nullptr)
-        : dabgpu_ofdm_demod_stream_frame_sync_mode(
-              m_ctx, m_mode, reinterpret_cast<const float*>(m_frame.data()), m_freq_coarse, &fine, m_cfg.sync.fine_freq_update_beta,
-              m_frame_bits.data(), nullptr, m_fetch_debug ? reinterpret_cast<float*>(m_frame_fft.data()) : nullptr);
-    if (rc != DABGPU_OK) fail("dabgpu_ofdm_demod_stream_frame_sync", rc);
-    m_freq_fine = fine;
-    m_total_frames_read++;
-    // the decoders of this process get the whole frame decoded in one go (mode I: the DAB layer above the soft bits is mode I only)
-    if (m_mode == 1) dabgpu_frame_batcher::on_frame(this, m_frame_bits.data());
-    m_on_frame.Notify(tcb::span<const viterbi_bit_t>(m_frame_bits.data(), m_frame_bits.size()));
+// :565-572 wait for a free slot, swap buffers, start the workers: upload, demodulation, fine-frequency update and -- for the decoders of
+// this process that listen -- the frame's FIC / MSC decode, enqueued; the delivery thread picks the results up
+void OFDM_Demod::SubmitFrame() {
+    bool decoded = false;
+    if (m_mode == 1) {
+        std::vector<dabgpu_subchannel> subs;
+        bool fic = false;
+        const uint64_t version = dabgpu_frame_batcher::subscription(subs, fic);
+        if (version != m_subs_version) {
+            const int rc = dabgpu_receiver_set_subchannels(m_rx, subs.data(), (int)subs.size(), fic ? 1 : 0);
+            if (rc != DABGPU_OK) fail("dabgpu_receiver_set_subchannels", rc);
+            m_subs_version = version;
+        }
+        decoded = fic || !subs.empty();
+    }
+    {
+        std::unique_lock<std::mutex> lock(m_mu);
+        m_cv_done.wait(lock, [this] { return m_frames_in_flight < m_depth; });
+    }
+    RethrowDeliveryError();
+    uint64_t gen = 0;
+    const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
+    const int rc = dabgpu_receiver_submit_frame(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, m_fetch_debug ? 1 : 0, dabgpu_tie_rule_from_env(), &gen);
+    if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_frame", rc);
+    float* stage = nullptr;
+    (void)dabgpu_receiver_stage(m_rx, &stage, nullptr);
+    m_stage = reinterpret_cast<std::complex<float>*>(stage);
+    {
+        std::lock_guard<std::mutex> lock(m_mu);
+        m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, decoded});
+        m_frames_in_flight++;
+    }
+    m_cv_items.notify_one();
+}
+
+// :581-639 the coordinator's role: everything a frame publishes, in submission order
+void OFDM_Demod::DeliveryThread() {
+    for (;;) {
+        Item it;
+        {
+            std::unique_lock<std::mutex> lock(m_mu);
+            m_cv_items.wait(lock, [this] { return m_stop || !m_items.empty(); });
+            if (m_items.empty()) return;
+            it = m_items.front();
+            m_items.pop_front();
+            m_busy = true;
+        }
+        bool failed;
+        { std::lock_guard<std::mutex> lock(m_mu); failed = (bool)m_error; }
+        try {
+            switch (it.kind) {
+            case Item::SYNC:
+                m_freq_coarse = it.coarse;
+                m_freq_fine = it.fine;
+                m_fine_time_offset = it.offset;
+                break;
+            case Item::RESET:
+                m_total_frames_desync++;
+                m_freq_coarse = 0.0f;
+                m_freq_fine = 0.0f;
+                m_fine_time_offset = 0;
+                break;
+            case Item::FRAME: {
+                if (failed) break;                       // after a device error nothing more is delivered; Process() rethrows it
+                dabgpu_receiver_frame fr;
+                const int rc = dabgpu_receiver_wait_frame(m_rx, it.gen, &fr);
+                if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_frame", rc);
+                m_freq_fine = fr.freq_fine;
+                m_total_frames_read++;
+                m_bits_ptr = fr.bits;
+                m_bits_len = fr.n_bits;
+                if (it.views) {
+                    std::memcpy(static_cast<void*>(m_frame_fft.data()), fr.fft, m_frame_fft.size() * sizeof(m_frame_fft[0]));
+                    if (m_mode == 1) std::memcpy(static_cast<void*>(m_frame_dqpsk.data()), fr.dqpsk, (m_params.nb_frame_symbols - 1) * m_params.nb_data_carriers * sizeof(m_frame_dqpsk[0]));
+                }
+                // the decoders of this process find the frame's FIBs and sub-channel bytes already decoded (mode I: the DAB layer above
+                // the soft bits is mode I only)
+                if (it.decoded) dabgpu_frame_batcher::on_frame_decoded(this, dabgpu_receiver_session(m_rx), it.gen, fr.bits);
+                m_on_frame.Notify(tcb::span<const viterbi_bit_t>(fr.bits, fr.n_bits));
+                break;
+            }
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(m_mu);
+            if (!m_error) m_error = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_mu);
+            if (it.kind == Item::FRAME) m_frames_in_flight--;
+            m_busy = false;
+        }
+        m_cv_done.notify_all();
+    }
 }

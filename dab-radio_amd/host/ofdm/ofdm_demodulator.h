@@ -4,25 +4,39 @@
 // What runs where:
 //   host  : the 5-state framing machine (Process, :235-275), sample buffering, the L1 power statistics used only to
 //           find the first NULL symbol (:291-347, :922-950) -- control flow over a few scalars per 100 samples
-//   device: coarse frequency sync + fine time sync (one launch per frame, dabgpu_ofdm_sync_host_sync),
-//           PLL + cyclic-prefix phase + 77 x FFT + DQPSK + de-interleave + soft bits + fine-frequency loop
-//           (one launch per frame, dabgpu_ofdm_demod_stream_frame_sync)
-// Ordering contract (replaces the reader / coordinator / pipeline threads of ofdm_demodulator_threads.h): per frame,
-// coarse sync -> fine time sync -> demodulation -> fine-frequency update -> On_OFDM_Frame observers, all before the
-// next frame's sync; observers are called on the thread that calls Process().
+//   device: coarse frequency sync + fine time sync, PLL + cyclic-prefix phase + 77 x FFT + DQPSK + de-interleave + soft bits +
+//           fine-frequency loop, and -- when FIC_Decoder / MSC_Decoder objects of this process listen (dab/dabgpu_frame_batcher.h) -- the
+//           frame's FIC and sub-channel decode: all ENQUEUED per frame through the receiver pipeline (dabgpu_receiver_*, include/dabgpu.h),
+//           the frequency state resident on the device.
+// Threads (the reference's reader / coordinator / pipeline threads, ofdm_demodulator.cpp:550-639, as two):
+//   reader   = the caller of Process(): frames the stream into page-locked staging buffers and submits; it waits for the device in two
+//              places only -- for the synchroniser's record once it has buffered on to where the earliest possible frame would end (or
+//              when the next Process() begins), and for a free slot when `depth` frames are already in flight (:565 WaitEnd)
+//   delivery = one internal thread, the coordinator's role (:621-638): waits for frame k's results, publishes the getters' values, calls
+//              the On_OFDM_Frame observers -- serialised, in frame order, while the reader buffers and submits frame k + 1
+// Ordering contract: per frame, coarse sync -> fine time sync -> demodulation -> fine-frequency update; frame k + 1's synchroniser sees
+// frame k's update (device stream order).  The getters return the state as of the frame delivered last (and the resets since): inside
+// an observer they are that frame's values, whatever the reader has submitted meanwhile.  Synchronize() (not in the reference) returns
+// when every frame handed to the device has been delivered -- call it before reading the counters at the end of a stream; the
+// destructor does.  DABGPU_MIRROR_DEPTH = frames in flight (1..6, default 3; 1 = the reference's double buffer).
 // nb_desired_threads is accepted for source compatibility and ignored (the device kernel replaces the thread pool).
 #pragma once
 
 #include <stddef.h>
 #include <stdint.h>
 #include <complex>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "utility/observable.h"
 #include "utility/span.h"
 #include "viterbi_config.h"
 #include "./ofdm_params.h"
 
-struct dabgpu_ctx;
+struct dabgpu_receiver;
 
 struct OFDM_Demod_Config {
     struct {
@@ -64,6 +78,7 @@ public:
 
     void Process(tcb::span<const std::complex<float>> block);
     void Reset();
+    void Synchronize();
 
     OFDM_Params GetOFDMParams() const { return m_params; }
     State GetState() const { return m_state; }
@@ -78,7 +93,7 @@ public:
     int GetTotalFramesDesync() const { return m_total_frames_desync; }
     tcb::span<const std::complex<float>> GetFrameFFT() const { return m_frame_fft; }
     tcb::span<const std::complex<float>> GetFrameDataVec() const { return m_frame_dqpsk; }
-    tcb::span<const viterbi_bit_t> GetFrameDataBits() const { return m_frame_bits; }
+    tcb::span<const viterbi_bit_t> GetFrameDataBits() const { return {m_bits_ptr, m_bits_len}; }
     tcb::span<const float> GetImpulseResponse() const { return m_impulse_response; }
     tcb::span<const float> GetCoarseFrequencyResponse() const { return m_frequency_response; }
     tcb::span<const std::complex<float>> GetCorrelationTimeBuffer() const { return m_corr; }
@@ -90,40 +105,61 @@ public:
 private:
     size_t FindNullPowerDip(tcb::span<const std::complex<float>> buf);
     size_t ReadNullPRS(tcb::span<const std::complex<float>> buf);
-    void RunSync();
     size_t ReadSymbols(tcb::span<const std::complex<float>> buf);
-    void DemodulateFrame();
+    void Run(tcb::span<const std::complex<float>> buf);
+    void SubmitSync();
+    bool ResolveSync();
+    void SubmitFrame();
+    void ResetReader();
     float L1Average(const std::complex<float>* block, size_t n) const;
     void UpdateSignalAverage(tcb::span<const std::complex<float>> block);
+    void DeliveryThread();
+    void RethrowDeliveryError();
 
     OFDM_Demod_Config m_cfg;
     State m_state = FINDING_NULL_POWER_DIP;
     const OFDM_Params m_params;
     int m_mode = 0;                          // transmission mode 1..4 matching m_params
-    dabgpu_ctx* m_ctx = nullptr;
-    int m_total_frames_read = 0;
-    int m_total_frames_desync = 0;
-    bool m_is_found_coarse = false;
-    float m_freq_coarse = 0.0f;
-    float m_freq_fine = 0.0f;
-    int m_fine_time_offset = 0;
+    dabgpu_receiver* m_rx = nullptr;
+    // ---- reader side ----
     bool m_null_start_found = false;
     bool m_null_end_found = false;
     float m_signal_l1_average = 0.0f;
     bool m_fetch_debug = false;
-    // null search ring (nb_null_period), NULL+PRS correlation window, frame under assembly (76 symbols + NULL)
+    // null search ring (nb_null_period), NULL+PRS correlation window
     std::vector<std::complex<float>> m_ring;
     size_t m_ring_index = 0, m_ring_length = 0;
     std::vector<std::complex<float>> m_corr;
     size_t m_corr_length = 0;
-    std::vector<std::complex<float>> m_frame;
-    size_t m_frame_length = 0;
-    // results
-    std::vector<viterbi_bit_t> m_frame_bits;
-    bool m_pinned_frame = false, m_pinned_bits = false;      // m_frame / m_frame_bits page-locked (dabgpu_host_pin)
+    // the staging buffer under assembly (page-locked, the receiver's): NULL | PRS | ... ; samples buffered, where the frame ends
+    std::complex<float>* m_stage = nullptr;
+    size_t m_stage_length = 0, m_stage_capacity = 0, m_frame_end = 0;
+    bool m_sync_pending = false;             // the synchroniser's record has not been collected yet
+    size_t m_spec_pos = 0;                   // Run(): position in the span from which samples were buffered past the PRS slot
+    int m_reader_time_offset = 0;
+    uint64_t m_subs_version = ~0ull;         // batcher subscription the receiver was last given
+    int m_depth = 3;
+    // ---- published by the delivery thread, in submission order ----
+    int m_total_frames_read = 0;
+    int m_total_frames_desync = 0;
+    float m_freq_coarse = 0.0f;
+    float m_freq_fine = 0.0f;
+    int m_fine_time_offset = 0;
+    const viterbi_bit_t* m_bits_ptr = nullptr;
+    size_t m_bits_len = 0;
+    std::vector<viterbi_bit_t> m_frame_bits;                 // what GetFrameDataBits() shows before the first frame
     std::vector<std::complex<float>> m_frame_fft;
     std::vector<std::complex<float>> m_frame_dqpsk;
     std::vector<float> m_impulse_response;
     std::vector<float> m_frequency_response;
     Observable<tcb::span<const viterbi_bit_t>> m_on_frame;
+    // ---- reader -> delivery ----
+    struct Item { enum Kind { SYNC, RESET, FRAME } kind; float coarse, fine; int offset; uint64_t gen; bool views; bool decoded; };
+    std::mutex m_mu;
+    std::condition_variable m_cv_items, m_cv_done;
+    std::deque<Item> m_items;
+    int m_frames_in_flight = 0;
+    bool m_busy = false, m_stop = false;
+    std::exception_ptr m_error;
+    std::thread m_thread;
 };

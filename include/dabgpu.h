@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define DABGPU_ABI_VERSION 1
+/* 2: symbols_per_block = 0 no longer measures (dabgpu_ofdm_tune does, explicitly); receiver pipeline (dabgpu_receiver_*) */
+#define DABGPU_ABI_VERSION 2
 
 /* Mode I geometry (src/ofdm/dab_ofdm_params_ref.cpp:13-21, src/dab/constants/dab_parameters.h:31-40) */
 #define DABGPU_NB_FRAME_SYMBOLS 76
@@ -477,6 +478,56 @@ int dabgpu_frame_session_fetch_fib_group(dabgpu_frame_session *s, uint64_t gener
                                          uint32_t *crc_ok_mask, uint64_t *path_error);
 int dabgpu_frame_session_fetch_cif(dabgpu_frame_session *s, uint64_t generation, const dabgpu_subchannel *sc, int cif,
                                    uint8_t *h_bytes, size_t capacity, size_t *n_bytes, uint64_t *path_error);
+
+/* --------------------------------------------------------------------------------------------------
+ * Receiver pipeline: one receiver's per-frame device work without a host wait in between.
+ * Replaces the hand-over between OFDM_Demod's reader thread, its coordinator / pipeline threads and the observers that decode the frame
+ * (src/ofdm/ofdm_demodulator.cpp:550-577 double buffer + WaitEnd / SignalStart, :581-639 CoordinatorThread; src/basic_radio/basic_radio.cpp:41-65).
+ * The OFDM_Demod mirror class is built on it (dab-radio_amd/host/ofdm/ofdm_demodulator.cpp): its reader side buffers samples into a
+ * pinned staging buffer and submits, a delivery thread waits for frames and calls the observers.
+ *
+ *   staging buffer   dabgpu_receiver_stage(): page-locked host memory the caller assembles "NULL symbol | frame" in, as complex float;
+ *                    capacity = nb_null_period + (nb_fft - nb_cyclic_prefix) + samples per frame.  dabgpu_receiver_submit_frame moves on to
+ *                    the next of three buffers; the one just submitted stays readable (the caller copies the frame's trailing NULL symbol
+ *                    out of it for the next correlation window, ofdm_demodulator.cpp:558-562).
+ *   frequency state  m_freq_coarse_offset / m_freq_fine_offset / m_is_found_coarse_freq_offset live on the DEVICE: submit_sync runs
+ *                    RunCoarseFreqSync + RunFineTimeSync (:360-548) on them, submit_frame demodulates with their sum (:672) and applies the
+ *                    frame's fine-frequency update (:606-618, :829-840), dabgpu_receiver_reset zeroes them (:277-289) -- all in submission
+ *                    order on one stream, so frame k + 1's synchroniser sees frame k's update without the host having seen it.
+ *   decode           frames of a mode I receiver are demodulated straight into the 8-frame history of a frame session
+ *                    (dabgpu_receiver_session; see "Frame session" above) and decoded there on a second stream -- the FIC when
+ *                    decode_fic, the sub-channels given -- the results fetched with dabgpu_frame_session_fetch_* by generation.
+ * Threads: submit_* / stage / reset / set_subchannels / wait_sync from ONE thread (the reader); wait_frame from one other (or the same).
+ * At most 7 frames may be submitted and not yet collected with wait_frame (the result slots are a ring of 8).
+ */
+typedef struct dabgpu_receiver dabgpu_receiver;
+typedef struct {
+    uint64_t generation;
+    const int8_t *bits;        /* the frame's soft bits, On_OFDM_Frame() layout, in page-locked memory of the receiver: valid until 7 more frames were submitted */
+    size_t n_bits;
+    float freq_fine;           /* m_freq_fine_offset after this frame's update */
+    float total_phase;         /* sum of the frame's cyclic-prefix angles */
+    const float *fft;          /* GetFrameFFT() [nb_frame_symbols + 1][nb_fft] complex, only when the frame was submitted with want_views */
+    const float *dqpsk;        /* GetFrameDataVec() [nb_frame_symbols - 1][nb_data_carriers] complex, mode I + want_views */
+} dabgpu_receiver_frame;
+/* h_prs_fft_ref / h_carrier_mapper as for dabgpu_create (mode I; NULL = built-in tables; must be NULL in modes II-IV) */
+int dabgpu_receiver_create(dabgpu_receiver **out, int device, int transmission_mode, const float *h_prs_fft_ref, const int *h_carrier_mapper);
+void dabgpu_receiver_destroy(dabgpu_receiver *rx);
+dabgpu_frame_session *dabgpu_receiver_session(dabgpu_receiver *rx);      /* owned by the receiver */
+/* what is decoded for the frames submitted from now on (mode I; n <= 64) */
+int dabgpu_receiver_set_subchannels(dabgpu_receiver *rx, const dabgpu_subchannel *h_subchannels, int n, int decode_fic);
+int dabgpu_receiver_stage(dabgpu_receiver *rx, float **h_stage, size_t *capacity_samples);
+int dabgpu_receiver_reset(dabgpu_receiver *rx);
+/* PRS slot = nb_fft samples from sample prs_sample of the current staging buffer (m_correlation_time_buffer[nb_null_period ...]); asynchronous */
+int dabgpu_receiver_submit_sync(dabgpu_receiver *rx, const dabgpu_sync_cfg *cfg, size_t prs_sample);
+/* blocks until the record of the last submit_sync is in host memory: freq_coarse / freq_fine / is_found_coarse after the synchroniser,
+ * fine_time_offset, sync_valid (0: the caller resets, :529-532); h_impulse / h_freq_response [nb_fft] dB, may be NULL */
+int dabgpu_receiver_wait_sync(dabgpu_receiver *rx, dabgpu_sync_state *out, float *h_impulse, float *h_freq_response);
+/* the frame = samples-per-frame samples from sample frame_sample of the current staging buffer (nb_null_period + fine_time_offset); asynchronous:
+ * upload, demodulation, fine-frequency update with `beta`, decode, results to host memory.  *generation counts the frames submitted. */
+int dabgpu_receiver_submit_frame(dabgpu_receiver *rx, size_t frame_sample, float fine_freq_update_beta, int want_views, int tie_rule,
+                                 uint64_t *generation);
+int dabgpu_receiver_wait_frame(dabgpu_receiver *rx, uint64_t generation, dabgpu_receiver_frame *out);
 
 /* ==================================================================================================
  * Transmission modes II, III and IV (geometries of src/ofdm/dab_ofdm_params_ref.cpp:11-60).

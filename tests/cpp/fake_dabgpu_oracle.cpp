@@ -213,4 +213,107 @@ int dabgpu_frame_session_fetch_cif(dabgpu_frame_session* s, uint64_t gen, const 
     return DABGPU_ERR_NOT_READY;
 }
 
+
+// ---- receiver pipeline: computed at submission (the host code's queues, threads and waits are what runs under the sanitizers) ----
+struct dabgpu_receiver {
+    int mode = 1;
+    dab_ofdm_geometry g;
+    dabgpu_ctx* ctx = nullptr;
+    dabgpu_frame_session* ses = nullptr;
+    std::vector<float> stage[3];
+    int cur = 0;
+    dabgpu_sync_state state = {0, 0, 0, 0, 0, 0};
+    dabgpu_sync_state record = {0, 0, 0, 0, 0, 0};
+    std::vector<float> imp, frq;
+    bool sync_pending = false, sync_coarse = false;
+    int decode_fic = 0;
+    std::mutex mu;                                       // result slots: written by the reader thread, read by the delivery thread
+    struct Slot { uint64_t gen = ~0ull; std::vector<int8_t> bits; float fine = 0, total = 0; std::vector<float> fft, dq; } slots[8];
+    uint64_t next = 0;
+};
+int dabgpu_receiver_create(dabgpu_receiver** out, int, int mode, const float*, const int* h_mapper) {
+    if (!out) return DABGPU_ERR_INVALID_ARG;
+    dabgpu_receiver* rx = new dabgpu_receiver();
+    if (dab_ofdm_geometry_get(mode, &rx->g)) { delete rx; return DABGPU_ERR_INVALID_ARG; }
+    rx->mode = mode;
+    dabgpu_create(&rx->ctx, 0, nullptr, mode == 1 ? h_mapper : nullptr);
+    dabgpu_frame_session_create(&rx->ses, 0);
+    const size_t cap = (size_t)rx->g.nb_null_period + (size_t)(rx->g.nb_fft - rx->g.nb_cp) + (size_t)rx->g.nb_frame_symbols * rx->g.nb_symbol_period + rx->g.nb_null_period;
+    for (auto& st : rx->stage) st.assign(2 * cap, 0.0f);
+    rx->imp.assign((size_t)rx->g.nb_fft, 0.0f); rx->frq.assign((size_t)rx->g.nb_fft, 0.0f);
+    *out = rx;
+    return DABGPU_OK;
+}
+void dabgpu_receiver_destroy(dabgpu_receiver* rx) { if (!rx) return; dabgpu_frame_session_destroy(rx->ses); dabgpu_destroy(rx->ctx); delete rx; }
+dabgpu_frame_session* dabgpu_receiver_session(dabgpu_receiver* rx) { return rx ? rx->ses : nullptr; }
+int dabgpu_receiver_set_subchannels(dabgpu_receiver* rx, const dabgpu_subchannel* subs, int n, int decode_fic) {
+    if (!rx) return DABGPU_ERR_INVALID_ARG;
+    const int st = dabgpu_frame_session_set_subchannels(rx->ses, subs, n);
+    if (st) return st;
+    rx->decode_fic = decode_fic;
+    return DABGPU_OK;
+}
+int dabgpu_receiver_stage(dabgpu_receiver* rx, float** h, size_t* cap) {
+    if (!rx || !h) return DABGPU_ERR_INVALID_ARG;
+    *h = rx->stage[rx->cur].data();
+    if (cap) *cap = rx->stage[rx->cur].size() / 2;
+    return DABGPU_OK;
+}
+int dabgpu_receiver_reset(dabgpu_receiver* rx) { if (!rx) return DABGPU_ERR_INVALID_ARG; rx->state = {0, 0, 0, 0, 0, 0}; return DABGPU_OK; }
+int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_sync_cfg* cfg, size_t prs_sample) {
+    if (!rx || !cfg || rx->sync_pending) return DABGPU_ERR_INVALID_ARG;
+    rx->sync_coarse = cfg->is_coarse_freq_correction != 0;
+    const int st = dabgpu_ofdm_sync_host_sync_mode(rx->ctx, rx->mode, rx->stage[rx->cur].data() + 2 * prs_sample, cfg, &rx->state, rx->imp.data(),
+                                                   rx->sync_coarse ? rx->frq.data() : nullptr);
+    rx->record = rx->state;
+    rx->sync_pending = true;
+    return st;
+}
+int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state* out, float* imp, float* frq) {
+    if (!rx || !out) return DABGPU_ERR_INVALID_ARG;
+    if (!rx->sync_pending) return DABGPU_ERR_NOT_READY;
+    rx->sync_pending = false;
+    *out = rx->record;
+    if (imp) std::memcpy(imp, rx->imp.data(), rx->imp.size() * sizeof(float));
+    if (frq && rx->sync_coarse) std::memcpy(frq, rx->frq.data(), rx->frq.size() * sizeof(float));
+    return DABGPU_OK;
+}
+int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie, uint64_t* generation) {
+    if (!rx || rx->sync_pending) return DABGPU_ERR_INVALID_ARG;
+    const size_t n_bits = (size_t)(rx->g.nb_frame_symbols - 1) * 2 * rx->g.nb_carriers;
+    std::vector<int8_t> bits(n_bits);
+    std::vector<float> fft(want_views ? (size_t)(rx->g.nb_frame_symbols + 1) * rx->g.nb_fft * 2 : 0);
+    float fine = rx->state.freq_fine, total = 0;
+    const float* iq = rx->stage[rx->cur].data() + 2 * frame_sample;
+    const int st = rx->mode == 1 ? dabgpu_ofdm_demod_stream_frame_sync(rx->ctx, iq, rx->state.freq_coarse, &fine, beta, bits.data(), &total, want_views ? fft.data() : nullptr, nullptr)
+                                 : dabgpu_ofdm_demod_stream_frame_sync_mode(rx->ctx, rx->mode, iq, rx->state.freq_coarse, &fine, beta, bits.data(), &total, want_views ? fft.data() : nullptr);
+    if (st) return st;
+    rx->state.freq_fine = fine;
+    uint64_t gen = 0;
+    if (rx->mode == 1) {
+        if (dabgpu_frame_session_push_frame(rx->ses, bits.data(), rx->decode_fic, tie, &gen)) return DABGPU_ERR_HIP;
+    } else {
+        gen = rx->next;
+    }
+    {
+        std::lock_guard<std::mutex> g(rx->mu);
+        auto& sl = rx->slots[gen % 8];
+        sl.gen = gen; sl.bits = std::move(bits); sl.fine = fine; sl.total = total; sl.fft = std::move(fft);
+        sl.dq.assign(want_views && rx->mode == 1 ? (size_t)(rx->g.nb_frame_symbols - 1) * rx->g.nb_carriers * 2 : 0, 0.0f);
+        rx->next = gen + 1;
+    }
+    rx->cur = (rx->cur + 1) % 3;
+    if (generation) *generation = gen;
+    return DABGPU_OK;
+}
+int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t gen, dabgpu_receiver_frame* out) {
+    if (!rx || !out) return DABGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(rx->mu);
+    auto& sl = rx->slots[gen % 8];
+    if (sl.gen != gen) return DABGPU_ERR_NOT_READY;
+    out->generation = gen; out->bits = sl.bits.data(); out->n_bits = sl.bits.size(); out->freq_fine = sl.fine; out->total_phase = sl.total;
+    out->fft = sl.fft.empty() ? nullptr : sl.fft.data(); out->dqpsk = sl.dq.empty() ? nullptr : sl.dq.data();
+    return DABGPU_OK;
+}
+
 }  // extern "C"

@@ -152,6 +152,7 @@ int main(int argc, char** argv) {
         if (got == 0) break;
         demod->Process(tcb::span<const std::complex<float>>(buf.data(), got));
     }
+    demod->Synchronize();                           // every frame handed to the device has come out of the observers
     if (g_bench) {
         const double sec = (now_us() - t_run) * 1e-6;
         auto stats = [](std::vector<double>& v, double& med, double& p99, double& mx) {

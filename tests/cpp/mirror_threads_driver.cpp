@@ -119,6 +119,7 @@ int main(int argc, char** argv) {
         Radio radio(subs, &serial[r]);
         demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { radio.frame(std::vector<viterbi_bit_t>(bits.begin(), bits.end()), false); });
         feed(*demod, iq[r], block);
+        demod->Synchronize();                                               // the last frames come out of the delivery thread
     }
 
     // ---- phase 2: all receivers at once; reader thread + radio thread (+ two decode workers) per receiver ----
@@ -137,6 +138,7 @@ int main(int argc, char** argv) {
                 auto demod = Create_OFDM_Demodulator(1);
                 demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { queues[r]->push(bits); });
                 feed(*demod, iq[r], block);
+                demod->Synchronize();
                 queues[r]->finish();
             });
         }
