@@ -506,7 +506,25 @@ struct dabgpu_msc_stream {
     int n_out_bytes;
     int next_slot;
     int stored;
+    // Consume (push_cif) only files the CIF in this page-locked twin of the ring; a slot crosses to the device when a call that reads the
+    // device ring comes (deinterleave_sync / decode_sync).  A decoder whose results come from its demodulator's frame session
+    // (dab-radio_amd/host/dab/dabgpu_frame_batcher.h) never reads its own ring: its DecodeCIF then costs a 3 KB host copy, not a DMA.
+    int8_t* h_ring;
+    uint32_t dirty;             // bit k: slot k of h_ring is newer than the device's
 };
+
+// the slots filed since the last device read, uploaded on the context's stream (the callers synchronise with it before they return, so
+// h_ring is not overwritten under a copy in flight)
+static int msc_stream_flush(dabgpu_msc_stream* s) {
+    for (int k = 0; k < 16 && s->dirty; k++) {
+        if (!(s->dirty >> k & 1u)) continue;
+        const int st = dabgpu_check_hip(hipMemcpyAsync(s->d_ring + (size_t)k * s->n_bits, s->h_ring + (size_t)k * s->n_bits, (size_t)s->n_bits,
+                                                       hipMemcpyHostToDevice, s->ctx->stream), "hipMemcpyAsync(msc stream ring)");
+        if (st) return st;
+        s->dirty &= ~(1u << k);
+    }
+    return DABGPU_OK;
+}
 
 extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* sc, dabgpu_msc_stream** out) {
     if (!c || !sc || !out) return DABGPU_ERR_INVALID_ARG;
@@ -521,8 +539,9 @@ extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* 
     DABGPU_BIND(c);
     dabgpu_msc_stream* s = new dabgpu_msc_stream();
     s->ctx = c; s->sc = *sc; s->n_bits = sc->length * 64; s->n_out_bytes = nb; s->next_slot = 0; s->stored = 0;
-    s->d_ring = nullptr; s->d_logical = nullptr;
+    s->d_ring = nullptr; s->d_logical = nullptr; s->h_ring = nullptr; s->dirty = 0;
     int st = dabgpu_check_hip(hipMalloc((void**)&s->d_ring, (size_t)16 * s->n_bits), "hipMalloc(ring)");
+    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&s->h_ring, (size_t)16 * s->n_bits, hipHostMallocDefault), "hipHostMalloc(ring)");
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_logical, (size_t)s->n_bits), "hipMalloc(logical)");
     if (!st) st = dabgpu_check_hip(hipMemset(s->d_ring, 0, (size_t)16 * s->n_bits), "hipMemset(ring)");
     if (st) { dabgpu_msc_stream_destroy(s); return st; }
@@ -542,16 +561,16 @@ extern "C" void dabgpu_msc_stream_destroy(dabgpu_msc_stream* s) {
     (void)hipSetDevice(s->ctx->device);
     if (s->d_ring) (void)hipFree(s->d_ring);
     if (s->d_logical) (void)hipFree(s->d_logical);
+    if (s->h_ring) { (void)hipStreamSynchronize(s->ctx->stream); (void)hipHostFree(s->h_ring); }
     delete s;
 }
 
 extern "C" int dabgpu_msc_stream_push_cif(dabgpu_msc_stream* s, const int8_t* h_bits) {
     if (!s || !h_bits) return DABGPU_ERR_INVALID_ARG;
-    DABGPU_BIND(s->ctx);
     DABGPU_HOST_LOCK(s->ctx);
-    // through the pinned staging ring: the caller's span is only valid during DecodeCIF (SURVEY 8b ownership)
-    int st = dabgpu_stage_h2d(s->ctx, s->d_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits, s->ctx->stream);
-    if (st) return st;
+    // copied here and now: the caller's span is only valid during DecodeCIF (SURVEY 8b ownership)
+    memcpy(s->h_ring + (size_t)s->next_slot * s->n_bits, h_bits, (size_t)s->n_bits);
+    s->dirty |= 1u << s->next_slot;
     s->next_slot = (s->next_slot + 1) % 16;                    // cif_deinterleaver.cpp:28-33
     if (s->stored < 16) s->stored++;
     return DABGPU_OK;
@@ -563,7 +582,8 @@ extern "C" int dabgpu_msc_stream_deinterleave_sync(dabgpu_msc_stream* s, int8_t*
     if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // cif_deinterleaver.cpp:40-42
     DABGPU_BIND(s->ctx);
     hipStream_t q = s->ctx->stream;
-    int st = dabgpu_check_hip(dabgpu_launch_cif_deinterleave(s->d_ring, s->n_bits, 16, (s->next_slot + 15) % 16, s->d_logical, q),
+    int st = msc_stream_flush(s);
+    if (!st) st = dabgpu_check_hip(dabgpu_launch_cif_deinterleave(s->d_ring, s->n_bits, 16, (s->next_slot + 15) % 16, s->d_logical, q),
                               "cif_deinterleave launch");
     if (!st) st = dabgpu_check_hip(hipMemcpyAsync(h_out, s->d_logical, (size_t)s->n_bits, hipMemcpyDeviceToHost, q), "hipMemcpyAsync");
     if (!st) st = dabgpu_check_hip(hipStreamSynchronize(q), "hipStreamSynchronize");
@@ -575,6 +595,9 @@ extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_ou
     DABGPU_HOST_LOCK(s->ctx);
     *n_out = 0;
     if (s->stored < 16) return DABGPU_ERR_NOT_READY;           // msc_decoder.cpp:60-63
+    DABGPU_BIND(s->ctx);
+    const int fst = msc_stream_flush(s);
+    if (fst) return fst;
     dabgpu_cw_desc D = s->proto;
     D.newest_slot = (uint32_t)((s->next_slot + 15) % 16);
     dabgpu_codeword_result R;

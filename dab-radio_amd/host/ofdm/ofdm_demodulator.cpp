@@ -2,6 +2,8 @@
 #include "./ofdm_demodulator.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +15,7 @@
 #include "dab/dabgpu_shared_context.h"
 
 namespace {
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 [[noreturn]] void fail(const char* what, int st) {
     throw std::runtime_error(std::string("OFDM_Demod: ") + what + ": " + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
 }
@@ -50,6 +53,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     if ((st = dabgpu_receiver_stage(m_rx, &stage, &m_stage_capacity)) != DABGPU_OK) { dabgpu_receiver_destroy(m_rx); fail("dabgpu_receiver_stage", st); }
     m_stage = reinterpret_cast<std::complex<float>*>(stage);
     if (const char* d = std::getenv("DABGPU_MIRROR_DEPTH")) m_depth = std::min(6, std::max(1, std::atoi(d)));
+    if (const char* d = std::getenv("DABGPU_MIRROR_PROFILE")) m_profile = std::atoi(d) != 0;
     m_ring.assign(params.nb_null_period, {0.0f, 0.0f});
     m_corr.assign(params.nb_null_period + params.nb_symbol_period, {0.0f, 0.0f});
     m_frame_bits.assign((params.nb_frame_symbols - 1) * params.nb_data_carriers * 2, 0);
@@ -73,6 +77,12 @@ OFDM_Demod::~OFDM_Demod() {
     if (m_thread.joinable()) m_thread.join();
     dabgpu_frame_batcher::remove_producer(this);
     dabgpu_receiver_destroy(m_rx);
+    if (m_profile && m_total_frames_read > 0) {
+        const double n = (double)m_total_frames_read;
+        std::fprintf(stderr, "OFDM_Demod profile, us per frame over %d frames: reader { wait for the synchroniser %.1f, wait for a slot %.1f, submit %.1f } "
+                             "delivery { wait for the frame %.1f, batcher %.1f, observers %.1f }\n", m_total_frames_read, m_t_sync_wait / n,
+                     m_t_slot_wait / n, m_t_submit / n, m_t_frame_wait / n, m_t_batcher / n, m_t_observers / n);
+    }
 }
 
 void OFDM_Demod::RethrowDeliveryError() {
@@ -234,8 +244,10 @@ void OFDM_Demod::SubmitSync() {
 // the record of the synchroniser submitted last; false = the impulse-peak test failed and the receiver was reset (:529-532)
 bool OFDM_Demod::ResolveSync() {
     dabgpu_sync_state st;
+    const double t0 = m_profile ? now_us() : 0.0;
     const int rc = dabgpu_receiver_wait_sync(m_rx, &st, m_impulse_response.data(),
                                              m_cfg.sync.is_coarse_freq_correction ? m_frequency_response.data() : nullptr);
+    if (m_profile) m_t_sync_wait += now_us() - t0;
     m_sync_pending = false;
     if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_sync", rc);
     {
@@ -283,10 +295,12 @@ void OFDM_Demod::SubmitFrame() {
         }
         decoded = fic || !subs.empty();
     }
+    const double t0 = m_profile ? now_us() : 0.0;
     {
         std::unique_lock<std::mutex> lock(m_mu);
         m_cv_done.wait(lock, [this] { return m_frames_in_flight < m_depth; });
     }
+    const double t1 = m_profile ? now_us() : 0.0;
     RethrowDeliveryError();
     uint64_t gen = 0;
     const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
@@ -295,6 +309,7 @@ void OFDM_Demod::SubmitFrame() {
     float* stage = nullptr;
     (void)dabgpu_receiver_stage(m_rx, &stage, nullptr);
     m_stage = reinterpret_cast<std::complex<float>*>(stage);
+    if (m_profile) { m_t_slot_wait += t1 - t0; m_t_submit += now_us() - t1; }
     {
         std::lock_guard<std::mutex> lock(m_mu);
         m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, decoded});
@@ -333,8 +348,10 @@ void OFDM_Demod::DeliveryThread() {
             case Item::FRAME: {
                 if (failed) break;                       // after a device error nothing more is delivered; Process() rethrows it
                 dabgpu_receiver_frame fr;
+                const double t0 = m_profile ? now_us() : 0.0;
                 const int rc = dabgpu_receiver_wait_frame(m_rx, it.gen, &fr);
                 if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_frame", rc);
+                const double t1 = m_profile ? now_us() : 0.0;
                 m_freq_fine = fr.freq_fine;
                 m_total_frames_read++;
                 m_bits_ptr = fr.bits;
@@ -346,7 +363,9 @@ void OFDM_Demod::DeliveryThread() {
                 // the decoders of this process find the frame's FIBs and sub-channel bytes already decoded (mode I: the DAB layer above
                 // the soft bits is mode I only)
                 if (it.decoded) dabgpu_frame_batcher::on_frame_decoded(this, dabgpu_receiver_session(m_rx), it.gen, fr.bits);
+                const double t2 = m_profile ? now_us() : 0.0;
                 m_on_frame.Notify(tcb::span<const viterbi_bit_t>(fr.bits, fr.n_bits));
+                if (m_profile) { m_t_frame_wait += t1 - t0; m_t_batcher += t2 - t1; m_t_observers += now_us() - t2; }
                 break;
             }
             }

@@ -162,4 +162,7 @@ private:
     bool m_busy = false, m_stop = false;
     std::exception_ptr m_error;
     std::thread m_thread;
+    // DABGPU_MIRROR_PROFILE=1: where the two threads spend their time, microseconds, printed by the destructor
+    bool m_profile = false;
+    double m_t_sync_wait = 0, m_t_slot_wait = 0, m_t_submit = 0, m_t_frame_wait = 0, m_t_observers = 0, m_t_batcher = 0;
 };

@@ -43,6 +43,8 @@ with tempfile.TemporaryDirectory() as d:
             print(res.stderr[-2000:], file=sys.stderr)
             sys.exit(res.returncode)
         runs[name] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]            # DABGPU_MIRROR_PROFILE=1
+        if prof: runs[name]["profile"] = prof[-1]
 out = dict(runs["frame_batcher_one_thread"])
 out["what"] = ("OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame from one caller thread; the frame batcher (default) decodes a "
                "frame's FIC and sub-channels in one batched device call when OFDM_Demod completes it, the classes pick their bytes up "
