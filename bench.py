@@ -582,12 +582,14 @@ def dry_run(args, rank, world):
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))
     shard.barrier(dist if world > 1 else None)
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    mine = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(mine, dist if world > 1 else None)
+    per_rank = shard.all_ranks(mine / args.steps * 1e3, dist if world > 1 else None)
     covered = shard.sum_over_ranks(n, dist if world > 1 else None)
     if rank == 0:
         print(json.dumps({"metric": "dab_mode1_frames_per_sec", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "dry-run (no kernels)",
+                          "vs_baseline": None, "dtype": "f32", "data": "dry-run (no kernels)", "ms_per_step_per_rank": per_rank,
                           "config": {"workload": args.workload, "units_per_rank": n, "units_covered": covered, "first_unit_rank0": first}}))
     if world > 1:
         dist.destroy_process_group()
@@ -713,6 +715,7 @@ def main():
         region[1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = shard.all_ranks(elapsed / args.steps * 1e3, dist, device)        # every rank's own clock over the same barrier-to-barrier region
     elapsed = shard.max_over_ranks(elapsed, dist, device)
     ms_per_step = elapsed / args.steps * 1e3
     if region:
@@ -772,6 +775,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": config,
             "x_realtime": value / REALTIME_FRAMES_PER_S,
+            "ms_per_step_per_rank": per_rank_ms,
             "roofline": hbm_roofline("ofdm_demod_kernel", k_ms, units),
             "check": check,
         }

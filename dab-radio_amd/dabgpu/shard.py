@@ -35,3 +35,16 @@ def sum_over_ranks(value, dist=None, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_ranks(value, dist=None, device=None):
+    """the python float of every rank, in rank order (a list of one when not distributed): the per-rank step times of a scaling run,
+    which show a straggler that the max over ranks hides"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    import torch
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device or "cpu")
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.cpu()]

@@ -26,6 +26,9 @@ def test_plain_launch_spawns_two_ranks_and_prints_one_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 5
     assert d["config"]["units_per_rank"] == 1024 and d["config"]["units_covered"] == 2048      # weak scaling: every rank its own 1024 frames
     assert d["ms_per_step"] >= 2.0                                                              # max over ranks: rank 1 sleeps 2 ms per step
+    # every rank's own step time travels with the line (a straggler shows): rank 0 sleeps 1 ms per step, rank 1 two
+    assert len(d["ms_per_step_per_rank"]) == 2 and d["ms_per_step_per_rank"][1] > d["ms_per_step_per_rank"][0] >= 1.0
+    assert max(d["ms_per_step_per_rank"]) <= d["ms_per_step"] * 1.001
 
 
 def test_full_workload_shards_8192_ensembles_per_rank():

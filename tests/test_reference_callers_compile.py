@@ -1,6 +1,6 @@
 """The reference's own callers must compile against the mirror headers unchanged (`basic_radio` links unchanged).
 A scratch COPY of /root/reference/src gets the six mirror headers laid over it, then every caller of the hot path is run through
-`g++ -fsyntax-only`: src/basic_radio/basic_radio.cpp (:41-65 FIC/MSC slicing), basic_fic_runner.cpp (:7,20,44-48 FIC_Decoder),
+`g++ -fsyntax-only` -- and, below, COMPILED TO OBJECTS AND LINKED: src/basic_radio/basic_radio.cpp (:41-65 FIC/MSC slicing), basic_fic_runner.cpp (:7,20,44-48 FIC_Decoder),
 basic_audio_channel.cpp (:6,12 MSC_Decoder), basic_{dab,dab_plus,data_packet}_channel.cpp (DecodeCIF, AAC_Frame_Processor) and
 examples/app_helpers/app_ofdm_blocks.h (:25-58 OFDM_Demod).  Skipped where /root/reference is absent (the GPU box)."""
 import os
@@ -60,3 +60,126 @@ def test_app_ofdm_blocks_compiles_against_the_mirror_demodulator(overlay, tmp_pa
     tu = tmp_path / "tu.cpp"
     tu.write_text('#include "app_helpers/app_ofdm_blocks.h"\nint main() { return 0; }\n')
     _syntax_only(["-I" + src, "-I" + os.path.join(REF, "examples"), "-I" + os.path.join(ROOT, "include"), "-I" + fmt, str(tu)])
+
+
+# ---- link, not just parse --------------------------------------------------------------------------------------------------------------
+# INTEGRATION.md's recipe: the mirror's sources REPLACE the reference's in its tree and are compiled there, against the reference's own
+# utility/span.h, utility/observable.h, viterbi_config.h, database entities and constants (the minimal equivalents under
+# dab-radio_amd/host/ exist only so that this repository builds stand-alone: tcb::span here has one template parameter, the reference's
+# two, so objects of the two worlds do not mix -- which is exactly what a link shows and a syntax check does not).
+MIRROR_SOURCES = ["ofdm/ofdm_demodulator.cpp", "dab/fic/fic_decoder.cpp", "dab/msc/msc_decoder.cpp", "dab/msc/cif_deinterleaver.cpp",
+                  "dab/algorithms/dab_viterbi_decoder.cpp", "dab/audio/aac_frame_processor.cpp",
+                  "dab/dabgpu_frame_batcher.cpp", "dab/dabgpu_frame_batcher.h", "dab/dabgpu_shared_context.cpp", "dab/dabgpu_shared_context.h"]
+
+
+@pytest.fixture(scope="module")
+def linked_overlay(overlay, tmp_path_factory):
+    src, fmt = overlay
+    if not os.path.exists(os.path.join(ROOT, "dab-radio_amd", "libdabgpu.so")):
+        import __graft_entry__ as g
+        g.build()
+    for f in MIRROR_SOURCES:
+        shutil.copyfile(os.path.join(HOST, f), os.path.join(src, f))
+    out = tmp_path_factory.mktemp("ref_objects")
+
+    def compile_tu(path, extra=()):
+        obj = os.path.join(out, os.path.basename(path).replace(".cpp", "") + ".o")
+        res = subprocess.run(["g++", "-std=c++17", "-O1", "-DFMT_HEADER_ONLY", "-I" + src, "-I" + os.path.join(REF, "examples"),
+                              "-I" + os.path.join(ROOT, "include"), "-I" + fmt, *extra, "-c", path, "-o", obj], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (path, res.stderr[-3000:])
+        return obj
+
+    def link(objs, exe):
+        lib_dir = os.path.join(ROOT, "dab-radio_amd")
+        res = subprocess.run(["g++", *objs, "-L" + lib_dir, "-ldabgpu", "-Wl,-rpath," + lib_dir, "-pthread", "-o", exe], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, "unresolved symbols between the reference's callers and the mirror classes:\n" + res.stderr[-4000:]
+        return exe
+
+    mirror = {f: compile_tu(os.path.join(src, f)) for f in MIRROR_SOURCES if f.endswith(".cpp")}
+    return dict(src=src, out=str(out), compile=compile_tu, link=link, mirror=mirror)
+
+
+def test_basic_fic_runner_links_against_the_mirror_fic_decoder(linked_overlay, tmp_path):
+    """src/basic_radio/basic_fic_runner.cpp (:20 make_unique<FIC_Decoder>, :27-29 OnFIB().Attach, :44-48 DecodeFIBGroup) with everything it
+    pulls in -- FIG processor, FIG handler, database updater, logging, character sets: the reference's objects -- and the mirror FIC_Decoder"""
+    L = linked_overlay
+    drv = tmp_path / "fic_driver.cpp"
+    drv.write_text("""
+#include <vector>
+#include "basic_radio/basic_fic_runner.h"
+#include "dab/constants/dab_parameters.h"
+#include "dab/database/dab_database_updater.h"
+int main() {
+    const DAB_Parameters params = get_dab_parameters(1);
+    BasicFICRunner runner(params);
+    std::vector<viterbi_bit_t> fic((size_t)params.nb_fic_bits, 0);
+    runner.Process(fic);
+    return (int)runner.GetDatabaseUpdater().GetStatistics().nb_total;
+}
+""")
+    objs = [L["compile"](os.path.join(L["src"], f)) for f in ("basic_radio/basic_fic_runner.cpp", "dab/fic/fig_processor.cpp", "dab/radio_fig_handler.cpp",
+                                                            "dab/database/dab_database_updater.cpp", "dab/dab_logging.cpp", "dab/constants/charsets.cpp")]
+    objs += [L["compile"](str(drv)), L["mirror"]["dab/fic/fic_decoder.cpp"], L["mirror"]["dab/dabgpu_frame_batcher.cpp"], L["mirror"]["dab/dabgpu_shared_context.cpp"]]
+    L["link"](objs, os.path.join(L["out"], "fic_driver"))
+
+
+def test_ofdm_block_links_against_the_mirror_demodulator(linked_overlay, tmp_path):
+    """examples/app_helpers/app_ofdm_blocks.h:25-58 (OFDM_Block: constructor arguments from the reference's own get_DAB_OFDM_params /
+    get_DAB_PRS_reference / get_DAB_mapper_ref objects, On_OFDM_Frame().Attach, Process) and ofdm_helpers.h's Create_OFDM_Demodulator"""
+    L = linked_overlay
+    drv = tmp_path / "ofdm_driver.cpp"
+    drv.write_text("""
+#include "app_helpers/app_ofdm_blocks.h"
+#include "ofdm/ofdm_helpers.h"
+int main(int argc, char**) {
+    OFDM_Block block(1, 1);
+    auto demod = Create_OFDM_Demodulator(argc);
+    block.run(65536);
+    auto& d = block.get_ofdm_demod();
+    d.Reset();
+    return d.GetTotalFramesRead() + (int)d.GetFrameDataBits().size() + (int)d.GetState() + (demod == nullptr);
+}
+""")
+    objs = [L["compile"](os.path.join(L["src"], f)) for f in ("ofdm/dab_ofdm_params_ref.cpp", "ofdm/dab_prs_ref.cpp", "ofdm/dab_mapper_ref.cpp")]
+    objs += [L["compile"](str(drv)), L["mirror"]["ofdm/ofdm_demodulator.cpp"], L["mirror"]["dab/dabgpu_frame_batcher.cpp"], L["mirror"]["dab/dabgpu_shared_context.cpp"]]
+    L["link"](objs, os.path.join(L["out"], "ofdm_driver"))
+
+
+def test_msc_side_links_against_the_mirror_decoders(linked_overlay, tmp_path):
+    """what Basic_Audio_Channel / Basic_DAB_Plus_Channel do with the decoders (basic_audio_channel.cpp:12 make_unique<MSC_Decoder>(subchannel),
+    basic_dab_plus_channel.cpp:47-51 DecodeCIF -> AAC_Frame_Processor::Process) in a translation unit of its own: the channel classes
+    themselves pull in the audio decoders (vendor/faad2, vendor/mpg123 -- empty submodules here), so they stay syntax-checked above"""
+    L = linked_overlay
+    drv = tmp_path / "msc_driver.cpp"
+    drv.write_text("""
+#include <memory>
+#include <vector>
+#include "dab/algorithms/dab_viterbi_decoder.h"
+#include "dab/audio/aac_frame_processor.h"
+#include "dab/constants/puncture_codes.h"
+#include "dab/database/dab_database_entities.h"
+#include "dab/msc/cif_deinterleaver.h"
+#include "dab/msc/msc_decoder.h"
+int main() {
+    Subchannel sc((subchannel_id_t)0);
+    sc.start_address = 0; sc.length = 48; sc.is_uep = false; sc.eep_prot_level = 2; sc.eep_type = EEP_Type::TYPE_A; sc.is_complete = true;
+    auto msc = std::make_unique<MSC_Decoder>(sc);
+    auto aac = std::make_unique<AAC_Frame_Processor>();
+    std::vector<viterbi_bit_t> cif(55296, 0);
+    auto bytes = msc->DecodeCIF(cif);
+    if (!bytes.empty()) aac->Process(bytes);
+    CIF_Deinterleaver deint(48 * 8);
+    deint.Consume(tcb::span<const viterbi_bit_t>(cif).first(48 * 64));
+    std::vector<viterbi_bit_t> logical(48 * 64);
+    const bool ok = deint.Deinterleave(logical);
+    DAB_Viterbi_Decoder vit;
+    vit.set_traceback_length(96);
+    vit.reset();
+    const size_t used = vit.update(cif, PI_X, 24);
+    std::vector<uint8_t> out(1);
+    return (int)(vit.chainback(out) + used + (ok ? 1 : 0));
+}
+""")
+    objs = [L["compile"](str(drv))] + [L["mirror"][f] for f in ("dab/msc/msc_decoder.cpp", "dab/msc/cif_deinterleaver.cpp", "dab/algorithms/dab_viterbi_decoder.cpp",
+                                                              "dab/audio/aac_frame_processor.cpp", "dab/dabgpu_frame_batcher.cpp", "dab/dabgpu_shared_context.cpp")]
+    L["link"](objs, os.path.join(L["out"], "msc_driver"))
