@@ -162,11 +162,24 @@ def cpu_baseline(seconds_target=12.0):
     except OSError:
         pass
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cpus": os.cpu_count(),
+            "host_logical_cpus": os.cpu_count(), "calibration": cpu_calibration(),
             "single_thread_value": n1 / dt1,
             "sample": f"{done} frame demods (PLL+CP-phase+76xFFT2048+DQPSK+demap) cycling 4 distinct synthetic frames, "
                       f"{cores} host threads x {per_thread} frames, oracle/dab_oracle_ofdm.c dab_demod_frame "
                       f"(FFTW absent -> oracle's own radix-4/8 FFT), {dt:.1f} s wall"}
+
+
+def cpu_calibration():
+    """port / reference time ratios on the parts of the reference that compile (tools/cpu_calibration.py, measured in the build container where
+    /root/reference exists; the committed summary travels with the repository): how to read a `kind: "port"` baseline"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05", "cpu_calibration.json")) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    return {"source": "profiles/r05/cpu_calibration.json (tools/cpu_calibration.py: reference objects compiled in place vs this port, one thread, build container)",
+            "port_time_over_reference_time": {r["piece"]: r["port_time_over_reference_time"] for r in doc.get("rows", [])},
+            "not_calibrated": doc.get("not_calibrated")}
 
 
 def hbm_roofline(kernel, k_ms, frames):
@@ -559,7 +572,7 @@ def cpu_baseline_full(sample, seconds_target=14.0):
         ok &= bool(np.array_equal(r["msc"], sample["payload"][e][cifs].reshape(4, -1)))
     done = per_thread * cores
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": 1.0 / dt1,
-            "decoded_bytes_equal_transmitted": ok,
+            "decoded_bytes_equal_transmitted": ok, "calibration": cpu_calibration(),
             "sample": f"{done} frames through oracle/dab_oracle_chain.c dab_receive_frames (coarse + fine sync, PLL + CP phase + 76 x FFT2048 + DQPSK + demap, "
                       f"fine-frequency update, 4 FIB groups, 18 sub-channels x 4 CIFs: CIF de-interleaver + K=7 Viterbi + descrambler), "
                       f"{cores} host threads x {per_thread} frames of the receivers the GPU decoded (incl. {warm} settling frames each), {dt:.1f} s wall"}

@@ -135,10 +135,57 @@ static inline dab_cf32 pll_sample(dab_cf32 v, size_t i4, int k, float f, float d
     return y;
 }
 
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+#include <immintrin.h>
+/* The same element arithmetic eight samples at a time (two groups of four): every operation below is the lane-wise form of one line of
+ * pll_sample -- same operands, same order, same roundings (vfmadd = fmaf, vroundps nearest-even = rintf) -- so the result is pll_sample's
+ * bit for bit (tests/test_oracle_pins.py holds both to the reference's AVX2 object).  Without it the CPU baseline of bench.py would time a
+ * scalar emulation of a loop the reference runs in AVX2 (tools/cpu_calibration.py). */
+__attribute__((target("avx2,fma")))
+static size_t pll_groups_avx2(const dab_cf32 *x, dab_cf32 *y, size_t nv, float f, float dt_norm) {
+    const __m256 kf = _mm256_setr_ps(0.0f, 1.0f, 2.0f, 3.0f, 0.0f, 1.0f, 2.0f, 3.0f);
+    const __m256 step_sin = _mm256_mul_ps(kf, _mm256_set1_ps(f));
+    const __m256 step_cos = _mm256_add_ps(step_sin, _mm256_set1_ps(0.25f));
+    const __m256 a5 = _mm256_set1_ps(CH_A5), a4 = _mm256_set1_ps(CH_A4), a3 = _mm256_set1_ps(CH_A3), a2 = _mm256_set1_ps(CH_A2),
+                 a1 = _mm256_set1_ps(CH_A1), a0 = _mm256_set1_ps(CH_A0), q = _mm256_set1_ps(0.25f);
+    const __m256i deint = _mm256_setr_epi32(0, 2, 4, 6, 1, 3, 5, 7);
+    size_t i = 0;
+    for (; i + 8 <= nv; i += 8) {
+        const float b0 = dt_norm + (float)i * f, b1 = dt_norm + (float)(i + 4) * f;
+        const __m256 base = _mm256_setr_ps(b0, b0, b0, b0, b1, b1, b1, b1);
+        __m256 dc = _mm256_add_ps(base, step_cos), ds = _mm256_add_ps(base, step_sin);
+        dc = _mm256_sub_ps(dc, _mm256_round_ps(dc, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+        ds = _mm256_sub_ps(ds, _mm256_round_ps(ds, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+        __m256 zc = _mm256_mul_ps(dc, dc), zs = _mm256_mul_ps(ds, ds);
+        __m256 pc = _mm256_fmadd_ps(a5, zc, a4), ps = _mm256_fmadd_ps(a5, zs, a4);
+        pc = _mm256_fmadd_ps(pc, zc, a3); ps = _mm256_fmadd_ps(ps, zs, a3);
+        pc = _mm256_fmadd_ps(pc, zc, a2); ps = _mm256_fmadd_ps(ps, zs, a2);
+        pc = _mm256_fmadd_ps(pc, zc, a1); ps = _mm256_fmadd_ps(ps, zs, a1);
+        pc = _mm256_fmadd_ps(pc, zc, a0); ps = _mm256_fmadd_ps(ps, zs, a0);
+        const __m256 c = _mm256_mul_ps(_mm256_mul_ps(pc, _mm256_sub_ps(zc, q)), dc);
+        const __m256 s = _mm256_mul_ps(_mm256_mul_ps(ps, _mm256_sub_ps(zs, q)), ds);
+        /* eight interleaved (re, im) pairs -> re[8], im[8] in sample order */
+        const __m256 v0 = _mm256_loadu_ps((const float *)(x + i)), v1 = _mm256_loadu_ps((const float *)(x + i + 4));
+        const __m256 p0 = _mm256_permutevar8x32_ps(v0, deint), p1 = _mm256_permutevar8x32_ps(v1, deint);     /* re0..3 im0..3 | re4..7 im4..7 */
+        const __m256 re = _mm256_permute2f128_ps(p0, p1, 0x20), im = _mm256_permute2f128_ps(p0, p1, 0x31);
+        const __m256 yr = _mm256_fmadd_ps(c, re, _mm256_xor_ps(_mm256_mul_ps(s, im), _mm256_set1_ps(-0.0f)));   /* fmaf(c, re, -(s * im)) */
+        const __m256 yi = _mm256_fmadd_ps(c, im, _mm256_mul_ps(s, re));                                        /* fmaf(c, im, s * re) */
+        const __m256 lo = _mm256_unpacklo_ps(yr, yi), hi = _mm256_unpackhi_ps(yr, yi);                         /* per 128-bit half: pairs 0,1 | 2,3 */
+        _mm256_storeu_ps((float *)(y + i), _mm256_permute2f128_ps(lo, hi, 0x20));
+        _mm256_storeu_ps((float *)(y + i + 4), _mm256_permute2f128_ps(lo, hi, 0x31));
+    }
+    return i;
+}
+#endif
+
 DAB_HOT
 void dab_apply_pll(const dab_cf32 *x, dab_cf32 *y, size_t n, float freq_norm, float dt_norm) {
     const size_t nv = (n / 4) * 4;
-    for (size_t i = 0; i < nv; i += 4)
+    size_t i = 0;
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) i = pll_groups_avx2(x, y, nv, freq_norm, dt_norm);
+#endif
+    for (; i < nv; i += 4)
         for (int k = 0; k < 4; k++)
             y[i + k] = pll_sample(x[i + k], i, k, freq_norm, dt_norm);
     if (nv < n) {                                        /* apply_pll.cpp:115-116 */
