@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-mixed", action="store_true", help="demod, N = 1: skip extra.configs3_mixed (configs[3] on a heterogeneous multiplex at --extra-ensembles)")
     ap.add_argument("--no-chain", action="store_true", help="demod, N = 1: skip extra.chain (the unsynchronised-stream chain at --extra-ensembles)")
     ap.add_argument("--lanes", choices=("alternate", "split"), default="alternate",
                     help="full / extras with two frames in flight: frame j wholly on stream j mod 2, or all demodulations on one (high-priority) stream and all decodes on the other")
@@ -267,7 +268,7 @@ class Pipeline:
     demod(j-1), ...; demod(j) overwrites the slot of frame j-H, last read by msc(j-H+4) -> waits for it; synced: the synchroniser of
     frame j reads the fine-frequency word frame j-1's phase tail wrote -> demod(j) waits for demod(j-1)."""
 
-    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1, synced=True, noise=0.05, lanes="alternate"):
+    def __init__(self, ctx, dabgpu, torch, device, E, n_distinct, seed, inflight=1, layout=1, synced=True, noise=0.05, lanes="alternate", mux_layout=None):
         import dabsynth
         self.torch, self.E, self.inflight, self.synced, self.dabgpu = torch, E, inflight, synced, dabgpu
         # lanes = "alternate": frame j entirely on stream j mod inflight; "split" (inflight = 2): every demodulation on stream 0 (high
@@ -280,7 +281,8 @@ class Pipeline:
         prs, mapper, _ = dabgpu.host_tables()
         # two stored transmission frames that repeat (8 CIFs of changing payload, time interleaved): decoded bytes then prove WHICH
         # ring slots / ages / frames in flight they came from (tools/dabsynth.py)
-        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs, noise=0.0 if synced else noise)
+        # mux_layout: the multiplex every ensemble carries (tools/dabsynth.py: canonical_layout() = 18 x 48 CU EEP 3-A by default, mixed_layout())
+        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs, noise=0.0 if synced else noise, layout=mux_layout)
         if synced:
             self.slices, self.cfo, self.toff = dabsynth.ensemble_slices(self.iq, self.mux.n, seed + 2, SLICE_LEAD, SLICE_SAMPLES, noise=noise)
             del self.iq
@@ -291,7 +293,8 @@ class Pipeline:
         else:
             self.iq_f = torch.view_as_real(self.iq)                # [2][E][196608][2]
         self.frame_of_slot = {}                                # ring slot -> number of the frame it holds
-        self.n_sub = dabsynth.N_SUB
+        self.n_sub = len(self.mux.layout)
+        self.cif_bytes = self.mux.cif_out_bytes
         self.hist = torch.zeros((E, self.H, 230400), dtype=torch.int8, device=device)
         self.ctxs = [ctx] + [dabgpu.Context(device.index) for _ in range(inflight - 1)]
         if self.lanes == "split":
@@ -301,10 +304,10 @@ class Pipeline:
         mk = lambda shape, dt: [torch.zeros(shape, dtype=dt, device=device) for _ in range(inflight)]     # noqa: E731
         self.corr = mk((E, 76, 2), torch.float32)
         self.fic_out, self.fic_res = mk((E, 4, 96), torch.uint8), mk((E * 4, 16), torch.uint8)
-        self.msc_out, self.msc_res = mk((E, 4, self.n_sub * dabsynth.SUB_BYTES), torch.uint8), mk((E * 4 * self.n_sub, 16), torch.uint8)
+        self.msc_out, self.msc_res = mk((E, 4, self.cif_bytes), torch.uint8), mk((E * 4 * self.n_sub, 16), torch.uint8)
         self.subs = self.mux.subchannels(dabgpu)
         self.fic_steps = E * dabsynth.FIC_STEPS_PER_FRAME
-        self.msc_steps = E * dabsynth.MSC_STEPS_PER_FRAME
+        self.msc_steps = E * self.mux.msc_steps_per_frame
         self.stride = self.H * 230400
         self.j = 0                                  # next frame number
         self.ev_demod, self.ev_msc = {}, {}
@@ -350,12 +353,12 @@ class Pipeline:
 
     def msc(self, slot, k=0):
         self.ctxs[k].msc_decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.msc_out[k],
-                                       4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
+                                       4 * self.cif_bytes, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
 
     def decode(self, slot, k=0):
         """FIC + MSC of the frame in ring slot `slot` in one call (dabgpu_decode_frames_layout: the FIB groups ride in the MSC launch)"""
         self.ctxs[k].decode_frames(self.hist, self.E, self.stride, self.H, slot, self.subs, self.fic_out[k], self.fic_res[k], self.msc_out[k],
-                                   4 * self.n_sub * 192, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
+                                   4 * self.cif_bytes, self.msc_res[k], stream=self.streams[k].cuda_stream, bits_layout=self.layout)
 
     def step(self, on_demod=None, decode=None):
         """one transmission frame of every ensemble: (sync ->) demod -> FIC + MSC   (decode = self.fic: configs[2])"""
@@ -439,13 +442,12 @@ class Pipeline:
         for k in sorted(self.last_frame_of_lane):                    # the outputs of the last frame of every lane
             j = self.last_frame_of_lane[k]
             out["frames_checked"].append(int(j))
-            cifs = [(4 * j + c - 15) % P for c in range(4)]
-            exp = self.mux.payload[idx][:, cifs]                      # [E, 4, n_sub, 192]
+            exp = torch.stack([self.mux.expected_cif(4 * j + c)[idx] for c in range(4)], dim=1)      # [E, 4, bytes of a CIF's sub-channels]
             res_f = self.fic_res[k].cpu().numpy().view(np.dtype(dabgpu.RESULT_DTYPE)).reshape(E, 4)
             out["fib_crc_pass"] += int(np.unpackbits(res_f["crc_ok_mask"].astype("<u4").view(np.uint8)).sum())
             out["fib_bytes_equal_transmitted"] &= bool(torch.equal(self.fic_out[k], self.mux.fibs[idx, j % self.mux.n_frames]))
             if not fic_only:
-                out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k].view(E, 4, self.n_sub, 192), exp))
+                out["msc_bytes_equal_transmitted"] &= bool(torch.equal(self.msc_out[k], exp))
         if fic_only:
             del out["msc_bytes_equal_transmitted"]
         if self.synced:
@@ -531,6 +533,55 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     del p
     torch.cuda.empty_cache()
     return c2, c3, host_sample
+
+
+def extras_mixed(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1, synced=True, lanes="alternate"):
+    """configs[3] on a HETEROGENEOUS multiplex (tools/dabsynth.py::mixed_layout: 14 sub-channels, 8 sizes, EEP 3-A / EEP 2-B / three UEP rows /
+    the 8 CU EEP 2-A case -- msc_decoder.cpp:77-154, subchannel_protection_tables.h:21-139): the same calls as configs[3], and the decode alone
+    under every forced mapping beside the one DABGPU_VIT_MAP_AUTO's cost model takes"""
+    import dabsynth
+    mux_layout = dabsynth.mixed_layout()
+    dabsynth.check_layout(mux_layout, dabgpu)
+    p = Pipeline(ctx, dabgpu, torch, device, E, n_distinct, seed=11, inflight=2, layout=layout, synced=synced, lanes=lanes, mux_layout=mux_layout)
+    p.tune()
+    p.fill()
+    torch.cuda.synchronize()
+    chosen, model = ctx.multiplex_mapping(E, p.subs)
+    names = {1: "wave", 2: "lane", 3: "octet"}
+    ab = {}
+    for m in (2, 3, 1):                                          # the decode call alone (FIC + MSC of one frame of every ensemble), mapping forced
+        for c in p.ctxs:
+            c.viterbi_set_mapping(m)
+        p.timed(p.decode, 1)
+        ab[names[m]] = p.timed(p.decode, reps if m != 1 else 2)
+    for c in p.ctxs:
+        c.viterbi_set_mapping(0)
+    p.timed(p.decode, 1)
+    t_dec = p.timed(p.decode, reps)
+    t_demod = p.timed(p.demod, reps)
+    p.fill()
+    t0 = time.perf_counter()
+    for k in range(2 * reps):
+        p.step()
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / (2 * reps) * 1e3
+    chk = p.check(dabgpu)
+    steps = p.msc_steps + p.fic_steps
+    out = {"workload": f"configs[3] on a mixed multiplex: {E} concurrent synthetic ensembles x {len(mux_layout)} sub-channels "
+                       "(EEP 3-A 3 x 48 / 3 x 60 / 2 x 72 CU, EEP 2-B 2 x 42 CU, UEP rows 35 / 38 / 43 = 128 / 160 / 192 kbit/s, EEP 2-A 8 CU; 832 of 864 CU)",
+           "ensembles": E, "sub_channels": [{k: d[k] for k in ("start", "length", "is_uep", "uep_index", "eep_level", "eep_type", "nbytes")} | {"trellis_steps": sum(32 * L for _, L in d["segments"]) + 6}
+                                            for d in mux_layout],
+           "trellis_steps_per_frame": {"msc": p.mux.msc_steps_per_frame, "fic": 4 * 774},
+           "ms_per_step": t_all, "frames_per_s": E / t_all * 1e3, "x_realtime": E / t_all * 1e3 / REALTIME_FRAMES_PER_S, "frames_in_flight": 2,
+           "kernel_ms": {"sync_and_demod_one_call" if synced else "ofdm_demod": t_demod, "fic_and_msc_one_call": t_dec},
+           "mapping": {"auto_chose": names[chosen], "cost_model_us": model, "decode_call_ms_forced": ab, "decode_call_ms_auto": t_dec,
+                       "what": "DABGPU_VIT_MAP_AUTO takes ONE mapping for all sub-channels of a call (include/dabgpu.h); the forced timings are the same call, same "
+                               "inputs, mapping set with dabgpu_viterbi_set_mapping"},
+           "trellis_steps_per_s_decode_call": steps / (t_dec * 1e-3),
+           "check": chk}
+    del p
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline_full(sample, seconds_target=14.0):
@@ -824,6 +875,9 @@ def main():
             c2, c3, host_sample = extras_configs23(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"),
                                                    synced=not args.aligned, lanes=args.lanes)
             line["extra"] = {"configs2": c2, "configs3": c3}
+            if not args.no_mixed:
+                line["extra"]["configs3_mixed"] = extras_mixed(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"),
+                                                               synced=not args.aligned, lanes=args.lanes)
             if not args.no_chain:
                 import bench_chain
                 line["extra"]["chain"] = bench_chain.run_chain(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct,

@@ -222,25 +222,16 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     std::vector<int> order((size_t)n_sub);
     for (int k = 0; k < n_sub; k++) order[(size_t)k] = k;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return plans[(size_t)a].n_steps > plans[(size_t)b].n_steps; });
-    const size_t gps_all = (n_ens * 4 + 63) / 64;
     const double n_simd = (double)device_waves(c) / 8.0;
     int k_wave = n_sub;                                        // number of (longest) sub-channels left to viterbi_kernel
     int octet = 0;                                             // the others: eight lanes per codeword instead of one
     if ((uint64_t)hist_frames * 230400u < ((uint64_t)1 << 32) && c->vit_mapping != DABGPU_VIT_MAP_WAVE) {
-        if (c->vit_mapping == DABGPU_VIT_MAP_LANE || c->vit_mapping == DABGPU_VIT_MAP_OCTET) {
-            k_wave = 0;
-            octet = c->vit_mapping == DABGPU_VIT_MAP_OCTET;
-        } else {
-            double sum_steps = 0.0, max_st = 0.0;
-            for (int j = 0; j < n_sub; j++) { sum_steps += (double)plans[(size_t)j].n_steps; max_st = std::max(max_st, (double)plans[(size_t)j].n_steps); }
-            const double groups = (double)n_sub * (double)gps_all, mean = sum_steps / (double)n_sub;
-            const double gather = 3.3e-6 * sum_steps * (double)(n_ens * 4);
-            const double t_wave = (double)(n_ens * 4) * (0.0189e-3 * sum_steps + 0.038 * (double)n_sub);
-            const double t_lane = 0.5 * std::max(max_st, std::ceil(groups / n_simd) * mean) + gather;
-            const double t_oct = 0.095 * std::max(2.0 * max_st, std::ceil(8.0 * groups / n_simd) * mean) + gather;
-            if (t_lane < t_wave || t_oct < t_wave) { k_wave = 0; octet = t_oct < t_lane; }
+        std::vector<uint32_t> steps((size_t)n_sub);
+        for (int j = 0; j < n_sub; j++) steps[(size_t)j] = plans[(size_t)j].n_steps;
+        const int m = dabgpu_host_choose_msc_mapping(c->vit_mapping, n_simd, n_ens, steps.data(), n_sub, nullptr);
+        if (m != DABGPU_VIT_MAP_WAVE) { k_wave = 0; octet = m == DABGPU_VIT_MAP_OCTET; }
+        if (c->vit_mapping == DABGPU_VIT_MAP_AUTO)
             if (const char* e = getenv("DABGPU_VIT_HYBRID_K")) { const int v = atoi(e); if (v >= 0 && v <= n_sub) k_wave = v; }   // tests
-        }
     }
     const int n_lane = n_sub - k_wave;
     // the FIC inside the MSC launch?  (every sub-channel in a batch mapping, one slice -- checked again below where the slices are known)
@@ -333,6 +324,19 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         if (k_wave == 0) return DABGPU_OK;
     }
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
+}
+
+// which mapping dabgpu_msc_decode_frames* / dabgpu_decode_frames_layout take for this multiplex and batch right now (the context's setting, or
+// the cost model's choice under DABGPU_VIT_MAP_AUTO), and what the model expects of each
+extern "C" int dabgpu_multiplex_mapping(dabgpu_ctx* c, size_t n_ens, const dabgpu_subchannel* h_sub, int n_sub, int* mapping, double* model_us3) {
+    if (!c || !h_sub || n_sub <= 0 || !mapping) { dabgpu_set_error("multiplex_mapping: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    std::vector<dabgpu_msc_plan> plans;
+    const int pst = dabgpu_host_build_msc_plans(h_sub, n_sub, plans, nullptr, nullptr, nullptr);
+    if (pst) return pst;
+    std::vector<uint32_t> steps((size_t)n_sub);
+    for (int j = 0; j < n_sub; j++) steps[(size_t)j] = plans[(size_t)j].n_steps;
+    *mapping = dabgpu_host_choose_msc_mapping(c->vit_mapping, (double)device_waves(c) / 8.0, n_ens, steps.data(), n_sub, model_us3);
+    return DABGPU_OK;
 }
 
 extern "C" int dabgpu_msc_decode_frames(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, size_t ens_stride, int hist_frames,

@@ -255,6 +255,24 @@ int dabgpu_host_choose_mapping(int forced_mapping, double n_simd, size_t n_cw, s
     return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;
 }
 
+// The MSC of n_ens ensembles that share a multiplex of n_sub sub-channels (steps[j] trellis steps each, 4 CIFs per call): the same cost
+// model, groups = n_sub x ceil(4 n_ens / 64).  AUTO compares the three pure choices (a partial viterbi_kernel launch is one lockstep round of
+// wavefronts and measured 2x its share of a full one: hybrids did not pay).  model_us (may be null) receives the modelled WAVE / LANE / OCTET
+// times in microseconds.
+int dabgpu_host_choose_msc_mapping(int forced_mapping, double n_simd, size_t n_ens, const uint32_t* steps, int n_sub, double* model_us) {
+    double sum_steps = 0.0, max_st = 0.0;
+    for (int j = 0; j < n_sub; j++) { sum_steps += (double)steps[j]; max_st = std::max(max_st, (double)steps[j]); }
+    const double groups = (double)n_sub * (double)((n_ens * 4 + 63) / 64), mean = n_sub ? sum_steps / (double)n_sub : 0.0;
+    const double gather = 3.3e-6 * sum_steps * (double)(n_ens * 4);
+    const double t_wave = (double)(n_ens * 4) * (0.0189e-3 * sum_steps + 0.038 * (double)n_sub);
+    const double t_lane = 0.5 * std::max(max_st, std::ceil(groups / n_simd) * mean) + gather;
+    const double t_oct = 0.095 * std::max(2.0 * max_st, std::ceil(8.0 * groups / n_simd) * mean) + gather;
+    if (model_us) { model_us[0] = t_wave; model_us[1] = t_lane; model_us[2] = t_oct; }
+    if (forced_mapping != DABGPU_VIT_MAP_AUTO) return forced_mapping;
+    if (t_lane < t_wave || t_oct < t_wave) return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;
+    return DABGPU_VIT_MAP_WAVE;
+}
+
 int dabgpu_host_validate_codeword(const dabgpu_codeword& d, size_t i) {
     if (d.flags & DABGPU_CW_DEPUNCTURED) {            // mother code handed over: no segment tables, any length, direct source only
         if (d.n_steps < 1 || d.n_steps > (1u << 24) || d.n_slots != 0 || !d.d_src || !d.d_out) {

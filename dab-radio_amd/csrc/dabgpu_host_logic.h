@@ -77,6 +77,9 @@ int dabgpu_host_validate_codeword(const dabgpu_codeword& d, size_t i);
 // DABGPU_VIT_MAP_AUTO: cost model of the three decoder mappings (n_simd = SIMDs of the device); forced_mapping != AUTO is returned as is
 int dabgpu_host_choose_mapping(int forced_mapping, double n_simd, size_t n_cw, size_t n_groups, double sum_cw_steps, double sum_group_steps,
                                double max_steps, bool staged_gather);
+// the same for the MSC of n_ens ensembles sharing a multiplex (steps[j] = trellis steps of sub-channel j); model_us[3] (may be null) = the
+// modelled WAVE / LANE / OCTET times
+int dabgpu_host_choose_msc_mapping(int forced_mapping, double n_simd, size_t n_ens, const uint32_t* steps, int n_sub, double* model_us);
 // the device-side plans of a multiplex's sub-channels (msc_decoder.cpp:77-154): DABGPU_OK, or DABGPU_ERR_INVALID_ARG for an invalid
 // profile / a sub-channel outside the 864 capacity units / more than 64 sub-channels
 int dabgpu_host_build_msc_plans(const dabgpu_subchannel* subs, int n_sub, std::vector<dabgpu_msc_plan>& plans, uint32_t* cif_out_bytes,

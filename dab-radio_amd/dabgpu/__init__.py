@@ -64,6 +64,7 @@ ABI_SYMBOLS = [
     "dabgpu_frame_session_fetch_fib_group", "dabgpu_frame_session_fetch_cif",
     "dabgpu_viterbi_decode_depunctured_host_sync", "dabgpu_stream_bank_process_ring_retained",
     "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
+    "dabgpu_multiplex_mapping",
     "dabgpu_receiver_create", "dabgpu_receiver_destroy", "dabgpu_receiver_session", "dabgpu_receiver_set_subchannels", "dabgpu_receiver_stage",
     "dabgpu_receiver_reset", "dabgpu_receiver_submit_sync", "dabgpu_receiver_wait_sync", "dabgpu_receiver_submit_frame", "dabgpu_receiver_wait_frame",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
@@ -453,6 +454,15 @@ class Context:
     def viterbi_set_mapping(self, mapping):
         """0 = auto, 1 = one wavefront per codeword, 2 = one lane per codeword, 3 = eight lanes per codeword (include/dabgpu.h DABGPU_VIT_MAP_*)."""
         check(lib().dabgpu_viterbi_set_mapping(self._h, int(mapping)), "dabgpu_viterbi_set_mapping")
+
+    def multiplex_mapping(self, n_ensembles, subchannels):
+        """(mapping the MSC decode of this multiplex takes: 1 wave / 2 lane / 3 octet, modelled microseconds of the three)"""
+        n = len(subchannels)
+        arr = (SubChannel * n)(*subchannels)
+        m, us = C.c_int(0), (C.c_double * 3)()
+        lib().dabgpu_multiplex_mapping.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        check(lib().dabgpu_multiplex_mapping(self._h, n_ensembles, arr, n, C.byref(m), us), "dabgpu_multiplex_mapping")
+        return m.value, {"wave": us[0], "lane": us[1], "octet": us[2]}
 
     def viterbi_decode_batch(self, codewords, results, tie_rule=0, stream=None):
         """codewords: list/ctypes array of Codeword (host); results: device buffer of n CodewordResult"""

@@ -395,6 +395,12 @@ int dabgpu_decode_frames_layout(dabgpu_ctx *ctx, const int8_t *d_bits_history, s
                                 size_t out_ensemble_stride, dabgpu_codeword_result *d_msc_results, int tie_rule, int bits_layout,
                                 void *stream);
 
+/* Which mapping the MSC of `n_ensembles` ensembles carrying this multiplex takes right now -- the context's setting (dabgpu_viterbi_set_mapping) or,
+ * under DABGPU_VIT_MAP_AUTO, the cost model's choice (one mapping for all sub-channels of a call) -- and the modelled times of WAVE / LANE / OCTET in
+ * microseconds (model_us3 may be NULL).  Host only: launches nothing. */
+int dabgpu_multiplex_mapping(dabgpu_ctx *ctx, size_t n_ensembles, const dabgpu_subchannel *h_subchannels, int n_subchannels, int *mapping,
+                             double *model_us3);
+
 /* Ring forms: ensemble e decodes the frame in slot d_newest_slot[e] of its own frame-history ring d_hist + e*ensemble_stride
  * (each ensemble at its own ring position, as dabgpu_stream_bank_process_ring leaves them); a negative slot skips the ensemble
  * (its result records come back with n_out_bytes = 0).  FIB bytes [n_ensembles][4][96], results [n_ensembles][4]. */

@@ -12,6 +12,53 @@ FIC_STEPS_PER_FRAME = 4 * 774
 MSC_STEPS_PER_FRAME = 4 * N_SUB * 1542
 
 
+def canonical_layout():
+    """18 x 48 CU EEP 3-A (PI_8 x 45 blocks, PI_7 x 3 blocks, 192 bytes per CIF) filling all 864 CU"""
+    return [dict(start=SUB_CU * s, length=SUB_CU, is_uep=0, uep_index=0, eep_level=2, eep_type=0, segments=[(8, 45), (7, 3)], nbytes=SUB_BYTES)
+            for s in range(N_SUB)]
+
+
+def mixed_layout():
+    """A multiplex as they are on air: 14 sub-channels of 8 sizes and 4 protection families on 832 of the 864 capacity units --
+    eight DAB+ services EEP 3-A (3 x 48 CU = 64 kbit/s, 3 x 60 CU = 80 kbit/s, 2 x 72 CU = 96 kbit/s), two EEP 2-B (42 CU = 64 kbit/s), three
+    MP2 services on UEP (table rows 35 / 38 / 43: 128 kbit/s level 3 = 96 CU with 4 padding bits, 160 kbit/s level 5 = 80 CU, 192 kbit/s
+    level 5 = 96 CU) and one 8 CU EEP 2-A data service (the n = 1 special case of msc_decoder.cpp:77-94 / subchannel_protection_tables.h:88-139).
+    segments = [(PI, L blocks of 128 mother bits)], nbytes = decoded bytes per CIF: ETSI EN 300 401 tables 7, 9, 10, written out here for
+    the generator (the product derives them from its own copy of the tables; check_layout compares the two)."""
+    subs, at = [], 0
+
+    def add(length, segments, nbytes, **kw):
+        nonlocal at
+        d = dict(start=at, length=length, is_uep=0, uep_index=0, eep_level=0, eep_type=0, segments=segments, nbytes=nbytes)
+        d.update(kw)
+        subs.append(d)
+        at += length
+    for n6, count in ((8, 3), (10, 3), (12, 2)):                     # EEP 3-A, length = 6 n: L1 = 6n - 3 blocks of PI_8, L2 = 3 of PI_7, 24 n bytes
+        for _ in range(count):
+            add(6 * n6, [(8, 6 * n6 - 3), (7, 3)], 24 * n6, eep_level=2)
+    for _ in range(2):                                               # EEP 2-B, length = 21 n (n = 2): L1 = 24n - 3 of PI_6, L2 = 3 of PI_5, 96 n bytes
+        add(42, [(6, 45), (5, 3)], 192, eep_level=1, eep_type=1)
+    add(96, [(16, 11), (9, 22), (6, 60), (10, 3)], 384, is_uep=1, uep_index=35)     # 128 kbit/s, protection level 3, 4 padding bits
+    add(80, [(5, 11), (4, 19), (2, 87), (4, 3)], 480, is_uep=1, uep_index=38)       # 160 kbit/s, level 5
+    add(96, [(6, 11), (4, 20), (2, 110), (5, 3)], 576, is_uep=1, uep_index=43)      # 192 kbit/s, level 5
+    add(8, [(13, 5), (12, 1)], 24, eep_level=1)                                     # EEP 2-A, n = 1
+    return subs
+
+
+def check_layout(layout, dabgpu):
+    """the generator's plans against the product's (dabgpu_subchannel_plan): a row typed wrongly above must not pass as a decoder bug"""
+    import ctypes as C
+    L = dabgpu.lib()
+    for d in layout:
+        sc = dabgpu.SubChannel(d["start"], d["length"], d["is_uep"], d["uep_index"], d["eep_level"], d["eep_type"])
+        pi, lx, nb = (C.c_int * 4)(), (C.c_int * 4)(), C.c_int(0)
+        n = L.dabgpu_subchannel_plan(C.byref(sc), pi, lx, C.byref(nb))
+        got = [(pi[k], lx[k]) for k in range(n) if lx[k] > 0]
+        assert got == [sg for sg in d["segments"] if sg[1] > 0] and nb.value == d["nbytes"], (d, got, nb.value)
+        kept = sum(4 * L_ * (8 + p) for p, L_ in d["segments"]) + 12
+        assert kept <= d["length"] * 64, (d, kept)
+
+
 def prbs_bytes(n):
     reg, out = 0xFFFF, np.empty(n, np.uint8)
     for k in range(n):
@@ -190,12 +237,16 @@ class Multiplex:
     in flight in the wrong order, decode to another CIF's payload or to garbage -- with one repeated frame they would not show).
     Decoded CIF r (counted from the first frame) carries payload[(r - 15) mod period]; frame j carries fibs[j mod (period / 4)]."""
 
-    def __init__(self, n, seed, device, period=8, superframes=False, rs_errors=0):
+    def __init__(self, n, seed, device, period=8, superframes=False, rs_errors=0, layout=None):
         """superframes: every sub-channel carries DAB+ audio super frames (5 logical frames each; period must be a multiple of 20 CIFs so
         that the stored frames repeat whole super frames) drawn from 32 generated ones, each RS codeword with rs_errors damaged symbols
-        -- the payload the DAB+ outer code downstream of the channel decoder has real work on"""
+        -- the payload the DAB+ outer code downstream of the channel decoder has real work on.
+        layout: the multiplex (canonical_layout() by default, mixed_layout(), ...): capacity units no sub-channel occupies carry random bits"""
         assert period % 4 == 0 and period >= 4
         assert not superframes or period % 20 == 0
+        self.layout = layout if layout is not None else canonical_layout()
+        canonical = layout is None
+        assert canonical or not superframes
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         self.n, self.period, self.n_frames = n, period, period // 4
@@ -219,32 +270,53 @@ class Multiplex:
             pl = sfs.reshape(n, N_SUB, period // 5, 5, SUB_BYTES).reshape(n, N_SUB, period, SUB_BYTES).transpose(0, 2, 1, 3)
             self.payload = torch.from_numpy(np.ascontiguousarray(pl)).to(device)
             torch.randint(0, 256, (1,), generator=g, device=device)                                # (keeps the generator's stream position simple)
-        else:
+        elif canonical:
             self.payload = torch.randint(0, 256, (n, period, N_SUB, SUB_BYTES), generator=g, device=device, dtype=torch.uint8)
-        pr192 = torch.from_numpy(prbs_bytes(SUB_BYTES)).to(device)
-        kidx = torch.from_numpy(kept_index([(8, 45), (7, 3)])).to(device)                               # EEP 3-A, n = 8
-        logical = torch.empty((n, period, N_SUB, 3072), dtype=torch.uint8, device=device)
-        for e0 in range(0, n, 64):
-            logical[e0:e0 + 64] = conv_encode(bytes_to_bits(self.payload[e0:e0 + 64] ^ pr192))[..., kidx]
-        # time interleaver: transmitted CIF s carries bit i of the logical frame that is bitrev4(i mod 16) CIFs older
-        # (the receiver takes bit i from the CIF that is 15 - bitrev4(i mod 16) CIFs old, cif_deinterleaver.cpp:57-68)
-        tx = torch.empty_like(logical)
-        for k in range(16):
-            d = int("{:04b}".format(k)[::-1], 2)
-            for s_ in range(period):
-                tx[:, s_, :, k::16] = logical[:, (s_ - d) % period, :, k::16]
+        if canonical:
+            self.payloads = [self.payload[:, :, s_] for s_ in range(N_SUB)]                          # per sub-channel [n][period][bytes]
+        else:
+            self.payloads = [torch.randint(0, 256, (n, period, d["nbytes"]), generator=g, device=device, dtype=torch.uint8) for d in self.layout]
+        self.sub_bytes = [d["nbytes"] for d in self.layout]
+        self.cif_out_bytes = sum(self.sub_bytes)
+        self.msc_steps_per_frame = 4 * sum(sum(32 * L for _, L in d["segments"]) + 6 for d in self.layout)
+        # the CIFs as transmitted: random bits where no sub-channel lives, every sub-channel coded, punctured and time interleaved
+        tx = torch.randint(0, 2, (n, period, 55296), generator=g, device=device, dtype=torch.uint8) if not canonical else \
+            torch.empty((n, period, 55296), dtype=torch.uint8, device=device)
+        plans = {}
+        for d, pay in zip(self.layout, self.payloads):
+            key = (tuple(d["segments"]), d["nbytes"])
+            if key not in plans:
+                plans[key] = (torch.from_numpy(prbs_bytes(d["nbytes"])).to(device), torch.from_numpy(kept_index(list(d["segments"]))).to(device))
+            pr, kidx = plans[key]
+            nk = kidx.numel()
+            assert nk <= d["length"] * 64
+            logical = torch.empty((n, period, nk), dtype=torch.uint8, device=device)
+            for e0 in range(0, n, 64):
+                logical[e0:e0 + 64] = conv_encode(bytes_to_bits(pay[e0:e0 + 64] ^ pr))[..., kidx]
+            # time interleaver: transmitted CIF s carries bit i of the logical frame that is bitrev4(i mod 16) CIFs older
+            # (the receiver takes bit i from the CIF that is 15 - bitrev4(i mod 16) CIFs old, cif_deinterleaver.cpp:57-68); the
+            # sub-channel's padding bits (beyond the code word) keep their random filling
+            sub = tx[:, :, d["start"] * 64:d["start"] * 64 + nk]
+            for k in range(16):
+                dd = int("{:04b}".format(k)[::-1], 2)
+                for s_ in range(period):
+                    sub[:, s_, k::16] = logical[:, (s_ - dd) % period, k::16]
         cifs = tx.reshape(n, nf, 4 * 55296)
         self.frame_bits = torch.cat([fic_tx.reshape(n, nf, 9216), cifs], dim=2).reshape(n, nf, 75, 3072)
 
     def subchannels(self, dabgpu):
-        return [dabgpu.SubChannel(SUB_CU * s, SUB_CU, 0, 0, 2, 0) for s in range(N_SUB)]
+        return [dabgpu.SubChannel(d["start"], d["length"], d["is_uep"], d["uep_index"], d["eep_level"], d["eep_type"]) for d in self.layout]
+
+    def expected_cif(self, cif_index):
+        """decoded bytes of CIF number cif_index (counted from the first stored frame), all sub-channels back to back: [n][cif_out_bytes]"""
+        return torch.cat([p[:, (cif_index - 15) % self.period] for p in self.payloads], dim=1)
 
 
-def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8, superframes=False, rs_errors=0):
+def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8, superframes=False, rs_errors=0, layout=None):
     """IQ of n_ensembles ensembles built from n_distinct (<= 64) seeded multiplexes: ensemble e carries
     multiplex e % n_distinct; every ensemble gets its own noise realisation.  Returns (iq [period / 4][E][196608] complex64 -- the
     period / 4 transmission frames that repeat -- and the Multiplex)."""
-    mux = Multiplex(n_distinct, seed, device, period, superframes=superframes, rs_errors=rs_errors)
+    mux = Multiplex(n_distinct, seed, device, period, superframes=superframes, rs_errors=rs_errors, layout=layout)
     nf = mux.n_frames
     iq = torch.empty((nf, n_ensembles, NB_FRAME_SAMPLES), dtype=torch.complex64, device=device)
     g = torch.Generator(device=device)
