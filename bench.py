@@ -243,6 +243,17 @@ def viterbi_roofline(kernel, steps, k_ms, lanes):
            "issue_efficiency": {"frac": achieved / own_peak, "peak": own_peak,
                                 "peak_definition": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9} GHz x {int(per_wave)} codewords per wavefront / ({instr} VALU "
                                                    f"instructions per wavefront-step of THIS kernel x {VIT_CYCLES_PER_INSTR} cycles)"}}
+    if per_wave == 64.0:
+        # where the instructions of a trellis step go, and what each part costs in launch time (timing-only variants, tools/abl_lanes.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r05", "abl_vit_lanes.json")) as fh:
+                ab = json.load(fh)
+            out["instr_per_step"] = ab["instr_per_step"]
+            out["ablation"] = {"source": "profiles/r05/abl_vit_lanes.json (tools/abl_lanes.py, 4096 ensembles, gather + trellis call)",
+                               "ms": {t: round(v["msc_call_ms"], 3) for t, v in ab["variants"].items() if not t.startswith("stagger")},
+                               "reading": ab["reading"]}
+        except (OSError, ValueError, KeyError):
+            pass
     if ev:
         out["issue_efficiency"]["counters"] = {"source": ev["source"], "kernel": ev["kernel"], "valu_instructions_per_wavefront_step": ev["instr_per_step"],
                                                "clock_ghz_under_profiler": ev["clock_ghz_profiled"],
