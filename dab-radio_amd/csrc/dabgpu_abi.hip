@@ -107,6 +107,7 @@ void dabgpu_destroy(dabgpu_ctx* c) {
     for (float* p : c->d_mode_prs) if (p) (void)hipFree(p);
     for (float* p : c->d_mode_prs_time_ref) if (p) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
+    for (void* p : c->parked) if (p) (void)hipFree(p);
     for (auto& sl : c->stage) {
         if (sl.pending) (void)hipEventSynchronize(sl.ev);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
@@ -245,7 +246,7 @@ static int ofdm_demod_any(dabgpu_ctx* c, const void* d_iq, int src, size_t n_fra
     hipStream_t s = (hipStream_t)stream;      // NULL = the HIP default (null) stream
     float* corr = d_cp_corr;
     if (!corr) {     // the kernel always produces the correlation; park it in context scratch when unwanted
-        int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr);
+        int st = dabgpu_scratch(c, 0, n_frames * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr, s);
         if (st) return st;
     }
     if (symbols_per_block <= 0)
@@ -403,7 +404,7 @@ int dabgpu_ofdm_sync_demod_frames(dabgpu_ctx* c, const float* d_iq, size_t n_str
     hipStream_t s = (hipStream_t)stream;
     float* corr = d_cp_corr;
     int st;
-    if (!corr && (st = dabgpu_scratch(c, 0, n_streams * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr))) return st;
+    if (!corr && (st = dabgpu_scratch(c, 0, n_streams * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float), (void**)&corr, s))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_sync(d_iq + 2 * prs_offset_samples, stream_stride_samples, (int)n_streams, cfg, d_states, nullptr, nullptr,
                                                  c->d_tw, c->d_prs, c->d_prs_time_ref, nullptr, 1, s), "ofdm_sync_kernel launch"))) return st;
     if (symbols_per_block <= 0) symbols_per_block = demod_cached_spb(c, n_streams, dabgpu_host_spb_variant(0, bits_layout, true));
@@ -574,11 +575,30 @@ int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const 
     return DABGPU_OK;
 }
 
-// grow-only scratch slots owned by the context (never shrinks; freed in dabgpu_destroy)
-int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out) {
+// grow-only scratch slots owned by the context (freed in dabgpu_destroy).
+// HIP graphs: a captured graph holds the ADDRESSES of the slots it was captured with.  `user` = the stream of a capturable entry point:
+//   * growth needed while `user` is capturing -> DABGPU_ERR_INVALID_ARG (hipMalloc would invalidate the capture with an obscure error);
+//   * once a call of this context has run under capture, a slot that grows later (a larger eager call) PARKS its old buffer until
+//     dabgpu_destroy instead of freeing it: a replay of the earlier graph then still reads and writes memory the context owns.
+int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out, hipStream_t user, bool user_given) {
     if ((size_t)slot >= c->scratch.size()) { c->scratch.resize(slot + 1, nullptr); c->scratch_bytes.resize(slot + 1, 0); }
+    bool capturing = false;
+    if (user_given) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(user, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) { capturing = true; c->captured_once = true; }
+        else (void)hipGetLastError();
+    }
     if (c->scratch_bytes[slot] < bytes) {
-        if (c->scratch[slot]) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
+        if (capturing) {
+            dabgpu_set_error("this call needs more device scratch than the context holds (slot %d: %zu -> %zu bytes): run it once with these shapes before capturing", slot,
+                             c->scratch_bytes[slot], bytes);
+            return DABGPU_ERR_INVALID_ARG;
+        }
+        if (c->scratch[slot]) {
+            if (c->captured_once) c->parked.push_back(c->scratch[slot]);
+            else { (void)hipStreamSynchronize(c->stream); if (user_given && user != c->stream) (void)hipStreamSynchronize(user); (void)hipFree(c->scratch[slot]); }
+            c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0;
+        }
         int st = dabgpu_check_hip(hipMalloc(&c->scratch[slot], bytes), "hipMalloc(scratch)");
         if (st) return st;
         c->scratch_bytes[slot] = bytes;
@@ -586,3 +606,5 @@ int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out) {
     *out = c->scratch[slot];
     return DABGPU_OK;
 }
+int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out) { return dabgpu_scratch(c, slot, bytes, out, nullptr, false); }
+int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out, hipStream_t user) { return dabgpu_scratch(c, slot, bytes, out, user, true); }

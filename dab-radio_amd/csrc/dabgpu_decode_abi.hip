@@ -39,7 +39,7 @@ static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, u
     const int n_waves = (int)std::min<size_t>(n, (size_t)device_waves(c));
     const size_t words = ((size_t)max_steps + 63) & ~(size_t)63;
     uint64_t* d_scratch = nullptr;
-    int st = dabgpu_scratch(c, 11 + slot_off, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch);
+    int st = dabgpu_scratch(c, 11 + slot_off, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch, s);
     if (st) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi(d_descs, (int)n, d_scratch, words, n_waves, (int)max_out_bytes, d_results,
                                                   tie_rule ? 1 : 0, c->d_vit_tables, s), "viterbi_kernel launch");
@@ -80,8 +80,8 @@ static int run_viterbi_lanes(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, const
                              int octet, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0, uint32_t groups_per_sub = 0) {
     int st;
     uint32_t *d_sym = nullptr, *d_dec = nullptr;
-    if ((st = dabgpu_scratch(c, 18 + slot_off, sym_rows * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
-    if ((st = dabgpu_scratch(c, 19 + slot_off, dec_rows * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+    if ((st = dabgpu_scratch(c, 18 + slot_off, sym_rows * 64 * sizeof(uint32_t), (void**)&d_sym, s))) return st;
+    if ((st = dabgpu_scratch(c, 19 + slot_off, dec_rows * 128 * sizeof(uint32_t), (void**)&d_dec, s))) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi_lanes(d_groups, n_groups, max_in_rows, d_descs, d_sym, d_dec, d_results,
                                                         tie_rule ? 1 : 0, ring4, c->d_vit_tables, d_sched, octet, device_waves(c) / 32, groups_per_sub, s),
                             "vit_lanes_kernel launch");
@@ -95,13 +95,13 @@ static int run_lanes_uniform(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_
     if (st) return st;
     const uint32_t dec_rows = dabgpu_vit_alloc_steps(n_steps), in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(seg_pi, seg_steps));
     uint2* d_sched = nullptr;
-    if ((st = dabgpu_scratch(c, 25 + slot_off, (size_t)dec_rows * sizeof(uint2), (void**)&d_sched))) return st;
+    if ((st = dabgpu_scratch(c, 25 + slot_off, (size_t)dec_rows * sizeof(uint2), (void**)&d_sched, s))) return st;
     if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_uniform(d_sched, dec_rows, seg_pi, seg_steps, c->d_vit_tables, s), "vit_sched launch"))) return st;
     const size_t slice_groups = std::max<size_t>(1, lanes_max_rows() / dec_rows);
     for (size_t cw0 = 0; cw0 < n; cw0 += slice_groups * 64) {
         const size_t n_cw = std::min(n - cw0, slice_groups * 64), n_groups = (n_cw + 63) / 64;
         dabgpu_vit_group* d_groups = nullptr;
-        if ((st = dabgpu_scratch(c, 17 + slot_off, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+        if ((st = dabgpu_scratch(c, 17 + slot_off, n_groups * sizeof(dabgpu_vit_group), (void**)&d_groups, s))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform(d_groups, n_cw, n_steps, seg_pi, seg_steps, s), "vit_groups launch"))) return st;
         if ((st = run_viterbi_lanes(c, d_descs + cw0, d_groups, n_groups, n_groups * in_rows, n_groups * dec_rows, in_rows, tie_rule, ring4,
                                     d_sched, octet, d_results + cw0, s, slot_off))) return st;
@@ -122,7 +122,7 @@ extern "C" int dabgpu_viterbi_decode_batch(dabgpu_ctx* c, const dabgpu_codeword*
     DABGPU_BIND(c);
     hipStream_t s = (hipStream_t)stream;
     dabgpu_cw_desc* d_descs = nullptr;
-    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    int st = dabgpu_scratch(c, 10, n * sizeof(dabgpu_cw_desc), (void**)&d_descs, s);
     if (st) return st;
     if ((st = dabgpu_stage_h2d(c, d_descs, h_cw, n * sizeof(dabgpu_cw_desc), s))) return st;
     // (h_cw is consumed when this returns, the caller may reuse it: small tables go through the pinned staging ring, large ones through
@@ -151,7 +151,7 @@ static int fic_decode_any(dabgpu_ctx* c, const int8_t* d_bits, size_t n_frames, 
     hipStream_t s = (hipStream_t)stream;
     const size_t n = n_frames * 4;
     dabgpu_cw_desc* d_descs = nullptr;
-    int st = dabgpu_scratch(c, 10 + FIC_SLOTS, n * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    int st = dabgpu_scratch(c, 10 + FIC_SLOTS, n * sizeof(dabgpu_cw_desc), (void**)&d_descs, s);
     if (st) return st;
     st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs, d_bits, n_frames, frame_stride, d_fib_bytes, d_slots, s), "fic_build_descs launch");
     if (st) return st;
@@ -210,9 +210,9 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     const int8_t* fic_bits = d_slots ? d_hist : d_hist + (size_t)newest_frame_slot * DABGPU_NB_FRAME_BITS;
     dabgpu_cw_desc* d_descs = nullptr;
     dabgpu_msc_plan* d_plans = nullptr;
-    int st = dabgpu_scratch(c, 10, (n + n_fic) * sizeof(dabgpu_cw_desc), (void**)&d_descs);
+    int st = dabgpu_scratch(c, 10, (n + n_fic) * sizeof(dabgpu_cw_desc), (void**)&d_descs, s);
     if (st) return st;
-    if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans))) return st;
+    if ((st = dabgpu_scratch(c, 12, plans.size() * sizeof(dabgpu_msc_plan), (void**)&d_plans, s))) return st;
     // (the plans are staged and the descriptors built once the mapping of every sub-channel is known, below)
     // Which sub-channels go to the lane-per-codeword kernel?  The k longest can be left to viterbi_kernel (one wavefront per
     // codeword) and the rest given to vit_lanes_kernel in the same call; AUTO only compares the two pure choices k = 0 and
@@ -270,14 +270,14 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         const size_t max_gq = std::max<size_t>(1, lanes_max_rows() / dec_rows_per_gq);
         const size_t ens_per_slice = max_gq * 16;                       // 16 ensembles x 4 CIFs = one group per sub-channel
         uint64_t* d_lane_subs = nullptr;
-        if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs))) return st;
+        if ((st = dabgpu_scratch(c, 24, lane_subs.size() * sizeof(uint64_t), (void**)&d_lane_subs, s))) return st;
         if ((st = dabgpu_stage_h2d_cached(c, 1, d_lane_subs, lane_subs.data(), lane_subs.size() * sizeof(uint64_t), s))) return st;
         // the schedule table of every lane-mapped sub-channel, once per call
         const uint32_t sched_stride = dabgpu_vit_alloc_steps(lane_max_steps);
         const uint32_t fic_pi[4] = {16, 15, 0, 0}, fic_steps[4] = {32 * 21, 32 * 3, 0, 0};
         const uint32_t fic_dec_rows = dabgpu_vit_alloc_steps(774), fic_in_rows = dabgpu_vit_in_rows(dabgpu_vit_in_bytes(fic_pi, fic_steps));
         uint2* d_sched = nullptr;
-        if ((st = dabgpu_scratch(c, 25, ((size_t)n_lane * sched_stride + (fic_inside ? fic_dec_rows : 0)) * sizeof(uint2), (void**)&d_sched))) return st;
+        if ((st = dabgpu_scratch(c, 25, ((size_t)n_lane * sched_stride + (fic_inside ? fic_dec_rows : 0)) * sizeof(uint2), (void**)&d_sched, s))) return st;
         if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_msc(d_sched, sched_stride, d_plans, d_lane_subs, n_lane, c->d_vit_tables, s), "vit_sched launch"))) return st;
         for (size_t e0 = 0; e0 < n_ens; e0 += ens_per_slice) {
             const size_t ne = std::min(n_ens - e0, ens_per_slice);
@@ -285,7 +285,7 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             const size_t n_groups = (size_t)n_lane * gps;
             const size_t n_fic_groups = fic_inside ? (n_fic + 63) / 64 : 0;
             dabgpu_vit_group* d_groups = nullptr;
-            if ((st = dabgpu_scratch(c, 17, (n_groups + n_fic_groups) * sizeof(dabgpu_vit_group), (void**)&d_groups))) return st;
+            if ((st = dabgpu_scratch(c, 17, (n_groups + n_fic_groups) * sizeof(dabgpu_vit_group), (void**)&d_groups, s))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_msc(d_groups, d_plans, d_lane_subs, n_lane, n_sub, ne, gps, sched_stride, s), "vit_groups launch"))) return st;
             const size_t cw0 = e0 * 4 * (size_t)n_sub;
             // the staged gathers read the ring rows in aligned 16-byte chunks (natural order) / aligned 64-byte lines (class order)
@@ -312,8 +312,8 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             base.res_delta = (int64_t)(reinterpret_cast<const char*>(fic->d_results) - reinterpret_cast<const char*>(d_results + n));
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_groups_uniform_at(d_groups + n_groups, n_fic, 774, fic_pi, fic_steps, base, s), "vit_groups launch"))) return st;
             uint32_t *d_sym = nullptr, *d_dec = nullptr;
-            if ((st = dabgpu_scratch(c, 18, (sym_rows + n_fic_groups * fic_in_rows) * 64 * sizeof(uint32_t), (void**)&d_sym))) return st;
-            if ((st = dabgpu_scratch(c, 19, (dec_rows + n_fic_groups * fic_dec_rows) * 128 * sizeof(uint32_t), (void**)&d_dec))) return st;
+            if ((st = dabgpu_scratch(c, 18, (sym_rows + n_fic_groups * fic_in_rows) * 64 * sizeof(uint32_t), (void**)&d_sym, s))) return st;
+            if ((st = dabgpu_scratch(c, 19, (dec_rows + n_fic_groups * fic_dec_rows) * 128 * sizeof(uint32_t), (void**)&d_dec, s))) return st;
             // FIB groups are contiguous runs of 2304 soft bits; with 16-byte aligned frames the staged gather applies
             const int fic_kind = (((uintptr_t)fic_bits % 16 == 0) && (ens_stride % 16 == 0)) ? 3 : 0;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_prep(ring4, d_groups, n_groups, lane_max_in_rows, d_descs, d_sym, gps, s), "vit_prep launch"))) return st;
@@ -477,7 +477,10 @@ extern "C" int dabgpu_viterbi_decode_host_sync(dabgpu_ctx* c, const int8_t* h_sr
 extern "C" int dabgpu_viterbi_decode_depunctured_host_sync(dabgpu_ctx* c, const int8_t* h_mother, size_t n_steps, uint32_t start_state,
                                                            uint32_t end_state, uint8_t* h_out, size_t n_out_bytes, uint64_t* path_error, int tie_rule) {
     if (!c || !h_mother || (!h_out && n_out_bytes)) { dabgpu_set_error("viterbi_decode_depunctured_host_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
-    if (n_steps < 1 || n_steps > ((size_t)1 << 24)) { dabgpu_set_error("viterbi_decode_depunctured_host_sync: n_steps %zu out of range", n_steps); return DABGPU_ERR_INVALID_ARG; }
+    if (n_steps < 1 || n_steps > DABGPU_MAX_TRELLIS_STEPS) {
+        dabgpu_set_error("viterbi_decode_depunctured_host_sync: n_steps %zu out of range (1 .. %u)", n_steps, (unsigned)DABGPU_MAX_TRELLIS_STEPS);
+        return DABGPU_ERR_INVALID_ARG;
+    }
     if (n_out_bytes && n_out_bytes * 8 + 6 > n_steps) {
         dabgpu_set_error("viterbi_decode_depunctured_host_sync: a trace-back of %zu bytes starts at decision word %zu, only %zu steps were decoded",
                          n_out_bytes, n_out_bytes * 8 + 5, n_steps);

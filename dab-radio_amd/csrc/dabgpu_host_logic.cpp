@@ -275,8 +275,8 @@ int dabgpu_host_choose_msc_mapping(int forced_mapping, double n_simd, size_t n_e
 
 int dabgpu_host_validate_codeword(const dabgpu_codeword& d, size_t i) {
     if (d.flags & DABGPU_CW_DEPUNCTURED) {            // mother code handed over: no segment tables, any length, direct source only
-        if (d.n_steps < 1 || d.n_steps > (1u << 24) || d.n_slots != 0 || !d.d_src || !d.d_out) {
-            dabgpu_set_error("codeword %zu: DABGPU_CW_DEPUNCTURED needs 1 <= n_steps <= 2^24, n_slots = 0 and non-null addresses", i);
+        if (d.n_steps < 1 || d.n_steps > DABGPU_MAX_TRELLIS_STEPS || d.n_slots != 0 || !d.d_src || !d.d_out) {
+            dabgpu_set_error("codeword %zu: DABGPU_CW_DEPUNCTURED needs 1 <= n_steps <= %u, n_slots = 0 and non-null addresses", i, (unsigned)DABGPU_MAX_TRELLIS_STEPS);
             return DABGPU_ERR_INVALID_ARG;
         }
         return DABGPU_OK;
@@ -290,6 +290,11 @@ int dabgpu_host_validate_codeword(const dabgpu_codeword& d, size_t i) {
             return DABGPU_ERR_INVALID_ARG;
         }
         steps += d.seg_steps[k];
+    }
+    if (steps + 6 > DABGPU_MAX_TRELLIS_STEPS) {
+        dabgpu_set_error("codeword %zu: %llu trellis steps, at most %u are decoded (the decoded bytes of a code word are assembled in LDS)", i,
+                         (unsigned long long)steps + 6, (unsigned)DABGPU_MAX_TRELLIS_STEPS);
+        return DABGPU_ERR_INVALID_ARG;
     }
     if (steps + 6 != d.n_steps || ((d.n_steps - 6) & 7) || !d.d_src || !d.d_out) {
         dabgpu_set_error("codeword %zu: n_steps=%u does not equal sum(seg_steps)+6 with whole output bytes, or null address", i, d.n_steps);

@@ -31,6 +31,8 @@ struct dabgpu_ctx {
     float* d_mode_prs_time_ref[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<void*> scratch;      // grow-only device scratch slots
     std::vector<size_t> scratch_bytes;
+    std::vector<void*> parked;       // outgrown slots a captured graph may still address (dabgpu_scratch); freed with the context
+    bool captured_once = false;      // a capturable entry point of this context has run under hipStreamBeginCapture
     // Host-side entry points (*_host_sync, msc_stream_*, dabplus_process_frame_host_sync) share the context's stream and scratch
     // slots: they serialise on this lock, so decoder objects living on different threads (BasicThreadPool workers,
     // src/basic_radio/basic_radio.cpp:51-60) may share one context.  The batch entry points (device pointers + caller's stream)
@@ -62,6 +64,8 @@ int dabgpu_check_hip(hipError_t e, const char* what);
 int dabgpu_bind_device(const dabgpu_ctx* c);
 #define DABGPU_BIND(ctx) do { const int dabgpu_bind_st_ = dabgpu_bind_device(ctx); if (dabgpu_bind_st_) return dabgpu_bind_st_; } while (0)
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
+// the same from a capturable entry point launching on `user` (HIP graphs: see the definition)
+int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out, hipStream_t user);
 // device PRS spectrum / coarse-sync time reference of a transmission mode (mode I: the context's own tables)
 int dabgpu_mode_sync_tables(dabgpu_ctx* c, int mode, const float** d_prs, const float** d_prs_time_ref);
 

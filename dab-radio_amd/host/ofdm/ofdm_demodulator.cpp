@@ -34,6 +34,9 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     if (m_mode == 0) throw std::runtime_error("OFDM_Demod: the MI355X kernels implement the DAB transmission modes I-IV only");
     if (prs_fft_ref.size() < params.nb_fft || carrier_mapper.size() < params.nb_data_carriers)
         throw std::runtime_error("OFDM_Demod: PRS reference / carrier mapper too small");
+    if (dabgpu_abi_version() != DABGPU_ABI_VERSION)
+        throw std::runtime_error("OFDM_Demod: libdabgpu.so implements ABI version " + std::to_string(dabgpu_abi_version()) + ", these classes were built for " +
+                                 std::to_string(DABGPU_ABI_VERSION));
     const char* dev = std::getenv("DABGPU_DEVICE");
     int st;
     if (m_mode == 1) {

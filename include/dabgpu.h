@@ -17,7 +17,12 @@
  * dabgpu_msc_decode_frames*, dabgpu_decode_frames_layout) enqueue kernels only once they have run ONCE with the same shapes and the
  * same sub-channel list on the stream (scratch is grow-only, tables that depend on the sub-channel list are uploaded when they change):
  * such calls may be issued between hipStreamBeginCapture and hipStreamEndCapture.  A call that would have to upload a table during a
- * capture returns DABGPU_ERR_INVALID_ARG instead of invalidating it.  (tests/test_gpu_graph_capture.py)
+ * capture returns DABGPU_ERR_INVALID_ARG instead of invalidating it, and so does one that would have to grow the context's device scratch.
+ * A captured graph holds the addresses of the context's scratch and tables as they were at capture time.  It stays VALID while the context
+ * lives -- a later eager call with larger shapes gets new scratch, the outgrown buffers are kept until dabgpu_destroy once a call of the
+ * context has run under capture -- and it stays CORRECT only while no call with another sub-channel list, another mapping
+ * (dabgpu_viterbi_set_mapping, DABGPU_VIT_HYBRID_K) or larger shapes runs on the same context between its replays: those rewrite the plan and
+ * lane tables the graph's kernels read.  One context per captured pipeline.  (tests/test_gpu_graph_capture.py)
  *
  * All functions fail with DABGPU_ERR_NO_DEVICE when no gfx950 device is usable: there is no CPU
  * fallback behind this ABI.
@@ -289,11 +294,15 @@ typedef struct {
     uint32_t end_state;        /* DAB_Viterbi_Decoder::chainback(bytes_out, end_state), normally 0 */
     uint32_t flags;            /* DABGPU_CW_RAW: emit the decoder output without the energy-dispersal XOR */
 } dabgpu_codeword;
+/* longest code word any decoder entry point takes, in trellis steps (= information bits + 6): the one-wavefront-per-code-word kernel
+ * assembles a code word's decoded bytes in LDS (60 KB).  17x the longest DAB code word (a sub-channel of all 864 capacity units at rate 8/9:
+ * 27,648 steps); longer inputs return DABGPU_ERR_INVALID_ARG. */
+#define DABGPU_MAX_TRELLIS_STEPS 491526u
 #define DABGPU_CW_RAW 1u
 #define DABGPU_CW_DEPUNCTURED 8u  /* direct codewords only (n_slots == 0): d_src holds the MOTHER code, 4 soft bits per trellis step with the punctured
                                   positions already 0 (the caller ran DAB_Viterbi_Decoder::depuncture_symbols, dab_viterbi_decoder.cpp:131-181,
                                   for whatever puncture vectors and lengths it was given); seg_pi / seg_steps are ignored, n_steps may be any
-                                  value >= 1, (n_steps - 6) / 8 whole bytes are written.  Always decoded by the WAVE mapping. */
+                                  value in 1 .. DABGPU_MAX_TRELLIS_STEPS, (n_steps - 6) / 8 whole bytes are written.  Always decoded by the WAVE mapping. */
 #define DABGPU_CW_CLASSED 4u   /* ring codewords only: every ring row holds its cif_stride soft bits in time-interleaver class order;
                                   input bit i of a slot lives at d_src + slot offset + (i mod 16) * (cif_stride / 16) + i / 16, and
                                   d_src points at the sub-channel's first byte of class 0 (slot 0) */
@@ -438,11 +447,14 @@ int dabgpu_viterbi_decode_host_sync(dabgpu_ctx *ctx, const int8_t *h_src, size_t
 /* The general form of DAB_Viterbi_Decoder -- reset(start_state), update(...) any number of times with ANY puncture vector and ANY
  * requested_output_symbols, chainback(bytes_out, end_state) (src/dab/algorithms/dab_viterbi_decoder.cpp:109-181) -- collapsed into one call:
  * the caller de-punctures as it goes (kept symbols copied, punctured positions 0: :154-176) and hands over the mother code.
- *   h_mother     [4 * n_steps] int8, n_steps >= 1 = trellis steps since reset()
+ *   h_mother     [4 * n_steps] int8, 1 <= n_steps <= DABGPU_MAX_TRELLIS_STEPS = trellis steps since reset()
  *   n_out_bytes  bytes chainback() is asked for: its bits n_out_bytes * 8 - 1 .. 0 are traced back from decision word n_out_bytes * 8 + 5
  *                downwards, starting in end_state (the core's chainback behind :126); n_out_bytes * 8 + 6 <= n_steps (a trace-back that
  *                starts beyond the decoded steps reads decision words the reference never wrote in this run: DABGPU_ERR_INVALID_ARG)
- *   path_error   accumulated renormalisation + metric[end_state] after ALL n_steps steps (:127-128), may be NULL
+ *   path_error   accumulated renormalisation + metric[end_state] after ALL n_steps steps (:127-128), may be NULL.  (The reference calls the
+ *                core's get_error() WITHOUT an argument, dab_viterbi_decoder.cpp:127; which state that reads by default is defined in
+ *                vendor/viterbi_decoder, an empty submodule here.  Every in-tree caller chains back from end_state 0, where metric[end_state]
+ *                and metric[0] are the same number; for other end states the two readings may differ -- unpinned, like the oracle's.)
  * When the trace-back does not start at the last decoded step the forward pass runs twice (whole length for the path error, the prefix
  * for the bytes): the decisions of a prefix do not depend on what follows. */
 int dabgpu_viterbi_decode_depunctured_host_sync(dabgpu_ctx *ctx, const int8_t *h_mother, size_t n_steps, uint32_t start_state,

@@ -93,3 +93,58 @@ def test_first_call_with_new_sub_channels_refuses_to_run_inside_a_capture():
                                     stream=side.cuda_stream, bits_layout=p.layout)
     g2.replay()
     torch.cuda.synchronize()
+
+
+def test_graph_replays_after_a_larger_eager_call_and_growth_is_refused_inside_a_capture():
+    """A graph captured with 8 ensembles, then an eager call with 40 on the SAME context (its scratch slots grow): the outgrown buffers are
+    parked, not freed, so the replay still runs on memory the context owns and -- the sub-channel list being the same -- gives the eager
+    result.  And a call whose shapes need more scratch than the context holds refuses to run inside a capture."""
+    import torch
+    import dabgpu
+    small, side = build(8, 4, seed=13)
+    small.tune()
+    small.fill()
+    torch.cuda.synchronize()
+    ctx = small.ctxs[0]
+
+    def decode(p, k=0):
+        ctx.decode_frames(p.hist, p.E, p.stride, p.H, 0, p.subs, p.fic_out[k], p.fic_res[k], p.msc_out[k], 4 * p.cif_bytes, p.msc_res[k],
+                          stream=side.cuda_stream, bits_layout=p.layout)
+    decode(small)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in (small.fic_out[0], small.fic_res[0], small.msc_out[0], small.msc_res[0])]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        decode(small)
+    torch.cuda.synchronize()
+    # a larger batch on the same context, inside a capture first: refused (it would have to grow the scratch) ...
+    with torch.cuda.stream(side):
+        big = bench_pipeline_like(small, 40, seed=14)
+    torch.cuda.synchronize()
+    g_big = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception) as err:
+        with torch.cuda.graph(g_big, stream=side):
+            decode(big)
+    assert "before capturing" in str(err.value) or "capture" in str(err.value).lower()
+    torch.cuda.synchronize()
+    # ... then eagerly: fine, the slots grow
+    decode(big)
+    torch.cuda.synchronize()
+    for t in (small.fic_out[0], small.msc_out[0]):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    got = [small.fic_out[0], small.fic_res[0], small.msc_out[0], small.msc_res[0]]
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+
+
+def bench_pipeline_like(p, E, seed):
+    """a second Pipeline's buffers (history ring filled by its own demodulator context) decoded through p's context"""
+    import torch
+    import dabgpu
+    import bench
+    q = bench.Pipeline(dabgpu.Context(0), dabgpu, torch, torch.device("cuda", 0), E, 4, seed=seed, inflight=1, synced=True)
+    q.tune()
+    q.fill()
+    return q
