@@ -33,7 +33,8 @@ static int ensure_vit_tables(dabgpu_ctx* c) {
 // FIC and the MSC of a batch concurrently on two streams
 static const int FIC_SLOTS = 20;
 static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, uint32_t max_steps, uint32_t max_out_bytes,
-                       int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0) {
+                       int tie_rule, dabgpu_codeword_result* d_results, hipStream_t s, int slot_off = 0, size_t n_first = 0,
+                       dabgpu_codeword_result* d_results_rest = nullptr) {
     int st0 = ensure_vit_tables(c);
     if (st0) return st0;
     const int n_waves = (int)std::min<size_t>(n, (size_t)device_waves(c));
@@ -42,7 +43,7 @@ static int run_viterbi(dabgpu_ctx* c, const dabgpu_cw_desc* d_descs, size_t n, u
     int st = dabgpu_scratch(c, 11 + slot_off, (size_t)n_waves * words * sizeof(uint64_t), (void**)&d_scratch, s);
     if (st) return st;
     return dabgpu_check_hip(dabgpu_launch_viterbi(d_descs, (int)n, d_scratch, words, n_waves, (int)max_out_bytes, d_results,
-                                                  tie_rule ? 1 : 0, c->d_vit_tables, s), "viterbi_kernel launch");
+                                                  tie_rule ? 1 : 0, c->d_vit_tables, s, (int)n_first, d_results_rest), "viterbi_kernel launch");
 }
 
 extern "C" int dabgpu_viterbi_set_mapping(dabgpu_ctx* c, int mapping) {
@@ -242,7 +243,12 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         rows += dabgpu_vit_alloc_steps(774);           // 16 ensembles = 64 FIB groups = one more group of codewords in the launch's scratch
         fic_inside = n_ens <= std::max<size_t>(1, lanes_max_rows() / rows) * 16;
     }
-    if (fic && !fic_inside && (st = fic_decode_any(c, fic_bits, n_ens, ens_stride, d_slots, fic->d_fib_bytes, fic->d_results, tie_rule, stream))) return st;
+    // Everything in the one-wavefront-per-code-word mapping (a handful of ensembles: one receiver behind the classes is 4 + 72 code words):
+    // the FIB groups ride in the sub-channels' launch as code words n .. n + n_fic - 1 with their own result array -- the two launches used
+    // to run one after the other on the stream, 109 + 213 us for one ensemble of 18 sub-channels, for work that is independent
+    const bool fic_with_wave = fic != nullptr && !fic_inside && k_wave == n_sub &&
+                               dabgpu_host_choose_mapping(c->vit_mapping, n_simd, n_fic, (n_fic + 63) / 64, (double)n_fic * 774.0, (double)((n_fic + 63) / 64) * 774.0, 774.0, true) == DABGPU_VIT_MAP_WAVE;
+    if (fic && !fic_inside && !fic_with_wave && (st = fic_decode_any(c, fic_bits, n_ens, ens_stride, d_slots, fic->d_fib_bytes, fic->d_results, tie_rule, stream))) return st;
     // flag the lane-mapped sub-channels in the plans the descriptor builder reads, then stage the plans and build the descriptors
     for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
     if ((st = dabgpu_stage_h2d_cached(c, 0, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
@@ -322,6 +328,10 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
                                                                  c->d_vit_tables, d_sched, octet, device_waves(c) / 32, s), "vit_lanes_kernel launch"))) return st;
         }
         if (k_wave == 0) return DABGPU_OK;
+    }
+    if (fic_with_wave) {
+        if ((st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs + n, fic_bits, n_ens, ens_stride, fic->d_fib_bytes, d_slots, s), "fic_build_descs launch"))) return st;
+        return run_viterbi(c, d_descs, n + n_fic, std::max(max_steps, 774u), std::max(max_out, 96u), tie_rule, d_results, s, 0, n, fic->d_results);
     }
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
 }
@@ -709,10 +719,8 @@ static int session_decode(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_se
     sl.fic = decode_fic != 0;
     sl.subs = s->subs; sl.sub_off = s->sub_off; sl.sub_n = s->sub_n; sl.cif_out = s->cif_out;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
-    if (decode_fic) {
+    if (decode_fic && !n_sub) {
         if ((st = dabgpu_fic_decode_frames(c, d_frame, 1, DABGPU_NB_FRAME_BITS, s->d_fib, s->d_fres, tie_rule, q))) return st;
-        CK(hipMemcpyAsync(sl.h_fib, s->d_fib, 4 * 96, hipMemcpyDeviceToHost, q));
-        CK(hipMemcpyAsync(sl.h_fres, s->d_fres, 4 * sizeof(dabgpu_codeword_result), hipMemcpyDeviceToHost, q));
     }
     if (n_sub) {
         const size_t need = (size_t)4 * s->cif_out, need_r = (size_t)4 * n_sub * sizeof(dabgpu_codeword_result);
@@ -728,10 +736,18 @@ static int session_decode(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_se
             CK(hipHostMalloc((void**)&sl.h_mres, need_r, hipHostMallocDefault));
             sl.h_mres_cap = need_r;
         }
-        if ((st = dabgpu_msc_decode_frames(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
-                                           s->subs.data(), n_sub, s->d_msc, need, s->d_mres, tie_rule, q))) return st;
+        // the frame's FIC and sub-channels in one call (one launch in the wave mapping: msc_decode_any)
+        if (decode_fic) st = dabgpu_decode_frames_layout(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
+                                                         s->subs.data(), n_sub, s->d_fib, s->d_fres, s->d_msc, need, s->d_mres, tie_rule, DABGPU_BITS_NATURAL, q);
+        else st = dabgpu_msc_decode_frames(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
+                                           s->subs.data(), n_sub, s->d_msc, need, s->d_mres, tie_rule, q);
+        if (st) return st;
         CK(hipMemcpyAsync(sl.h_msc, s->d_msc, need, hipMemcpyDeviceToHost, q));
         CK(hipMemcpyAsync(sl.h_mres, s->d_mres, need_r, hipMemcpyDeviceToHost, q));
+    }
+    if (decode_fic) {
+        CK(hipMemcpyAsync(sl.h_fib, s->d_fib, 4 * 96, hipMemcpyDeviceToHost, q));
+        CK(hipMemcpyAsync(sl.h_fres, s->d_fres, 4 * sizeof(dabgpu_codeword_result), hipMemcpyDeviceToHost, q));
     }
 #undef CK
     return DABGPU_OK;

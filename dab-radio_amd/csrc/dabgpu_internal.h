@@ -161,7 +161,8 @@ extern "C" hipError_t dabgpu_launch_viterbi_octet(const dabgpu_vit_group* d_grou
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
-                                            hipStream_t stream);
+                                            hipStream_t stream, int n_first = 0 /* > 0: code words n_first .. n_cw - 1 report into d_results_rest[0 ..] */,
+                                            dabgpu_cw_result* d_results_rest = nullptr);
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
                                               size_t frame_stride, uint8_t* d_out, const int32_t* d_slots, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,

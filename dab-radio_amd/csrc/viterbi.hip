@@ -196,7 +196,7 @@ template <int TIE>
 __global__ __launch_bounds__(64)
 void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t* __restrict__ dec_scratch,
                     size_t scratch_words_per_wave, dabgpu_cw_result* __restrict__ results,
-                    const dabgpu_vit_tables* __restrict__ tables)
+                    const dabgpu_vit_tables* __restrict__ tables, int n_first, dabgpu_cw_result* __restrict__ results_rest)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char vsm[];
     uint16_t* pi_tab = reinterpret_cast<uint16_t*>(vsm);            // [25][8]: count | prefix << 8
@@ -239,7 +239,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         // lengths, dab_viterbi_decoder.cpp:131-181), the segment tables are not read and any n_steps >= 1 is a codeword
         const bool full_rate = (D.flags & DABGPU_CW_DEPUNCTURED) != 0;
         if (n_steps < (full_rate ? 1 : 7)) {          // skipped work item (ring decode of an ensemble without a new frame)
-            if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; results[cw] = R; }
+            if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; *(cw < n_first ? results + cw : results_rest + (cw - n_first)) = R; }
             continue;
         }
         // segment boundaries in trellis steps; the 6 tail steps use PI_8 == PI_X
@@ -377,7 +377,7 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
             R.path_error = renorm_total + end_metric;
             R.crc_ok_mask = crc_mask;
             R.n_out_bytes = (uint32_t)n_out;
-            results[cw] = R;
+            *(cw < n_first ? results + cw : results_rest + (cw - n_first)) = R;       // code words n_first .. report into a second array (the FIB groups of a frame decoded with its sub-channels)
         }
         __syncthreads();
     }
@@ -388,16 +388,17 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
 extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n_cw, uint64_t* d_scratch,
                                             size_t scratch_words_per_wave, int n_waves, int max_out_bytes,
                                             dabgpu_cw_result* d_results, int tie_rule, const dabgpu_vit_tables* d_tables,
-                                            hipStream_t stream)
+                                            hipStream_t stream, int n_first, dabgpu_cw_result* d_results_rest)
 {
     using namespace dabgpu;
+    if (n_first <= 0 || !d_results_rest) { n_first = n_cw; d_results_rest = d_results; }
     const size_t lds = 25 * 8 * 2 + 512 + 16 * 8 + (size_t)((max_out_bytes + 63 + 15) & ~15);
     if (tie_rule)
         hipLaunchKernelGGL(viterbi_kernel<1>, dim3((unsigned)n_waves), dim3(64), lds, stream,
-                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables);
+                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables, n_first, d_results_rest);
     else
         hipLaunchKernelGGL(viterbi_kernel<0>, dim3((unsigned)n_waves), dim3(64), lds, stream,
-                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables);
+                           d_descs, n_cw, d_scratch, scratch_words_per_wave, d_results, d_tables, n_first, d_results_rest);
     return hipGetLastError();
 }
 

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Puts a number on the single-stream drop-in (the C++ mirror classes driven like basic_radio_app drives the reference's,
 tests/cpp/mirror_harness in its timing mode): frames/s against the 10.42 frames/s of a live Mode-I signal, and the latency of every
-FIC_Decoder::DecodeFIBGroup / MSC_Decoder::DecodeCIF call (one synchronous launch + two copies each).  One ensemble, the canonical
-multiplex of 18 x 48 CU EEP 3-A sub-channels, unsynchronised stream with carrier offset and noise, read from a file in 65536-sample blocks
-(the reference app's default block size).
+FIC_Decoder::DecodeFIBGroup / MSC_Decoder::DecodeCIF call.  One ensemble, the canonical multiplex of 18 x 48 CU EEP 3-A sub-channels,
+unsynchronised stream with carrier offset and noise, read from a file in 65536-sample blocks (the reference app's default block size).
+Since round 5 OFDM_Demod is a pipeline (dabgpu_receiver_*: sync, demodulation, fine-frequency update and the frame's FIC + MSC decode
+enqueued per frame, observers on a delivery thread; DABGPU_MIRROR_DEPTH frames in flight, DABGPU_MIRROR_PROFILE=1 prints where the two
+threads spend their time); DABGPU_MIRROR_BATCH=0 = every decoder call its own synchronous launch + two copies.
 
-    python tools/bench_mirror.py [--frames 40] [--subchannels 18]
+    python tools/bench_mirror.py [--frames 600] [--subchannels 18]
 """
 import argparse, json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "dab-radio_amd")); sys.path.insert(0, os.p
 import numpy as np, torch, dabgpu, dabsynth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=120)
+ap.add_argument("--frames", type=int, default=600)
 ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
 ap.add_argument("--subchannels", type=int, default=18)
 a = ap.parse_args()
@@ -46,8 +48,8 @@ with tempfile.TemporaryDirectory() as d:
         prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]            # DABGPU_MIRROR_PROFILE=1
         if prof: runs[name]["profile"] = prof[-1]
 out = dict(runs["frame_batcher_one_thread"])
-out["what"] = ("OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame from one caller thread; the frame batcher (default) decodes a "
-               "frame's FIC and sub-channels in one batched device call when OFDM_Demod completes it, the classes pick their bytes up "
+out["what"] = ("OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame from one caller thread; OFDM_Demod's receiver pipeline decodes a "
+               "frame's FIC and sub-channels on the device, chained behind its demodulation, the classes pick their bytes up "
                "(dab-radio_amd/host/dab/dabgpu_frame_batcher.h; the first 4 frames of a stream decode call by call: the time de-interleaver's 16 CIFs)" % a.subchannels)
 out["call_by_call"] = dict(runs["call_by_call_one_thread"], what="DABGPU_MIRROR_BATCH=0: every DecodeFIBGroup / DecodeCIF is a synchronous launch + two copies (round 2's path)")
 out["with_decode_threads"] = {"threads": a.threads, "frame_batcher": runs["frame_batcher_decode_threads"], "call_by_call": runs["call_by_call_decode_threads"],
