@@ -304,7 +304,8 @@ float dab_undb20f(float db) {
 
 static dab_cf32 g_tw[DAB_NB_FFT];
 static int g_tw_ready = 0;
-static void ensure_tw(void) { if (!g_tw_ready) { dab_get_twiddles(g_tw); g_tw_ready = 1; } }
+static void ensure_tw1(void);
+static void ensure_tw(void) { if (!g_tw_ready) { dab_get_twiddles(g_tw); ensure_tw1(); g_tw_ready = 1; } }
 
 static inline dab_cf32 cadd(dab_cf32 a, dab_cf32 b) { dab_cf32 r = { a.re + b.re, a.im + b.im }; return r; }
 static inline dab_cf32 csub(dab_cf32 a, dab_cf32 b) { dab_cf32 r = { a.re - b.re, a.im - b.im }; return r; }
@@ -342,8 +343,114 @@ static inline void dft8(const dab_cf32 *a, dab_cf32 *b) {
     b[3] = cadd(d3, d7); b[7] = csub(d3, d7);
 }
 
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+/* The same transform four butterflies at a time: a vector holds four complex values of the pass's independent index (interleaved re, im),
+ * and every vector operation below is the lane-wise form of one scalar helper above -- cadd / csub (add, sub), mul_mi (swap + sign),
+ * mul_w8_1 / mul_w8_3 (the same sum / difference, the same product with SQRT_HALF), cmul (t = b.im * (w.im, w.re); re = fma(b.re, w.re, -t0),
+ * im = fma(b.re, w.im, t1)) -- same operands, same order, same roundings: bit-identical outputs (tests/test_oracle_pins.py and
+ * test_oracle_properties.py compare the two paths through DAB_ORACLE_SCALAR_FFT).  Only the CPU baseline's speed changes. */
+#define V8 __m256
+static dab_cf32 g_tw1[3][512];                       /* pass-1 twiddles g_tw[p * k], contiguous in p */
+__attribute__((target("avx2,fma"))) static inline V8 v_mul_mi(V8 a) {                        /* (im, -re) */
+    const V8 odd = _mm256_castsi256_ps(_mm256_setr_epi32(0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u));
+    return _mm256_xor_ps(_mm256_permute_ps(a, 0xB1), odd);
+}
+__attribute__((target("avx2,fma"))) static inline V8 v_cmul(V8 b, V8 w) {
+    const V8 even = _mm256_castsi256_ps(_mm256_setr_epi32((int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u, 0));
+    const V8 t = _mm256_xor_ps(_mm256_mul_ps(_mm256_movehdup_ps(b), _mm256_permute_ps(w, 0xB1)), even);      /* (-(b.im w.im), b.im w.re) */
+    return _mm256_fmadd_ps(_mm256_moveldup_ps(b), w, t);
+}
+__attribute__((target("avx2,fma"))) static inline V8 v_mul_w8_1(V8 a) {                      /* ((re + im) S, (im - re) S) */
+    const V8 sw = _mm256_permute_ps(a, 0xB1);
+    return _mm256_mul_ps(_mm256_blend_ps(_mm256_add_ps(a, sw), _mm256_sub_ps(a, sw), 0xAA), _mm256_set1_ps(SQRT_HALF));
+}
+__attribute__((target("avx2,fma"))) static inline V8 v_mul_w8_3(V8 a) {                      /* ((im - re) S, -((re + im) S)) */
+    const V8 odd = _mm256_castsi256_ps(_mm256_setr_epi32(0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u));
+    const V8 sw = _mm256_permute_ps(a, 0xB1);
+    return _mm256_xor_ps(_mm256_mul_ps(_mm256_blend_ps(_mm256_sub_ps(sw, a), _mm256_add_ps(a, sw), 0xAA), _mm256_set1_ps(SQRT_HALF)), odd);
+}
+__attribute__((target("avx2,fma"))) static inline void v_dft8(const V8 *a, V8 *b) {
+    const V8 c0 = _mm256_add_ps(a[0], a[4]), c1 = _mm256_sub_ps(a[0], a[4]);
+    const V8 c2 = _mm256_add_ps(a[2], a[6]), c3 = v_mul_mi(_mm256_sub_ps(a[2], a[6]));
+    const V8 c4 = _mm256_add_ps(a[1], a[5]), c5 = _mm256_sub_ps(a[1], a[5]);
+    const V8 c6 = _mm256_add_ps(a[3], a[7]), c7 = v_mul_mi(_mm256_sub_ps(a[3], a[7]));
+    const V8 d0 = _mm256_add_ps(c0, c2), d2 = _mm256_sub_ps(c0, c2);
+    const V8 d1 = _mm256_add_ps(c1, c3), d3 = _mm256_sub_ps(c1, c3);
+    const V8 d4 = _mm256_add_ps(c4, c6), d6 = v_mul_mi(_mm256_sub_ps(c4, c6));
+    const V8 d5 = v_mul_w8_1(_mm256_add_ps(c5, c7)), d7 = v_mul_w8_3(_mm256_sub_ps(c5, c7));
+    b[0] = _mm256_add_ps(d0, d4); b[4] = _mm256_sub_ps(d0, d4);
+    b[1] = _mm256_add_ps(d1, d5); b[5] = _mm256_sub_ps(d1, d5);
+    b[2] = _mm256_add_ps(d2, d6); b[6] = _mm256_sub_ps(d2, d6);
+    b[3] = _mm256_add_ps(d3, d7); b[7] = _mm256_sub_ps(d3, d7);
+}
+#define VLD(p) _mm256_loadu_ps((const float *)(p))
+#define VST(p, v) _mm256_storeu_ps((float *)(p), (v))
+#define VBC(w) _mm256_castpd_ps(_mm256_broadcast_sd((const double *)&(w)))              /* one complex value in all four slots */
+__attribute__((target("avx2,fma")))
+static void fft2048_core_avx2(const dab_cf32 *in, dab_cf32 *out, int conj_io) {
+    dab_cf32 x[DAB_NB_FFT], y[DAB_NB_FFT];
+    const V8 cj = conj_io ? _mm256_castsi256_ps(_mm256_setr_epi32(0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u, 0, (int)0x80000000u))
+                          : _mm256_setzero_ps();
+    V8 a[8], b[8];
+    /* pass 1: radix 4, four consecutive p per vector; the outputs of one p are contiguous: 4 x 4 transpose of complex values */
+    for (int p = 0; p < 512; p += 4) {
+        for (int j = 0; j < 4; j++) a[j] = _mm256_xor_ps(VLD(in + p + 512 * j), cj);
+        const V8 s02 = _mm256_add_ps(a[0], a[2]), d02 = _mm256_sub_ps(a[0], a[2]);
+        const V8 s13 = _mm256_add_ps(a[1], a[3]), d13 = v_mul_mi(_mm256_sub_ps(a[1], a[3]));
+        b[0] = _mm256_add_ps(s02, s13);
+        b[1] = v_cmul(_mm256_add_ps(d02, d13), VLD(&g_tw1[0][p]));
+        b[2] = v_cmul(_mm256_sub_ps(s02, s13), VLD(&g_tw1[1][p]));
+        b[3] = v_cmul(_mm256_sub_ps(d02, d13), VLD(&g_tw1[2][p]));
+        const __m256d t0 = _mm256_unpacklo_pd(_mm256_castps_pd(b[0]), _mm256_castps_pd(b[1])), t1 = _mm256_unpackhi_pd(_mm256_castps_pd(b[0]), _mm256_castps_pd(b[1]));
+        const __m256d t2 = _mm256_unpacklo_pd(_mm256_castps_pd(b[2]), _mm256_castps_pd(b[3])), t3 = _mm256_unpackhi_pd(_mm256_castps_pd(b[2]), _mm256_castps_pd(b[3]));
+        VST(y + 4 * p,      _mm256_castpd_ps(_mm256_permute2f128_pd(t0, t2, 0x20)));
+        VST(y + 4 * p + 4,  _mm256_castpd_ps(_mm256_permute2f128_pd(t1, t3, 0x20)));
+        VST(y + 4 * p + 8,  _mm256_castpd_ps(_mm256_permute2f128_pd(t0, t2, 0x31)));
+        VST(y + 4 * p + 12, _mm256_castpd_ps(_mm256_permute2f128_pd(t1, t3, 0x31)));
+    }
+    /* pass 2: radix 8, n = 512, s = 4: q = 0 .. 3 is one vector */
+    for (int p = 0; p < 64; p++) {
+        for (int j = 0; j < 8; j++) a[j] = VLD(y + 4 * (p + 64 * j));
+        v_dft8(a, b);
+        VST(x + 4 * (8 * p), b[0]);
+        for (int k = 1; k < 8; k++) VST(x + 4 * (8 * p + k), v_cmul(b[k], VBC(g_tw[4 * p * k])));
+    }
+    /* pass 3: radix 8, n = 64, s = 32 */
+    for (int p = 0; p < 8; p++) {
+        V8 w[8];
+        for (int k = 1; k < 8; k++) w[k] = VBC(g_tw[32 * p * k]);
+        for (int q = 0; q < 32; q += 4) {
+            for (int j = 0; j < 8; j++) a[j] = VLD(x + q + 32 * (p + 8 * j));
+            v_dft8(a, b);
+            VST(y + q + 32 * (8 * p), b[0]);
+            for (int k = 1; k < 8; k++) VST(y + q + 32 * (8 * p + k), v_cmul(b[k], w[k]));
+        }
+    }
+    /* pass 4: radix 8, n = 8, s = 256 */
+    for (int q = 0; q < 256; q += 4) {
+        for (int j = 0; j < 8; j++) a[j] = VLD(y + q + 256 * j);
+        v_dft8(a, b);
+        for (int k = 0; k < 8; k++) VST(out + q + 256 * k, _mm256_xor_ps(b[k], cj));
+    }
+}
+#undef VLD
+#undef VST
+#undef VBC
+#undef V8
+static void ensure_tw1(void) { for (int k = 1; k < 4; k++) for (int p = 0; p < 512; p++) g_tw1[k - 1][p] = g_tw[p * k]; }
+static int g_scalar_fft = -1;                        /* DAB_ORACLE_SCALAR_FFT=1: the scalar statement of the transform (the tests run both) */
+#endif
+
+#if !(defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES))
+static void ensure_tw1(void) {}
+#endif
+
 DAB_HOT
 static void fft2048_core(const dab_cf32 *in, dab_cf32 *out, int conj_io) {
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+    if (g_scalar_fft < 0) { const char *e = getenv("DAB_ORACLE_SCALAR_FFT"); g_scalar_fft = (e && e[0] == '1') || !(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")); }
+    if (!g_scalar_fft) { fft2048_core_avx2(in, out, conj_io); return; }
+#endif
     dab_cf32 x[DAB_NB_FFT], y[DAB_NB_FFT];
     dab_cf32 a[8], b[8];
     /* pass 1: radix 4, n=2048, s=1 */
@@ -413,11 +520,58 @@ static inline int8_t to_vbit(float x) {
     return (int8_t)(int)v;
 }
 
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+/* eight carriers at a time, lane by lane the statements of the scalar loop below: conj_mul's two FMAs, fabsf, the max as (ar < ai) ? ai : ar,
+ * IEEE division, -x * 127, truncation (vcvttps2dq: NaN -> INT_MIN, whose low byte is the scalar code's 0) */
+__attribute__((target("avx2,fma")))
+static int demap_avx2(const dab_cf32 *fft_i, const dab_cf32 *fft_ip1, const int *mapper, int8_t *bits, int n_vec) {
+    const int N = DAB_NB_DATA_CARRIERS, M = N / 2;
+    const __m256i deint = _mm256_setr_epi32(0, 2, 4, 6, 1, 3, 5, 7);
+    const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7FFFFFFF)), sign = _mm256_set1_ps(-0.0f), k127 = _mm256_set1_ps(127.0f);
+    const __m128i pick = _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    int i = 0;
+    for (; i + 8 <= n_vec; i += 8) {
+        int bin[8];
+        for (int k = 0; k < 8; k++) {
+            const int c = mapper[i + k];
+            const int kk = (c < M) ? (c - M) : (c - M + 1);
+            bin[k] = (DAB_NB_FFT + kk) % DAB_NB_FFT;
+        }
+        const __m128i b_lo = _mm_loadu_si128((const __m128i *)bin), b_hi = _mm_loadu_si128((const __m128i *)(bin + 4));
+        /* gathers of 64-bit (re, im) pairs, then re[8] / im[8] in carrier order */
+        const __m256 x0a = _mm256_castpd_ps(_mm256_i32gather_pd((const double *)fft_i, b_lo, 8)), x0b = _mm256_castpd_ps(_mm256_i32gather_pd((const double *)fft_i, b_hi, 8));
+        const __m256 x1a = _mm256_castpd_ps(_mm256_i32gather_pd((const double *)fft_ip1, b_lo, 8)), x1b = _mm256_castpd_ps(_mm256_i32gather_pd((const double *)fft_ip1, b_hi, 8));
+        const __m256 p0a = _mm256_permutevar8x32_ps(x0a, deint), p0b = _mm256_permutevar8x32_ps(x0b, deint);
+        const __m256 p1a = _mm256_permutevar8x32_ps(x1a, deint), p1b = _mm256_permutevar8x32_ps(x1b, deint);
+        const __m256 a = _mm256_permute2f128_ps(p0a, p0b, 0x20), b = _mm256_permute2f128_ps(p0a, p0b, 0x31);       /* x0 = fft_i:   re, im */
+        const __m256 c = _mm256_permute2f128_ps(p1a, p1b, 0x20), d = _mm256_permute2f128_ps(p1a, p1b, 0x31);       /* x1 = fft_ip1: re, im */
+        const __m256 dre = _mm256_fmadd_ps(b, d, _mm256_mul_ps(a, c));                                            /* fmaf(b, d, a * c) */
+        const __m256 dim = _mm256_fmadd_ps(b, c, _mm256_xor_ps(_mm256_mul_ps(a, d), sign));                       /* fmaf(b, c, -(a * d)) */
+        const __m256 ar = _mm256_and_ps(dre, absmask), ai = _mm256_and_ps(dim, absmask);
+        const __m256 A = _mm256_blendv_ps(ar, ai, _mm256_cmp_ps(ar, ai, _CMP_LT_OQ));                             /* (ar < ai) ? ai : ar */
+        const __m256 nr = _mm256_div_ps(dre, A), ni = _mm256_div_ps(dim, A);
+        const __m256 vr = _mm256_mul_ps(_mm256_xor_ps(nr, sign), k127);                                           /* -(+nr) * 127 */
+        const __m256 vi = _mm256_mul_ps(ni, k127);                                                                /* -(-ni) * 127 */
+        const __m256i ir = _mm256_cvttps_epi32(vr), ii = _mm256_cvttps_epi32(vi);
+        const __m128i r_lo = _mm_shuffle_epi8(_mm256_castsi256_si128(ir), pick), r_hi = _mm_shuffle_epi8(_mm256_extracti128_si256(ir, 1), pick);
+        const __m128i i_lo = _mm_shuffle_epi8(_mm256_castsi256_si128(ii), pick), i_hi = _mm_shuffle_epi8(_mm256_extracti128_si256(ii, 1), pick);
+        _mm_storel_epi64((__m128i *)(bits + i), _mm_unpacklo_epi32(r_lo, r_hi));
+        _mm_storel_epi64((__m128i *)(bits + i + N), _mm_unpacklo_epi32(i_lo, i_hi));
+    }
+    return i;
+}
+#endif
+
 /* ofdm_demodulator.cpp:842-889 */
 DAB_HOT
 void dab_dqpsk_demap(const dab_cf32 *fft_i, const dab_cf32 *fft_ip1, const int *mapper, int8_t *bits) {
     const int N = DAB_NB_DATA_CARRIERS, M = N / 2;
-    for (int i = 0; i < N; i++) {
+    int i0 = 0;
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+    if (g_scalar_fft < 0) { const char *e = getenv("DAB_ORACLE_SCALAR_FFT"); g_scalar_fft = (e && e[0] == '1') || !(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")); }
+    if (!g_scalar_fft) i0 = demap_avx2(fft_i, fft_ip1, mapper, bits, N);
+#endif
+    for (int i = i0; i < N; i++) {
         const int c = mapper[i];                                   /* :874 */
         const int k = (c < M) ? (c - M) : (c - M + 1);             /* carrier -768..-1,1..768 (:853-864) */
         const int bin = (DAB_NB_FFT + k) % DAB_NB_FFT;
