@@ -114,8 +114,71 @@ void dab_viterbi_reset(dab_viterbi *v, size_t starting_state) {
     memset(v->decisions, 0, v->max_steps * sizeof(uint64_t));
 }
 
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+#include <immintrin.h>
+/* The same trellis step sixteen butterflies per vector (what an upstream build does with its AVX2 core, so that bench.py's cpu_baseline_full
+ * does not time a scalar port of it): every vector operation is the lane-wise form of a statement of the scalar loop below -- u16 wrapping
+ * adds, the unsigned minimum, the decision as the scalar tie rule states it ((m1 <= m0) <=> min == m1; (m0 > m1) <=> !(min == m0)), the same
+ * renormalisation -- so metrics, decision words and the accumulated error are identical (tests/test_oracle_properties.py compares the two
+ * through DAB_ORACLE_SCALAR_VITERBI=1, incl. u16 wrap and renormalisation cases). */
+__attribute__((target("avx2,bmi2")))
+static uint64_t viterbi_steps_avx2(dab_viterbi *v, const int16_t *sym, size_t n_sym) {
+    uint64_t total = 0;
+    __m256i br[VR][2];
+    for (int r = 0; r < VR; r++) for (int h = 0; h < 2; h++) br[r][h] = _mm256_loadu_si256((const __m256i *)&v->branch[r][16 * h]);
+    const __m256i kmax = _mm256_set1_epi16((short)V_MAX_ERROR);
+    for (size_t s0 = 0; s0 < n_sym; s0 += VR) {
+        assert(v->current_decoded_bit < v->max_steps);
+        const uint16_t *old = v->metric[v->cur];
+        uint16_t *nw = v->metric[v->cur ^ 1];
+        uint32_t D0 = 0, D1 = 0;                                    /* bit s: decision of new state 2s / 2s + 1 */
+        for (int h = 0; h < 2; h++) {                               /* butterflies 16 h .. 16 h + 15 */
+            __m256i e = _mm256_setzero_si256();
+            for (int r = 0; r < VR; r++)
+                e = _mm256_add_epi16(e, _mm256_abs_epi16(_mm256_sub_epi16(br[r][h], _mm256_set1_epi16(sym[s0 + r]))));
+            const __m256i m = _mm256_sub_epi16(kmax, e);
+            const __m256i lo = _mm256_loadu_si256((const __m256i *)(old + 16 * h)), hi = _mm256_loadu_si256((const __m256i *)(old + 32 + 16 * h));
+            const __m256i m0 = _mm256_add_epi16(lo, e), m1 = _mm256_add_epi16(hi, m), m2 = _mm256_add_epi16(lo, m), m3 = _mm256_add_epi16(hi, e);
+            const __m256i n0 = _mm256_min_epu16(m0, m1), n1 = _mm256_min_epu16(m2, m3);
+            uint32_t k0, k1;
+            if (v->tie_rule) {
+                k0 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi16(n0, m1));
+                k1 = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi16(n1, m3));
+            } else {
+                k0 = ~(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi16(n0, m0));
+                k1 = ~(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi16(n1, m2));
+            }
+            D0 |= (uint32_t)_pext_u32(k0, 0xAAAAAAAAu) << (16 * h);
+            D1 |= (uint32_t)_pext_u32(k1, 0xAAAAAAAAu) << (16 * h);
+            /* new states 2s, 2s + 1 interleaved: nw[32 h .. 32 h + 31] */
+            const __m256i il = _mm256_unpacklo_epi16(n0, n1), ih = _mm256_unpackhi_epi16(n0, n1);
+            _mm256_storeu_si256((__m256i *)(nw + 32 * h), _mm256_permute2x128_si256(il, ih, 0x20));
+            _mm256_storeu_si256((__m256i *)(nw + 32 * h + 16), _mm256_permute2x128_si256(il, ih, 0x31));
+        }
+        v->decisions[v->current_decoded_bit] = _pdep_u64((uint64_t)D0, 0x5555555555555555ull) | _pdep_u64((uint64_t)D1, 0xAAAAAAAAAAAAAAAAull);
+        if (nw[0] >= V_RENORM_THRESH) {
+            uint16_t mn = nw[0];
+            for (int s = 1; s < VSTATES; s++) if (nw[s] < mn) mn = nw[s];
+            for (int s = 0; s < VSTATES; s++) nw[s] = (uint16_t)(nw[s] - mn);
+            total += mn;
+        }
+        v->cur ^= 1;
+        v->current_decoded_bit++;
+    }
+    return total;
+}
+static int g_scalar_viterbi = -1;
+#endif
+
 /* published ViterbiDecoderCpp scalar core: one trellis step = 32 butterflies on u16 metrics */
 static uint64_t viterbi_steps(dab_viterbi *v, const int16_t *sym, size_t n_sym) {
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(DAB_ORACLE_NO_CLONES)
+    if (g_scalar_viterbi < 0) {
+        const char *e = getenv("DAB_ORACLE_SCALAR_VITERBI");
+        g_scalar_viterbi = (e && e[0] == '1') || !(__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2"));
+    }
+    if (!g_scalar_viterbi) return viterbi_steps_avx2(v, sym, n_sym);
+#endif
     uint64_t total = 0;
     for (size_t s0 = 0; s0 < n_sym; s0 += VR) {
         assert(v->current_decoded_bit < v->max_steps);

@@ -114,3 +114,50 @@ def test_viterbi_decisions_layout(oracle):
     out, err = v.chainback(16)
     assert np.array_equal(out, data) and err == 0
     assert v.metrics()[0] == 0
+
+
+def test_avx2_trellis_step_of_the_oracle_equals_its_scalar_statement(tmp_path):
+    """The oracle's add-compare-select runs sixteen butterflies per vector where the CPU has AVX2 + BMI2 (what an upstream build does with
+    its SIMD core; otherwise bench.py's cpu_baseline_full would time a scalar port); DAB_ORACLE_SCALAR_VITERBI=1 selects the scalar
+    statement.  Decoded bytes, path errors, final metrics, every decision word and the consumed counts must be identical for both tie
+    rules -- on noisy code words, on -128 inputs (branch errors above 1016: the u16 complement wraps), on all-zero input (every compare a
+    tie), on weak signals (frequent renormalisation), from random start and end states."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, oracle as O
+rng = np.random.default_rng(int(sys.argv[2]))
+outs = []
+for tie in (0, 1):
+    for case in range(8):
+        n_bytes = [96, 192, 24, 576, 96, 96, 300, 48][case]
+        steps = n_bytes * 8 + 6
+        amp = [127, 127, 40, 127, 127, 5, 127, 127][case]
+        if case == 4:
+            soft = np.full(4 * steps, -128, np.int8)
+        elif case == 5:
+            soft = rng.integers(-amp, amp + 1, 4 * steps).astype(np.int8)
+        elif case == 6:
+            soft = np.zeros(4 * steps, np.int8)
+        else:
+            soft = (rng.integers(0, 2, 4 * steps) * 2 - 1).astype(np.int8) * amp
+            soft = np.clip(soft.astype(np.int32) + rng.integers(-90, 91, soft.size), -128, 127).astype(np.int8)
+        v = O.Viterbi(n_bytes * 8, tie)
+        v.reset(int(rng.integers(0, 64)))
+        used = v.update(soft, np.array([4], np.uint8), 4 * steps)
+        by, err = v.chainback(n_bytes, int(rng.integers(0, 64)))
+        outs.append(np.concatenate([by, np.frombuffer(np.uint64(err).tobytes(), np.uint8), v.metrics().view(np.uint8), v.decisions(steps).view(np.uint8),
+                                    np.frombuffer(np.uint64(used).tobytes(), np.uint8)]))
+np.save(sys.argv[1], np.concatenate(outs))
+''' % os.path.join(root, "oracle")
+    for seed in (1, 2):
+        got = []
+        for tag, env in (("vector", {}), ("scalar", {"DAB_ORACLE_SCALAR_VITERBI": "1"})):
+            out = tmp_path / f"{tag}_{seed}.npy"
+            subprocess.run([sys.executable, "-c", code, str(out), str(seed)], env=dict(os.environ, **env), check=True, timeout=300)
+            got.append(np.load(out))
+        assert got[0].size > 100000 and np.array_equal(got[0], got[1]), seed

@@ -155,10 +155,13 @@ doc = {"what": "one-thread time of the oracle port divided by the time of the re
        "threads": 1, "seconds_per_measurement": a.seconds, "rows": rows, "geometric_mean_port_over_reference": round(geo, 3),
        "ofdm_pieces_avx2_port_over_reference": [r["port_time_over_reference_time"] for r in ofdm],
        "not_calibrated": "FFT (FFTW3 absent), DQPSK / soft-bit stage and the synchroniser (same translation unit as <fftw3.h>), Viterbi ACS / chain-back "
-                         "(vendor/viterbi_decoder is an empty submodule): ~90 % of the CPU time of the full chain; for those the port IS the only CPU number there is",
-       "how_to_read_cpu_baseline": "bench.py's cpu_baseline / cpu_baseline_full time the port.  On the PLL -- ~45 % of the demodulator's flops, SURVEY 8a a8 -- the "
-                                   "reference's AVX2 object is faster than the port by the first row's factor; an upstream build with FFTW's SIMD transforms and the "
-                                   "AVX2 Viterbi core would be faster than the port by at least that on the whole chain.  The GPU / CPU ratio is a reported baseline, not the target."}
+                         "(vendor/viterbi_decoder is an empty submodule): most of the CPU time of the full chain; for those the port IS the only CPU number there is",
+       "how_to_read_cpu_baseline": "bench.py's cpu_baseline / cpu_baseline_full time the port.  Where the reference vectorises, the port does too since round 5 -- the PLL "
+                                   "(first row: at the speed of the reference's AVX2 object), the 2048-point transform, the DQPSK / soft-bit stage and the Viterbi "
+                                   "add-compare-select (AVX2 forms of the oracle's scalar statements, bit-identical, tests/test_oracle_pins.py / test_oracle_properties.py): "
+                                   "one frame demodulates in ~1.5 ms and the whole receive chain with 18 sub-channels takes ~4.7 ms on one core of the build container "
+                                   "(round 4: ~7.7 ms and ~13 ms).  FFTW's transform and the upstream SIMD Viterbi core may still be faster than these; the GPU / CPU "
+                                   "ratio is a reported baseline, not the target."}
 print(json.dumps(doc, indent=1))
 if a.out:
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
