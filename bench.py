@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--spb", type=int, default=0, help="data symbols per workgroup (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-mirror", action="store_true", help="demod, N = 1: skip extra.one_receiver (tests/cpp/mirror_harness: one receiver behind the C++ classes)")
     ap.add_argument("--no-mixed", action="store_true", help="demod, N = 1: skip extra.configs3_mixed (configs[3] on a heterogeneous multiplex at --extra-ensembles)")
     ap.add_argument("--no-chain", action="store_true", help="demod, N = 1: skip extra.chain (the unsynchronised-stream chain at --extra-ensembles)")
     ap.add_argument("--lanes", choices=("alternate", "split"), default="alternate",
@@ -889,6 +890,13 @@ def main():
             if not args.no_mixed:
                 line["extra"]["configs3_mixed"] = extras_mixed(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct, layout=int(args.hist_layout == "classed"),
                                                                synced=not args.aligned, lanes=args.lanes)
+            if not args.no_mirror:
+                # ONE receiver behind the drop-in classes (the path basic_radio would call): the C++ harness as a child process, ~4 s
+                try:
+                    import bench_mirror
+                    line["extra"]["one_receiver"] = bench_mirror.run_mirror(torch, dabgpu, frames=600, variants=("frame_batcher_one_thread",))
+                except Exception as ex:                                    # the harness is test plumbing: its absence must not cost the bench line
+                    line["extra"]["one_receiver"] = {"error": str(ex)[-300:]}
             if not args.no_chain:
                 import bench_chain
                 line["extra"]["chain"] = bench_chain.run_chain(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct,

@@ -125,3 +125,36 @@ def oracle_conj_mul(oracle, a, b):
     L.dab_conj_mul.argtypes = [CF, CF]
     r = L.dab_conj_mul(CF(float(a.real), float(a.imag)), CF(float(b.real), float(b.imag)))
     return r.re, r.im
+
+
+def test_two_receivers_with_reader_radio_and_worker_threads_on_the_device(oracle, tmp_path):
+    """tests/cpp/mirror_threads_driver on the real library: two OFDM_Demod receivers (each with its receiver pipeline, delivery thread and
+    frame session) in ONE process, first one after the other from one thread, then both at once with a reader thread, a radio thread and
+    two decode workers each -- the way basic_radio_app runs its OFDM and radio threads (examples/basic_radio_app.cpp:404-419).  The threaded
+    bytes (FIBs, sub-channel bytes, frame counts) must equal the serial ones receiver by receiver, and the two receivers' outputs differ.
+    (The same driver runs under ThreadSanitizer / ASan against the oracle-backed fake ABI in tests/test_host_sanitizers.py.)"""
+    import json
+    import stream_model as SM
+    driver = os.path.join(ROOT, "tests", "cpp", "mirror_threads_driver")
+    if not os.path.exists(driver):
+        import __graft_entry__ as g
+        g.build()
+    subs = [oracle.subchannel(0, 24, eep_level=2, eep_type=0), oracle.subchannel(60, 21, eep_level=1, eep_type=1)]
+    paths = []
+    for k in range(2):
+        stream, _ = SM.make_ensemble_stream(oracle, 9, subs, seed=900 + k, cfo=(1.1e-3, -2.4e-3)[k], timing_pad=(300, 4321)[k], noise=2.0)
+        p = tmp_path / f"rx{k}.c32"
+        stream.tofile(p)
+        paths.append(str(p))
+    args = [driver, "65536"]
+    for s in subs:
+        args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["ok"] and out["receivers"] == 2
+    for r in out["per_receiver"]:
+        assert r["frames"] >= 7 and r["fib_bytes"] >= 30 * 12 * (r["frames"] - 2) and r["cifs_with_output"] >= 2 * (4 * r["frames"] - 15) and r["threaded_equals_serial"]
+    assert out["per_receiver"][0]["digest"] != out["per_receiver"][1]["digest"]

@@ -12,46 +12,66 @@ threads spend their time); DABGPU_MIRROR_BATCH=0 = every decoder call its own sy
 import argparse, json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dab-radio_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
-import numpy as np, torch, dabgpu, dabsynth
+import numpy as np
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=600)
-ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
-ap.add_argument("--subchannels", type=int, default=18)
-a = ap.parse_args()
-dev = torch.device("cuda", 0)
-prs, mapper, _ = dabgpu.host_tables()
-mux = dabsynth.Multiplex(1, 21, dev)
-frames2 = dabsynth.modulate(mux.frame_bits[0], prs, mapper)                     # the two transmission frames that repeat (PRS + 75 symbols, NULL last)
-n = torch.arange(a.frames * dabsynth.NB_FRAME_SAMPLES + 2656 + 5000, device=dev, dtype=torch.float64)
-x = torch.cat([torch.zeros(5000 + 2656, dtype=torch.complex64, device=dev), frames2.reshape(-1).repeat((a.frames + 1) // 2)[:a.frames * dabsynth.NB_FRAME_SAMPLES]])
-x = x * torch.polar(torch.ones_like(n), 2 * np.pi * 1.3e-3 * n).to(torch.complex64)
-x[:5000] = x[-5000:]                                                              # some signal before the first NULL
-x = x + 0.02 * torch.view_as_complex(torch.randn((x.numel(), 2), device=dev))
-harness = os.path.join(ROOT, "tests", "cpp", "mirror_harness")
-with tempfile.TemporaryDirectory() as d:
-    path = os.path.join(d, "iq.c32")
-    x.cpu().numpy().astype(np.complex64).tofile(path)
-    args = [harness, path, d, "65536"]
-    for s in range(a.subchannels):
-        args += [str(48 * s), "48", "2", "0"]
-    runs = {}
-    for name, batch, threads in (("frame_batcher_one_thread", "1", 1), ("call_by_call_one_thread", "0", 1),
-                                 ("frame_batcher_decode_threads", "1", a.threads), ("call_by_call_decode_threads", "0", a.threads)):
-        env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(threads), DABGPU_MIRROR_BATCH=batch)
-        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-        res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
-        if res.returncode != 0:
-            print(res.stderr[-2000:], file=sys.stderr)
-            sys.exit(res.returncode)
-        runs[name] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]            # DABGPU_MIRROR_PROFILE=1
-        if prof: runs[name]["profile"] = prof[-1]
-out = dict(runs["frame_batcher_one_thread"])
-out["what"] = ("OFDM_Demod::Process + 4 x DecodeFIBGroup + 4 x %d x DecodeCIF per frame from one caller thread; OFDM_Demod's receiver pipeline decodes a "
-               "frame's FIC and sub-channels on the device, chained behind its demodulation, the classes pick their bytes up "
-               "(dab-radio_amd/host/dab/dabgpu_frame_batcher.h; the first 4 frames of a stream decode call by call: the time de-interleaver's 16 CIFs)" % a.subchannels)
-out["call_by_call"] = dict(runs["call_by_call_one_thread"], what="DABGPU_MIRROR_BATCH=0: every DecodeFIBGroup / DecodeCIF is a synchronous launch + two copies (round 2's path)")
-out["with_decode_threads"] = {"threads": a.threads, "frame_batcher": runs["frame_batcher_decode_threads"], "call_by_call": runs["call_by_call_decode_threads"],
-                              "what": "the sub-channels of a CIF decoded by %d threads, one task per sub-channel as basic_radio's thread pool runs them" % a.threads}
-print(json.dumps(out))
+
+
+def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, variants=("frame_batcher_one_thread", "call_by_call_one_thread",
+                                                                              "frame_batcher_decode_threads", "call_by_call_decode_threads")):
+    """the harness on a generated capture file; returns the JSON dict (None when the harness binary has not been built)"""
+    import dabsynth
+    harness = os.path.join(ROOT, "tests", "cpp", "mirror_harness")
+    if not os.path.exists(harness):
+        return None
+    dev = torch.device("cuda", 0)
+    prs, mapper, _ = dabgpu.host_tables()
+    mux = dabsynth.Multiplex(1, 21, dev)
+    frames2 = dabsynth.modulate(mux.frame_bits[0], prs, mapper)                     # the two transmission frames that repeat (PRS + 75 symbols, NULL last)
+    n = torch.arange(frames * dabsynth.NB_FRAME_SAMPLES + 2656 + 5000, device=dev, dtype=torch.float64)
+    x = torch.cat([torch.zeros(5000 + 2656, dtype=torch.complex64, device=dev), frames2.reshape(-1).repeat((frames + 1) // 2)[:frames * dabsynth.NB_FRAME_SAMPLES]])
+    x = x * torch.polar(torch.ones_like(n), 2 * np.pi * 1.3e-3 * n).to(torch.complex64)
+    x[:5000] = x[-5000:]                                                              # some signal before the first NULL
+    x = x + 0.02 * torch.view_as_complex(torch.randn((x.numel(), 2), device=dev))
+    table = {"frame_batcher_one_thread": ("1", 1), "call_by_call_one_thread": ("0", 1), "frame_batcher_decode_threads": ("1", threads),
+             "call_by_call_decode_threads": ("0", threads)}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "iq.c32")
+        x.cpu().numpy().astype(np.complex64).tofile(path)
+        del x, n
+        args = [harness, path, d, "65536"]
+        for s_ in range(subchannels):
+            args += [str(48 * s_), "48", "2", "0"]
+        runs = {}
+        for name in variants:
+            batch, nt = table[name]
+            env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(nt), DABGPU_MIRROR_BATCH=batch)
+            env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+            res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
+            if res.returncode != 0:
+                raise RuntimeError("mirror_harness failed: " + res.stderr[-2000:])
+            runs[name] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+            prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]            # DABGPU_MIRROR_PROFILE=1
+            if prof:
+                runs[name]["profile"] = prof[-1]
+    out = dict(runs["frame_batcher_one_thread"])
+    out["what"] = ("tests/cpp/mirror_harness: the C++ classes with the reference's signatures driven like basic_radio_app drives the reference's -- a capture file "
+                   "read in 65536-sample blocks -> OFDM_Demod::Process -> On_OFDM_Frame observers -> 4 x FIC_Decoder::DecodeFIBGroup + 4 x %d x MSC_Decoder::DecodeCIF per "
+                   "frame, ONE receiver, one caller thread; OFDM_Demod's receiver pipeline (dabgpu_receiver_*) enqueues sync, demodulation, fine-frequency update and "
+                   "the frame's FIC + sub-channel decode per frame, the classes pick their bytes up (the first 4 frames of a stream decode call by call: the time "
+                   "de-interleaver's 16 CIFs); x_realtime = frames/s over the 10.42 frames/s of a live Mode-I signal" % subchannels)
+    if "call_by_call_one_thread" in runs:
+        out["call_by_call"] = dict(runs["call_by_call_one_thread"], what="DABGPU_MIRROR_BATCH=0: every DecodeFIBGroup / DecodeCIF is a synchronous launch + two copies (round 2's path)")
+    if "frame_batcher_decode_threads" in runs:
+        out["with_decode_threads"] = {"threads": threads, "frame_batcher": runs["frame_batcher_decode_threads"], "call_by_call": runs.get("call_by_call_decode_threads"),
+                                      "what": "the sub-channels of a CIF decoded by %d threads the harness creates per CIF, one task per sub-channel as basic_radio's thread pool runs them" % threads}
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
+    ap.add_argument("--subchannels", type=int, default=18)
+    a = ap.parse_args()
+    import torch, dabgpu
+    print(json.dumps(run_mirror(torch, dabgpu, a.frames, a.subchannels, a.threads)))
