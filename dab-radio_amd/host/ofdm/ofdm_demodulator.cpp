@@ -96,6 +96,7 @@ void OFDM_Demod::RethrowDeliveryError() {
 
 // not in the reference: the point at which everything Process() was handed has come out of the observers
 void OFDM_Demod::Synchronize() {
+    CollectPendingSync();                     // (the state the getters show is the one the serial machine would be in after the samples handed in)
     {
         std::unique_lock<std::mutex> lock(m_mu);
         m_cv_done.wait(lock, [this] { return m_items.empty() && !m_busy; });
@@ -109,15 +110,18 @@ void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {
     // A record still outstanding from the previous block is collected first.  If the impulse-peak test failed, the samples that were
     // buffered behind the PRS slot meanwhile -- the rest of that block -- go through the NULL search they would have gone through
     // (:529-532 Reset, then FindNullPowerDip on the remainder of the block, with that block's signal average)
-    if (m_sync_pending) {
-        const size_t buffered = m_stage_length;
-        if (!ResolveSync()) {
-            const std::vector<std::complex<float>> rest(m_stage + m_corr.size(), m_stage + buffered);
-            Run(rest);
-        }
-    }
+    CollectPendingSync();
     UpdateSignalAverage(buf);
     Run(buf);
+}
+
+void OFDM_Demod::CollectPendingSync() {
+    if (!m_sync_pending) return;
+    const size_t buffered = m_stage_length;
+    if (!ResolveSync()) {
+        const std::vector<std::complex<float>> rest(m_stage + m_corr.size(), m_stage + buffered);
+        Run(rest);
+    }
 }
 
 void OFDM_Demod::Run(tcb::span<const std::complex<float>> buf) {

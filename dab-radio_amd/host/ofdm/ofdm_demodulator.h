@@ -108,6 +108,7 @@ private:
     size_t ReadSymbols(tcb::span<const std::complex<float>> buf);
     void Run(tcb::span<const std::complex<float>> buf);
     void SubmitSync();
+    void CollectPendingSync();
     bool ResolveSync();
     void SubmitFrame();
     void ResetReader();

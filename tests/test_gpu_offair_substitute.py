@@ -153,3 +153,41 @@ def test_mirror_classes_on_the_capture(oracle, capture, tmp_path, batch):
                 dec, _ = oracle.msc_decode_logical(s, lf, 0)
                 exp += np.uint32(dec.size).tobytes() + dec.tobytes()
     assert (out / "msc_0.bin").read_bytes() == bytes(exp)
+
+
+@pytest.mark.parametrize("block", [5000, 1 << 20, 250007], ids=["short_blocks", "blocks_of_several_frames", "odd_long_blocks"])
+def test_mirror_classes_with_other_block_sizes(oracle, capture, tmp_path, block):
+    """The receiver pipeline collects the synchroniser's record lazily -- at the next Process(), or in the middle of a block once the
+    samples of the earliest possible frame end are buffered -- and on a failed impulse-peak test replays what it buffered meanwhile (a block
+    remainder it kept, or a rewind inside the current block).  Which of those paths runs depends on the block size: blocks far shorter than a
+    frame, blocks of several frames (every frame's record is collected mid-block; the capture's three wiped phase-reference symbols exercise the
+    rewind) and an odd length in between must each give what the oracle state machine gives on THE SAME blocks (the block partition is part of the
+    reference's semantics: signal average and NULL search work block by block, ofdm_demodulator.cpp:235-347)."""
+    import stream_model as SM
+    if not os.path.exists(HARNESS):
+        import __graft_entry__ as g
+        g.build()
+    iq = capture["iq"]
+    model = SM.StreamModel(oracle)
+    for k in range(0, iq.size, block):
+        model.process(iq[k:k + block])
+    frames = [f["bits"] for f in model.out_frames]
+    nf = len(frames)
+    assert nf >= 45 and model.frames_desync >= 3
+    iq_path = tmp_path / "iq.c32"
+    iq.tofile(iq_path)
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    res = subprocess.run([HARNESS, str(iq_path), str(out), str(block), "0", "48", "2", "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert f"frames={nf} read={nf} desync={model.frames_desync} state={model.state}" in res.stdout, res.stdout
+    bits = np.fromfile(out / "frame_bits.bin", dtype=np.int8).reshape(nf, oracle.NB_FRAME_BITS)
+    assert np.array_equal(bits, np.stack(frames))
+    states = np.fromfile(out / "states.bin", dtype=np.float32).reshape(nf, 4)
+    for k, fr in enumerate(model.out_frames):
+        assert states[k, 0].view(np.uint32) == np.float32(fr["coarse"]).view(np.uint32) and states[k, 1].view(np.uint32) == np.float32(fr["fine"]).view(np.uint32)
+        assert int(states[k, 2]) == fr["offset"] and int(states[k, 3]) == fr["desync"], k
+    fibs, msc = SM.expected_decode(oracle, frames, capture["subs"][:1])
+    assert (out / "fibs.bin").read_bytes() == fibs
