@@ -155,3 +155,24 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle):
         ck(L.dabgpu_receiver_wait_sync(rx, C.byref(rec), None, None), "dabgpu_receiver_wait_sync")
     finally:
         L.dabgpu_receiver_destroy(rx)
+
+
+def test_receivers_come_and_go_without_leaking_device_memory():
+    """60 receivers created, used for one synchroniser call and destroyed (each owns two contexts, two streams, a frame session, three
+    page-locked staging buffers, events): the device's free memory afterwards is what it was after the first few"""
+    import dabgpu
+    import torch
+    L = _api(dabgpu)
+    cfg = dabgpu.sync_cfg_default()
+    free = []
+    for k in range(60):
+        rx = C.c_void_p()
+        dabgpu.check(L.dabgpu_receiver_create(C.byref(rx), 0, 1 + (k % 4 if k % 7 == 0 else 0), None, None), "dabgpu_receiver_create")
+        dabgpu.check(L.dabgpu_receiver_submit_sync(rx, C.byref(cfg), 100), "dabgpu_receiver_submit_sync")
+        rec = dabgpu.SyncState()
+        dabgpu.check(L.dabgpu_receiver_wait_sync(rx, C.byref(rec), None, None), "dabgpu_receiver_wait_sync")
+        L.dabgpu_receiver_destroy(rx)
+        if k in (9, 59):
+            torch.cuda.synchronize()
+            free.append(torch.cuda.mem_get_info()[0])
+    assert free[1] >= free[0] - (8 << 20), free
