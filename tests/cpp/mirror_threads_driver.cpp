@@ -10,6 +10,7 @@
 // threads, examples/app_helpers/app_ofdm_blocks.h:32-35) and decodes the FIC on itself and the sub-channels on two workers.  The bytes
 // of phase 2 must equal those of phase 1, receiver by receiver; prints one JSON line; exit status 0 only then.
 #include <atomic>
+#include <chrono>
 #include <complex>
 #include <condition_variable>
 #include <cstdio>
@@ -74,13 +75,21 @@ struct Radio {
 };
 
 struct FrameQueue {
-    std::mutex mu; std::condition_variable cv; std::deque<std::vector<viterbi_bit_t>> q; bool done = false;
-    void push(tcb::span<const viterbi_bit_t> b) { { std::lock_guard<std::mutex> g(mu); q.emplace_back(b.begin(), b.end()); } cv.notify_one(); }
+    std::mutex mu; std::condition_variable cv, cv_space; std::deque<std::vector<viterbi_bit_t>> q; bool done = false;
+    // two frames deep and blocking when full, like the reference app's ring buffer between its OFDM and radio threads
+    // (ThreadedRingBuffer<viterbi_bit_t>(nb_frame_bits * 2), examples/basic_radio_app.cpp:320): the radio side never falls more than two
+    // frames behind, well inside the 8 frames whose decoded bytes a demodulator's frame session keeps
+    void push(tcb::span<const viterbi_bit_t> b) {
+        { std::unique_lock<std::mutex> g(mu); cv_space.wait(g, [&] { return q.size() < 2; }); q.emplace_back(b.begin(), b.end()); }
+        cv.notify_one();
+    }
     bool pop(std::vector<viterbi_bit_t>& out) {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return done || !q.empty(); });
         if (q.empty()) return false;
         out = std::move(q.front()); q.pop_front();
+        lk.unlock();
+        cv_space.notify_one();
         return true;
     }
     void finish() { { std::lock_guard<std::mutex> g(mu); done = true; } cv.notify_all(); }
@@ -112,9 +121,12 @@ int main(int argc, char** argv) {
     for (a++; a < argc; a++) iq.push_back(load(argv[a]));
     const size_t R = iq.size();
 
+    // DABGPU_DRIVER_BENCH=1 (tools/bench_mirror_multi.py): only phase 2, decoders on the radio thread itself, timed -- R receivers in one
+    // process, each with its reader thread, its radio thread and its demodulator's delivery thread
+    const bool bench = std::getenv("DABGPU_DRIVER_BENCH") != nullptr;
     // ---- phase 1: one receiver at a time, one thread ----
     std::vector<Output> serial(R);
-    for (size_t r = 0; r < R; r++) {
+    for (size_t r = 0; r < R && !bench; r++) {
         auto demod = Create_OFDM_Demodulator(1);
         Radio radio(subs, &serial[r]);
         demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { radio.frame(std::vector<viterbi_bit_t>(bits.begin(), bits.end()), false); });
@@ -124,6 +136,14 @@ int main(int argc, char** argv) {
 
     // ---- phase 2: all receivers at once; reader thread + radio thread (+ two decode workers) per receiver ----
     std::vector<Output> threaded(R);
+    // start line: every receiver's objects exist (18 decoders = 18 device contexts each) before the first block is fed / the clock starts
+    std::mutex start_mu; std::condition_variable start_cv; size_t ready = 0;
+    auto t_start = std::chrono::steady_clock::now();
+    auto start_line = [&] {
+        std::unique_lock<std::mutex> lk(start_mu);
+        if (++ready == 2 * R) { t_start = std::chrono::steady_clock::now(); start_cv.notify_all(); }
+        else start_cv.wait(lk, [&] { return ready == 2 * R; });
+    };
     {
         std::vector<std::unique_ptr<FrameQueue>> queues;
         std::vector<std::thread> threads;
@@ -131,12 +151,14 @@ int main(int argc, char** argv) {
         for (size_t r = 0; r < R; r++) {
             threads.emplace_back([&, r] {                                   // radio thread: owns the decoders of receiver r
                 Radio radio(subs, &threaded[r]);
+                start_line();
                 std::vector<viterbi_bit_t> bits;
-                while (queues[r]->pop(bits)) radio.frame(bits, true);
+                while (queues[r]->pop(bits)) radio.frame(bits, !bench);
             });
             threads.emplace_back([&, r] {                                   // reader thread: owns the demodulator of receiver r
                 auto demod = Create_OFDM_Demodulator(1);
                 demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { queues[r]->push(bits); });
+                start_line();
                 feed(*demod, iq[r], block);
                 demod->Synchronize();
                 queues[r]->finish();
@@ -145,6 +167,14 @@ int main(int argc, char** argv) {
         for (auto& t : threads) t.join();
     }
 
+    if (bench) {
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        size_t frames = 0, bytes = 0;
+        for (size_t r = 0; r < R; r++) { frames += (size_t)threaded[r].frames; bytes += threaded[r].msc.size() + threaded[r].fibs.size(); }
+        std::printf("{\"receivers\": %zu, \"sub_channels\": %zu, \"frames\": %zu, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"x_realtime_per_receiver\": %.1f, "
+                    "\"decoded_bytes\": %zu}\n", R, subs.size(), frames, sec, frames / sec, frames / sec / (double)R / (2.048e6 / 196608.0), bytes);
+        return frames > 0 ? 0 : 1;
+    }
     bool ok = true;
     std::printf("{\"receivers\": %zu, \"sub_channels\": %zu, \"per_receiver\": [", R, subs.size());
     for (size_t r = 0; r < R; r++) {

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Several receivers in ONE process behind the drop-in C++ classes (tests/cpp/mirror_threads_driver in its timing mode): per receiver a reader
+thread (OFDM_Demod::Process from memory, 65536-sample blocks), the demodulator's delivery thread and a radio thread that takes the frames from a
+queue -- the reference app's OFDM / radio thread pair (examples/basic_radio_app.cpp:404-419) -- and calls FIC_Decoder + 18 MSC_Decoders.
+Whole-process frames/s and real-time factor per receiver.
+
+    python tools/bench_mirror_multi.py [--receivers 1 2 4 8] [--frames 300]
+"""
+import argparse, json, os, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dab-radio_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch, dabgpu, dabsynth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--receivers", type=int, nargs="+", default=[1, 2, 4, 8])
+ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--subchannels", type=int, default=18)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+prs, mapper, _ = dabgpu.host_tables()
+driver = os.path.join(ROOT, "tests", "cpp", "mirror_threads_driver")
+out = {"what": __doc__.split("\n\n")[0], "runs": []}
+with tempfile.TemporaryDirectory() as d:
+    paths = []
+    for k in range(max(a.receivers)):
+        mux = dabsynth.Multiplex(1, 21 + k, dev)
+        f2 = dabsynth.modulate(mux.frame_bits[0], prs, mapper)
+        n = torch.arange(a.frames * dabsynth.NB_FRAME_SAMPLES + 2656 + 5000, device=dev, dtype=torch.float64)
+        x = torch.cat([torch.zeros(5000 + 2656, dtype=torch.complex64, device=dev), f2.reshape(-1).repeat((a.frames + 1) // 2)[:a.frames * dabsynth.NB_FRAME_SAMPLES]])
+        x = x * torch.polar(torch.ones_like(n), 2 * np.pi * (1.3e-3 - 4e-4 * k) * n).to(torch.complex64)
+        x[:5000] = x[-5000:]
+        x = x + 0.02 * torch.view_as_complex(torch.randn((x.numel(), 2), device=dev))
+        p = os.path.join(d, f"rx{k}.c32")
+        x.cpu().numpy().astype(np.complex64).tofile(p)
+        paths.append(p)
+        del x, n
+    args0 = [driver, "65536"]
+    for s in range(a.subchannels):
+        args0 += [str(48 * s), "48", "2", "0"]
+    env = dict(os.environ, DABGPU_DRIVER_BENCH="1")
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for r in a.receivers:
+        res = subprocess.run(args0 + ["--"] + paths[:r], capture_output=True, text=True, env=env, timeout=900)
+        if res.returncode != 0:
+            print(res.stderr[-2000:], file=sys.stderr); sys.exit(res.returncode)
+        run = json.loads(res.stdout.strip().splitlines()[-1])
+        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]        # DABGPU_MIRROR_PROFILE=1
+        if prof:
+            run["profile"] = prof
+        out["runs"].append(run)
+print(json.dumps(out))
