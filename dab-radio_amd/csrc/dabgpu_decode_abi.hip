@@ -636,6 +636,43 @@ extern "C" int dabgpu_msc_stream_decode_sync(dabgpu_msc_stream* s, uint8_t* h_ou
 // dab-radio_amd/host/dab/dabgpu_frame_batcher.h for when a class may use them.
 // (struct dabgpu_frame_session: dabgpu_internal.h -- the receiver pipeline, receiver.hip, pushes frames that are already on the device)
 
+// the result block: [4][96] FIB bytes | [4] FIC results | [4][n_sub] MSC results | [4][cif_out] sub-channel bytes
+static size_t session_block_bytes(size_t n_sub, size_t cif_out) {
+    return 4 * 96 + (4 + 4 * n_sub) * sizeof(dabgpu_codeword_result) + 4 * cif_out;
+}
+static void block_pointers(uint8_t* base, size_t n_sub, uint8_t** fib, dabgpu_codeword_result** fres, dabgpu_codeword_result** mres, uint8_t** msc) {
+    *fib = base;
+    *fres = reinterpret_cast<dabgpu_codeword_result*>(base + 4 * 96);
+    *mres = *fres + 4;
+    *msc = reinterpret_cast<uint8_t*>(*mres + 4 * n_sub);
+}
+// (re)allocates the session's device block for n_sub sub-channels of cif_out bytes per CIF; the session's stream must be idle
+static int session_layout(dabgpu_frame_session* s, size_t n_sub, size_t cif_out) {
+    const size_t need = session_block_bytes(n_sub, cif_out);
+    if (need > s->block_bytes || !s->d_block) {
+        if (s->d_block) (void)hipFree(s->d_block);
+        s->d_block = nullptr; s->block_bytes = 0;
+        int st = dabgpu_check_hip(hipMalloc((void**)&s->d_block, need), "hipMalloc(session results)");
+        if (st) return st;
+        s->block_bytes = need;
+    }
+    block_pointers(s->d_block, n_sub, &s->d_fib, &s->d_fres, &s->d_mres, &s->d_msc);
+    return DABGPU_OK;
+}
+// the slot's pinned block for the session's current layout
+static int slot_block(dabgpu_frame_session* s, dabgpu_frame_session::slot& sl) {
+    const size_t need = session_block_bytes(s->subs.size(), s->cif_out);
+    if (sl.h_block_cap < need) {
+        if (sl.h_block) (void)hipHostFree(sl.h_block);
+        sl.h_block = nullptr; sl.h_block_cap = 0;
+        int st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_block, need, hipHostMallocDefault), "hipHostMalloc(session results)");
+        if (st) return st;
+        sl.h_block_cap = need;
+    }
+    block_pointers(sl.h_block, s->subs.size(), &sl.h_fib, &sl.h_fres, &sl.h_mres, &sl.h_msc);
+    return DABGPU_OK;
+}
+
 extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int device) {
     if (!out) return DABGPU_ERR_INVALID_ARG;
     *out = nullptr;
@@ -643,11 +680,9 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
     int st = dabgpu_create(&s->ctx, device, nullptr, nullptr);
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_hist, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMalloc(session history)");
     if (!st) st = dabgpu_check_hip(hipMemset(s->d_hist, 0, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMemset(session history)");
-    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_fib, 4 * 96), "hipMalloc(session)");
-    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_fres, 4 * sizeof(dabgpu_codeword_result)), "hipMalloc(session)");
+    if (!st) st = session_layout(s, 0, 0);
     for (auto& sl : s->slots) {
-        if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_fib, 4 * 96, hipHostMallocDefault), "hipHostMalloc(session)");
-        if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_fres, 4 * sizeof(dabgpu_codeword_result), hipHostMallocDefault), "hipHostMalloc(session)");
+        if (!st) st = slot_block(s, sl);
         if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate(session)");
     }
     if (st) { dabgpu_frame_session_destroy(s); return st; }
@@ -662,10 +697,7 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
         (void)hipStreamSynchronize(s->ctx->stream);
     }
     for (auto& sl : s->slots) {
-        if (sl.h_fib) (void)hipHostFree(sl.h_fib);
-        if (sl.h_fres) (void)hipHostFree(sl.h_fres);
-        if (sl.h_msc) (void)hipHostFree(sl.h_msc);
-        if (sl.h_mres) (void)hipHostFree(sl.h_mres);
+        if (sl.h_block) (void)hipHostFree(sl.h_block);
         if (sl.h_bits) (void)hipHostFree(sl.h_bits);
         if (sl.h_aux) (void)hipHostFree(sl.h_aux);
         if (sl.h_fft) (void)hipHostFree(sl.h_fft);
@@ -673,10 +705,7 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (s->d_hist) (void)hipFree(s->d_hist);
-    if (s->d_fib) (void)hipFree(s->d_fib);
-    if (s->d_fres) (void)hipFree(s->d_fres);
-    if (s->d_msc) (void)hipFree(s->d_msc);
-    if (s->d_mres) (void)hipFree(s->d_mres);
+    if (s->d_block) (void)hipFree(s->d_block);
     if (s->ctx) dabgpu_destroy(s->ctx);
     delete s;
 }
@@ -697,12 +726,7 @@ extern "C" int dabgpu_frame_session_set_subchannels(dabgpu_frame_session* s, con
     }
     int st = dabgpu_check_hip(hipStreamSynchronize(s->ctx->stream), "hipStreamSynchronize(session)");
     if (st) return st;
-    if (s->d_msc) { (void)hipFree(s->d_msc); s->d_msc = nullptr; }
-    if (s->d_mres) { (void)hipFree(s->d_mres); s->d_mres = nullptr; }
-    if (n) {
-        if ((st = dabgpu_check_hip(hipMalloc((void**)&s->d_msc, (size_t)4 * total), "hipMalloc(session msc)"))) return st;
-        if ((st = dabgpu_check_hip(hipMalloc((void**)&s->d_mres, (size_t)4 * n * sizeof(dabgpu_codeword_result)), "hipMalloc(session msc results)"))) return st;
-    }
+    if ((st = session_layout(s, (size_t)n, total))) return st;
     s->subs.assign(subs, subs + n); s->sub_off = off; s->sub_n = nb; s->cif_out = total;
     return DABGPU_OK;
 }
@@ -719,36 +743,22 @@ static int session_decode(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_se
     sl.fic = decode_fic != 0;
     sl.subs = s->subs; sl.sub_off = s->sub_off; sl.sub_n = s->sub_n; sl.cif_out = s->cif_out;
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
+    if ((st = slot_block(s, sl))) return st;
     if (decode_fic && !n_sub) {
         if ((st = dabgpu_fic_decode_frames(c, d_frame, 1, DABGPU_NB_FRAME_BITS, s->d_fib, s->d_fres, tie_rule, q))) return st;
     }
     if (n_sub) {
-        const size_t need = (size_t)4 * s->cif_out, need_r = (size_t)4 * n_sub * sizeof(dabgpu_codeword_result);
-        if (sl.h_msc_cap < need) {
-            if (sl.h_msc) (void)hipHostFree(sl.h_msc);
-            sl.h_msc = nullptr; sl.h_msc_cap = 0;
-            CK(hipHostMalloc((void**)&sl.h_msc, need, hipHostMallocDefault));
-            sl.h_msc_cap = need;
-        }
-        if (sl.h_mres_cap < need_r) {
-            if (sl.h_mres) (void)hipHostFree(sl.h_mres);
-            sl.h_mres = nullptr; sl.h_mres_cap = 0;
-            CK(hipHostMalloc((void**)&sl.h_mres, need_r, hipHostMallocDefault));
-            sl.h_mres_cap = need_r;
-        }
+        const size_t need = (size_t)4 * s->cif_out;
         // the frame's FIC and sub-channels in one call (one launch in the wave mapping: msc_decode_any)
         if (decode_fic) st = dabgpu_decode_frames_layout(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
                                                          s->subs.data(), n_sub, s->d_fib, s->d_fres, s->d_msc, need, s->d_mres, tie_rule, DABGPU_BITS_NATURAL, q);
         else st = dabgpu_msc_decode_frames(c, s->d_hist, 1, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, dabgpu_frame_session::H, hs,
                                            s->subs.data(), n_sub, s->d_msc, need, s->d_mres, tie_rule, q);
         if (st) return st;
-        CK(hipMemcpyAsync(sl.h_msc, s->d_msc, need, hipMemcpyDeviceToHost, q));
-        CK(hipMemcpyAsync(sl.h_mres, s->d_mres, need_r, hipMemcpyDeviceToHost, q));
     }
-    if (decode_fic) {
-        CK(hipMemcpyAsync(sl.h_fib, s->d_fib, 4 * 96, hipMemcpyDeviceToHost, q));
-        CK(hipMemcpyAsync(sl.h_fres, s->d_fres, 4 * sizeof(dabgpu_codeword_result), hipMemcpyDeviceToHost, q));
-    }
+    // one copy: the whole block with sub-channels, its FIC head without
+    if (n_sub || decode_fic)
+        CK(hipMemcpyAsync(sl.h_block, s->d_block, n_sub ? session_block_bytes((size_t)n_sub, s->cif_out) : session_block_bytes(0, 0), hipMemcpyDeviceToHost, q));
 #undef CK
     return DABGPU_OK;
 }
@@ -803,7 +813,8 @@ int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64
     return DABGPU_OK;
 }
 
-int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule) {
+int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule,
+                          hipEvent_t producer_done) {
     std::lock_guard<std::mutex> lock(s->mu);
     dabgpu_ctx* c = s->ctx;
     DABGPU_BIND(c);
@@ -819,6 +830,7 @@ int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t read
     }
     sl.fic = false; sl.subs.clear(); sl.sub_off.clear(); sl.sub_n.clear(); sl.cif_out = 0;
     if (decode && (st = session_decode(s, gen, sl, decode_fic, tie_rule))) return st;
+    if (producer_done && (st = dabgpu_check_hip(hipStreamWaitEvent(q, producer_done, 0), "hipStreamWaitEvent(session producer copies)"))) return st;
     if ((st = dabgpu_check_hip(hipEventRecord(sl.done, q), "hipEventRecord(session)"))) return st;
     sl.pending = true;
     sl.gen = gen;

@@ -179,7 +179,11 @@ struct dabgpu_frame_session {
     static constexpr int H = 8, R = 8;
     dabgpu_ctx* ctx = nullptr;
     int8_t* d_hist = nullptr;                       // [H][230400]
-    uint8_t* d_fib = nullptr; dabgpu_codeword_result* d_fres = nullptr;
+    // one device block per session, one pinned block per result slot: [4][96] FIB bytes | [4] FIC results | [4][n_sub] MSC results |
+    // [4][cif_out] sub-channel bytes -- a frame's results reach the host in ONE copy (they were four; each is an operation on the stream
+    // between two trellis launches)
+    uint8_t* d_block = nullptr; size_t block_bytes = 0;
+    uint8_t* d_fib = nullptr; dabgpu_codeword_result* d_fres = nullptr;       // (into d_block)
     uint8_t* d_msc = nullptr; dabgpu_codeword_result* d_mres = nullptr;
     std::vector<dabgpu_subchannel> subs;
     std::vector<uint32_t> sub_off, sub_n;           // byte offset / size of a sub-channel inside one CIF's output record
@@ -188,9 +192,9 @@ struct dabgpu_frame_session {
     struct slot {
         uint64_t gen = ~0ull; bool fic = false, pending = false;
         std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
-        uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // pinned: [4][96], [4]
-        uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // pinned: [4][cif_out], [4][n_sub]
-        size_t h_msc_cap = 0, h_mres_cap = 0;
+        uint8_t* h_block = nullptr; size_t h_block_cap = 0;                      // pinned, laid out like the session's d_block
+        uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // (into h_block) [4][96], [4]
+        uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // (into h_block) [4][cif_out], [4][n_sub]
         hipEvent_t done = nullptr;
         // receiver pipeline only (pinned, allocated at first use): the frame's soft bits, a few scalars of the producer, display views
         int8_t* h_bits = nullptr; float* h_aux = nullptr; float* h_fft = nullptr; float* h_dq = nullptr;
@@ -202,8 +206,10 @@ struct dabgpu_frame_session {
 // `producer` wait (device) for the decode that still reads the history slot.  No frame is pushed yet: dabgpu_session_commit does that.
 int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64_t* gen, int8_t** d_frame_bits, dabgpu_frame_session::slot** sl);
 // the frame reserved last is in its history slot once `ready` (recorded on the producer stream) has fired: the session's stream waits for
-// it, copies `bits_bytes` soft bits to the slot's h_bits (0 = no copy), decodes, records the slot's done event
-int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule);
+// it, copies `bits_bytes` soft bits to the slot's h_bits (0 = no copy), decodes, waits for `producer_done` (if given: copies the producer
+// still makes to the slot's pinned buffers on its own stream, beside the decode) and records the slot's done event
+int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule,
+                          hipEvent_t producer_done = nullptr);
 // result slot of a generation, waited for (DABGPU_ERR_NOT_READY: gone or never pushed); call with s->mu held
 int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out);
 

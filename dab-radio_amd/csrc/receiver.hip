@@ -4,10 +4,11 @@
 // The reference overlaps three things per frame (src/ofdm/ofdm_demodulator.cpp:550-577, :581-639): the reader thread buffers frame k + 1
 // and runs its PRS synchronisation while the pipeline threads demodulate frame k and the coordinator thread calls the observers, which
 // decode it (src/basic_radio/basic_radio.cpp:41-65).  Here the same overlap is two device streams and events:
-//   stream A (the receiver's context)   H2D PRS -> ofdm_sync_kernel -> D2H record           per frame, as soon as the PRS slot is buffered
-//                                       H2D frame -> ofdm_demod_kernel (soft bits straight into the frame session's history slot)
-//                                       -> ofdm_phase_kernel on the device-resident frequency state -> D2H scalars
-//   stream B (the frame session's)      waits for A's event -> D2H soft bits -> FIC + MSC decode of the frame -> D2H results -> done event
+//   stream A (the receiver's own,      H2D PRS -> ofdm_sync_kernel -> D2H record           per frame, as soon as the PRS slot is buffered
+//             top stream priority)     H2D frame -> ofdm_demod_kernel (soft bits straight into the frame session's history slot)
+//                                      -> ofdm_phase_kernel on the device-resident frequency state -> event `ready`
+//                                      -> D2H soft bits, scalars, display views -> event `copied`
+//   stream B (the frame session's)     waits for `ready` -> FIC + MSC decode of the frame -> ONE D2H of the result block -> waits for `copied` -> done event
 // The frequency state (m_freq_coarse_offset, m_freq_fine_offset, m_is_found_coarse_freq_offset) lives on the device: the synchroniser of
 // frame k + 1 reads the fine-frequency word frame k's phase kernel wrote, in stream order, and never waits for frame k's decode.
 // The host learns two things per frame and both late: the synchroniser's record (before it must know where the frame ends) and the
@@ -28,7 +29,9 @@ __global__ void rx_net_freq_kernel(const dabgpu_sync_state* __restrict__ st, flo
 }  // namespace
 
 struct dabgpu_receiver {
-    dabgpu_ctx* ctx = nullptr;               // tables of the mode + stream A
+    dabgpu_ctx* ctx = nullptr;               // tables of the mode
+    hipStream_t a = nullptr;                 // stream A, at the device's highest stream priority: its launches are tens of microseconds long and the
+                                             // host's frame position hangs on them; they must not queue behind another receiver's 0.2 ms trellis launch
     dabgpu_frame_session* ses = nullptr;     // history ring, decode, result slots + stream B
     int mode = 1;
     int geom[9] = {0};
@@ -48,6 +51,7 @@ struct dabgpu_receiver {
     dabgpu_sync_state* h_sync = nullptr; float* h_imp = nullptr;
     hipEvent_t sync_done = nullptr; bool sync_pending = false; bool sync_coarse = false;
     hipEvent_t ready = nullptr;              // frame demodulated (stream A) -> decode may start (stream B)
+    hipEvent_t copied = nullptr;             // the frame's soft bits, scalars and views are in the slot's pinned buffers (stream A, beside the decode)
     int decode_fic = 0;
 };
 
@@ -57,7 +61,7 @@ extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     if (!rx) return;
     if (rx->ctx) {
         (void)hipSetDevice(rx->ctx->device);
-        (void)hipStreamSynchronize(rx->ctx->stream);
+        if (rx->a) (void)hipStreamSynchronize(rx->a);
     }
     if (rx->ses) dabgpu_frame_session_destroy(rx->ses);          // (synchronises stream B)
     for (int k = 0; k < STAGES; k++) {
@@ -76,6 +80,8 @@ extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     if (rx->h_imp) (void)hipHostFree(rx->h_imp);
     if (rx->sync_done) (void)hipEventDestroy(rx->sync_done);
     if (rx->ready) (void)hipEventDestroy(rx->ready);
+    if (rx->copied) (void)hipEventDestroy(rx->copied);
+    if (rx->a) (void)hipStreamDestroy(rx->a);
     if (rx->ctx) dabgpu_destroy(rx->ctx);
     delete rx;
 }
@@ -91,6 +97,11 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     memcpy(rx->geom, geom, sizeof(geom));
     int st = dabgpu_create(&rx->ctx, device, h_prs, h_mapper);
     if (!st) st = dabgpu_frame_session_create(&rx->ses, device);
+    if (!st) {
+        int least = 0, greatest = 0;                                   // (numerically lower = higher priority; both 0 where priorities do not exist)
+        st = dabgpu_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        if (!st) st = dabgpu_check_hip(hipStreamCreateWithPriority(&rx->a, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority(receiver)");
+    }
     const size_t n_fft = (size_t)geom[3], n_sym = (size_t)geom[0], frame_samples = (size_t)geom[6];
     // NULL symbol | frame, the frame between nb_cyclic_prefix samples before and nb_fft - nb_cyclic_prefix - 1 after the expected position
     rx->stage_cap = (size_t)geom[2] + (n_fft - (size_t)geom[4]) + frame_samples;
@@ -109,6 +120,7 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_imp, 2 * n_fft * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, hipEventDisableTiming), "hipEventCreate(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->ready, hipEventDisableTiming), "hipEventCreate(receiver)");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->copied, hipEventDisableTiming), "hipEventCreate(receiver)");
     if (st) { dabgpu_receiver_destroy(rx); return st; }
     *out = rx;
     return DABGPU_OK;
@@ -136,7 +148,7 @@ extern "C" int dabgpu_receiver_reset(dabgpu_receiver* rx) {
     if (!rx) { dabgpu_set_error("receiver_reset: null receiver"); return DABGPU_ERR_INVALID_ARG; }
     DABGPU_BIND(rx->ctx);
     // :277-289 coarse = fine = 0, no coarse offset found -- behind everything already enqueued (a frame in flight keeps its offsets)
-    return dabgpu_check_hip(hipMemsetAsync(rx->d_state, 0, sizeof(dabgpu_sync_state), rx->ctx->stream), "hipMemsetAsync(receiver state)");
+    return dabgpu_check_hip(hipMemsetAsync(rx->d_state, 0, sizeof(dabgpu_sync_state), rx->a), "hipMemsetAsync(receiver state)");
 }
 
 extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_sync_cfg* cfg, size_t prs_sample) {
@@ -146,7 +158,7 @@ extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_syn
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_sync: the previous record has not been collected (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_ctx* c = rx->ctx;
     DABGPU_BIND(c);
-    hipStream_t a = c->stream;
+    hipStream_t a = rx->a;
     int st;
     CK(hipMemcpyAsync(rx->d_prs, rx->h_stage[rx->cur] + 2 * prs_sample, n_fft * 2 * sizeof(float), hipMemcpyHostToDevice, a));
     rx->sync_coarse = cfg->is_coarse_freq_correction != 0;
@@ -179,7 +191,7 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_ctx* c = rx->ctx;
     DABGPU_BIND(c);
-    hipStream_t a = c->stream;
+    hipStream_t a = rx->a;
     int st;
     uint64_t gen = 0;
     int8_t* d_bits = nullptr;
@@ -204,6 +216,7 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
         }
     }
     if (!sl->h_aux) CK(hipHostMalloc((void**)&sl->h_aux, 16 * sizeof(float), hipHostMallocDefault));
+    if (!sl->h_bits) CK(hipHostMalloc((void**)&sl->h_bits, DABGPU_NB_FRAME_BITS, hipHostMallocDefault));
     CK(hipMemcpyAsync(rx->d_iq, rx->h_stage[rx->cur] + 2 * frame_sample, frame_samples * 2 * sizeof(float), hipMemcpyHostToDevice, a));
     CK(hipEventRecord(rx->stage_free[rx->cur], a));
     rx->stage_pending[rx->cur] = true;
@@ -217,14 +230,18 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
         if ((st = dabgpu_ofdm_demod_frames_mode(c, rx->mode, rx->d_iq, 1, rx->d_small, d_bits, rx->d_corr, want_views ? rx->d_fft : nullptr, 0, a))) return st;
         if ((st = dabgpu_ofdm_phase_update_mode(c, rx->mode, rx->d_corr, 1, beta, rx->d_small + 2, d_fine, a))) return st;
     }
-    // h_aux: [0] fine-frequency word after this frame's update, [1] sum of the cyclic-prefix angles
+    // the decode may start; what the host reads of this frame -- soft bits, h_aux ([0] fine-frequency word after this frame's update, [1] sum of
+    // the cyclic-prefix angles), the display views -- is copied on THIS stream beside it (the 230 KB of soft bits used to sit on the session's
+    // stream in front of every trellis launch); the slot's done event waits for both
+    CK(hipEventRecord(rx->ready, a));
+    CK(hipMemcpyAsync(sl->h_bits, d_bits, frame_bits, hipMemcpyDeviceToHost, a));
     CK(hipMemcpyAsync(sl->h_aux, d_fine, sizeof(float), hipMemcpyDeviceToHost, a));
     CK(hipMemcpyAsync(sl->h_aux + 1, rx->d_small + 2, sizeof(float), hipMemcpyDeviceToHost, a));
     if (want_views) CK(hipMemcpyAsync(sl->h_fft, rx->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
     if (want_dq) CK(hipMemcpyAsync(sl->h_dq, rx->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
-    CK(hipEventRecord(rx->ready, a));
+    CK(hipEventRecord(rx->copied, a));
     const bool decode = rx->mode == 1 && (rx->decode_fic || !rx->ses->subs.empty());
-    if ((st = dabgpu_session_commit(rx->ses, gen, rx->ready, frame_bits, decode ? 1 : 0, rx->decode_fic, tie_rule))) return st;
+    if ((st = dabgpu_session_commit(rx->ses, gen, rx->ready, 0, decode ? 1 : 0, rx->decode_fic, tie_rule, rx->copied))) return st;
     // the next frame is assembled in the next staging buffer; its last upload (STAGES frames ago) has long finished
     rx->cur = (rx->cur + 1) % STAGES;
     if (rx->stage_pending[rx->cur]) {

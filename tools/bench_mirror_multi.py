@@ -15,12 +15,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--receivers", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--subchannels", type=int, default=18)
+ap.add_argument("--only-write", default=None, help="write the IQ files rx<k>.c32 into this directory and stop (tools/timeline_multi.sh)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 prs, mapper, _ = dabgpu.host_tables()
 driver = os.path.join(ROOT, "tests", "cpp", "mirror_threads_driver")
 out = {"what": __doc__.split("\n\n")[0], "runs": []}
 with tempfile.TemporaryDirectory() as d:
+    if a.only_write:
+        d = a.only_write
+        os.makedirs(d, exist_ok=True)
     paths = []
     for k in range(max(a.receivers)):
         mux = dabsynth.Multiplex(1, 21 + k, dev)
@@ -34,6 +38,8 @@ with tempfile.TemporaryDirectory() as d:
         x.cpu().numpy().astype(np.complex64).tofile(p)
         paths.append(p)
         del x, n
+    if a.only_write:
+        sys.exit(0)
     args0 = [driver, "65536"]
     for s in range(a.subchannels):
         args0 += [str(48 * s), "48", "2", "0"]
