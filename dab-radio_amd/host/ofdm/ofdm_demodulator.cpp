@@ -116,9 +116,12 @@ void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {
 }
 
 void OFDM_Demod::CollectPendingSync() {
-    if (!m_sync_pending) return;
-    const size_t buffered = m_stage_length;
-    if (!ResolveSync()) {
+    // (a loop: the replay can find the next NULL symbol inside the remainder and submit the next synchronisation; in the serial machine that
+    // one ran -- and, if it failed too, the search went on -- inside the same block, with the same signal average: it is resolved here, before
+    // the next block's average is taken, and never by Run()'s rewind, whose position would refer to a buffer that is gone)
+    while (m_sync_pending) {
+        const size_t buffered = m_stage_length;
+        if (ResolveSync()) return;
         const std::vector<std::complex<float>> rest(m_stage + m_corr.size(), m_stage + buffered);
         Run(rest);
     }
