@@ -157,11 +157,9 @@ void OFDM_Demod::Run(tcb::span<const std::complex<float>> buf) {
 
 // :277-289
 void OFDM_Demod::Reset() {
-    if (m_sync_pending) {                     // (a record in flight belongs to the state being abandoned)
-        dabgpu_sync_state st;
-        (void)dabgpu_receiver_wait_sync(m_rx, &st, nullptr, nullptr);
-        m_sync_pending = false;
-    }
+    // a record still in flight is collected first: the serial machine had its answer when the PRS slot was complete -- had the impulse-peak test
+    // failed, it had already reset itself (one more desync) and searched the rest of that block for the NULL symbol before this call
+    CollectPendingSync();
     ResetReader();
 }
 

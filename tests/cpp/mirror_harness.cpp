@@ -144,10 +144,22 @@ int main(int argc, char** argv) {
     });
 
     if (g_bench) demod->EnableDebugBuffers(false);
-    std::vector<std::complex<float>> buf(block);
+    // DABGPU_HARNESS_SCHEDULE = a text file of block lengths, one per Process() call (the last one repeats; a NEGATIVE entry -n = the caller
+    // calls Reset() and then hands n samples): the block size of argv is used without it
+    std::vector<long> schedule;
+    if (const char* sp = std::getenv("DABGPU_HARNESS_SCHEDULE")) {
+        std::ifstream sf(sp);
+        long v;
+        while (sf >> v) if (v != 0) schedule.push_back(v);
+    }
+    size_t max_block = block;
+    for (long v : schedule) max_block = std::max(max_block, (size_t)std::labs(v));
+    std::vector<std::complex<float>> buf(max_block);
     const double t_run = now_us();
-    while (in) {
-        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(block * sizeof(std::complex<float>)));
+    for (size_t call = 0; in; call++) {
+        long want = schedule.empty() ? (long)block : schedule[std::min(call, schedule.size() - 1)];
+        if (want < 0) { demod->Reset(); want = -want; }
+        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)((size_t)want * sizeof(std::complex<float>)));
         const size_t got = (size_t)in.gcount() / sizeof(std::complex<float>);
         if (got == 0) break;
         demod->Process(tcb::span<const std::complex<float>>(buf.data(), got));

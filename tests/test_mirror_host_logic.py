@@ -100,3 +100,46 @@ def test_frames_do_not_depend_on_the_block_size(harness, captures, tmp_path, whi
             got += raw[pos + 4:pos + 4 + n]
             pos += 4 + n
         assert bytes(got) == bytes(msc[si]), f"sub-channel {si}"
+
+
+@pytest.mark.parametrize("which,seed", [("a", 1), ("a", 2), ("b", 3), ("b", 4), ("a", 5), ("b", 6)])
+def test_random_block_lengths_and_caller_resets(harness, captures, tmp_path, which, seed):
+    """every Process() call gets its own length (log-uniform 100 .. 600,000 samples), and now and then the caller calls Reset() between two calls
+    (ofdm_demodulator.cpp:277-289: the GUI's button) -- also while a synchroniser's record is still in flight, which the serial machine had
+    long acted on: frames, counters and decoded bytes stay those of the serial machine fed the same calls"""
+    O, SM, subs = captures["O"], captures["SM"], captures["subs"]
+    iq, path = captures[which]
+    rng = np.random.default_rng(1000 + seed)
+    schedule, total = [], 0
+    while total < iq.size:
+        n = int(np.exp(rng.uniform(np.log(100.0), np.log(600000.0))))
+        if rng.random() < 0.04 and total > 0:
+            n = -n
+        schedule.append(n)
+        total += abs(n)
+    (tmp_path / "schedule.txt").write_text("\n".join(str(v) for v in schedule) + "\n")
+    model = SM.StreamModel(O)
+    pos = 0
+    for v in schedule:
+        if pos >= iq.size:
+            break
+        if v < 0:
+            model.reset()
+        model.process(iq[pos:pos + abs(v)])
+        pos += abs(v)
+    frames = [f["bits"] for f in model.out_frames]
+    nf = len(frames)
+    assert nf >= 8
+    fibs, msc = SM.expected_decode(O, frames, subs)
+    out = tmp_path / "out"
+    out.mkdir()
+    args = [harness, path, str(out), "65536", "0", "48", "2", "0", "120", "27", "0", "1"]
+    res = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, DABGPU_HARNESS_SCHEDULE=str(tmp_path / "schedule.txt")), timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert f"frames={nf} read={nf} desync={model.frames_desync} state=" in res.stdout, (res.stdout, nf, model.frames_desync)
+    bits = np.fromfile(out / "frame_bits.bin", dtype=np.int8).reshape(nf, O.NB_FRAME_BITS)
+    states = np.fromfile(out / "states.bin", dtype=np.float32).reshape(nf, 4)
+    for k, fr in enumerate(model.out_frames):
+        assert int(states[k, 2]) == fr["offset"] and int(states[k, 3]) == fr["desync"], f"frame {k}: fine time offset / desync count"
+        assert np.array_equal(bits[k], frames[k]), f"frame {k} soft bits"
+    assert (out / "fibs.bin").read_bytes() == bytes(fibs)
