@@ -1,6 +1,7 @@
 // dab/dabgpu_frame_batcher.cpp -- see dabgpu_frame_batcher.h
 #include "./dabgpu_frame_batcher.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -35,6 +36,7 @@ struct State {
     std::vector<std::unique_ptr<Producer>> producers;      // index = cif_id::src
 };
 State& S() { static State s; return s; }
+std::atomic<unsigned long long> n_fib_batched{0}, n_fib_own{0}, n_cif_batched{0}, n_cif_own{0};
 
 bool same(const dabgpu_subchannel& a, const dabgpu_subchannel& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
 
@@ -128,8 +130,11 @@ bool fetch_fib_group(const int8_t* group_bits, int group, uint8_t* bytes96, uint
         for (uint64_t back = 0; back < KEEP && back < p.next_gen; back++) {          // newest first
             const Producer::Frame& f = p.frames[(p.next_gen - 1 - back) % KEEP];
             if (f.gen != p.next_gen - 1 - back) continue;
-            if (std::memcmp(f.bits.data() + (size_t)group * GROUP_BITS, group_bits, GROUP_BITS) == 0)
-                return dabgpu_frame_session_fetch_fib_group(p.session, f.gen, group, bytes96, crc_mask, path_error) == DABGPU_OK;
+            if (std::memcmp(f.bits.data() + (size_t)group * GROUP_BITS, group_bits, GROUP_BITS) == 0) {
+                const bool ok = dabgpu_frame_session_fetch_fib_group(p.session, f.gen, group, bytes96, crc_mask, path_error) == DABGPU_OK;
+                if (ok) n_fib_batched++;
+                return ok;
+            }
         }
     }
     return false;
@@ -165,7 +170,12 @@ bool fetch_cif(cif_id id, const dabgpu_subchannel& sc, uint8_t* bytes, size_t ca
     State& s = S();
     std::lock_guard<std::mutex> g(s.mu);
     if (id.src < 0 || id.src >= (int)s.producers.size() || !s.producers[(size_t)id.src] || !s.producers[(size_t)id.src]->session) return false;
-    return dabgpu_frame_session_fetch_cif(s.producers[(size_t)id.src]->session, id.gen, &sc, id.cif, bytes, capacity, n_bytes, path_error) == DABGPU_OK;
+    const bool ok = dabgpu_frame_session_fetch_cif(s.producers[(size_t)id.src]->session, id.gen, &sc, id.cif, bytes, capacity, n_bytes, path_error) == DABGPU_OK;
+    if (ok) n_cif_batched++;
+    return ok;
 }
+
+Counters counters() { return Counters{n_fib_batched.load(), n_fib_own.load(), n_cif_batched.load(), n_cif_own.load()}; }
+void count_call_by_call(bool fib_group) { if (fib_group) n_fib_own++; else n_cif_own++; }
 
 }  // namespace dabgpu_frame_batcher

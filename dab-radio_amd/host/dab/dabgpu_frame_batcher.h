@@ -49,4 +49,9 @@ cif_id match_cif(const int8_t* slice_bits, size_t start_bit, size_t n_bits, cif_
 bool fetch_cif(cif_id id, const dabgpu_subchannel& sc, uint8_t* bytes, size_t capacity, size_t* n_bytes, uint64_t* path_error);
 inline cif_id successor(cif_id a) { cif_id b; b.src = a.src; b.gen = a.cif == 3 ? a.gen + 1 : a.gen; b.cif = a.cif == 3 ? 0 : a.cif + 1; return b; }
 
+// how the decoders of this process got their results so far (diagnostics: tests, DABGPU_MIRROR_PROFILE): picked up from a frame's batched
+// decode, or decoded on their own, call by call (the first 16 CIFs of a decoder, frames submitted before it existed, a consumer that fell behind)
+struct Counters { unsigned long long fib_groups_batched, fib_groups_call_by_call, cifs_batched, cifs_call_by_call; };
+Counters counters();
+void count_call_by_call(bool fib_group);
 }  // namespace dabgpu_frame_batcher

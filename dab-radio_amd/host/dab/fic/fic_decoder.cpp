@@ -25,6 +25,7 @@ void FIC_Decoder::DecodeFIBGroup(tcb::span<const viterbi_bit_t> encoded_bits, co
                                                          &m_last_error, dabgpu_tie_rule_from_env());
         if (st != DABGPU_OK)
             throw std::runtime_error(std::string("FIC_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
+        dabgpu_frame_batcher::count_call_by_call(true);
     }
     const size_t fib_bytes = m_decoded_bytes.size() / m_nb_fibs_per_group;
     for (size_t i = 0; i < m_nb_fibs_per_group; i++)                                   // :103-116

@@ -66,5 +66,6 @@ tcb::span<uint8_t> MSC_Decoder::DecodeCIF(tcb::span<const viterbi_bit_t> buf) {
     if (st == DABGPU_ERR_NOT_READY) return {};                                          // :60-63
     if (st != DABGPU_OK)
         throw std::runtime_error(std::string("MSC_Decoder: ") + dabgpu_strerror(st) + " -- " + dabgpu_last_error());
+    dabgpu_frame_batcher::count_call_by_call(false);
     return tcb::span<uint8_t>(m_decoded_bytes.data(), n_out);
 }

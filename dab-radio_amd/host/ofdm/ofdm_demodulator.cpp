@@ -291,7 +291,14 @@ size_t OFDM_Demod::ReadSymbols(tcb::span<const std::complex<float>> buf) {
 // :565-572 wait for a free slot, swap buffers, start the workers: upload, demodulation, fine-frequency update and -- for the decoders of
 // this process that listen -- the frame's FIC / MSC decode, enqueued; the delivery thread picks the results up
 void OFDM_Demod::SubmitFrame() {
-    bool decoded = false;
+    const double t0 = m_profile ? now_us() : 0.0;
+    {
+        std::unique_lock<std::mutex> lock(m_mu);
+        m_cv_done.wait(lock, [this] { return m_frames_in_flight < m_depth; });
+    }
+    const double t1 = m_profile ? now_us() : 0.0;
+    // what the decoders of this process listen to NOW -- asked after the wait for a slot: an observer that created a decoder while this thread
+    // waited is heard one frame earlier.  (Frames already submitted keep their layout; the decoders decode those call by call.)
     if (m_mode == 1) {
         std::vector<dabgpu_subchannel> subs;
         bool fic = false;
@@ -301,14 +308,7 @@ void OFDM_Demod::SubmitFrame() {
             if (rc != DABGPU_OK) fail("dabgpu_receiver_set_subchannels", rc);
             m_subs_version = version;
         }
-        decoded = fic || !subs.empty();
     }
-    const double t0 = m_profile ? now_us() : 0.0;
-    {
-        std::unique_lock<std::mutex> lock(m_mu);
-        m_cv_done.wait(lock, [this] { return m_frames_in_flight < m_depth; });
-    }
-    const double t1 = m_profile ? now_us() : 0.0;
     RethrowDeliveryError();
     uint64_t gen = 0;
     const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
@@ -320,7 +320,7 @@ void OFDM_Demod::SubmitFrame() {
     if (m_profile) { m_t_slot_wait += t1 - t0; m_t_submit += now_us() - t1; }
     {
         std::lock_guard<std::mutex> lock(m_mu);
-        m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, decoded});
+        m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, m_mode == 1});
         m_frames_in_flight++;
     }
     m_cv_items.notify_one();
@@ -368,9 +368,10 @@ void OFDM_Demod::DeliveryThread() {
                     std::memcpy(static_cast<void*>(m_frame_fft.data()), fr.fft, m_frame_fft.size() * sizeof(m_frame_fft[0]));
                     if (m_mode == 1) std::memcpy(static_cast<void*>(m_frame_dqpsk.data()), fr.dqpsk, (m_params.nb_frame_symbols - 1) * m_params.nb_data_carriers * sizeof(m_frame_dqpsk[0]));
                 }
-                // the decoders of this process find the frame's FIBs and sub-channel bytes already decoded (mode I: the DAB layer above
-                // the soft bits is mode I only)
-                if (it.decoded) dabgpu_frame_batcher::on_frame_decoded(this, dabgpu_receiver_session(m_rx), it.gen, fr.bits);
+                // the decoders of this process find the frame's FIBs and sub-channel bytes already decoded (mode I: the DAB layer above the
+                // soft bits is mode I only).  Every frame is shown to the batcher while somebody listens, also one submitted before the
+                // listener existed: it has no results to pick up, but a new MSC_Decoder counts its 16 consecutive CIFs from it
+                if (it.batch) dabgpu_frame_batcher::on_frame_decoded(this, dabgpu_receiver_session(m_rx), it.gen, fr.bits);
                 const double t2 = m_profile ? now_us() : 0.0;
                 m_on_frame.Notify(tcb::span<const viterbi_bit_t>(fr.bits, fr.n_bits));
                 if (m_profile) { m_t_frame_wait += t1 - t0; m_t_batcher += t2 - t1; m_t_observers += now_us() - t2; }

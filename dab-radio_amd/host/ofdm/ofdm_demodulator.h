@@ -155,7 +155,7 @@ private:
     std::vector<float> m_frequency_response;
     Observable<tcb::span<const viterbi_bit_t>> m_on_frame;
     // ---- reader -> delivery ----
-    struct Item { enum Kind { SYNC, RESET, FRAME } kind; float coarse, fine; int offset; uint64_t gen; bool views; bool decoded; };
+    struct Item { enum Kind { SYNC, RESET, FRAME } kind; float coarse, fine; int offset; uint64_t gen; bool views; bool batch; };
     std::mutex m_mu;
     std::condition_variable m_cv_items, m_cv_done;
     std::deque<Item> m_items;

@@ -1,0 +1,152 @@
+"""Decoders that come and go while the stream runs (tests/cpp/mirror_lifecycle_driver.cpp): basic_radio creates a channel's MSC_Decoder when the
+FIG database completes its entry -- some frames into the stream -- and drops it when the service is deselected
+(src/basic_radio/basic_radio.cpp:67-120, basic_audio_channel.cpp:12).  Every change of the set changes what the frame batcher subscribes to, so the
+receiver's frame session gets a new decode layout between two frames that are in flight (dabgpu_receiver_set_subchannels ->
+dabgpu_frame_session_set_subchannels: the device result block and the pinned blocks of the slots are laid out anew), and a fresh decoder's own
+time de-interleaver starts empty whatever the session already holds.  Expected bytes: each decoder is an independent
+CIF_Deinterleaver + decode over exactly the CIFs of its lifetime (cif_deinterleaver.cpp:13-71, msc_decoder.cpp:46-154), composed from the oracle.
+
+CPU: the driver linked with the oracle-backed ABI (tests/cpp/fake_dabgpu_oracle.cpp): the classes' host logic.  -m gpu: the same driver on libdabgpu.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import test_mirror_host_logic as T
+
+ROOT = T.ROOT
+DRIVER = os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver")
+# id -> (start CU, length CU, EEP level index, type B)
+SUBS = {0: (0, 48, 2, 0), 1: (120, 27, 0, 1), 2: (200, 60, 2, 0), 3: (300, 24, 1, 0), 4: (400, 42, 1, 1), 5: (48, 72, 2, 0)}
+SCRIPTS = {
+    # the usual start: the FIC decoder first, the services appear one by one a few frames later, one is dropped and one re-created
+    "services_appear": [(0, "fic", 1), (3, "add", 0), (3, "add", 1), (5, "add", 2), (9, "del", 1), (11, "add", 3), (14, "add", 1), (17, "del", 0), (17, "del", 2)],
+    # a change at every frame for a while (every one a new layout with frames in flight), then nothing listens, then everything at once
+    "churn": [(1, "add", 0), (2, "add", 1), (3, "add", 2), (4, "del", 0), (5, "add", 3), (6, "add", 4), (7, "del", 2), (8, "add", 5), (9, "fic", 1), (10, "del", 1),
+              (11, "del", 3), (11, "del", 4), (11, "del", 5), (11, "fic", 0), (15, "add", 0), (15, "add", 1), (15, "add", 2), (15, "add", 3), (15, "add", 4), (15, "fic", 1)],
+}
+
+
+def expected(O, frames, script):
+    subs = {k: O.subchannel(v[0], v[1], eep_level=v[2], eep_type=v[3]) for k, v in SUBS.items()}
+    alive, fic_on = {}, False
+    msc = {}
+    fibs = bytearray()
+    for f, bits in enumerate(frames):
+        for fr, op, ident in script:
+            if fr != f:
+                continue
+            if op == "add":
+                alive[ident] = O.Deinterleaver(subs[ident].length * 8)
+            elif op == "del":
+                alive.pop(ident, None)
+            else:
+                fic_on = bool(ident)
+        if fic_on:
+            for g in range(4):
+                eb, em, _ = O.fic_decode_group(bits[g * 2304:(g + 1) * 2304], 0)
+                for i in range(3):
+                    if em & (1 << i):
+                        fibs += np.uint32(f).tobytes() + eb[32 * i:32 * i + 30].tobytes()
+        for c in range(4):
+            cif = bits[9216 + c * 55296:9216 + (c + 1) * 55296]
+            for ident in sorted(alive):
+                s = subs[ident]
+                alive[ident].consume(cif[s.start_address * 64:(s.start_address + s.length) * 64])
+                lf = alive[ident].deinterleave()
+                rec = msc.setdefault(ident, bytearray())
+                if lf is None:
+                    rec += np.array([f, c, 0], np.uint32).tobytes()
+                else:
+                    dec, _ = O.msc_decode_logical(s, lf, 0)
+                    rec += np.array([f, c, dec.size], np.uint32).tobytes() + dec.tobytes()
+    return bytes(fibs), {k: bytes(v) for k, v in msc.items()}
+
+
+@pytest.fixture(scope="module")
+def stream(tmp_path_factory):
+    import oracle as O
+    import stream_model as SM
+    O.build()
+    subs = [O.subchannel(v[0], v[1], eep_level=v[2], eep_type=v[3]) for v in SUBS.values()]
+    iq, truth = SM.make_ensemble_stream(O, 22, subs, seed=77)
+    model = SM.StreamModel(O)
+    for k in range(0, iq.size, 65536):
+        model.process(iq[k:k + 65536])
+    frames = [f["bits"] for f in model.out_frames]
+    assert len(frames) >= 21
+    d = tmp_path_factory.mktemp("lifecycle")
+    iq.tofile(d / "iq.c32")
+    return dict(O=O, frames=frames, path=str(d / "iq.c32"), truth=truth)
+
+
+@pytest.fixture(scope="module")
+def fake_driver(tmp_path_factory):
+    d = tmp_path_factory.mktemp("lifecycle_fake")
+    objs = []
+    for src in T.ORACLE_SRCS:
+        o = d / (src + ".o")
+        subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-w", "-mavx2", "-mbmi2", "-mfma", "-c", os.path.join(T.ORACLE, src), "-o", str(o)],
+                       check=True, timeout=600)
+        objs.append(str(o))
+    exe = d / "mirror_lifecycle_fake"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + T.HOST, "-I" + os.path.join(ROOT, "include"), "-I" + T.CSRC, "-I" + T.ORACLE,
+                    os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver.cpp"), os.path.join(ROOT, "tests", "cpp", "fake_dabgpu_oracle.cpp"),
+                    os.path.join(T.CSRC, "dabgpu_host_logic.cpp")] + [os.path.join(T.HOST, s) for s in T.MIRROR_SRCS] + objs + ["-lm", "-o", str(exe)],
+                   check=True, timeout=900)
+    return str(exe)
+
+
+def run_and_compare(exe, stream, tmp_path, name, batch, depth, env_extra=None):
+    O, frames = stream["O"], stream["frames"]
+    script = SCRIPTS[name]
+    lines = []
+    for fr, op, ident in script:
+        lines.append(f"{fr} add {ident} {SUBS[ident][0]} {SUBS[ident][1]} {SUBS[ident][2]} {SUBS[ident][3]}" if op == "add" else f"{fr} {op} {ident}")
+    (tmp_path / "script.txt").write_text("\n".join(lines) + "\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, DABGPU_MIRROR_BATCH=batch, DABGPU_MIRROR_DEPTH=str(depth))
+    env.update(env_extra or {})
+    res = subprocess.run([exe, stream["path"], str(out), "65536", str(tmp_path / "script.txt")], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert f"frames={len(frames)}" in res.stdout, res.stdout
+    fibs, msc = expected(O, frames, script)
+    got_fibs = (out / "fibs.bin").read_bytes() if (out / "fibs.bin").exists() else b""
+    assert got_fibs == fibs, "FIBs"
+    assert len(fibs) >= 34 * 12 * 4, "the FIC decoder must have run on several frames"
+    n_out = 0
+    for ident, exp in msc.items():
+        got = (out / f"msc_{ident}.bin").read_bytes()
+        assert got == exp, f"decoder {ident}"
+        n_out += len(exp)
+    assert n_out > 8000, "sub-channel bytes must have come out (16 CIFs after a decoder's creation)"
+    # where the results came from: with the batcher most FIB groups and -- from a decoder's 16th CIF on -- most CIFs are picked up from the frames'
+    # batched decodes (not the frames that were in flight when the set changed); without it everything is decoded call by call
+    import re
+    k = {m.group(1): int(m.group(2)) for m in re.finditer(r"(\w+)=(\d+)", res.stdout)}
+    if batch != "1":
+        assert k["fib_groups_batched"] == 0 and k["cifs_batched"] == 0 and k["cifs_call_by_call"] > 0, k
+    elif name == "services_appear":
+        # long stretches without a change: a change costs the frames that were in flight (`depth` of them) and a new decoder its first 16 CIFs
+        assert k["fib_groups_batched"] >= 0.6 * (k["fib_groups_batched"] + k["fib_groups_call_by_call"]), k
+        assert k["cifs_batched"] >= 0.5 * (k["cifs_batched"] + k["cifs_call_by_call"]), k
+    elif depth <= 3:
+        assert k["fib_groups_batched"] >= 8 and k["cifs_batched"] >= 5, k
+    return k
+
+
+@pytest.mark.parametrize("name,batch,depth", [("services_appear", "1", 3), ("services_appear", "0", 3), ("churn", "1", 3), ("churn", "1", 1), ("churn", "1", 6)])
+def test_decoders_come_and_go_host_logic(fake_driver, stream, tmp_path, name, batch, depth):
+    run_and_compare(fake_driver, stream, tmp_path, name, batch, depth)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch,depth", [("services_appear", "1", 3), ("services_appear", "0", 3), ("churn", "1", 3), ("churn", "1", 1), ("churn", "1", 6)])
+def test_decoders_come_and_go_on_the_device(stream, tmp_path, name, batch, depth):
+    if not os.path.exists(DRIVER):
+        import __graft_entry__ as g
+        g.build()
+    run_and_compare(DRIVER, stream, tmp_path, name, batch, depth,
+                    {"LD_LIBRARY_PATH": os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")})
