@@ -118,3 +118,37 @@ def test_mirror_classes_with_two_receivers_and_decoder_threads(tmp_path, two_rec
         # logical frames from the 16th CIF on -- through the batcher's sessions where the decoders had caught up with them
         assert r["frames"] >= 5 and r["fib_bytes"] >= 30 * 12 * (r["frames"] - 2) and r["cifs_with_output"] >= 2 * (4 * r["frames"] - 15) and r["threaded_equals_serial"]
     assert out["per_receiver"][0]["digest"] != out["per_receiver"][1]["digest"]
+
+
+def test_decoders_created_and_dropped_on_the_delivery_thread_under_thread_sanitizer(tmp_path):
+    """tests/cpp/mirror_lifecycle_driver (decoders created / destroyed inside the frame observer, i.e. on OFDM_Demod's delivery thread, while the reader
+    thread asks the frame batcher what is listened to and submits frames) with the "churn" script of tests/test_mirror_lifecycle.py, instrumented"""
+    lib_of("libtsan.so")
+    import oracle as O
+    import stream_model as SM
+    import test_mirror_lifecycle as L
+    O.build()
+    subs = [O.subchannel(v[0], v[1], eep_level=v[2], eep_type=v[3]) for v in L.SUBS.values()]
+    iq, _ = SM.make_ensemble_stream(O, 18, subs, seed=78)
+    iq.tofile(tmp_path / "iq.c32")
+    lines = []
+    for fr, op, ident in L.SCRIPTS["churn"]:
+        lines.append(f"{fr} add {ident} {L.SUBS[ident][0]} {L.SUBS[ident][1]} {L.SUBS[ident][2]} {L.SUBS[ident][3]}" if op == "add" else f"{fr} {op} {ident}")
+    (tmp_path / "script.txt").write_text("\n".join(lines) + "\n")
+    san = ["-fsanitize=thread"]
+    objs = []
+    for src in ORACLE_SRCS:
+        o = tmp_path / f"lc_{src}.o"
+        run(["gcc", "-O1", "-g", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-w", "-DDAB_ORACLE_NO_CLONES"] + san + ["-c", os.path.join(ORACLE, src), "-o", str(o)], timeout=600)
+        objs.append(str(o))
+    exe = tmp_path / "mirror_lifecycle_tsan"
+    run(["g++", "-O1", "-g", "-std=c++17", "-pthread"] + san + ["-I" + HOST, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + ORACLE,
+         os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver.cpp"), os.path.join(ROOT, "tests", "cpp", "fake_dabgpu_oracle.cpp"),
+         os.path.join(CSRC, "dabgpu_host_logic.cpp")] + [os.path.join(HOST, s) for s in MIRROR_SRCS + ["dab/msc/cif_deinterleaver.cpp", "dab/algorithms/dab_viterbi_decoder.cpp"]] +
+        objs + ["-lm", "-o", str(exe)], timeout=900)
+    out = tmp_path / "out"
+    out.mkdir()
+    res = run([str(exe), str(tmp_path / "iq.c32"), str(out), "65536", str(tmp_path / "script.txt")],
+              env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"), timeout=1200)
+    assert "ThreadSanitizer" not in res.stderr, res.stderr[-3000:]
+    assert "frames=1" in res.stdout and "cifs_batched=" in res.stdout, res.stdout

@@ -143,3 +143,52 @@ def test_random_block_lengths_and_caller_resets(harness, captures, tmp_path, whi
         assert int(states[k, 2]) == fr["offset"] and int(states[k, 3]) == fr["desync"], f"frame {k}: fine time offset / desync count"
         assert np.array_equal(bits[k], frames[k]), f"frame {k} soft bits"
     assert (out / "fibs.bin").read_bytes() == bytes(fibs)
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_other_transmission_modes_with_random_block_lengths(harness, tmp_path, mode):
+    """the reader's framing in the geometries of modes II-IV (dab_ofdm_params_ref.cpp:22-60) -- earliest frame end, staging capacity, NULL search window --
+    on a noisy stream where the short phase reference symbols of modes II / III fail the impulse-peak test now and then: random Process() lengths
+    and caller resets, against the serial machine"""
+    import oracle as O
+    import modes_model as MM
+    import stream_model as SM
+    O.build()
+    rng = np.random.default_rng(40 + mode)
+    g = O.geometry(mode)
+    sent = [rng.integers(0, 2, g.nb_frame_bits, dtype=np.uint8) for _ in range(10)]
+    tx = O.apply_pll(np.concatenate([MM.make_tx_frame(O, mode, b, rng) for b in sent]), 2.1 / g.nb_fft, 0.2)
+    stream = np.concatenate([tx[g.nb_null_period:g.nb_null_period + 6000 + 77], tx])
+    stream = ((stream + 0.05 * (rng.standard_normal(stream.size) + 1j * rng.standard_normal(stream.size))) / 39.2).astype(np.complex64)
+    stream.tofile(tmp_path / "iq.c32")
+    schedule, total = [], 0
+    while total < stream.size:
+        n = int(np.exp(rng.uniform(np.log(100.0), np.log(3.0 * g.nb_frame_samples))))
+        if rng.random() < 0.04 and total > 0:
+            n = -n
+        schedule.append(n)
+        total += abs(n)
+    (tmp_path / "schedule.txt").write_text("\n".join(str(v) for v in schedule) + "\n")
+    model = SM.StreamModel(O, mode)
+    model.cfg.impulse_peak_threshold_db = 8.0
+    pos = 0
+    for v in schedule:
+        if pos >= stream.size:
+            break
+        if v < 0:
+            model.reset()
+        model.process(stream[pos:pos + abs(v)])
+        pos += abs(v)
+    nf = len(model.out_frames)
+    assert nf >= 4
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, DABGPU_HARNESS_MODE=str(mode), DABGPU_HARNESS_PEAK_DB="8", DABGPU_HARNESS_SCHEDULE=str(tmp_path / "schedule.txt"))
+    res = subprocess.run([harness, str(tmp_path / "iq.c32"), str(out), "16384"], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert f"frames={nf} read={nf} desync={model.frames_desync} state={model.state}" in res.stdout, (res.stdout, nf, model.frames_desync, model.state)
+    bits = np.fromfile(out / "frame_bits.bin", dtype=np.int8).reshape(nf, g.nb_frame_bits)
+    states = np.fromfile(out / "states.bin", dtype=np.float32).reshape(nf, 4)
+    for k, fr in enumerate(model.out_frames):
+        assert int(states[k, 2]) == fr["offset"] and int(states[k, 3]) == fr["desync"], (mode, k)
+        assert np.array_equal(bits[k], fr["bits"]), (mode, k)
