@@ -28,6 +28,29 @@ SCRIPTS = {
 }
 
 
+def random_script(seed, n_frames=21):
+    """every frame, with probability 0.45, one change: a decoder that is not alive appears, one that is alive goes, or the FIC decoder is toggled"""
+    rng = np.random.default_rng(seed)
+    alive, fic, script = set(), False, []
+    for f in range(n_frames):
+        while rng.random() < 0.45:
+            kind = rng.integers(0, 5)
+            if kind <= 1 and len(alive) < len(SUBS):
+                ident = int(rng.choice(sorted(set(SUBS) - alive)))
+                alive.add(ident); script.append((f, "add", ident))
+            elif kind <= 3 and alive:
+                ident = int(rng.choice(sorted(alive)))
+                alive.discard(ident); script.append((f, "del", ident))
+            elif kind == 4:
+                fic = not fic
+                script.append((f, "fic", int(fic)))
+    return script
+
+
+for _seed in (1, 2, 3, 4):
+    SCRIPTS[f"random_{_seed}"] = random_script(_seed)
+
+
 def expected(O, frames, script):
     subs = {k: O.subchannel(v[0], v[1], eep_level=v[2], eep_type=v[3]) for k, v in SUBS.items()}
     alive, fic_on = {}, False
@@ -115,13 +138,13 @@ def run_and_compare(exe, stream, tmp_path, name, batch, depth, env_extra=None):
     fibs, msc = expected(O, frames, script)
     got_fibs = (out / "fibs.bin").read_bytes() if (out / "fibs.bin").exists() else b""
     assert got_fibs == fibs, "FIBs"
-    assert len(fibs) >= 34 * 12 * 4, "the FIC decoder must have run on several frames"
+    assert name.startswith("random") or len(fibs) >= 34 * 12 * 4, "the FIC decoder must have run on several frames"
     n_out = 0
     for ident, exp in msc.items():
         got = (out / f"msc_{ident}.bin").read_bytes()
         assert got == exp, f"decoder {ident}"
         n_out += len(exp)
-    assert n_out > 8000, "sub-channel bytes must have come out (16 CIFs after a decoder's creation)"
+    assert name.startswith("random") or n_out > 8000, "sub-channel bytes must have come out (16 CIFs after a decoder's creation)"
     # where the results came from: with the batcher most FIB groups and -- from a decoder's 16th CIF on -- most CIFs are picked up from the frames'
     # batched decodes (not the frames that were in flight when the set changed); without it everything is decoded call by call
     import re
@@ -132,18 +155,22 @@ def run_and_compare(exe, stream, tmp_path, name, batch, depth, env_extra=None):
         # long stretches without a change: a change costs the frames that were in flight (`depth` of them) and a new decoder its first 16 CIFs
         assert k["fib_groups_batched"] >= 0.6 * (k["fib_groups_batched"] + k["fib_groups_call_by_call"]), k
         assert k["cifs_batched"] >= 0.5 * (k["cifs_batched"] + k["cifs_call_by_call"]), k
-    elif depth <= 3:
+    elif name == "churn" and depth <= 3:
         assert k["fib_groups_batched"] >= 8 and k["cifs_batched"] >= 5, k
     return k
 
 
-@pytest.mark.parametrize("name,batch,depth", [("services_appear", "1", 3), ("services_appear", "0", 3), ("churn", "1", 3), ("churn", "1", 1), ("churn", "1", 6)])
+CASES = [("services_appear", "1", 3), ("services_appear", "0", 3), ("churn", "1", 3), ("churn", "1", 1), ("churn", "1", 6),
+         ("random_1", "1", 3), ("random_2", "1", 2), ("random_3", "1", 4), ("random_4", "1", 3)]
+
+
+@pytest.mark.parametrize("name,batch,depth", CASES)
 def test_decoders_come_and_go_host_logic(fake_driver, stream, tmp_path, name, batch, depth):
     run_and_compare(fake_driver, stream, tmp_path, name, batch, depth)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,batch,depth", [("services_appear", "1", 3), ("services_appear", "0", 3), ("churn", "1", 3), ("churn", "1", 1), ("churn", "1", 6)])
+@pytest.mark.parametrize("name,batch,depth", CASES)
 def test_decoders_come_and_go_on_the_device(stream, tmp_path, name, batch, depth):
     if not os.path.exists(DRIVER):
         import __graft_entry__ as g
