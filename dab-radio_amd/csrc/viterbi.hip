@@ -68,27 +68,28 @@ __device__ __forceinline__ uint32_t xchg(uint32_t m, int lane) {
 
 struct LaneConst {
     int sig[6];       // +sigma pattern of the lane's butterfly at phase p (4 x int8)
-    int nsig[6];      // -sigma
     int um[6];        // -1 when the lane holds the upper predecessor (state bit 5 = lane bit 5-p) at phase p, else 0
-    int up1[6];       // -um (0 or 1)
+    int up1[6];       // -um (0 or 1), minus 1 under tie rule 1
 };
 
-// one trellis step at phase P: survivors, and the lane's decision bit (1 = upper predecessor s+32) shifted into `hist`
+// one trellis step at phase P: survivors, and the lane's decision bit (1 = upper predecessor s+32) shifted into `hist`.
+// Nine instructions in the DPP phases: symbol broadcast, one dot, add, subtract, add with the lane exchange, 16-bit minimum, three for the decision
+// bit.  What a lone wavefront (one receiver's frame: 76 code words on 1024 SIMDs) spends per step barely depends on their number or on the length
+// of the chain between two metrics (~50 ns per step with 6 to 11 instructions and chains of 2 to 5: tools/abl_wave.py, profiles/r05/ab_notes.md).
 template <int P, int TIE>
 __device__ __forceinline__ void acs_step(uint32_t& metric, uint32_t& hist, const LaneConst& K, int ysym, int lane) {
+    // own predecessor at branch cost e = 508 - dot, partner at 1016 - e = 508 + dot; the dot does not depend on the metrics
+    const uint32_t ds = (uint32_t)__builtin_amdgcn_sdot4(K.sig[P], ysym, 0, false);
     const uint32_t m508 = metric + 508u;
-    const uint32_t p508 = xchg<P>(m508, lane);
-    // own predecessor at branch cost e = 508 - dot, partner at 1016 - e = 508 + dot
-    const uint32_t c_self = (uint32_t)__builtin_amdgcn_sdot4(K.nsig[P], ysym, (int)m508, false);
-    const uint32_t c_part = (uint32_t)__builtin_amdgcn_sdot4(K.sig[P], ysym, (int)p508, false);
+    const uint32_t c_self = m508 - ds;
+    const uint32_t c_part = xchg<P>(m508, lane) + ds;                    // (the DPP phases: one v_add_u32_dpp)
     const uint16_t cs = (uint16_t)c_self, cp = (uint16_t)c_part;          // u16 wrap like the reference core
     // lower lanes: upper predecessor = partner, chosen iff cp < cs (TIE 0) / <= (TIE 1);
-    // upper lanes: upper predecessor = self,    chosen iff cs < cp (TIE 0) / <= (TIE 1)
+    // upper lanes: upper predecessor = self,    chosen iff cs < cp (TIE 0) / <= (TIE 1)      (K.up1 holds the tie rule's -1)
     int d = (int)cp - (int)cs;
     d = (d ^ K.um[P]) + K.up1[P];
-    if constexpr (TIE != 0) d -= 1;
     hist = __builtin_amdgcn_alignbit(hist, (uint32_t)d, 31);          // hist = hist << 1 | sign(d)
-    metric = (uint32_t)((cs < cp) ? cs : cp);
+    metric = (uint32_t)__builtin_elementwise_min(cs, cp);             // v_min_u16: one instruction for compare + select
 }
 
 // the reference's renormalisation (dab_viterbi_decoder.cpp:31-41): when metric[0] reaches the threshold, subtract the minimum
@@ -192,6 +193,40 @@ __device__ __forceinline__ void chainback_block(int& l4, uint32_t& acc, uint32_t
     }
 }
 
+// The same 48 steps when all of them exist (6 <= tb, tb + 48 <= n_steps) and their three history words are already in registers.
+// The survivor is ONE path: its lane is wave-uniform, so the walk is scalar -- v_readlane_b32 of the history word at the survivor's lane,
+// s_bfe / s_lshl / s_or on the lane index and on the byte in flight -- instead of a ds_bpermute round trip and vector bit work per step,
+// and free of the per-step bounds tests of chainback_block.  The caller loads the NEXT block's words before it calls this one: the walk
+// used to stop at every 16th step for a global load nothing depended on.
+__device__ __forceinline__ void chainback_block_full(int& l4, uint32_t& acc, uint32_t& outreg, int tb, int lane, const uint32_t (&W)[3],
+                                                     unsigned char* obytes, const unsigned char* prbs, bool raw) {
+    const int kb = tb >> 3;
+    const int rel = (lane - (kb - 1)) & 63;
+    int cur = __builtin_amdgcn_readfirstlane(l4) >> 2;
+    uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);
+#pragma unroll
+    for (int u = VBLOCK - 1; u >= 0; u--) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)W[u >> 4], cur);
+        const uint32_t d = (w >> (15 - (u & 15))) & 1u;
+        const int q = 5 - (u % 6);
+        cur = (cur & ~(1 << q)) | (int)(d << q);
+        a |= d << (7 - ((u + 2) & 7));
+        if (((u + 2) & 7) == 0) {
+            const int c = ((u - 6) >> 3) + 1;
+            outreg = (rel == c) ? a : outreg;
+            a = 0;
+            const int k = kb - 1 + c;
+            if ((k & 63) == 0) {
+                const int kk = k + lane;
+                const unsigned char pb = raw ? (unsigned char)0 : prbs[kk % PRBS_PERIOD];
+                obytes[kk] = (unsigned char)(outreg ^ pb);
+            }
+        }
+    }
+    l4 = cur << 2;
+    acc = a;
+}
+
 template <int TIE>
 __global__ __launch_bounds__(64)
 void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t* __restrict__ dec_scratch,
@@ -217,16 +252,15 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
 #pragma unroll
     for (int p = 0; p < 6; p++) {
         const unsigned sp = rotl6((unsigned)lane, p) & 31u;
-        int v = 0, nv = 0;
+        int v = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int sg = parity7((2u * sp) & G[r]) ? 1 : -1;
             v |= (sg & 0xFF) << (8 * r);
-            nv |= ((-sg) & 0xFF) << (8 * r);
         }
-        K.sig[p] = v; K.nsig[p] = nv;
+        K.sig[p] = v;
         K.um[p] = ((lane >> (5 - p)) & 1) ? -1 : 0;
-        K.up1[p] = -K.um[p];
+        K.up1[p] = -K.um[p] - (TIE != 0 ? 1 : 0);
     }
 
     uint16_t* my_dec16 = reinterpret_cast<uint16_t*>(dec_scratch + (size_t)blockIdx.x * scratch_words_per_wave);
@@ -308,27 +342,35 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         uint64_t renorm_total = 0;
         uint32_t hist = 0;
 
-        for (int t0 = 0; t0 < n_steps; t0 += VBLOCK) {
-            // ---- fetch + time de-interleave ----
-            int ypk[3];
+        // ---- fetch + time de-interleave, one block AHEAD of the trellis: the loads of block t0 + 48 are in flight while block t0 runs (a lone
+        // wavefront has nothing else to hide their latency behind: 33 blocks x ~2 us of a 1542-step codeword were spent waiting) ----
+        int ynext[3];
+        auto fetch = [&](int t0f) {
 #pragma unroll
             for (int q = 0; q < 3; q++) {
-                const int step = t0 + 16 * q + (lane >> 2);
+                const int step = t0f + 16 * q + (lane >> 2);
                 int y = 0;
-                if (step < n_steps && ((fkeep >> q) & 1)) {
-                    y = src_base[age_off[fidx[q] & 15] + (unsigned long long)((unsigned)fidx[q] >> ish)];
-                    y = max(y, -127);          // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
-                }
+                if (step < n_steps && ((fkeep >> q) & 1)) y = src_base[age_off[fidx[q] & 15] + (unsigned long long)((unsigned)fidx[q] >> ish)];
+                ynext[q] = y;
+                // this lane's position in the next block
+                frem[q] -= VBLOCK;
+                fidx[q] += finc[q];
+                if (frem[q] <= 0 && step + VBLOCK < n_steps) locate(q, step + VBLOCK);      // crossed into another segment (rare)
+            }
+        };
+        fetch(0);
+        for (int t0 = 0; t0 < n_steps; t0 += VBLOCK) {
+            int ypk[3], ycur[3] = {ynext[0], ynext[1], ynext[2]};
+            if (t0 + VBLOCK < n_steps) fetch(t0 + VBLOCK);
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int y = max(ycur[q], -127);      // soft-bit domain is [-127, +127] (viterbi_config.h:12-14)
                 // pack the 4 symbols of a step into one dword in every lane of the quad
                 const int y0 = __builtin_amdgcn_mov_dpp(y, 0x00, 0xF, 0xF, true);   // quad_perm [0,0,0,0]
                 const int y1 = __builtin_amdgcn_mov_dpp(y, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
                 const int y2 = __builtin_amdgcn_mov_dpp(y, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
                 const int y3 = __builtin_amdgcn_mov_dpp(y, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
                 ypk[q] = (y0 & 0xFF) | ((y1 & 0xFF) << 8) | ((y2 & 0xFF) << 16) | (y3 << 24);
-                // this lane's position in the next block
-                frem[q] -= VBLOCK;
-                fidx[q] += finc[q];
-                if (frem[q] <= 0 && step + VBLOCK < n_steps) locate(q, step + VBLOCK);      // crossed into another segment (rare)
             }
             forward_block<TIE>(metric, hist, renorm_total, K, ypk, t0, n_steps, lane, my_dec16);
         }
@@ -346,8 +388,24 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
         // ---- chain-back over steps n_steps-1 .. 6 in aligned blocks of 48 ----
         const bool raw = (D.flags & DABGPU_CW_RAW) != 0;
         uint32_t acc = 0, outreg = 0;
+        uint32_t wnext[3] = {0, 0, 0};
+        bool have_next = false;
         for (int tb = ((n_steps - 1) / VBLOCK) * VBLOCK; tb >= 0; tb -= VBLOCK) {
-            chainback_block(l4, acc, outreg, tb, n_steps, lane, my_dec16, obytes, prbs, raw);
+            if (tb >= VBLOCK && tb + VBLOCK <= n_steps) {                       // a whole block above the first one (wave-uniform)
+                uint32_t wc[3];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    wc[r] = have_next ? wnext[r] : (uint32_t)__builtin_nontemporal_load(&my_dec16[(size_t)((tb >> 4) + r) * 64 + lane]);
+                have_next = tb - VBLOCK >= VBLOCK;                               // the block below is whole too: its words, now
+                if (have_next) {
+#pragma unroll
+                    for (int r = 0; r < 3; r++) wnext[r] = (uint32_t)__builtin_nontemporal_load(&my_dec16[(size_t)(((tb - VBLOCK) >> 4) + r) * 64 + lane]);
+                }
+                chainback_block_full(l4, acc, outreg, tb, lane, wc, obytes, prbs, raw);
+            } else {
+                have_next = false;
+                chainback_block(l4, acc, outreg, tb, n_steps, lane, my_dec16, obytes, prbs, raw);
+            }
         }
         __syncthreads();
 
