@@ -513,8 +513,8 @@ def extras_configs23(ctx, dabgpu, torch, device, E, n_distinct, reps=6, layout=1
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / (2 * reps) * 1e3
     chk = p.check(dabgpu)
-    # DABGPU_VIT_MAP_AUTO's switch points for the FIC (include/dabgpu.h): wave -> octet at ~700 frames, octet -> lane at ~12000
-    lanes_fic = 64 if E >= 12000 else (8 if E >= 700 else 0)
+    # DABGPU_VIT_MAP_AUTO's switch points for the FIC (include/dabgpu.h): wave -> octet at 1024 frames, octet -> lane at 10256
+    lanes_fic = 64 if E >= 10256 else (8 if E >= 1024 else 0)
     fic_kernel = {64: "vit_lanes_kernel (FIC)", 8: "vit_octet_kernel (FIC)", 0: "viterbi_kernel (FIC)"}[lanes_fic]
     path = ("per frame and receiver: dabgpu_ofdm_sync_demod_frames (coarse + fine PRS synchronisation -> demodulation at the position and with the "
             "carrier offset found -> fine-frequency update; carrier offsets +-5 kHz, timing offsets +-100 samples)" if synced else

@@ -248,9 +248,13 @@ int dabgpu_host_choose_mapping(int forced_mapping, double n_simd, size_t n_cw, s
     if (n_groups == 0) return DABGPU_VIT_MAP_WAVE;
     const double mean = sum_group_steps / (double)n_groups;
     const double gather = (staged_gather ? 3.3e-6 : 8.5e-6) * sum_cw_steps;
-    const double t_wave = 0.0189e-3 * sum_cw_steps + 0.038 * (double)n_cw;
-    const double t_lane = 0.5 * std::max(max_steps, std::ceil((double)n_groups / n_simd) * mean) + gather;
-    const double t_oct = 0.095 * std::max(2.0 * max_steps, std::ceil(8.0 * (double)n_groups / n_simd) * mean) + gather;
+    // microseconds.  viterbi_kernel (re-fitted in round 5, after its chain-back went scalar): the latency of the longest code word on a lone wavefront
+    // (~0.08 us per trellis step) + the throughput share of every code word -- 229 / 317 / 445 / 660 us for 32 / 64 / 100 / 160 ensembles of
+    // 18 x 48 CU + FIC, 163 / 510 / 1926 us for the FIC of 1024 / 4096 / 16384 frames (tools/exp/map_crossover.py, profiles/r05/bench_fic_v4.json:
+    // the fit is within 9 %).  The batch mappings: their rounds of wavefronts + the gather + ~20 us for their three set-up launches.
+    const double t_wave = 0.08 * max_steps + 2.2e-5 * sum_cw_steps + 0.0113 * (double)n_cw;
+    const double t_lane = 0.5 * std::max(max_steps, std::ceil((double)n_groups / n_simd) * mean) + gather + 20.0;
+    const double t_oct = 0.095 * std::max(2.0 * max_steps, std::ceil(8.0 * (double)n_groups / n_simd) * mean) + gather + 20.0;
     if (t_wave <= t_lane && t_wave <= t_oct) return DABGPU_VIT_MAP_WAVE;
     return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;
 }
@@ -264,9 +268,9 @@ int dabgpu_host_choose_msc_mapping(int forced_mapping, double n_simd, size_t n_e
     for (int j = 0; j < n_sub; j++) { sum_steps += (double)steps[j]; max_st = std::max(max_st, (double)steps[j]); }
     const double groups = (double)n_sub * (double)((n_ens * 4 + 63) / 64), mean = n_sub ? sum_steps / (double)n_sub : 0.0;
     const double gather = 3.3e-6 * sum_steps * (double)(n_ens * 4);
-    const double t_wave = (double)(n_ens * 4) * (0.0189e-3 * sum_steps + 0.038 * (double)n_sub);
-    const double t_lane = 0.5 * std::max(max_st, std::ceil(groups / n_simd) * mean) + gather;
-    const double t_oct = 0.095 * std::max(2.0 * max_st, std::ceil(8.0 * groups / n_simd) * mean) + gather;
+    const double t_wave = 0.08 * max_st + (double)(n_ens * 4) * (2.2e-5 * sum_steps + 0.0113 * (double)n_sub);
+    const double t_lane = 0.5 * std::max(max_st, std::ceil(groups / n_simd) * mean) + gather + 20.0;
+    const double t_oct = 0.095 * std::max(2.0 * max_st, std::ceil(8.0 * groups / n_simd) * mean) + gather + 20.0;
     if (model_us) { model_us[0] = t_wave; model_us[1] = t_lane; model_us[2] = t_oct; }
     if (forced_mapping != DABGPU_VIT_MAP_AUTO) return forced_mapping;
     if (t_lane < t_wave || t_oct < t_wave) return t_oct < t_lane ? DABGPU_VIT_MAP_OCTET : DABGPU_VIT_MAP_LANE;

@@ -322,9 +322,9 @@ typedef struct {
  *   OCTET  eight lanes per codeword, 8 codewords per wavefront (viterbi_octet.hip), over the same groups and scratch as LANE --
  *          for the batches in between: when LANE would leave most SIMDs without a wavefront (64 codewords are indivisible there)
  * AUTO (default) compares a cost model of the three for the call at hand (LANE needs ~0.5 us per trellis step of its longest
- * schedule however small the batch, OCTET ~0.19 us, WAVE ~0.019 ns per codeword and step + 0.038 us per codeword): e.g. the FIC
- * goes WAVE -> OCTET at ~700 frames and OCTET -> LANE at ~12000, the 18 x 48 CU multiplex WAVE -> OCTET at ~60 ensembles and
- * OCTET -> LANE at ~600
+ * schedule however small the batch, OCTET ~0.19 us, WAVE ~0.08 us per step of the longest codeword + 0.022 ns per codeword and step +
+ * 0.011 us per codeword): e.g. the FIC goes WAVE -> OCTET at ~1000 frames and OCTET -> LANE at ~10000, the 18 x 48 CU multiplex
+ * WAVE -> OCTET at ~65 ensembles and OCTET -> LANE at ~560
  * (dabgpu_viterbi_decode_batch: only when every codeword of the batch has the same n_steps / segments; forcing LANE or OCTET on
  * a mixed generic batch runs WAVE).
  */
