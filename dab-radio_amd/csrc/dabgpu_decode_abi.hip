@@ -252,8 +252,15 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
     // flag the lane-mapped sub-channels in the plans the descriptor builder reads, then stage the plans and build the descriptors
     for (int j = k_wave; j < n_sub; j++) plans[(size_t)order[(size_t)j]].lane_mapped = 1;
     if ((st = dabgpu_stage_h2d_cached(c, 0, d_plans, plans.data(), plans.size() * sizeof(dabgpu_msc_plan), s))) return st;
-    if ((st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
-                                                       d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch"))) return st;
+    // (the FIB groups' descriptors behind the sub-channels' in the same launch when they join the sub-channels' trellis launch)
+    const bool fic_descs_here = fic_inside || fic_with_wave;
+    if (fic_descs_here)
+        st = dabgpu_check_hip(dabgpu_launch_msc_fic_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub, d_out, out_ens_stride,
+                                                          (int)off, d_slots, classed, fic_bits, fic->d_fib_bytes, s), "msc_fic_build_descs launch");
+    else
+        st = dabgpu_check_hip(dabgpu_launch_msc_build(d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub,
+                                                      d_out, out_ens_stride, (int)off, d_slots, classed, s), "msc_build_descs launch");
+    if (st) return st;
     if (n_lane > 0) {
         // group (li, gq) = lane-mapped sub-channel li of ensemble-CIFs 64 gq .. 64 gq + 63; ensembles are sliced so that a launch
         // stays inside the scratch bound
@@ -307,7 +314,6 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
             // one slice (e0 = 0): the FIB groups of the newest frames behind the MSC's groups -- descriptors n .., schedule, symbol and
             // decision areas behind the MSC's, results into the caller's FIC array
             const size_t sym_rows = sym_rows_per_gq * gps, dec_rows = dec_rows_per_gq * gps;
-            if ((st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs + n, fic_bits, n_ens, ens_stride, fic->d_fib_bytes, d_slots, s), "fic_build_descs launch"))) return st;
             if ((st = dabgpu_check_hip(dabgpu_launch_vit_sched_uniform(d_sched + (size_t)n_lane * sched_stride, fic_dec_rows, fic_pi, fic_steps, c->d_vit_tables, s),
                                        "vit_sched launch"))) return st;
             dabgpu_vit_group_base base;
@@ -329,10 +335,8 @@ static int msc_decode_any(dabgpu_ctx* c, const int8_t* d_hist, size_t n_ens, siz
         }
         if (k_wave == 0) return DABGPU_OK;
     }
-    if (fic_with_wave) {
-        if ((st = dabgpu_check_hip(dabgpu_launch_fic_build(d_descs + n, fic_bits, n_ens, ens_stride, fic->d_fib_bytes, d_slots, s), "fic_build_descs launch"))) return st;
+    if (fic_with_wave)
         return run_viterbi(c, d_descs, n + n_fic, std::max(max_steps, 774u), std::max(max_out, 96u), tie_rule, d_results, s, 0, n, fic->d_results);
-    }
     return run_viterbi(c, d_descs, n, max_steps, max_out, tie_rule, d_results, s);
 }
 

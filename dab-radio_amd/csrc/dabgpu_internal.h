@@ -165,6 +165,10 @@ extern "C" hipError_t dabgpu_launch_viterbi(const dabgpu_cw_desc* d_descs, int n
                                             dabgpu_cw_result* d_results_rest = nullptr);
 extern "C" hipError_t dabgpu_launch_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_bits, size_t n_frames,
                                               size_t frame_stride, uint8_t* d_out, const int32_t* d_slots, hipStream_t stream);
+extern "C" hipError_t dabgpu_launch_msc_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
+                                                  int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
+                                                  uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
+                                                  int classed, const int8_t* d_fic_bits, uint8_t* d_fib_out, hipStream_t stream);
 extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
                                               int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
                                               uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,

@@ -28,6 +28,9 @@ __global__ void rx_net_freq_kernel(const dabgpu_sync_state* __restrict__ st, flo
 }
 }  // namespace
 
+// the device record's head: the state, then the 4 scalars; the responses follow at REC_HEAD
+static constexpr size_t REC_SMALL = (sizeof(dabgpu_sync_state) + 15) & ~(size_t)15, REC_HEAD = REC_SMALL + 4 * sizeof(float);
+
 struct dabgpu_receiver {
     dabgpu_ctx* ctx = nullptr;               // tables of the mode
     hipStream_t a = nullptr;                 // stream A, at the device's highest stream priority: its launches are tens of microseconds long and the
@@ -42,13 +45,16 @@ struct dabgpu_receiver {
     int cur = 0;
     float* d_prs = nullptr;                  // nb_fft samples of the PRS slot
     float* d_iq = nullptr;                   // one frame, aligned
-    dabgpu_sync_state* d_state = nullptr;    // the receiver's frequency state + the last synchroniser record
-    float* d_small = nullptr;                // [0] net offset of the frame, [2] sum of the cyclic-prefix angles
+    // one device record: [frequency state + last synchroniser record | 4 scalars | impulse response | coarse frequency response] -- the host reads
+    // the state and the scalars after a frame in ONE copy (the head), the head and the responses after a synchronisation
+    void* d_rec = nullptr;
+    dabgpu_sync_state* d_state = nullptr;    // (into d_rec)
+    float* d_small = nullptr;                // (into d_rec) [0] net offset of the frame, [2] sum of the cyclic-prefix angles
     float* d_corr = nullptr;
-    float* d_imp = nullptr;                  // impulse response | coarse frequency response, nb_fft floats each
+    float* d_imp = nullptr;                  // (into d_rec) impulse response | coarse frequency response, nb_fft floats each
     float* d_fft = nullptr; float* d_dq = nullptr;
     // pinned: the synchroniser's record and responses
-    dabgpu_sync_state* h_sync = nullptr; float* h_imp = nullptr;
+    unsigned char* h_rec = nullptr;          // laid out like d_rec
     hipEvent_t sync_done = nullptr; bool sync_pending = false; bool sync_coarse = false;
     hipEvent_t ready = nullptr;              // frame demodulated (stream A) -> decode may start (stream B)
     hipEvent_t copied = nullptr;             // the frame's soft bits, scalars and views are in the slot's pinned buffers (stream A, beside the decode)
@@ -70,14 +76,11 @@ extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     }
     if (rx->d_prs) (void)hipFree(rx->d_prs);
     if (rx->d_iq) (void)hipFree(rx->d_iq);
-    if (rx->d_state) (void)hipFree(rx->d_state);
-    if (rx->d_small) (void)hipFree(rx->d_small);
+    if (rx->d_rec) (void)hipFree(rx->d_rec);
     if (rx->d_corr) (void)hipFree(rx->d_corr);
-    if (rx->d_imp) (void)hipFree(rx->d_imp);
     if (rx->d_fft) (void)hipFree(rx->d_fft);
     if (rx->d_dq) (void)hipFree(rx->d_dq);
-    if (rx->h_sync) (void)hipHostFree(rx->h_sync);
-    if (rx->h_imp) (void)hipHostFree(rx->h_imp);
+    if (rx->h_rec) (void)hipHostFree(rx->h_rec);
     if (rx->sync_done) (void)hipEventDestroy(rx->sync_done);
     if (rx->ready) (void)hipEventDestroy(rx->ready);
     if (rx->copied) (void)hipEventDestroy(rx->copied);
@@ -111,13 +114,16 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     }
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_prs, n_fft * 2 * sizeof(float)), "hipMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_iq, frame_samples * 2 * sizeof(float)), "hipMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_state, sizeof(dabgpu_sync_state)), "hipMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipMemset(rx->d_state, 0, sizeof(dabgpu_sync_state)), "hipMemset(receiver)");
-    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_small, 4 * sizeof(float)), "hipMalloc(receiver)");
+    const size_t rec_bytes = REC_HEAD + 2 * n_fft * sizeof(float);
+    if (!st) st = dabgpu_check_hip(hipMalloc(&rx->d_rec, rec_bytes), "hipMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMemset(rx->d_rec, 0, rec_bytes), "hipMemset(receiver)");
+    if (!st) {
+        rx->d_state = static_cast<dabgpu_sync_state*>(rx->d_rec);
+        rx->d_small = reinterpret_cast<float*>(static_cast<unsigned char*>(rx->d_rec) + REC_SMALL);
+        rx->d_imp = reinterpret_cast<float*>(static_cast<unsigned char*>(rx->d_rec) + REC_HEAD);
+    }
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_corr, n_sym * 2 * sizeof(float)), "hipMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_imp, 2 * n_fft * sizeof(float)), "hipMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_sync, sizeof(dabgpu_sync_state), hipHostMallocDefault), "hipHostMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_imp, 2 * n_fft * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver)");
+    if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_rec, rec_bytes, hipHostMallocDefault), "hipHostMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, hipEventDisableTiming), "hipEventCreate(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->ready, hipEventDisableTiming), "hipEventCreate(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->copied, hipEventDisableTiming), "hipEventCreate(receiver)");
@@ -163,8 +169,10 @@ extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_syn
     CK(hipMemcpyAsync(rx->d_prs, rx->h_stage[rx->cur] + 2 * prs_sample, n_fft * 2 * sizeof(float), hipMemcpyHostToDevice, a));
     rx->sync_coarse = cfg->is_coarse_freq_correction != 0;
     if ((st = dabgpu_ofdm_sync_mode(c, rx->mode, rx->d_prs, 1, n_fft, cfg, rx->d_state, rx->d_imp, rx->sync_coarse ? rx->d_imp + n_fft : nullptr, a))) return st;
-    CK(hipMemcpyAsync(rx->h_sync, rx->d_state, sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
-    CK(hipMemcpyAsync(rx->h_imp, rx->d_imp, (rx->sync_coarse ? 2 : 1) * n_fft * sizeof(float), hipMemcpyDeviceToHost, a));
+    // (two copies on purpose: head + responses in one is 48 bytes over 16 KiB, and a device-to-host copy above 16 KiB takes a slower path in the
+    //  runtime -- +18 us until the record is on the host, tools/exp/ab_mirror.sh)
+    CK(hipMemcpyAsync(rx->h_rec, rx->d_rec, REC_HEAD, hipMemcpyDeviceToHost, a));
+    CK(hipMemcpyAsync(rx->h_rec + REC_HEAD, rx->d_imp, (rx->sync_coarse ? 2 : 1) * n_fft * sizeof(float), hipMemcpyDeviceToHost, a));
     CK(hipEventRecord(rx->sync_done, a));
     rx->sync_pending = true;
     return DABGPU_OK;
@@ -177,10 +185,11 @@ extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state*
     int st;
     CK(hipEventSynchronize(rx->sync_done));
     rx->sync_pending = false;
-    *out = *rx->h_sync;
+    *out = *reinterpret_cast<const dabgpu_sync_state*>(rx->h_rec);
+    const float* h_imp = reinterpret_cast<const float*>(rx->h_rec + REC_HEAD);
     const size_t n_fft = (size_t)rx->geom[3];
-    if (h_impulse) memcpy(h_impulse, rx->h_imp, n_fft * sizeof(float));
-    if (h_freq_response && rx->sync_coarse) memcpy(h_freq_response, rx->h_imp + n_fft, n_fft * sizeof(float));
+    if (h_impulse) memcpy(h_impulse, h_imp, n_fft * sizeof(float));
+    if (h_freq_response && rx->sync_coarse) memcpy(h_freq_response, h_imp + n_fft, n_fft * sizeof(float));
     return DABGPU_OK;
 }
 
@@ -215,7 +224,7 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
             sl->h_dq_cap = dq_bytes;
         }
     }
-    if (!sl->h_aux) CK(hipHostMalloc((void**)&sl->h_aux, 16 * sizeof(float), hipHostMallocDefault));
+    if (!sl->h_aux) CK(hipHostMalloc((void**)&sl->h_aux, REC_HEAD, hipHostMallocDefault));
     if (!sl->h_bits) CK(hipHostMalloc((void**)&sl->h_bits, DABGPU_NB_FRAME_BITS, hipHostMallocDefault));
     CK(hipMemcpyAsync(rx->d_iq, rx->h_stage[rx->cur] + 2 * frame_sample, frame_samples * 2 * sizeof(float), hipMemcpyHostToDevice, a));
     CK(hipEventRecord(rx->stage_free[rx->cur], a));
@@ -230,13 +239,12 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
         if ((st = dabgpu_ofdm_demod_frames_mode(c, rx->mode, rx->d_iq, 1, rx->d_small, d_bits, rx->d_corr, want_views ? rx->d_fft : nullptr, 0, a))) return st;
         if ((st = dabgpu_ofdm_phase_update_mode(c, rx->mode, rx->d_corr, 1, beta, rx->d_small + 2, d_fine, a))) return st;
     }
-    // the decode may start; what the host reads of this frame -- soft bits, h_aux ([0] fine-frequency word after this frame's update, [1] sum of
+    // the decode may start; what the host reads of this frame -- soft bits, h_aux (the head of the device record: the frequency state after this frame's update, the sum of
     // the cyclic-prefix angles), the display views -- is copied on THIS stream beside it (the 230 KB of soft bits used to sit on the session's
     // stream in front of every trellis launch); the slot's done event waits for both
     CK(hipEventRecord(rx->ready, a));
     CK(hipMemcpyAsync(sl->h_bits, d_bits, frame_bits, hipMemcpyDeviceToHost, a));
-    CK(hipMemcpyAsync(sl->h_aux, d_fine, sizeof(float), hipMemcpyDeviceToHost, a));
-    CK(hipMemcpyAsync(sl->h_aux + 1, rx->d_small + 2, sizeof(float), hipMemcpyDeviceToHost, a));
+    CK(hipMemcpyAsync(sl->h_aux, rx->d_rec, REC_HEAD, hipMemcpyDeviceToHost, a));
     if (want_views) CK(hipMemcpyAsync(sl->h_fft, rx->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
     if (want_dq) CK(hipMemcpyAsync(sl->h_dq, rx->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
     CK(hipEventRecord(rx->copied, a));
@@ -274,8 +282,8 @@ extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generati
     out->generation = generation;
     out->bits = sl->h_bits;
     out->n_bits = (size_t)rx->geom[8];
-    out->freq_fine = sl->h_aux[0];
-    out->total_phase = sl->h_aux[1];
+    out->freq_fine = reinterpret_cast<const dabgpu_sync_state*>(sl->h_aux)->freq_fine;
+    out->total_phase = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(sl->h_aux) + REC_SMALL)[2];
     out->fft = sl->h_fft;
     out->dqpsk = sl->h_dq;
     return DABGPU_OK;

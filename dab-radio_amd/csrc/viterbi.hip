@@ -466,10 +466,9 @@ namespace dabgpu {
 // FIC: 4 FIB groups per frame, PI_16 x 21 blocks, PI_15 x 3 blocks, tail (fic_decoder.cpp:53-84)
 // slots != nullptr: frame fr is slot slots[fr] of ensemble fr's frame-history ring (frame_stride = bytes per ensemble),
 // a negative slot = no new frame for that ensemble (descriptor with n_steps = 0: the decoder skips it)
-__global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits, size_t n_frames, size_t frame_stride,
-                                       uint8_t* out, const int32_t* slots)
+__device__ __forceinline__ void fic_build_one(size_t i, dabgpu_cw_desc* descs, const int8_t* bits, size_t n_frames, size_t frame_stride,
+                                              uint8_t* out, const int32_t* slots)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_frames * 4) return;
     const size_t fr = i >> 2, g = i & 3;
     dabgpu_cw_desc D = {};
@@ -488,13 +487,18 @@ __global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits
     descs[i] = D;
 }
 
+__global__ void fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* bits, size_t n_frames, size_t frame_stride,
+                                       uint8_t* out, const int32_t* slots)
+{
+    fic_build_one((size_t)blockIdx.x * blockDim.x + threadIdx.x, descs, bits, n_frames, frame_stride, out, slots);
+}
+
 // MSC: codeword (ensemble e, cif c, sub-channel s) reads its logical frame through the time de-interleaver
 // straight out of the history of demodulated frames (msc_decoder.cpp:46-75 + cif_deinterleaver.cpp:36-71)
-__global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride,
-                                       int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub,
-                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots, int classed)
+__device__ __forceinline__ void msc_build_one(size_t i, dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride,
+                                              int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub,
+                                              uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots, int classed)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_ens = (size_t)4 * n_sub;
     if (i >= n_ens * per_ens) return;
     const size_t e = i / per_ens;
@@ -518,6 +522,25 @@ __global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist
     D.cif_stride = 55296;
     if (P.lane_mapped) D.flags |= DABGPU_CW_LANE_MAPPED;
     descs[i] = D;
+}
+
+__global__ void msc_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride,
+                                       int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub,
+                                       uint8_t* out, size_t out_ens_stride, int cif_out_bytes, const int32_t* slots, int classed)
+{
+    msc_build_one((size_t)blockIdx.x * blockDim.x + threadIdx.x, descs, hist, n_ens, ens_stride, hist_frames, newest_frame_slot, plans, n_sub, out,
+                  out_ens_stride, cif_out_bytes, slots, classed);
+}
+
+// both in one launch: descriptors 0 .. 4 n_ens n_sub - 1 = the sub-channels' code words, then the 4 n_ens FIB groups of the newest frames (a frame's
+// FIC decoded with its sub-channels: a launch less between two trellis launches of a single receiver)
+__global__ void msc_fic_build_descs_kernel(dabgpu_cw_desc* descs, const int8_t* hist, size_t n_ens, size_t ens_stride, int hist_frames,
+                                           int newest_frame_slot, const dabgpu_msc_plan* plans, int n_sub, uint8_t* out, size_t out_ens_stride,
+                                           int cif_out_bytes, const int32_t* slots, int classed, const int8_t* fic_bits, uint8_t* fib_out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n_msc = n_ens * 4 * (size_t)n_sub;
+    if (i < n_msc) msc_build_one(i, descs, hist, n_ens, ens_stride, hist_frames, newest_frame_slot, plans, n_sub, out, out_ens_stride, cif_out_bytes, slots, classed);
+    else fic_build_one(i - n_msc, descs + n_msc, fic_bits, n_ens, ens_stride, fib_out, slots);
 }
 
 // CIF_Deinterleaver::Deinterleave as a stand-alone gather (cif_deinterleaver.cpp:36-71); the decoder itself never
@@ -561,5 +584,17 @@ extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int
     hipLaunchKernelGGL(dabgpu::msc_build_descs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
                        d_descs, d_hist, n_ens, ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub, d_out,
                        out_ens_stride, cif_out_bytes, d_slots, classed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dabgpu_launch_msc_fic_build(dabgpu_cw_desc* d_descs, const int8_t* d_hist, size_t n_ens, size_t ens_stride,
+                                                  int hist_frames, int newest_frame_slot, const dabgpu_msc_plan* d_plans, int n_sub,
+                                                  uint8_t* d_out, size_t out_ens_stride, int cif_out_bytes, const int32_t* d_slots,
+                                                  int classed, const int8_t* d_fic_bits, uint8_t* d_fib_out, hipStream_t stream)
+{
+    const size_t n = n_ens * 4 * ((size_t)n_sub + 1);
+    hipLaunchKernelGGL(dabgpu::msc_fic_build_descs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_descs, d_hist, n_ens,
+                       ens_stride, hist_frames, newest_frame_slot, d_plans, n_sub, d_out, out_ens_stride, cif_out_bytes, d_slots, classed,
+                       d_fic_bits, d_fib_out);
     return hipGetLastError();
 }
