@@ -102,8 +102,26 @@ def test_frames_do_not_depend_on_the_block_size(harness, captures, tmp_path, whi
         assert bytes(got) == bytes(msc[si]), f"sub-channel {si}"
 
 
+REAL_HARNESS = os.path.join(ROOT, "tests", "cpp", "mirror_harness")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,seed,depth", [("a", 11, 3), ("b", 12, 1), ("a", 13, 6), ("b", 14, 3)])
+def test_random_block_lengths_and_caller_resets_on_the_device(captures, tmp_path, which, seed, depth):
+    """the same schedules through the real library: the synchroniser's record really is in flight when the next block (or the caller's Reset()) arrives"""
+    if not os.path.exists(REAL_HARNESS):
+        import __graft_entry__ as g
+        g.build()
+    env = {"LD_LIBRARY_PATH": os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), "DABGPU_MIRROR_DEPTH": str(depth)}
+    check_random_schedule(REAL_HARNESS, captures, tmp_path, which, seed, env)
+
+
 @pytest.mark.parametrize("which,seed", [("a", 1), ("a", 2), ("b", 3), ("b", 4), ("a", 5), ("b", 6)])
 def test_random_block_lengths_and_caller_resets(harness, captures, tmp_path, which, seed):
+    check_random_schedule(harness, captures, tmp_path, which, seed, {})
+
+
+def check_random_schedule(harness, captures, tmp_path, which, seed, env_extra):
     """every Process() call gets its own length (log-uniform 100 .. 600,000 samples), and now and then the caller calls Reset() between two calls
     (ofdm_demodulator.cpp:277-289: the GUI's button) -- also while a synchroniser's record is still in flight, which the serial machine had
     long acted on: frames, counters and decoded bytes stay those of the serial machine fed the same calls"""
@@ -134,7 +152,7 @@ def test_random_block_lengths_and_caller_resets(harness, captures, tmp_path, whi
     out = tmp_path / "out"
     out.mkdir()
     args = [harness, path, str(out), "65536", "0", "48", "2", "0", "120", "27", "0", "1"]
-    res = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, DABGPU_HARNESS_SCHEDULE=str(tmp_path / "schedule.txt")), timeout=900)
+    res = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, DABGPU_HARNESS_SCHEDULE=str(tmp_path / "schedule.txt"), **env_extra), timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     assert f"frames={nf} read={nf} desync={model.frames_desync} state=" in res.stdout, (res.stdout, nf, model.frames_desync)
     bits = np.fromfile(out / "frame_bits.bin", dtype=np.int8).reshape(nf, O.NB_FRAME_BITS)
