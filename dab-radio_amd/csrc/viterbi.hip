@@ -276,20 +276,12 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
             if (lane == 0) { dabgpu_cw_result R; R.path_error = 0; R.crc_ok_mask = 0; R.n_out_bytes = 0; *(cw < n_first ? results + cw : results_rest + (cw - n_first)) = R; }
             continue;
         }
-        // segment boundaries in trellis steps; the 6 tail steps use PI_8 == PI_X
-        int seg_end[5], seg_pi[5], seg_in0[5];
-        {
-            int st = 0, in0 = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                seg_pi[k] = (int)D.seg_pi[k];
-                seg_in0[k] = in0;
-                st += (int)D.seg_steps[k];
-                in0 += ((int)D.seg_steps[k] >> 3) * (8 + seg_pi[k]);
-                seg_end[k] = st;
-            }
-            seg_pi[4] = 8; seg_in0[4] = in0; seg_end[4] = st + 6;
-        }
+        // segment boundaries in trellis steps; the 6 tail steps use PI_8 == PI_X.  Scalars, not arrays: an array indexed by the lane's segment number
+        // ends up in private memory, and a kernel with a private segment pays for scratch at every dispatch
+        const int sp0 = (int)D.seg_pi[0], sp1 = (int)D.seg_pi[1], sp2 = (int)D.seg_pi[2], sp3 = (int)D.seg_pi[3];
+        const int se0 = (int)D.seg_steps[0], se1 = se0 + (int)D.seg_steps[1], se2 = se1 + (int)D.seg_steps[2], se3 = se2 + (int)D.seg_steps[3], se4 = se3 + 6;
+        const int si1 = ((int)D.seg_steps[0] >> 3) * (8 + sp0), si2 = si1 + ((int)D.seg_steps[1] >> 3) * (8 + sp1),
+                  si3 = si2 + ((int)D.seg_steps[2] >> 3) * (8 + sp2), si4 = si3 + ((int)D.seg_steps[3] >> 3) * (8 + sp3);
 
         // time de-interleaver (cif_deinterleaver.cpp:57-68): input bit i comes from the CIF that is 15 - bitrev4(i mod 16) CIFs
         // old; the byte offset of that CIF inside the frame-history ring depends on i mod 16 only -> 16-entry table per codeword
@@ -321,12 +313,12 @@ void viterbi_kernel(const dabgpu_cw_desc* __restrict__ descs, int n_cw, uint64_t
                 fidx[q] = 4 * step + rbit; finc[q] = 4 * VBLOCK; frem[q] = 0x40000000; fkeep |= 1 << q;
                 return;
             }
-            int k = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) k += (step >= seg_end[u]) ? 1 : 0;
-            int sstart = 0, send = seg_end[0], pi = seg_pi[0], in0 = seg_in0[0];
-#pragma unroll
-            for (int u = 1; u < 5; u++) if (k == u) { sstart = seg_end[u - 1]; send = seg_end[u]; pi = seg_pi[u]; in0 = seg_in0[u]; }
+            // (sums of increments, not a chain of selects: the compiler turns such a chain back into a table in private memory)
+            const int c0 = step >= se0 ? -1 : 0, c1 = step >= se1 ? -1 : 0, c2 = step >= se2 ? -1 : 0, c3 = step >= se3 ? -1 : 0;
+            const int sstart = (c0 & se0) + (c1 & (se1 - se0)) + (c2 & (se2 - se1)) + (c3 & (se3 - se2));
+            const int send = se0 + (c0 & (se1 - se0)) + (c1 & (se2 - se1)) + (c2 & (se3 - se2)) + (c3 & (se4 - se3));
+            const int pi = sp0 + (c0 & (sp1 - sp0)) + (c1 & (sp2 - sp1)) + (c2 & (sp3 - sp2)) + (c3 & (8 - sp3));
+            const int in0 = (c0 & si1) + (c1 & (si2 - si1)) + (c2 & (si3 - si2)) + (c3 & (si4 - si3));
             const int sis = step - sstart;
             const uint16_t e = pi_tab[pi * 8 + (sis & 7)];
             const int cnt = e & 0xFF, pre = e >> 8;
