@@ -154,7 +154,9 @@ def run_and_compare(exe, stream, tmp_path, name, batch, depth, env_extra=None):
     elif name == "services_appear":
         # long stretches without a change: a change costs the frames that were in flight (`depth` of them) and a new decoder its first 16 CIFs
         assert k["fib_groups_batched"] >= 0.6 * (k["fib_groups_batched"] + k["fib_groups_call_by_call"]), k
-        assert k["cifs_batched"] >= 0.5 * (k["cifs_batched"] + k["cifs_call_by_call"]), k
+        # (with every change heard as late as the pipeline allows -- depth + 1 frames -- and 4 more frames until 16 consecutive CIFs match, 40 %
+        #  of this script's CIFs are still picked up; usually it is 60-70 %)
+        assert k["cifs_batched"] >= 0.3 * (k["cifs_batched"] + k["cifs_call_by_call"]), k
     elif name == "churn" and depth <= 3:
         assert k["fib_groups_batched"] >= 8 and k["cifs_batched"] >= 5, k
     return k
