@@ -12,6 +12,7 @@
 // the decoders picked up from the frames' batched decodes and how many they decoded call by call.
 // The expected files are composed from the oracle in tests/test_mirror_lifecycle.py (CPU: linked with tests/cpp/fake_dabgpu_oracle.cpp;
 // -m gpu: with libdabgpu.so, where every change of the set is a new decode layout of the receiver's frame session while frames are in flight).
+#include <algorithm>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -97,9 +98,20 @@ int main(int argc, char** argv) {
         }
         frame++;
     });
-    std::vector<std::complex<float>> buf(block);
-    while (in) {
-        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)(block * sizeof(std::complex<float>)));
+    // DABGPU_HARNESS_SCHEDULE as in mirror_harness.cpp: a text file of block lengths, one per Process() call; a negative entry = Reset() first
+    std::vector<long> schedule;
+    if (const char* sp = std::getenv("DABGPU_HARNESS_SCHEDULE")) {
+        std::ifstream sf(sp);
+        long v;
+        while (sf >> v) if (v != 0) schedule.push_back(v);
+    }
+    size_t max_block = block;
+    for (long v : schedule) max_block = std::max(max_block, (size_t)std::labs(v));
+    std::vector<std::complex<float>> buf(max_block);
+    for (size_t call = 0; in; call++) {
+        long want = schedule.empty() ? (long)block : schedule[std::min(call, schedule.size() - 1)];
+        if (want < 0) { demod->Reset(); want = -want; }
+        in.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)((size_t)want * sizeof(std::complex<float>)));
         const size_t got = (size_t)in.gcount() / sizeof(std::complex<float>);
         if (got == 0) break;
         demod->Process(tcb::span<const std::complex<float>>(buf.data(), got));
