@@ -4,7 +4,7 @@ hardened captures of tests/test_mirror_host_logic.py (drop-outs: losses of lock 
 (tests/test_mirror_lifecycle.py::random_script), a random length for every Process() call, caller resets, 1-6 frames in flight, frame batcher on and off --
 against the oracle composition: every decoder an independent time de-interleaver + decode over exactly the CIFs it was handed.
 
-    python tools/fuzz_mirror_lifecycle.py FIRST_SEED LAST_SEED
+    python tools/fuzz_mirror_lifecycle.py FIRST_SEED LAST_SEED            # FUZZ_REAL=1 on a GPU box: the same through libdabgpu.so
 """
 import os, sys, subprocess, shutil, tempfile
 import numpy as np
@@ -16,14 +16,18 @@ import test_mirror_lifecycle as L
 O.build()
 W = tempfile.mkdtemp(prefix="fuzz_lifecycle_")
 objs = []
-for src in T.ORACLE_SRCS:
+for src in ([] if os.environ.get("FUZZ_REAL") == "1" else T.ORACLE_SRCS):
     o = os.path.join(W, src + ".o")
     subprocess.run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-w", "-mavx2", "-mbmi2", "-mfma", "-c", os.path.join(T.ORACLE, src), "-o", o], check=True)
     objs.append(o)
-EXE = os.path.join(W, "mirror_lifecycle_fake")
-subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + T.HOST, "-I" + os.path.join(ROOT, "include"), "-I" + T.CSRC, "-I" + T.ORACLE,
-                os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver.cpp"), os.path.join(ROOT, "tests", "cpp", "fake_dabgpu_oracle.cpp"),
-                os.path.join(T.CSRC, "dabgpu_host_logic.cpp")] + [os.path.join(T.HOST, s) for s in T.MIRROR_SRCS] + objs + ["-lm", "-o", EXE], check=True)
+REAL = os.environ.get("FUZZ_REAL") == "1"          # FUZZ_REAL=1 (on a GPU box): the driver built by __graft_entry__.build() on libdabgpu.so instead
+EXE = os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver") if REAL else os.path.join(W, "mirror_lifecycle_fake")
+if REAL:
+    os.environ["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", "")
+else:
+  subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + T.HOST, "-I" + os.path.join(ROOT, "include"), "-I" + T.CSRC, "-I" + T.ORACLE,
+                  os.path.join(ROOT, "tests", "cpp", "mirror_lifecycle_driver.cpp"), os.path.join(ROOT, "tests", "cpp", "fake_dabgpu_oracle.cpp"),
+                  os.path.join(T.CSRC, "dabgpu_host_logic.cpp")] + [os.path.join(T.HOST, s) for s in T.MIRROR_SRCS] + objs + ["-lm", "-o", EXE], check=True)
 subs = [O.subchannel(v[0], v[1], eep_level=v[2], eep_type=v[3]) for v in L.SUBS.values()]
 caps = {}
 for name, c in {"a": dict(n_frames=26, seed=21, dropouts=((6, -0.03, 14000), (14, -0.03, 60000), (19, 0.2, 30000))),
