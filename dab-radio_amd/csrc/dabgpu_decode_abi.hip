@@ -688,6 +688,8 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
     for (auto& sl : s->slots) {
         if (!st) st = slot_block(s, sl);
         if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming), "hipEventCreate(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming), "hipEventCreate(session)");
     }
     if (st) { dabgpu_frame_session_destroy(s); return st; }
     *out = s;
@@ -707,6 +709,8 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
         if (sl.h_fft) (void)hipHostFree(sl.h_fft);
         if (sl.h_dq) (void)hipHostFree(sl.h_dq);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
+        if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
     }
     if (s->d_hist) (void)hipFree(s->d_hist);
     if (s->d_block) (void)hipFree(s->d_block);
@@ -773,6 +777,7 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
     dabgpu_ctx* c = s->ctx;
     DABGPU_BIND(c);
     hipStream_t q = c->stream;
+    if (s->next_reserve != s->next_gen) { dabgpu_set_error("frame_session_push_frame: a reserved frame has not been committed"); return DABGPU_ERR_INVALID_ARG; }
     const uint64_t gen = s->next_gen;
     const int hs = (int)(gen % dabgpu_frame_session::H);
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
@@ -789,6 +794,7 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
     sl.pending = true;
     sl.gen = gen;
     s->next_gen = gen + 1;
+    s->next_reserve = gen + 1;
     if (generation) *generation = gen;
     return DABGPU_OK;
 }
@@ -796,7 +802,13 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
 int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64_t* gen_out, int8_t** d_frame_bits, dabgpu_frame_session::slot** slot_out) {
     std::lock_guard<std::mutex> lock(s->mu);
     DABGPU_BIND(s->ctx);
-    const uint64_t gen = s->next_gen;
+    const uint64_t gen = s->next_reserve;
+    // the commits (decode enqueued) may lag the reservations by a few frames (dabgpu_receiver_submit_demod / _submit_decode on two threads), but the
+    // result slot and the history slot of `gen` must be free: R - 1 frames at most may be reserved and not yet waited for
+    if (gen >= s->next_gen + (uint64_t)(dabgpu_frame_session::R - 1)) {
+        dabgpu_set_error("session_reserve: %d frames reserved and not committed (at most %d)", (int)(gen - s->next_gen), dabgpu_frame_session::R - 1);
+        return DABGPU_ERR_NOT_READY;
+    }
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
     int st;
     if (sl.pending) {
@@ -806,11 +818,17 @@ int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64
     // history slot gen % H holds frame gen - H, which the decodes of the frames gen - H .. gen - 4 read (5 frames = 16 CIFs + the frame's own
     // 4): the producer may overwrite it once the decode of frame gen - 4 has run (the decodes run in order on one stream)
     if (gen >= 4) {
+        if (gen - 4 >= s->next_gen) {
+            dabgpu_set_error("session_reserve: the decode of frame %llu has not been submitted, frame %llu would overwrite what it reads (at most 4 frames "
+                             "between dabgpu_receiver_submit_demod and dabgpu_receiver_submit_decode)", (unsigned long long)(gen - 4), (unsigned long long)gen);
+            return DABGPU_ERR_NOT_READY;
+        }
         dabgpu_frame_session::slot& old = s->slots[(gen - 4) % dabgpu_frame_session::R];
         if (old.pending && old.gen == gen - 4 &&
             (st = dabgpu_check_hip(hipStreamWaitEvent(producer, old.done, 0), "hipStreamWaitEvent(session history)"))) return st;
     }
     sl.gen = ~0ull;
+    s->next_reserve = gen + 1;
     *gen_out = gen;
     *d_frame_bits = s->d_hist + (size_t)(gen % dabgpu_frame_session::H) * DABGPU_NB_FRAME_BITS;
     *slot_out = &sl;
@@ -826,7 +844,7 @@ int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t read
     hipStream_t q = c->stream;
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
     int st;
-    if ((st = dabgpu_check_hip(hipStreamWaitEvent(q, ready, 0), "hipStreamWaitEvent(session producer)"))) return st;
+    if (ready && (st = dabgpu_check_hip(hipStreamWaitEvent(q, ready, 0), "hipStreamWaitEvent(session producer)"))) return st;
     if (bits_bytes) {
         if (!sl.h_bits && (st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_bits, DABGPU_NB_FRAME_BITS, hipHostMallocDefault), "hipHostMalloc(session bits)"))) return st;
         if ((st = dabgpu_check_hip(hipMemcpyAsync(sl.h_bits, s->d_hist + (size_t)(gen % dabgpu_frame_session::H) * DABGPU_NB_FRAME_BITS, bits_bytes,

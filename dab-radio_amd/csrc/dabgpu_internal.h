@@ -192,7 +192,8 @@ struct dabgpu_frame_session {
     std::vector<dabgpu_subchannel> subs;
     std::vector<uint32_t> sub_off, sub_n;           // byte offset / size of a sub-channel inside one CIF's output record
     uint32_t cif_out = 0;
-    uint64_t next_gen = 0;
+    uint64_t next_gen = 0;                          // next generation to be committed (decode enqueued), in order
+    uint64_t next_reserve = 0;                      // next generation to be reserved (>= next_gen: a producer may run ahead of the commits)
     struct slot {
         uint64_t gen = ~0ull; bool fic = false, pending = false;
         std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
@@ -200,6 +201,7 @@ struct dabgpu_frame_session {
         uint8_t* h_fib = nullptr; dabgpu_codeword_result* h_fres = nullptr;      // (into h_block) [4][96], [4]
         uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // (into h_block) [4][cif_out], [4][n_sub]
         hipEvent_t done = nullptr;
+        hipEvent_t ev_ready = nullptr, ev_copied = nullptr;                    // receiver pipeline: frame demodulated / its host copies made (producer stream)
         // receiver pipeline only (pinned, allocated at first use): the frame's soft bits, a few scalars of the producer, display views
         int8_t* h_bits = nullptr; float* h_aux = nullptr; float* h_fft = nullptr; float* h_dq = nullptr;
         size_t h_fft_cap = 0, h_dq_cap = 0;

@@ -15,6 +15,7 @@
 // frame's results (dabgpu_receiver_wait_frame, on whatever thread delivers frames).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <atomic>
 
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
@@ -56,9 +57,7 @@ struct dabgpu_receiver {
     // pinned: the synchroniser's record and responses
     unsigned char* h_rec = nullptr;          // laid out like d_rec
     hipEvent_t sync_done = nullptr; bool sync_pending = false; bool sync_coarse = false;
-    hipEvent_t ready = nullptr;              // frame demodulated (stream A) -> decode may start (stream B)
-    hipEvent_t copied = nullptr;             // the frame's soft bits, scalars and views are in the slot's pinned buffers (stream A, beside the decode)
-    int decode_fic = 0;
+    std::atomic<int> decode_fic{0};          // (written by set_subchannels, read where the decode is submitted: possibly another thread)
 };
 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
@@ -82,8 +81,6 @@ extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     if (rx->d_dq) (void)hipFree(rx->d_dq);
     if (rx->h_rec) (void)hipHostFree(rx->h_rec);
     if (rx->sync_done) (void)hipEventDestroy(rx->sync_done);
-    if (rx->ready) (void)hipEventDestroy(rx->ready);
-    if (rx->copied) (void)hipEventDestroy(rx->copied);
     if (rx->a) (void)hipStreamDestroy(rx->a);
     if (rx->ctx) dabgpu_destroy(rx->ctx);
     delete rx;
@@ -125,8 +122,6 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_corr, n_sym * 2 * sizeof(float)), "hipMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_rec, rec_bytes, hipHostMallocDefault), "hipHostMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, hipEventDisableTiming), "hipEventCreate(receiver)");
-    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->ready, hipEventDisableTiming), "hipEventCreate(receiver)");
-    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->copied, hipEventDisableTiming), "hipEventCreate(receiver)");
     if (st) { dabgpu_receiver_destroy(rx); return st; }
     *out = rx;
     return DABGPU_OK;
@@ -139,7 +134,7 @@ extern "C" int dabgpu_receiver_set_subchannels(dabgpu_receiver* rx, const dabgpu
     if (rx->mode != 1 && (n > 0 || decode_fic)) { dabgpu_set_error("receiver_set_subchannels: the DAB layer above the soft bits exists for transmission mode I only"); return DABGPU_ERR_UNSUPPORTED; }
     const int st = dabgpu_frame_session_set_subchannels(rx->ses, subs, n);
     if (st) return st;
-    rx->decode_fic = decode_fic ? 1 : 0;
+    rx->decode_fic.store(decode_fic ? 1 : 0);
     return DABGPU_OK;
 }
 
@@ -193,8 +188,9 @@ extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state*
     return DABGPU_OK;
 }
 
-extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie_rule, uint64_t* generation) {
-    if (!rx) { dabgpu_set_error("receiver_submit_frame: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+// Stream A's share of a frame: upload, demodulation into the session's history slot, fine-frequency update, the copies the host reads.  The slot's
+// ev_ready fires when the soft bits are in the history slot, ev_copied when the host copies are made.
+static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation, dabgpu_frame_session::slot** slot_out) {
     const size_t frame_samples = (size_t)rx->geom[6], n_fft = (size_t)rx->geom[3], n_sym = (size_t)rx->geom[0], frame_bits = (size_t)rx->geom[8];
     if (frame_sample + frame_samples > rx->stage_cap) { dabgpu_set_error("receiver_submit_frame: the frame lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
@@ -242,14 +238,12 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
     // the decode may start; what the host reads of this frame -- soft bits, h_aux (the head of the device record: the frequency state after this frame's update, the sum of
     // the cyclic-prefix angles), the display views -- is copied on THIS stream beside it (the 230 KB of soft bits used to sit on the session's
     // stream in front of every trellis launch); the slot's done event waits for both
-    CK(hipEventRecord(rx->ready, a));
+    CK(hipEventRecord(sl->ev_ready, a));
     CK(hipMemcpyAsync(sl->h_bits, d_bits, frame_bits, hipMemcpyDeviceToHost, a));
     CK(hipMemcpyAsync(sl->h_aux, rx->d_rec, REC_HEAD, hipMemcpyDeviceToHost, a));
     if (want_views) CK(hipMemcpyAsync(sl->h_fft, rx->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
     if (want_dq) CK(hipMemcpyAsync(sl->h_dq, rx->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
-    CK(hipEventRecord(rx->copied, a));
-    const bool decode = rx->mode == 1 && (rx->decode_fic || !rx->ses->subs.empty());
-    if ((st = dabgpu_session_commit(rx->ses, gen, rx->ready, 0, decode ? 1 : 0, rx->decode_fic, tie_rule, rx->copied))) return st;
+    CK(hipEventRecord(sl->ev_copied, a));
     // the next frame is assembled in the next staging buffer; its last upload (STAGES frames ago) has long finished
     rx->cur = (rx->cur + 1) % STAGES;
     if (rx->stage_pending[rx->cur]) {
@@ -257,8 +251,48 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
         rx->stage_pending[rx->cur] = false;
     }
     if (generation) *generation = gen;
+    if (slot_out) *slot_out = sl;
     return DABGPU_OK;
 }
+
+// one call, one thread: the decode is enqueued behind the demodulation with device-side waits (stream B waits for ev_ready, and for ev_copied before
+// the slot's done event)
+extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie_rule, uint64_t* generation) {
+    if (!rx) { dabgpu_set_error("receiver_submit_frame: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    uint64_t gen = 0;
+    dabgpu_frame_session::slot* sl = nullptr;
+    int st = submit_demod(rx, frame_sample, beta, want_views, &gen, &sl);
+    if (st) return st;
+    DABGPU_BIND(rx->ctx);
+    const int fic = rx->decode_fic.load();
+    bool decode;
+    { std::lock_guard<std::mutex> lock(rx->ses->mu); decode = rx->mode == 1 && (fic || !rx->ses->subs.empty()); }
+    if ((st = dabgpu_session_commit(rx->ses, gen, sl->ev_ready, 0, decode ? 1 : 0, fic, tie_rule, sl->ev_copied))) return st;
+    if (generation) *generation = gen;
+    return DABGPU_OK;
+}
+
+// two calls, possibly two threads: submit_demod enqueues stream A's share and returns; submit_decode waits ON THE HOST until the frame is demodulated
+// and then enqueues the decode.  No device-side wait of one stream for another remains: with several receivers in a process two of them share a
+// hardware queue, and a queue whose head waits for another queue's event holds back the other receiver's work behind it.
+extern "C" int dabgpu_receiver_submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation) {
+    if (!rx) { dabgpu_set_error("receiver_submit_demod: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    return submit_demod(rx, frame_sample, beta, want_views, generation, nullptr);
+}
+
+extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t generation, int tie_rule) {
+    if (!rx) { dabgpu_set_error("receiver_submit_decode: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    dabgpu_frame_session* s = rx->ses;
+    DABGPU_BIND(s->ctx);
+    dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];
+    int st = dabgpu_check_hip(hipEventSynchronize(sl->ev_ready), "hipEventSynchronize(receiver frame demodulated)");
+    if (st) return st;
+    const int fic = rx->decode_fic.load();
+    bool decode;
+    { std::lock_guard<std::mutex> lock(s->mu); decode = rx->mode == 1 && (fic || !s->subs.empty()); }
+    return dabgpu_session_commit(s, generation, nullptr, 0, decode ? 1 : 0, fic, tie_rule, nullptr);
+}
+
 
 extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generation, dabgpu_receiver_frame* out) {
     if (!rx || !out) { dabgpu_set_error("receiver_wait_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
@@ -279,6 +313,8 @@ extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generati
         std::lock_guard<std::mutex> lock(s->mu);
         if (sl->gen == generation) sl->pending = false;
     }
+    // (the host copies of the producer stream: already behind `done` after dabgpu_receiver_submit_frame, on their own after _submit_decode)
+    { int st = dabgpu_check_hip(hipEventSynchronize(sl->ev_copied), "hipEventSynchronize(receiver copies)"); if (st) return st; }
     out->generation = generation;
     out->bits = sl->h_bits;
     out->n_bits = (size_t)rx->geom[8];

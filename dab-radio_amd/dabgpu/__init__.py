@@ -23,7 +23,7 @@ NB_FRAME_BITS = 230400
 NB_FIC_BITS = 9216
 NB_FIB_GROUP_BITS = 2304
 NB_CIF_BITS = 55296
-ABI_VERSION = 2                          # DABGPU_ABI_VERSION of include/dabgpu.h
+ABI_VERSION = 3                          # DABGPU_ABI_VERSION of include/dabgpu.h
 BITS_NATURAL, BITS_MSC_CLASSED = 0, 1     # dabgpu_ofdm_demod_frames_history / dabgpu_msc_decode_frames_layout
 
 
@@ -67,6 +67,7 @@ ABI_SYMBOLS = [
     "dabgpu_multiplex_mapping",
     "dabgpu_receiver_create", "dabgpu_receiver_destroy", "dabgpu_receiver_session", "dabgpu_receiver_set_subchannels", "dabgpu_receiver_stage",
     "dabgpu_receiver_reset", "dabgpu_receiver_submit_sync", "dabgpu_receiver_wait_sync", "dabgpu_receiver_submit_frame", "dabgpu_receiver_wait_frame",
+    "dabgpu_receiver_submit_demod", "dabgpu_receiver_submit_decode",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",
 ]
 

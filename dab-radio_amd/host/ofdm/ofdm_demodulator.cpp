@@ -67,6 +67,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     m_impulse_response.assign(params.nb_fft, 0.0f);
     m_frequency_response.assign(params.nb_fft, 0.0f);
     m_thread = std::thread([this] { DeliveryThread(); });
+    m_decode_thread = std::thread([this] { DecodeThread(); });
 }
 
 OFDM_Demod::~OFDM_Demod() {
@@ -77,7 +78,9 @@ OFDM_Demod::~OFDM_Demod() {
         m_stop = true;
     }
     m_cv_items.notify_all();
+    m_cv_decode.notify_all();
     if (m_thread.joinable()) m_thread.join();
+    if (m_decode_thread.joinable()) m_decode_thread.join();
     dabgpu_frame_batcher::remove_producer(this);
     dabgpu_receiver_destroy(m_rx);
     if (m_profile && m_total_frames_read > 0) {
@@ -295,6 +298,8 @@ void OFDM_Demod::SubmitFrame() {
     {
         std::unique_lock<std::mutex> lock(m_mu);
         m_cv_done.wait(lock, [this] { return m_frames_in_flight < m_depth; });
+        // (the demodulation of frame g overwrites what the decode of frame g - 4 reads: never more than 4 frames ahead of the decode thread)
+        m_cv_decoded.wait(lock, [this] { return m_frames_submitted < m_decodes_submitted + 4 || (bool)m_error; });
     }
     const double t1 = m_profile ? now_us() : 0.0;
     // what the decoders of this process listen to NOW -- asked after the wait for a slot: an observer that created a decoder while this thread
@@ -312,8 +317,10 @@ void OFDM_Demod::SubmitFrame() {
     RethrowDeliveryError();
     uint64_t gen = 0;
     const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
-    const int rc = dabgpu_receiver_submit_frame(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, m_fetch_debug ? 1 : 0, dabgpu_tie_rule_from_env(), &gen);
-    if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_frame", rc);
+    // this thread enqueues the frame's upload, demodulation and fine-frequency update; the decode thread waits for the demodulation and enqueues the
+    // decode (dabgpu_receiver_submit_demod / _submit_decode: no stream waits for another on the device, and half the runtime calls leave this thread)
+    const int rc = dabgpu_receiver_submit_demod(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, m_fetch_debug ? 1 : 0, &gen);
+    if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_demod", rc);
     float* stage = nullptr;
     (void)dabgpu_receiver_stage(m_rx, &stage, nullptr);
     m_stage = reinterpret_cast<std::complex<float>*>(stage);
@@ -322,8 +329,37 @@ void OFDM_Demod::SubmitFrame() {
         std::lock_guard<std::mutex> lock(m_mu);
         m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, m_mode == 1});
         m_frames_in_flight++;
+        m_frames_submitted++;
+        m_to_decode.push_back(gen);
     }
     m_cv_items.notify_one();
+    m_cv_decode.notify_one();
+}
+
+// the generations in submission order: wait (on the host) until the frame is demodulated, enqueue its decode
+void OFDM_Demod::DecodeThread() {
+    for (;;) {
+        uint64_t gen;
+        {
+            std::unique_lock<std::mutex> lock(m_mu);
+            m_cv_decode.wait(lock, [this] { return m_stop || !m_to_decode.empty(); });
+            if (m_to_decode.empty()) return;
+            gen = m_to_decode.front();
+            m_to_decode.pop_front();
+        }
+        try {
+            const int rc = dabgpu_receiver_submit_decode(m_rx, gen, dabgpu_tie_rule_from_env());
+            if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_decode", rc);
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(m_mu);
+            if (!m_error) m_error = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_mu);
+            m_decodes_submitted = gen + 1;
+        }
+        m_cv_decoded.notify_all();
+    }
 }
 
 // :581-639 the coordinator's role: everything a frame publishes, in submission order
@@ -357,6 +393,11 @@ void OFDM_Demod::DeliveryThread() {
                 if (failed) break;                       // after a device error nothing more is delivered; Process() rethrows it
                 dabgpu_receiver_frame fr;
                 const double t0 = m_profile ? now_us() : 0.0;
+                {
+                    std::unique_lock<std::mutex> lock(m_mu);                     // (the decode thread has enqueued this frame's decode)
+                    m_cv_decoded.wait(lock, [&] { return m_decodes_submitted > it.gen || (bool)m_error; });
+                    if (m_error) break;
+                }
                 const int rc = dabgpu_receiver_wait_frame(m_rx, it.gen, &fr);
                 if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_frame", rc);
                 const double t1 = m_profile ? now_us() : 0.0;

@@ -163,6 +163,13 @@ private:
     bool m_busy = false, m_stop = false;
     std::exception_ptr m_error;
     std::thread m_thread;
+    // ---- reader -> decode thread: the generations whose demodulation is enqueued; it waits (host) for each and enqueues the frame's decode ----
+    std::deque<uint64_t> m_to_decode;
+    uint64_t m_decodes_submitted = 0;        // generations 0 .. m_decodes_submitted - 1 have their decode enqueued
+    uint64_t m_frames_submitted = 0;         // generations handed to the device by the reader
+    std::condition_variable m_cv_decode, m_cv_decoded;
+    std::thread m_decode_thread;
+    void DecodeThread();
     // DABGPU_MIRROR_PROFILE=1: where the two threads spend their time, microseconds, printed by the destructor
     bool m_profile = false;
     double m_t_sync_wait = 0, m_t_slot_wait = 0, m_t_submit = 0, m_t_frame_wait = 0, m_t_observers = 0, m_t_batcher = 0;

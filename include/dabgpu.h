@@ -37,8 +37,9 @@
 extern "C" {
 #endif
 
-/* 2: symbols_per_block = 0 no longer measures (dabgpu_ofdm_tune does, explicitly); receiver pipeline (dabgpu_receiver_*) */
-#define DABGPU_ABI_VERSION 2
+/* 2: symbols_per_block = 0 no longer measures (dabgpu_ofdm_tune does, explicitly); receiver pipeline (dabgpu_receiver_*)
+ * 3: dabgpu_receiver_submit_demod / _submit_decode (the OFDM_Demod mirror class needs them) */
+#define DABGPU_ABI_VERSION 3
 
 /* Mode I geometry (src/ofdm/dab_ofdm_params_ref.cpp:13-21, src/dab/constants/dab_parameters.h:31-40) */
 #define DABGPU_NB_FRAME_SYMBOLS 76
@@ -545,6 +546,14 @@ int dabgpu_receiver_wait_sync(dabgpu_receiver *rx, dabgpu_sync_state *out, float
  * upload, demodulation, fine-frequency update with `beta`, decode, results to host memory.  *generation counts the frames submitted. */
 int dabgpu_receiver_submit_frame(dabgpu_receiver *rx, size_t frame_sample, float fine_freq_update_beta, int want_views, int tie_rule,
                                  uint64_t *generation);
+/* The same in two calls, for two threads (what the OFDM_Demod mirror does): submit_demod enqueues the upload, the demodulation, the fine-frequency
+ * update and the copies of what the host reads, and returns; submit_decode(generation) -- once per frame, in the order of the generations --
+ * waits on the HOST until that frame is demodulated and then enqueues its decode.  No stream waits for another on the device (several receivers of
+ * a process share hardware queues: a queue whose head waits holds back the other receiver's work behind it), and the thread that frames the stream
+ * issues half the runtime calls.  At most 4 frames may be between the two calls (the decode of frame g reads the history slot frame g + 4 overwrites:
+ * DABGPU_ERR_NOT_READY); dabgpu_receiver_wait_frame(g) only after submit_decode(g) has returned.  Replaces the same hand-over as above. */
+int dabgpu_receiver_submit_demod(dabgpu_receiver *rx, size_t frame_sample, float fine_freq_update_beta, int want_views, uint64_t *generation);
+int dabgpu_receiver_submit_decode(dabgpu_receiver *rx, uint64_t generation, int tie_rule);
 int dabgpu_receiver_wait_frame(dabgpu_receiver *rx, uint64_t generation, dabgpu_receiver_frame *out);
 
 /* ==================================================================================================

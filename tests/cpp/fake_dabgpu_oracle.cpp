@@ -5,6 +5,7 @@
 // Results are the oracle's, i.e. the ones the device produces (that equality is what the -m gpu tests establish); here only the
 // threading and memory behaviour of the host code is under test.
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -226,7 +227,7 @@ struct dabgpu_receiver {
     dabgpu_sync_state record = {0, 0, 0, 0, 0, 0};
     std::vector<float> imp, frq;
     bool sync_pending = false, sync_coarse = false;
-    int decode_fic = 0;
+    std::atomic<int> decode_fic{0};
     std::mutex mu;                                       // result slots: written by the reader thread, read by the delivery thread
     struct Slot { uint64_t gen = ~0ull; std::vector<int8_t> bits; float fine = 0, total = 0; std::vector<float> fft, dq; } slots[8];
     uint64_t next = 0;
@@ -278,7 +279,7 @@ int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state* out, float
     if (frq && rx->sync_coarse) std::memcpy(frq, rx->frq.data(), rx->frq.size() * sizeof(float));
     return DABGPU_OK;
 }
-int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie, uint64_t* generation) {
+int dabgpu_receiver_submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation) {
     if (!rx || rx->sync_pending) return DABGPU_ERR_INVALID_ARG;
     const size_t n_bits = (size_t)(rx->g.nb_frame_symbols - 1) * 2 * rx->g.nb_carriers;
     std::vector<int8_t> bits(n_bits);
@@ -289,14 +290,10 @@ int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float
                                  : dabgpu_ofdm_demod_stream_frame_sync_mode(rx->ctx, rx->mode, iq, rx->state.freq_coarse, &fine, beta, bits.data(), &total, want_views ? fft.data() : nullptr);
     if (st) return st;
     rx->state.freq_fine = fine;
-    uint64_t gen = 0;
-    if (rx->mode == 1) {
-        if (dabgpu_frame_session_push_frame(rx->ses, bits.data(), rx->decode_fic, tie, &gen)) return DABGPU_ERR_HIP;
-    } else {
-        gen = rx->next;
-    }
+    uint64_t gen;
     {
         std::lock_guard<std::mutex> g(rx->mu);
+        gen = rx->next;
         auto& sl = rx->slots[gen % 8];
         sl.gen = gen; sl.bits = std::move(bits); sl.fine = fine; sl.total = total; sl.fft = std::move(fft);
         sl.dq.assign(want_views && rx->mode == 1 ? (size_t)(rx->g.nb_frame_symbols - 1) * rx->g.nb_carriers * 2 : 0, 0.0f);
@@ -305,6 +302,23 @@ int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float
     rx->cur = (rx->cur + 1) % 3;
     if (generation) *generation = gen;
     return DABGPU_OK;
+}
+// the decode of a demodulated frame: the frame session's push (its generations count the same frames)
+int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t gen, int tie) {
+    if (!rx) return DABGPU_ERR_INVALID_ARG;
+    if (rx->mode != 1) return DABGPU_OK;
+    std::vector<int8_t> bits;
+    { std::lock_guard<std::mutex> g(rx->mu); if (rx->slots[gen % 8].gen != gen) return DABGPU_ERR_NOT_READY; bits = rx->slots[gen % 8].bits; }
+    uint64_t sgen = 0;
+    if (dabgpu_frame_session_push_frame(rx->ses, bits.data(), rx->decode_fic, tie, &sgen) || sgen != gen) return DABGPU_ERR_HIP;
+    return DABGPU_OK;
+}
+int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie, uint64_t* generation) {
+    uint64_t gen = 0;
+    int st = dabgpu_receiver_submit_demod(rx, frame_sample, beta, want_views, &gen);
+    if (!st) st = dabgpu_receiver_submit_decode(rx, gen, tie);
+    if (!st && generation) *generation = gen;
+    return st;
 }
 int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t gen, dabgpu_receiver_frame* out) {
     if (!rx || !out) return DABGPU_ERR_INVALID_ARG;

@@ -36,12 +36,17 @@ def _api(dabgpu):
     L.dabgpu_receiver_wait_sync.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dabgpu_receiver_submit_frame.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.dabgpu_receiver_wait_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.dabgpu_receiver_submit_demod.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.POINTER(C.c_uint64)]
+    L.dabgpu_receiver_submit_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
     L.dabgpu_frame_session_fetch_fib_group.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.dabgpu_frame_session_fetch_cif.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     return L
 
 
-def test_receiver_pipeline_equals_the_oracle_composition(oracle):
+@pytest.mark.parametrize("calls", ["submit_frame", "submit_demod_then_decode"])
+def test_receiver_pipeline_equals_the_oracle_composition(oracle, calls):
+    """calls: dabgpu_receiver_submit_frame (one call: the decode waits for the demodulation on the device), or dabgpu_receiver_submit_demod followed -- here
+    two frames LATER, as another thread would -- by dabgpu_receiver_submit_decode (the host waits; no stream waits for another): the same bytes"""
     import dabgpu
     import stream_model as SM
     O = oracle
@@ -61,7 +66,7 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle):
         st_o = O.SyncState(0.0, 0.0, 0, 0, 0, 0)
         conj_ref, time_ref = O.sync_refs()
         deint = [O.Deinterleaver(s.length * 8) for s in subs_o]
-        pending, expected = [], {}
+        pending, expected, undecoded = [], {}, []
         for j in range(n_frames + 1):
             if j < n_frames:
                 # the receiver expects the PRS `toff` samples before where it is: NULL | PRS slot | ... of frame j in the staging buffer
@@ -87,7 +92,13 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle):
                 r = O.demod_frame(stage[NULL + off:NULL + off + FRAME].copy(), f)
                 st_o.freq_fine = float(O.update_fine_freq(st_o.freq_fine, r["total_phase"]))
                 gen = C.c_uint64()
-                ck(L.dabgpu_receiver_submit_frame(rx, NULL + off, cfg.fine_freq_update_beta, 0, 0, C.byref(gen)), "dabgpu_receiver_submit_frame")
+                if calls == "submit_frame":
+                    ck(L.dabgpu_receiver_submit_frame(rx, NULL + off, cfg.fine_freq_update_beta, 0, 0, C.byref(gen)), "dabgpu_receiver_submit_frame")
+                else:
+                    ck(L.dabgpu_receiver_submit_demod(rx, NULL + off, cfg.fine_freq_update_beta, 0, C.byref(gen)), "dabgpu_receiver_submit_demod")
+                    undecoded.append(j)
+                    while len(undecoded) > 2:
+                        ck(L.dabgpu_receiver_submit_decode(rx, undecoded.pop(0), 0), "dabgpu_receiver_submit_decode")
                 assert gen.value == j
                 exp = dict(bits=r["bits"], fine=np.float32(st_o.freq_fine), total=np.float32(r["total_phase"]))
                 exp["fib"] = [O.fic_decode_group(r["bits"][g * 2304:(g + 1) * 2304], 0) for g in range(4)]
@@ -105,6 +116,8 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle):
             # collect late: three frames in flight
             while pending and (len(pending) > 3 or j == n_frames):
                 g = pending.pop(0)
+                while undecoded and undecoded[0] <= g:
+                    ck(L.dabgpu_receiver_submit_decode(rx, undecoded.pop(0), 0), "dabgpu_receiver_submit_decode")
                 fr = Frame()
                 ck(L.dabgpu_receiver_wait_frame(rx, g, C.byref(fr)), "dabgpu_receiver_wait_frame")
                 e = expected.pop(g)
