@@ -690,7 +690,6 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
         if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate(session)");
         if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming), "hipEventCreate(session)");
         if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming), "hipEventCreate(session)");
-        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_bits, hipEventDisableTiming), "hipEventCreate(session)");
     }
     if (st) { dabgpu_frame_session_destroy(s); return st; }
     *out = s;
@@ -712,7 +711,6 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
         if (sl.ev_copied) (void)hipEventDestroy(sl.ev_copied);
-        if (sl.ev_bits) (void)hipEventDestroy(sl.ev_bits);
     }
     if (s->d_hist) (void)hipFree(s->d_hist);
     if (s->d_block) (void)hipFree(s->d_block);

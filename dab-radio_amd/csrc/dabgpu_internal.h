@@ -202,7 +202,6 @@ struct dabgpu_frame_session {
         uint8_t* h_msc = nullptr; dabgpu_codeword_result* h_mres = nullptr;      // (into h_block) [4][cif_out], [4][n_sub]
         hipEvent_t done = nullptr;
         hipEvent_t ev_ready = nullptr, ev_copied = nullptr;                    // receiver pipeline: frame demodulated / its host copies made (producer stream)
-        hipEvent_t ev_bits = nullptr; bool bits_elsewhere = false;             // ... / its soft bits copied by dabgpu_receiver_submit_decode on a third stream
         // receiver pipeline only (pinned, allocated at first use): the frame's soft bits, a few scalars of the producer, display views
         int8_t* h_bits = nullptr; float* h_aux = nullptr; float* h_fft = nullptr; float* h_dq = nullptr;
         size_t h_fft_cap = 0, h_dq_cap = 0;

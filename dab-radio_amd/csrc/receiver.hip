@@ -67,7 +67,6 @@ extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     if (rx->ctx) {
         (void)hipSetDevice(rx->ctx->device);
         if (rx->a) (void)hipStreamSynchronize(rx->a);
-        (void)hipStreamSynchronize(rx->ctx->stream);             // (soft-bit copies of the two-call form)
     }
     if (rx->ses) dabgpu_frame_session_destroy(rx->ses);          // (synchronises stream B)
     for (int k = 0; k < STAGES; k++) {
@@ -191,8 +190,7 @@ extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state*
 
 // Stream A's share of a frame: upload, demodulation into the session's history slot, fine-frequency update, the copies the host reads.  The slot's
 // ev_ready fires when the soft bits are in the history slot, ev_copied when the host copies are made.
-static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation, dabgpu_frame_session::slot** slot_out,
-                        bool bits_elsewhere) {
+static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation, dabgpu_frame_session::slot** slot_out) {
     const size_t frame_samples = (size_t)rx->geom[6], n_fft = (size_t)rx->geom[3], n_sym = (size_t)rx->geom[0], frame_bits = (size_t)rx->geom[8];
     if (frame_sample + frame_samples > rx->stage_cap) { dabgpu_set_error("receiver_submit_frame: the frame lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
@@ -241,10 +239,7 @@ static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, in
     // the cyclic-prefix angles), the display views -- is copied on THIS stream beside it (the 230 KB of soft bits used to sit on the session's
     // stream in front of every trellis launch); the slot's done event waits for both
     CK(hipEventRecord(sl->ev_ready, a));
-    // (two-call form: the 230 KB of soft bits are copied by dabgpu_receiver_submit_decode on a third stream -- behind them on THIS stream the next
-    //  frame's synchroniser would wait 20 us longer for its turn; the scalars and the views stay here: the next frame overwrites their sources)
-    sl->bits_elsewhere = bits_elsewhere;
-    if (!bits_elsewhere) CK(hipMemcpyAsync(sl->h_bits, d_bits, frame_bits, hipMemcpyDeviceToHost, a));
+    CK(hipMemcpyAsync(sl->h_bits, d_bits, frame_bits, hipMemcpyDeviceToHost, a));
     CK(hipMemcpyAsync(sl->h_aux, rx->d_rec, REC_HEAD, hipMemcpyDeviceToHost, a));
     if (want_views) CK(hipMemcpyAsync(sl->h_fft, rx->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
     if (want_dq) CK(hipMemcpyAsync(sl->h_dq, rx->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
@@ -266,7 +261,7 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
     if (!rx) { dabgpu_set_error("receiver_submit_frame: null receiver"); return DABGPU_ERR_INVALID_ARG; }
     uint64_t gen = 0;
     dabgpu_frame_session::slot* sl = nullptr;
-    int st = submit_demod(rx, frame_sample, beta, want_views, &gen, &sl, false);
+    int st = submit_demod(rx, frame_sample, beta, want_views, &gen, &sl);
     if (st) return st;
     DABGPU_BIND(rx->ctx);
     const int fic = rx->decode_fic.load();
@@ -282,7 +277,7 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
 // hardware queue, and a queue whose head waits for another queue's event holds back the other receiver's work behind it.
 extern "C" int dabgpu_receiver_submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation) {
     if (!rx) { dabgpu_set_error("receiver_submit_demod: null receiver"); return DABGPU_ERR_INVALID_ARG; }
-    return submit_demod(rx, frame_sample, beta, want_views, generation, nullptr, true);
+    return submit_demod(rx, frame_sample, beta, want_views, generation, nullptr);
 }
 
 extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t generation, int tie_rule) {
@@ -292,11 +287,6 @@ extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t gener
     dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];
     int st = dabgpu_check_hip(hipEventSynchronize(sl->ev_ready), "hipEventSynchronize(receiver frame demodulated)");
     if (st) return st;
-    if (sl->bits_elsewhere) {                     // the frame's soft bits to the host, on the receiver context's own (otherwise idle) stream
-        const int8_t* d_bits = s->d_hist + (size_t)(generation % dabgpu_frame_session::H) * DABGPU_NB_FRAME_BITS;
-        if ((st = dabgpu_check_hip(hipMemcpyAsync(sl->h_bits, d_bits, (size_t)rx->geom[8], hipMemcpyDeviceToHost, rx->ctx->stream), "hipMemcpyAsync(receiver soft bits)"))) return st;
-        if ((st = dabgpu_check_hip(hipEventRecord(sl->ev_bits, rx->ctx->stream), "hipEventRecord(receiver soft bits)"))) return st;
-    }
     const int fic = rx->decode_fic.load();
     bool decode;
     { std::lock_guard<std::mutex> lock(s->mu); decode = rx->mode == 1 && (fic || !s->subs.empty()); }
@@ -325,7 +315,6 @@ extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generati
     }
     // (the host copies of the producer stream: already behind `done` after dabgpu_receiver_submit_frame, on their own after _submit_decode)
     { int st = dabgpu_check_hip(hipEventSynchronize(sl->ev_copied), "hipEventSynchronize(receiver copies)"); if (st) return st; }
-    if (sl->bits_elsewhere) { int st = dabgpu_check_hip(hipEventSynchronize(sl->ev_bits), "hipEventSynchronize(receiver soft bits)"); if (st) return st; }
     out->generation = generation;
     out->bits = sl->h_bits;
     out->n_bits = (size_t)rx->geom[8];
