@@ -17,6 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--repeats", type=int, default=40)
 ap.add_argument("--subchannels", type=int, default=18)
+ap.add_argument("--cli", default=None, help="another build of dabgpu_radio_cli (A/B of builds)")
+ap.add_argument("--libdir", default=None, help="directory of the libdabgpu.so that build runs on")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 prs, mapper, _ = dabgpu.host_tables()
@@ -33,14 +35,14 @@ capture = torch.clamp(torch.round(sv / peak * 127.0 + 127.5), 0, 255).to(torch.u
 del x, n, sv
 torch.cuda.synchronize()
 
-cli = os.path.join(ROOT, "dab-radio_amd", "host", "apps", "dabgpu_radio_cli")
+cli = a.cli or os.path.join(ROOT, "dab-radio_amd", "host", "apps", "dabgpu_radio_cli")
 tmp = tempfile.TemporaryDirectory()
 args = [cli, "--configuration", "dab+ofdm", "--ofdm-input-mode", "raw_u8", "--radio-fib-output", os.path.join(tmp.name, "fibs.bin"),
         "--radio-msc-output", os.path.join(tmp.name, "msc_")]
 for s in range(a.subchannels):
     args += ["--radio-subchannel", f"{48 * s},48,3,A"]
 env = dict(os.environ)
-env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+env["LD_LIBRARY_PATH"] = (a.libdir or os.path.join(ROOT, "dab-radio_amd")) + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
 p = subprocess.Popen(args, stdin=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
 samples = []                                                 # (seconds, repetitions written, VmRSS kB, device bytes used)
 written = [0]
