@@ -189,3 +189,41 @@ def test_receivers_come_and_go_without_leaking_device_memory():
             torch.cuda.synchronize()
             free.append(torch.cuda.mem_get_info()[0])
     assert free[1] >= free[0] - (8 << 20), free
+
+
+def test_decoder_contexts_and_streams_come_and_go_without_leaking():
+    """what an MSC_Decoder owns -- a context of its own and a 16-CIF stream on it (dab/msc/msc_decoder.cpp; basic_radio creates one per selected
+    service and drops it on deselection) -- created, fed 17 CIFs, decoded and destroyed 120 times: device memory and the process's resident set
+    afterwards are what they were after the first twenty"""
+    import re
+    import dabgpu
+    import torch
+    L = dabgpu.lib()
+    L.dabgpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
+    L.dabgpu_destroy.argtypes = [C.c_void_p]
+    L.dabgpu_msc_stream_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.dabgpu_msc_stream_destroy.argtypes = [C.c_void_p]
+    L.dabgpu_msc_stream_push_cif.argtypes = [C.c_void_p, C.c_void_p]
+    L.dabgpu_msc_stream_decode_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_int]
+    rng = np.random.default_rng(3)
+    marks = []
+    for k in range(120):
+        length = (24, 48, 72, 27)[k % 4]
+        sc = dabgpu.SubChannel(0, length, False, 0, 2 if length != 27 else 0, 0 if length != 27 else 1)
+        ctx, st = C.c_void_p(), C.c_void_p()
+        dabgpu.check(L.dabgpu_create(C.byref(ctx), 0, None, None), "dabgpu_create")
+        dabgpu.check(L.dabgpu_msc_stream_create(ctx, C.byref(sc), C.byref(st)), "dabgpu_msc_stream_create")
+        cif = rng.integers(-127, 128, length * 64, dtype=np.int8)
+        out = np.zeros(length * 8, np.uint8)
+        n, err = C.c_size_t(), C.c_uint64()
+        for c in range(17):
+            dabgpu.check(L.dabgpu_msc_stream_push_cif(st, cif.ctypes.data), "dabgpu_msc_stream_push_cif")
+            rc = L.dabgpu_msc_stream_decode_sync(st, out.ctypes.data, C.byref(n), C.byref(err), 0)
+            assert rc == (0 if c >= 15 else 4), (k, c, rc)                 # 4 = DABGPU_ERR_NOT_READY: the time de-interleaver is filling
+        L.dabgpu_msc_stream_destroy(st)
+        L.dabgpu_destroy(ctx)
+        if k in (19, 119):
+            torch.cuda.synchronize()
+            rss = int(re.search(r"VmRSS:\s+(\d+)", open("/proc/self/status").read()).group(1))
+            marks.append((torch.cuda.mem_get_info()[0], rss))
+    assert marks[1][0] >= marks[0][0] - (8 << 20) and marks[1][1] <= marks[0][1] + 16 * 1024, marks
