@@ -79,6 +79,7 @@ public:
     void Process(tcb::span<const std::complex<float>> block);
     void Reset();
     void Synchronize();
+#define DABGPU_MIRROR_HAS_SYNCHRONIZE 1
 
     OFDM_Params GetOFDMParams() const { return m_params; }
     State GetState() const { return m_state; }

@@ -4,7 +4,7 @@
 // from a given frame on) + the MSC_Decoders alive at that frame.
 //
 //   mirror_lifecycle_driver <iq.c32> <out_dir> <block_size> <script.txt>
-//   script lines:  <frame> add <id> <start_cu> <length_cu> <eep_level> <eep_type_b>      before frame <frame> is decoded
+//   script lines:  <frame> add <id> <start_cu> <length_cu> <eep_level> <eep_type_b> [<is_uep> <uep_index>]      before frame <frame> is decoded
 //                  <frame> del <id>
 //                  <frame> fic <0|1>
 // Output: out_dir/msc_<id>.bin = records { u32 frame, u32 cif, u32 n, n bytes } of every DecodeCIF call of decoder <id> (n = 0 while its time
@@ -34,7 +34,7 @@ void append(const std::string& path, const void* data, size_t n) {
     std::ofstream f(path, std::ios::binary | std::ios::app);
     f.write(static_cast<const char*>(data), (std::streamsize)n);
 }
-struct Event { int frame; std::string op; int id, start, length, level, type_b; };
+struct Event { int frame; std::string op; int id, start, length, level, type_b, is_uep, uep_index; };
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -49,9 +49,9 @@ int main(int argc, char** argv) {
         std::string line;
         while (std::getline(sf, line)) {
             std::istringstream ls(line);
-            Event e{0, "", 0, 0, 0, 0, 0};
+            Event e{0, "", 0, 0, 0, 0, 0, 0, 0};
             if (!(ls >> e.frame >> e.op)) continue;
-            if (e.op == "add") ls >> e.id >> e.start >> e.length >> e.level >> e.type_b;
+            if (e.op == "add") { ls >> e.id >> e.start >> e.length >> e.level >> e.type_b; if (!(ls >> e.is_uep >> e.uep_index)) e.is_uep = e.uep_index = 0; }
             else ls >> e.id;
             script.push_back(e);
         }
@@ -70,6 +70,8 @@ int main(int argc, char** argv) {
                 sc.length = (subchannel_size_t)e.length;
                 sc.eep_prot_level = (eep_protection_level_t)e.level;
                 sc.eep_type = e.type_b ? EEP_Type::TYPE_B : EEP_Type::TYPE_A;
+                sc.is_uep = e.is_uep != 0;
+                sc.uep_prot_index = (uep_protection_index_t)e.uep_index;
                 sc.is_complete = true;
                 msc[e.id] = std::make_unique<MSC_Decoder>(sc);
             } else if (e.op == "del") {

@@ -147,8 +147,9 @@ class StreamModel:
                 pos += self.read_symbols(rest)
 
 
-def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=1234, noise=3.0, amplitude=1.0 / 39.2, payload=None):
-    """n_frames transmission frames: FIC = 4 groups of 3 CRC-valid random FIBs, MSC = the listed EEP sub-channels
+def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=1234, noise=3.0, amplitude=1.0 / 39.2, payload=None, fib_data=None):
+    """n_frames transmission frames: FIC = 4 groups of 3 CRC-valid FIBs (random bytes, or fib_data [n_frames][4][3][30] -- e.g. the FIGs of
+    tools/dabfig.py -- to which the CRC is added by the encoder), MSC = the listed EEP / UEP sub-channels
     (random payload, time interleaved across CIFs), other capacity units random bits; then CFO, noise, a lead-in of
     noise-only samples so that the NULL detector has a level to compare with.
     Returns (stream c64, dict with the transmitted fib bytes [n_frames][4][90] and payload per sub-channel [n_cif][nbytes])."""
@@ -163,6 +164,8 @@ def make_ensemble_stream(oracle, n_frames, subs, seed, cfo=1.8e-3, timing_pad=12
         tx = oracle.time_interleave(lf)
         cif_bits[:, s.start_address * 64:(s.start_address + s.length) * 64] = tx
     fibs = rng.integers(0, 256, (n_frames, 4, 90), dtype=np.uint8)
+    if fib_data is not None:
+        fibs = np.ascontiguousarray(fib_data, dtype=np.uint8).reshape(n_frames, 4, 90)
     frames = []
     for f in range(n_frames):
         bits = np.empty(oracle.NB_FRAME_BITS, np.uint8)
