@@ -657,10 +657,11 @@ def dry_run(args, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))
+    own = time.perf_counter() - t0                      # this rank's own steps, before it waits for the others (as in main())
     shard.barrier(dist if world > 1 else None)
     mine = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(mine, dist if world > 1 else None)
-    per_rank = shard.all_ranks(mine / args.steps * 1e3, dist if world > 1 else None)
+    per_rank = shard.all_ranks(own / args.steps * 1e3, dist if world > 1 else None)
     covered = shard.sum_over_ranks(n, dist if world > 1 else None)
     if rank == 0:
         print(json.dumps({"metric": "dab_mode1_frames_per_sec", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

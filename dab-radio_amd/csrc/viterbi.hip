@@ -83,7 +83,8 @@ __device__ __forceinline__ void acs_step(uint32_t& metric, uint32_t& hist, const
     const uint32_t m508 = metric + 508u;
     const uint32_t c_self = m508 - ds;
     const uint32_t c_part = xchg<P>(m508, lane) + ds;                    // (the DPP phases: one v_add_u32_dpp)
-    const uint16_t cs = (uint16_t)c_self, cp = (uint16_t)c_part;          // u16 wrap like the reference core
+    // core model 0 (scalar core): the uint16_t sums wrap; model 1 (SIMD cores): adds_epu16, they saturate at 65535 (two v_min_u32)
+    const uint16_t cs = (uint16_t)(TIE ? min(c_self, 65535u) : c_self), cp = (uint16_t)(TIE ? min(c_part, 65535u) : c_part);
     // lower lanes: upper predecessor = partner, chosen iff cp < cs (TIE 0) / <= (TIE 1);
     // upper lanes: upper predecessor = self,    chosen iff cs < cp (TIE 0) / <= (TIE 1)      (K.up1 holds the tie rule's -1)
     int d = (int)cp - (int)cs;

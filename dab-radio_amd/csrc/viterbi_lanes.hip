@@ -78,8 +78,8 @@ __device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t
         for (int i = 0; i < 16; i++) {
             const int s = vl_sigma(vl_ins_zero(i, Q));
             const s2 c1 = C[s], c2 = C[7 - s];
-            const s2 t1 = add16(M[i], c1), t2 = add16(M[i + 16], c2);         // new state 2b:   lower + e | upper + (1016 - e)
-            const s2 t3 = add16(M[i], c2), t4 = add16(M[i + 16], c1);         // new state 2b+1: lower + (1016 - e) | upper + e
+            const s2 t1 = addm<TIE>(M[i], c1), t2 = addm<TIE>(M[i + 16], c2);         // new state 2b:   lower + e | upper + (1016 - e)
+            const s2 t3 = addm<TIE>(M[i], c2), t4 = addm<TIE>(M[i + 16], c1);         // new state 2b+1: lower + (1016 - e) | upper + e
             N[2 * i] = min16(t1, t2);
             N[2 * i + 1] = min16(t3, t4);
             // decision 1 = upper predecessor: TIE 0 iff lower > upper (sign of upper - lower); TIE 1 iff !(lower < upper)
@@ -92,8 +92,8 @@ __device__ __forceinline__ void vl_step(const s2 (&M)[32], s2 (&N)[32], uint32_t
 #pragma unroll
         for (int b = 0; b < 32; b++) {
             const int s = vl_sigma(b);
-            const s2 lower = add16(__builtin_shufflevector(M[b], M[b], 0, 0), C[s]);          // (old[b] + e, old[b] + 1016 - e)
-            const s2 upper = add16(__builtin_shufflevector(M[b], M[b], 1, 1), C[7 - s]);      // (old[b+32] + 1016 - e, old[b+32] + e)
+            const s2 lower = addm<TIE>(__builtin_shufflevector(M[b], M[b], 0, 0), C[s]);          // (old[b] + e, old[b] + 1016 - e)
+            const s2 upper = addm<TIE>(__builtin_shufflevector(M[b], M[b], 1, 1), C[7 - s]);      // (old[b+32] + 1016 - e, old[b+32] + e)
             N[b] = min16(lower, upper);
             D[b] = TIE ? satsub16(lower, upper) : satsub16(upper, lower);
         }

@@ -87,8 +87,8 @@ __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane
             if (ra & rb) continue;
             const int rbb = ra | rb, s = vo_reg_pat(ra, Q);
             const s2 c1 = C[s], c2 = C[7 - s];
-            const s2 t1 = add16(M[ra], c1), t2 = add16(M[rbb], c2);           // new state 2b:   lower + e | upper + (1016 - e)
-            const s2 t3 = add16(M[ra], c2), t4 = add16(M[rbb], c1);           // new state 2b+1: lower + (1016 - e) | upper + e
+            const s2 t1 = addm<TIE>(M[ra], c1), t2 = addm<TIE>(M[rbb], c2);           // new state 2b:   lower + e | upper + (1016 - e)
+            const s2 t3 = addm<TIE>(M[ra], c2), t4 = addm<TIE>(M[rbb], c1);           // new state 2b+1: lower + (1016 - e) | upper + e
             M[ra] = min16(t1, t2);
             M[rbb] = min16(t3, t4);
             D[ra] = TIE ? satsub16(t1, t2) : satsub16(t2, t1);
@@ -98,8 +98,8 @@ __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int s = vo_reg_pat(r, Q);
-            const s2 lower = add16(__builtin_shufflevector(M[r], M[r], 0, 0), C[s]);
-            const s2 upper = add16(__builtin_shufflevector(M[r], M[r], 1, 1), C[7 - s]);
+            const s2 lower = addm<TIE>(__builtin_shufflevector(M[r], M[r], 0, 0), C[s]);
+            const s2 upper = addm<TIE>(__builtin_shufflevector(M[r], M[r], 1, 1), C[7 - s]);
             M[r] = min16(lower, upper);
             D[r] = TIE ? satsub16(lower, upper) : satsub16(upper, lower);
         }
@@ -107,8 +107,8 @@ __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int s = vo_reg_pat(r, Q);
-            const s2 own = add16(M[r], C[s]);                                  // this lane's predecessor -> this lane's new state (cost e)
-            const s2 give = add16(M[r], C[7 - s]);                             // this lane's predecessor -> the partner's new state (1016 - e)
+            const s2 own = addm<TIE>(M[r], C[s]);                                  // this lane's predecessor -> this lane's new state (cost e)
+            const s2 give = addm<TIE>(M[r], C[7 - s]);                             // this lane's predecessor -> the partner's new state (1016 - e)
             const s2 recv = as_s2((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u32(give), 0x128, 0xF, 0xF, true));
             M[r] = min16(own, recv);
             // lanes with bit 3 clear hold the LOWER predecessor: upper - lower = recv - own; the others: own - recv = -(recv - own).
@@ -121,7 +121,7 @@ __device__ __forceinline__ void vo_step(s2 (&M)[4], uint32_t ysym, const vo_lane
             const int s = vo_reg_pat(r, Q);
             // (the lanes that hold the upper predecessor use the complemented table, folded into their weights: their x is the
             // candidate for the PARTNER's new state, their y the one for their own)
-            const uint32_t x = as_u32(add16(M[r], C[s])), y = as_u32(add16(M[r], C[7 - s]));
+            const uint32_t x = as_u32(addm<TIE>(M[r], C[s])), y = as_u32(addm<TIE>(M[r], C[7 - s]));
             s2 lo, up;
             if constexpr (Q == 4) { const auto v = __builtin_amdgcn_permlane16_swap(x, y, false, false); lo = as_s2(v[0]); up = as_s2(v[1]); }
             else { const auto v = __builtin_amdgcn_permlane32_swap(x, y, false, false); lo = as_s2(v[0]); up = as_s2(v[1]); }

@@ -16,6 +16,14 @@ constexpr int VL_PRBS = 511;
 __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
 __device__ __forceinline__ s2 add16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
+// candidate = metric + branch cost under core model TIE: 0 = the scalar core's uint16_t sum, it wraps; 1 = the SIMD cores'
+// adds_epu16, it saturates at 65535 -- on the biased representation (stored = value - 32768) that is the SIGNED saturating add of a
+// non-negative cost: v_pk_add_i16 ... clamp, the same single instruction
+template <int TIE>
+__device__ __forceinline__ s2 addm(s2 a, s2 b) {
+    if constexpr (TIE != 0) return __builtin_elementwise_add_sat(a, b);
+    else return add16(a, b);
+}
 __device__ __forceinline__ s2 sub16(s2 a, s2 b) { return __builtin_bit_cast(s2, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
 __device__ __forceinline__ s2 min16(s2 a, s2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s2 satsub16(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }

@@ -47,7 +47,7 @@ uint64_t DAB_Viterbi_Decoder::chainback(tcb::span<uint8_t> bytes_out, const size
     if (m_current_decoded_bit == 0)
         throw std::invalid_argument("DAB_Viterbi_Decoder::chainback: nothing was decoded since reset()");
     uint64_t path_error = 0;
-    const int tie = std::getenv("DABGPU_TIE_RULE") ? std::atoi(std::getenv("DABGPU_TIE_RULE")) : 0;
+    const int tie = dabgpu_core_model_from_env();
     const int st = dabgpu_viterbi_decode_depunctured_host_sync(m_ctx, m_mother.data(), m_current_decoded_bit, (uint32_t)m_start_state,
                                                                (uint32_t)end_state, bytes_out.data(), bytes_out.size(), &path_error, tie);
     if (st == DABGPU_ERR_INVALID_ARG)           // a trace-back that starts beyond the decoded steps (the reference would read stale decision words)

@@ -31,7 +31,20 @@ dabgpu_ctx* dabgpu_private_context() {
     return ctx;
 }
 
-int dabgpu_tie_rule_from_env() {
-    const char* t = std::getenv("DABGPU_TIE_RULE");
-    return t ? std::atoi(t) : 0;
+int dabgpu_core_model_from_env() {
+    if (const char* c = std::getenv("DABGPU_VITERBI_CORE")) {
+        const std::string v = c;
+        if (v == "simd" || v == "1") return 1;
+        if (v == "scalar" || v == "0") return 0;
+        throw std::runtime_error("DABGPU_VITERBI_CORE must be 'scalar' or 'simd', not '" + v + "'");
+    }
+    if (const char* t = std::getenv("DABGPU_TIE_RULE")) return std::atoi(t) ? 1 : 0;
+    // what src/dab/algorithms/dab_viterbi_decoder.cpp:51-73 selects when the reference is built on this host with its default preset
+#if defined(__x86_64__) || defined(__i386__)
+    return (__builtin_cpu_supports("avx2") || __builtin_cpu_supports("sse4.1")) ? 1 : 0;
+#elif defined(__aarch64__)
+    return 1;
+#else
+    return 0;
+#endif
 }

@@ -148,8 +148,12 @@ void dab_scrambler_bytes(uint8_t *out, size_t n);
 uint16_t dab_crc16(const uint8_t *x, size_t n);
 
 /* Viterbi decoder: restates DAB_Viterbi_Decoder (src/dab/algorithms/dab_viterbi_decoder.cpp:84-181)
- * over the published ViterbiDecoderCpp scalar core. tie_rule 0: scalar core (upper predecessor only
- * if strictly smaller); 1: SIMD cores (min + cmpeq, upper predecessor on ties). */
+ * over the published ViterbiDecoderCpp cores.  `tie_rule` is the CORE MODEL (the name is kept for the callers):
+ *   0 = the scalar core (ViterbiDecoder_Scalar): uint16_t sums that WRAP, upper predecessor only if strictly smaller;
+ *   1 = the SIMD cores (ViterbiDecoder_AVX_u16 / _SSE_u16 / _NEON_u16, what dab_viterbi_decoder.cpp:51-73 selects on an
+ *       AVX2 / SSE4.1 / AArch64 build host): adds_epu16 sums that SATURATE at 65535, min_epu16 survivors, decision = cmpeq(survivor,
+ *       upper candidate), i.e. the upper predecessor on ties.
+ * Both remain restatements ("parity unpinned"): the vendor sources are an empty submodule here. */
 typedef struct dab_viterbi dab_viterbi;
 dab_viterbi *dab_viterbi_create(size_t traceback_length, int tie_rule);
 void   dab_viterbi_destroy(dab_viterbi *v);

@@ -138,7 +138,9 @@ static uint64_t viterbi_steps_avx2(dab_viterbi *v, const int16_t *sym, size_t n_
                 e = _mm256_add_epi16(e, _mm256_abs_epi16(_mm256_sub_epi16(br[r][h], _mm256_set1_epi16(sym[s0 + r]))));
             const __m256i m = _mm256_sub_epi16(kmax, e);
             const __m256i lo = _mm256_loadu_si256((const __m256i *)(old + 16 * h)), hi = _mm256_loadu_si256((const __m256i *)(old + 32 + 16 * h));
-            const __m256i m0 = _mm256_add_epi16(lo, e), m1 = _mm256_add_epi16(hi, m), m2 = _mm256_add_epi16(lo, m), m3 = _mm256_add_epi16(hi, e);
+            /* core model 1 (the upstream SIMD cores): _mm*_adds_epu16, the candidates SATURATE at 65535; model 0 (the scalar core): they wrap */
+            const __m256i m0 = v->tie_rule ? _mm256_adds_epu16(lo, e) : _mm256_add_epi16(lo, e), m1 = v->tie_rule ? _mm256_adds_epu16(hi, m) : _mm256_add_epi16(hi, m);
+            const __m256i m2 = v->tie_rule ? _mm256_adds_epu16(lo, m) : _mm256_add_epi16(lo, m), m3 = v->tie_rule ? _mm256_adds_epu16(hi, e) : _mm256_add_epi16(hi, e);
             const __m256i n0 = _mm256_min_epu16(m0, m1), n1 = _mm256_min_epu16(m2, m3);
             uint32_t k0, k1;
             if (v->tie_rule) {
@@ -192,10 +194,13 @@ static uint64_t viterbi_steps(dab_viterbi *v, const int16_t *sym, size_t n_sym) 
                 e = (uint16_t)(e + (uint16_t)(d < 0 ? -d : d));
             }
             const uint16_t m  = (uint16_t)(V_MAX_ERROR - e);
-            const uint16_t m0 = (uint16_t)(old[s] + e);
-            const uint16_t m1 = (uint16_t)(old[s + VSTATES / 2] + m);
-            const uint16_t m2 = (uint16_t)(old[s] + m);
-            const uint16_t m3 = (uint16_t)(old[s + VSTATES / 2] + e);
+            /* core model 0: uint16_t arithmetic of the scalar core, the sum wraps; model 1: adds_epu16 of the SIMD cores, it saturates */
+#define V_ADD(a, b) (v->tie_rule ? (uint16_t)((unsigned)(a) + (unsigned)(b) > 65535u ? 65535u : (unsigned)(a) + (unsigned)(b)) : (uint16_t)((a) + (b)))
+            const uint16_t m0 = V_ADD(old[s], e);
+            const uint16_t m1 = V_ADD(old[s + VSTATES / 2], m);
+            const uint16_t m2 = V_ADD(old[s], m);
+            const uint16_t m3 = V_ADD(old[s + VSTATES / 2], e);
+#undef V_ADD
             const int d0 = v->tie_rule ? (m1 <= m0) : (m0 > m1);
             const int d1 = v->tie_rule ? (m3 <= m2) : (m2 > m3);
             nw[2 * s]     = d0 ? m1 : m0;

@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import stream_model as SM
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "dab-radio_amd", "host", "apps", "dabgpu_radio_cli")
@@ -56,7 +58,7 @@ def expected_decode(oracle, frames_bits, subs):
     deint = [oracle.Deinterleaver(s.length * 8) for s in subs]
     for bits in frames_bits:
         for g in range(4):
-            eb, em, _ = oracle.fic_decode_group(bits[g * 2304:(g + 1) * 2304], 0)
+            eb, em, _ = oracle.fic_decode_group(bits[g * 2304:(g + 1) * 2304], SM.mirror_core_model())
             for i in range(3):
                 if em & (1 << i):
                     fibs += eb[32 * i:32 * i + 30].tobytes()
@@ -66,7 +68,7 @@ def expected_decode(oracle, frames_bits, subs):
                 deint[si].consume(cif[s.start_address * 64:(s.start_address + s.length) * 64])
                 lf = deint[si].deinterleave()
                 if lf is not None:
-                    msc[si] += oracle.msc_decode_logical(s, lf, 0)[0].tobytes()
+                    msc[si] += oracle.msc_decode_logical(s, lf, SM.mirror_core_model())[0].tobytes()
     return bytes(fibs), [bytes(m) for m in msc]
 
 

@@ -10,6 +10,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import stream_model as SM_CORE
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "tests", "cpp", "mirror_harness")
@@ -74,7 +76,7 @@ def test_cpp_mirror_stream_matches_oracle(oracle, tmp_path, decode_threads, batc
     n_valid = 0
     for k, fr in enumerate(model.out_frames):
         for g in range(4):
-            eb, em, ee = oracle.fic_decode_group(fr["bits"][g * 2304:(g + 1) * 2304], 0)
+            eb, em, ee = oracle.fic_decode_group(fr["bits"][g * 2304:(g + 1) * 2304], SM_CORE.mirror_core_model())
             assert int(st[k * 4 + g, :4].view(np.uint32)[0]) == em and int(st[k * 4 + g, 4:].view(np.uint64)[0]) == ee
             for i in range(3):
                 if em & (1 << i):
@@ -101,7 +103,7 @@ def test_cpp_mirror_stream_matches_oracle(oracle, tmp_path, decode_threads, batc
                 if lf is None:
                     exp_msc[si] += np.uint32(0).tobytes()
                 else:
-                    dec, _ = oracle.msc_decode_logical(s, lf, 0)
+                    dec, _ = oracle.msc_decode_logical(s, lf, SM_CORE.mirror_core_model())
                     exp_msc[si] += np.uint32(dec.size).tobytes() + dec.tobytes()
                     t = 4 * (k + first_tx_frame) + c - 15
                     n_msc_ok += int(np.array_equal(dec, truth["payload"][si][t]))

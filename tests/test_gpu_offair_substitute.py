@@ -12,6 +12,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import stream_model as SM_CORE
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "dab-radio_amd", "host", "apps", "dabgpu_radio_cli")
@@ -150,7 +152,7 @@ def test_mirror_classes_on_the_capture(oracle, capture, tmp_path, batch):
             if lf is None:
                 exp += np.uint32(0).tobytes()
             else:
-                dec, _ = oracle.msc_decode_logical(s, lf, 0)
+                dec, _ = oracle.msc_decode_logical(s, lf, SM_CORE.mirror_core_model())
                 exp += np.uint32(dec.size).tobytes() + dec.tobytes()
     assert (out / "msc_0.bin").read_bytes() == bytes(exp)
 

@@ -166,6 +166,92 @@ def test_viterbi_equals_int64_dynamic_programme_on_long_codewords(oracle, shape)
     assert done == 12
 
 
+def dp_decode_core(y, n_steps, n_out_bits, core):
+    """the two upstream cores as MODELS of their published add-compare-select, over Python integers: core 0 = ViterbiDecoder_Scalar (uint16_t sums
+    that wrap, `m0 > m1`), core 1 = the SIMD cores (adds_epu16: the sums saturate at 65535; min_epu16; decision = cmpeq(survivor, upper candidate));
+    both with the reference's renormalisation (dab_viterbi_decoder.cpp:31-41).  Returns (bits, path error, largest candidate sum seen before reduction)"""
+    metric = [5080] * 64
+    metric[0] = 0
+    total, biggest = 0, 0
+    choice = np.zeros((n_steps, 64), dtype=np.int8)
+    par = [[int(parity(sr & g)) for g in G] for sr in range(128)]
+    for t in range(n_steps):
+        new = [0] * 64
+        for n in range(64):
+            cand = []
+            for p in (n >> 1, (n >> 1) | 32):
+                sr = ((p << 1) | (n & 1)) & 0x7F
+                e = sum(abs((127 if par[sr][r] else -127) - int(y[4 * t + r])) for r in range(4))
+                v = metric[p] + e
+                biggest = max(biggest, v)
+                cand.append(min(v, 65535) if core else (v & 0xFFFF))
+            up = (cand[1] <= cand[0]) if core else (cand[1] < cand[0])
+            choice[t, n] = up
+            new[n] = cand[1] if up else cand[0]
+        if new[0] >= 60455:
+            mn = min(new)
+            new = [v - mn for v in new]
+            total += mn
+        metric = new
+    s = 0
+    bits = np.zeros(n_steps, dtype=np.uint8)
+    for t in range(n_steps - 1, -1, -1):
+        bits[t] = s & 1
+        s = ((s >> 1) | 32) if choice[t, s] else (s >> 1)
+    return bits[:n_out_bits], total + metric[0], biggest
+
+
+def test_u16_candidate_sums_cannot_reach_65535():
+    """Where the two upstream cores could differ besides ties: the scalar core's uint16_t sums wrap, the SIMD cores' adds_epu16 saturates.  For THIS code
+    (K = 7, polynomials 133 171 145 133) and symbols in [-127, 127] (include/dabgpu.h: -128 is read as -127) no input makes a sum reach 65535, so the two models differ in the tie rule only:
+      * after the first six steps every state has a path from every state of six steps ago, hence  metric(s) - min metric <= 254 * d(s ^ s*), d = the
+        weight of the lightest path from the all-zero state to that state difference (the code is linear) -- the fixed point computed below: 15 bits;
+      * a candidate adds one branch (<= 4 x 254; the complementary cost 1016 - e of the butterfly stays in [0, 1016] too), and the reference renormalises as soon as metric[0] >= 60455 (dab_viterbi_decoder.cpp:31-41), so before
+        any step min metric <= metric[0] <= 60454:  candidate <= 60454 + 254 * (15 + 4) = 65280 < 65535;
+      * in the first six steps after reset() the level is at most 5080 + 6 * 1016.
+    The bound is computed from the polynomials here (nothing shared with the oracle or the kernels) and then attacked: the hardest inputs a hill climb
+    finds (erasures up to just below the renormalisation threshold, then 15-17 steps of extreme symbols) stay below it, and both core models -- and the
+    oracle under both -- decode them identically."""
+    d = [10 ** 9] * 64
+    d[0] = 0
+    for _ in range(64):
+        nd = [min(d[p] + int(sum(parity((((p << 1) | (n & 1)) & 0x7F) & g) for g in G)) for p in (n >> 1, (n >> 1) | 32)) for n in range(64)]
+        nd[0] = 0
+        if nd == d:
+            break
+        d = nd
+    spread_bits = max(d)
+    assert spread_bits == 15
+    bound = 60454 + 254 * (spread_bits + 4)
+    assert bound == 65280 and bound < 65535
+    import oracle as O
+    O.build()
+    rng = np.random.default_rng(5)
+    worst = 0
+    for n_a in (117, 118, 119):                                   # 508 per erased step: 59436, 59944, 60452 -- the last is 3 below the threshold
+        n_steps = 134                                              # 128 message bits + the 6 tail steps the chain-back skips
+        n_b = n_steps - n_a
+        y = np.concatenate([np.zeros(4 * n_a, np.int64), rng.choice([-127, 127], size=4 * n_b)])
+        _, _, best = dp_decode_core(y, n_steps, 8, 0)
+        for _ in range(60):                                        # hill climb on the extreme symbols
+            y2 = y.copy()
+            y2[4 * n_a + rng.integers(0, 4 * n_b)] = rng.choice([-127, 127, 0])
+            b2 = dp_decode_core(y2, n_steps, 8, 0)[2]
+            if b2 >= best:
+                y, best = y2, b2
+        worst = max(worst, best)
+        n_bits = n_steps - 6
+        r0, r1 = dp_decode_core(y, n_steps, n_bits, 0), dp_decode_core(y, n_steps, n_bits, 1)
+        assert r0[2] == r1[2] <= bound
+        for core, r in ((0, r0), (1, r1)):
+            v = O.Viterbi(n_steps, core)
+            v.reset(0)
+            assert v.update(y.astype(np.int8), np.array([4], np.uint8), 4 * n_steps) == 4 * n_steps
+            got, err = v.chainback(n_bits // 8, 0)
+            assert err == r[1] and np.array_equal(got, np.packbits(r[0])), (n_a, core)
+    assert 60454 < worst <= bound, worst                          # the attack does get past the threshold level, and not past the bound
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # PRS synchroniser: float64 model of ofdm_demodulator.cpp:360-548
 # ---------------------------------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import stream_model as SM_CORE
 import test_mirror_host_logic as T
 
 ROOT = T.ROOT
@@ -68,7 +69,7 @@ def expected(O, frames, script):
                 fic_on = bool(ident)
         if fic_on:
             for g in range(4):
-                eb, em, _ = O.fic_decode_group(bits[g * 2304:(g + 1) * 2304], 0)
+                eb, em, _ = O.fic_decode_group(bits[g * 2304:(g + 1) * 2304], SM_CORE.mirror_core_model())
                 for i in range(3):
                     if em & (1 << i):
                         fibs += np.uint32(f).tobytes() + eb[32 * i:32 * i + 30].tobytes()
@@ -82,7 +83,7 @@ def expected(O, frames, script):
                 if lf is None:
                     rec += np.array([f, c, 0], np.uint32).tobytes()
                 else:
-                    dec, _ = O.msc_decode_logical(s, lf, 0)
+                    dec, _ = O.msc_decode_logical(s, lf, SM_CORE.mirror_core_model())
                     rec += np.array([f, c, dec.size], np.uint32).tobytes() + dec.tobytes()
     return bytes(fibs), {k: bytes(v) for k, v in msc.items()}
 
