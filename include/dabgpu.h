@@ -64,6 +64,7 @@ enum {
     DABGPU_ERR_NOT_READY = 4,      /* e.g. time de-interleaver has fewer than 16 CIFs */
     DABGPU_ERR_UNSUPPORTED = 5     /* transmission mode other than I */
 };
+enum { DABGPU_CORE_SCALAR = 0, DABGPU_CORE_SIMD = 1 };    /* values of the `tie_rule` argument: "CORE MODEL" at the channel decoder below */
 
 typedef struct dabgpu_ctx dabgpu_ctx;
 
@@ -273,8 +274,16 @@ int dabgpu_ofdm_sync_demod_frames(dabgpu_ctx *ctx, const float *d_iq, size_t n_s
  * CRC_Calculator<uint16_t> as used by the FIC (src/dab/fic/fic_decoder.cpp:19-31,103-116) and
  * CIF_Deinterleaver::Deinterleave (src/dab/msc/cif_deinterleaver.cpp:36-71).
  *
- * tie_rule: 0 = upstream scalar core (upper predecessor only when strictly smaller), 1 = upstream SIMD cores
- * (min + compare-equal: upper predecessor on ties).  Decoded bytes differ only on exact metric ties.
+ * tie_rule = the CORE MODEL (the argument keeps its round-1 name): which of the upstream ViterbiDecoderCpp cores the decoder restates.
+ *   DABGPU_CORE_SCALAR (0)  ViterbiDecoder_Scalar: uint16_t candidate sums that WRAP, the upper predecessor only when strictly smaller;
+ *   DABGPU_CORE_SIMD   (1)  ViterbiDecoder_AVX_u16 / _SSE_u16 / _NEON_u16 -- what src/dab/algorithms/dab_viterbi_decoder.cpp:51-73 selects on
+ *                           an AVX2 / SSE4.1 / AArch64 build host, i.e. the reference's default -march=native build on x86: adds_epu16 sums
+ *                           that SATURATE at 65535, min_epu16 survivors, decision = cmpeq(survivor, upper candidate): the upper predecessor on ties.
+ * For this code and soft bits in [-127, 127] no candidate sum can reach 65535 (at most 60454 + 254 * 19 = 65280: tests/test_independent_pins.py::
+ * test_u16_candidate_sums_cannot_reach_65535 derives the bound from the polynomials and attacks it), so the two models give different bytes only
+ * where two candidates tie exactly; both are implemented in full anyway.  Neither is pinned to upstream output here (vendor/viterbi_decoder is an
+ * empty submodule): "parity unpinned" for the core, DESIGN.md 3.6.  The C++ classes pick the model the reference's build would have picked on
+ * the host they run on (DABGPU_VITERBI_CORE=scalar|simd overrides; DABGPU_TIE_RULE=0|1 is the older spelling).
  * Soft bits are int8 in [-127,+127], 0 = punctured/erased (src/viterbi_config.h:11-14); -128 is read as -127.
  */
 typedef struct {
