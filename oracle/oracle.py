@@ -651,6 +651,31 @@ def coarse_freq_sync(prs_sym, state, cfg=None, prs_time_ref=None):
 # reference objects (only present where /root/reference was available at build time)
 # ------------------------------------------------------------------------------------------------
 _ref = None
+_ref_dec = None
+_REF_DEC_SO = os.path.join(_HERE, "_ref", "libdab_ref_decoders.so")
+
+
+def ref_decoders():
+    """oracle/_ref/libdab_ref_decoders.so (the reference's fic_decoder.cpp / msc_decoder.cpp / cif_deinterleaver.cpp compiled in place, over the RESTATED
+    Viterbi core: oracle/ref_harness_decoders.cpp) or None when it was never built"""
+    global _ref_dec
+    if _ref_dec is None:
+        build()
+        if not os.path.exists(_REF_DEC_SO):
+            return None
+        R = C.CDLL(_REF_DEC_SO)
+        R.ref_dec_set_core_model.argtypes = [C.c_int]
+        R.ref_fic_create.restype = C.c_void_p
+        R.ref_fic_create.argtypes = [C.c_size_t, C.c_size_t]
+        R.ref_fic_destroy.argtypes = [C.c_void_p]
+        R.ref_fic_decode_group.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        R.ref_msc_create.restype = C.c_void_p
+        R.ref_msc_create.argtypes = [C.c_int] * 7
+        R.ref_msc_destroy.argtypes = [C.c_void_p]
+        R.ref_msc_decode_cif.restype = C.c_long
+        R.ref_msc_decode_cif.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _ref_dec = R
+    return _ref_dec
 
 
 def ref():
