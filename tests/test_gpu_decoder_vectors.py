@@ -69,7 +69,7 @@ def test_every_protection_profile_equals_the_reference_decoders_output(ctx, vect
     fx, cs, cifs = vectors["fx"], vectors["cases"], vectors["cifs"]
     H, n_checked, refused = 8, 0, []
     if bits_layout == 1:
-        idx = dabgpu.classed_to_natural_index()                      # classed[k] = natural[idx[k]]
+        idx = dabgpu.classed_to_natural_index()                      # natural == classed[idx]
     ctx.viterbi_set_mapping(mapping)
     try:
         for m in range(cifs.shape[0]):
@@ -91,7 +91,9 @@ def test_every_protection_profile_equals_the_reference_decoders_output(ctx, vect
             for t in range(cifs.shape[1]):
                 hist[0, t // 4, 9216 + (t % 4) * 55296: 9216 + (t % 4 + 1) * 55296] = cifs[m, t]
             if bits_layout == 1:
-                hist = hist[:, :, idx]
+                classed = np.empty_like(hist)
+                classed[:, :, idx] = hist
+                hist = classed
             d_hist = torch.from_numpy(np.ascontiguousarray(hist)).cuda()
             total = sum(nb for _, nb in ok)
             d_out = torch.zeros((1, 4, total), dtype=torch.uint8, device="cuda")
