@@ -458,3 +458,9 @@ int dabgpu_wav_parse_header(const uint8_t* bytes, size_t n_bytes, dabgpu_wav_hea
 }
 
 }  // extern "C"
+
+extern "C" int dabgpu_subchannel_validate(const dabgpu_subchannel* sc) {
+    if (!sc) { dabgpu_set_error("subchannel_validate: null descriptor"); return DABGPU_ERR_INVALID_ARG; }
+    std::vector<dabgpu_msc_plan> one;
+    return dabgpu_host_build_msc_plans(sc, 1, one, nullptr, nullptr, nullptr);
+}

@@ -23,7 +23,7 @@ NB_FRAME_BITS = 230400
 NB_FIC_BITS = 9216
 NB_FIB_GROUP_BITS = 2304
 NB_CIF_BITS = 55296
-ABI_VERSION = 3                          # DABGPU_ABI_VERSION of include/dabgpu.h
+ABI_VERSION = 4                          # DABGPU_ABI_VERSION of include/dabgpu.h
 BITS_NATURAL, BITS_MSC_CLASSED = 0, 1     # dabgpu_ofdm_demod_frames_history / dabgpu_msc_decode_frames_layout
 
 
@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "dabgpu_get_prs_fft_ref", "dabgpu_get_carrier_mapper", "dabgpu_get_fft_twiddles",
     "dabgpu_ofdm_demod_frames", "dabgpu_ofdm_phase_update", "dabgpu_ofdm_demod_frames_host_sync", "dabgpu_ofdm_demod_stream_frame_sync",
     "dabgpu_sync_cfg_default", "dabgpu_ofdm_sync", "dabgpu_ofdm_sync_host_sync",
-    "dabgpu_viterbi_set_mapping", "dabgpu_ofdm_auto_symbols_per_block", "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_msc_decode_frames",
+    "dabgpu_viterbi_set_mapping", "dabgpu_ofdm_auto_symbols_per_block", "dabgpu_viterbi_decode_batch", "dabgpu_fic_decode_frames", "dabgpu_subchannel_plan", "dabgpu_subchannel_validate", "dabgpu_msc_decode_frames",
     "dabgpu_fic_decode_group_host_sync", "dabgpu_viterbi_decode_host_sync", "dabgpu_msc_stream_create",
     "dabgpu_msc_stream_destroy", "dabgpu_msc_stream_push_cif", "dabgpu_msc_stream_deinterleave_sync",
     "dabgpu_msc_stream_decode_sync",

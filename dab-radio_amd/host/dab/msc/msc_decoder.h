@@ -1,6 +1,8 @@
 // dab/msc/msc_decoder.h -- MSC_Decoder with the reference's public interface (src/dab/msc/msc_decoder.h:16-38)
-// over the MI355X C ABI: the sub-channel's 16-CIF ring stays in device memory; one launch per CIF does the time
-// de-interleave (by index), de-puncture (by index), Viterbi and descrambling.
+// over the MI355X C ABI.  In a receiver (an OFDM_Demod of this process feeds it) the decoder picks its bytes up from the demodulator's
+// batched decode of the whole frame and owns NO device object; decoded call by call (bits from a file, the first frames after its
+// creation) it creates, on that first call, a context of its own and a 16-CIF device ring: one launch per CIF does the time de-interleave
+// (by index), de-puncture (by index), Viterbi and descrambling.
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -22,8 +24,9 @@ public:
 
 private:
     const Subchannel m_subchannel;
-    dabgpu_msc_stream* m_stream;
-    struct dabgpu_ctx* m_ctx;          // this decoder's own device context (stream + scratch): decoders of different threads run side by side
+    void EnsureStream();
+    dabgpu_msc_stream* m_stream;       // null until the first call-by-call decode
+    struct dabgpu_ctx* m_ctx;          // then: this decoder's own device context (stream + scratch): decoders of different threads run side by side
     std::vector<uint8_t> m_decoded_bytes;
     uint64_t m_last_error = 0;
     // frame batcher (dab/dabgpu_frame_batcher.h): the sub-channel as registered, the batcher CIF consumed last, how many in a row

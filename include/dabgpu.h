@@ -39,7 +39,7 @@ extern "C" {
 
 /* 2: symbols_per_block = 0 no longer measures (dabgpu_ofdm_tune does, explicitly); receiver pipeline (dabgpu_receiver_*)
  * 3: dabgpu_receiver_submit_demod / _submit_decode (the OFDM_Demod mirror class needs them) */
-#define DABGPU_ABI_VERSION 3
+#define DABGPU_ABI_VERSION 4
 
 /* Mode I geometry (src/ofdm/dab_ofdm_params_ref.cpp:13-21, src/dab/constants/dab_parameters.h:31-40) */
 #define DABGPU_NB_FRAME_SYMBOLS 76
@@ -375,6 +375,11 @@ typedef struct {
 /* (PI, L) plan of a sub-channel as MSC_Decoder::DecodeEEP/DecodeUEP derive it (src/dab/msc/msc_decoder.cpp:77-131,
  * src/dab/constants/subchannel_protection_tables.h); returns the number of segments (<= 4) or -1 */
 int dabgpu_subchannel_plan(const dabgpu_subchannel *sc, int *pi4, int *l4, int *n_decoded_bytes);
+/* DABGPU_OK when the decoders accept the descriptor: a profile of the tables, inside the 864 capacity units of a CIF, and consuming no more
+ * soft bits than the sub-channel holds (UEP table row 34 as the reference lists it does: the reference's decoder runs out of symbols inside
+ * its third update(), dab_viterbi_decoder.cpp:157-160; here the descriptor is refused); else DABGPU_ERR_INVALID_ARG with the reason in
+ * dabgpu_last_error().  Host only, no device needed: what MSC_Decoder's constructor checks before anything is created (ABI 4). */
+int dabgpu_subchannel_validate(const dabgpu_subchannel *sc);
 
 /*
  * MSC of whole frames for many ensembles that share one multiplex configuration.  The time de-interleaver reads

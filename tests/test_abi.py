@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(dabgpu):
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/dabgpu.h but not exported"
     assert sorted(dabgpu.ABI_SYMBOLS) == syms
-    assert L.dabgpu_abi_version() == 3
+    assert L.dabgpu_abi_version() == 4
 
 
 def test_host_tables_match_oracle(dabgpu, oracle):

@@ -32,8 +32,11 @@ x = x + 0.02 * torch.view_as_complex(torch.randn((x.numel(), 2), device=dev))
 sv = torch.view_as_real(x)
 peak = float(sv.abs().max().item())
 capture = torch.clamp(torch.round(sv / peak * 127.0 + 127.5), 0, 255).to(torch.uint8).cpu().numpy().reshape(-1).tobytes()
-del x, n, sv
+del x, n, sv, f2, mux
 torch.cuda.synchronize()
+torch.cuda.empty_cache()
+_free0, _total0 = torch.cuda.mem_get_info()
+baseline_device = _total0 - _free0              # what THIS process (torch's context) holds on the device before the receiver starts: subtracted below
 
 cli = a.cli or os.path.join(ROOT, "dab-radio_amd", "host", "apps", "dabgpu_radio_cli")
 tmp = tempfile.TemporaryDirectory()
@@ -85,7 +88,8 @@ sub_bytes = [int(v) for v in re.findall(r"subchannel\d+_bytes=(\d+)", r.group(4)
 
 def at(frac):
     k = min(len(samples) - 1, int(len(samples) * frac))
-    return {"repetitions_written": samples[k][1], "host_rss_MB": round(samples[k][2] / 1024, 1), "device_used_MB": round(samples[k][3] / 2**20, 1)}
+    return {"repetitions_written": samples[k][1], "host_rss_MB": round(samples[k][2] / 1024, 1), "device_used_MB": round(samples[k][3] / 2**20, 1),
+            "receiver_device_MB": round((samples[k][3] - baseline_device) / 2**20, 1)}
 
 
 frames = int(m.group(1))
@@ -93,7 +97,7 @@ out = {"what": __doc__.split("\n\n")[0], "frames_per_repetition": a.frames, "rep
        "frames_read": frames, "frames_desync": int(m.group(2)), "radio_frames": int(r.group(1)), "fibs_crc_ok": int(r.group(2)),
        "fib_groups_with_failures": int(r.group(3)), "sub_channel_bytes": sorted(set(sub_bytes)), "seconds": round(t1 - t0, 2),
        "frames_per_s_incl_pipe": round(frames / (t1 - t0), 1), "signal_minutes": round(frames * 0.096 / 60, 1),
-       "memory_at_25_percent": at(0.25), "memory_at_60_percent": at(0.6), "memory_at_end": at(0.92), "samples": len(samples)}
+       "measuring_process_device_MB": round(baseline_device / 2**20, 1), "memory_at_25_percent": at(0.25), "memory_at_60_percent": at(0.6), "memory_at_end": at(0.92), "samples": len(samples)}
 # every repetition re-acquires: at most the first frame (coarse timing) and the cut last one are lost per repetition; the sub-channel
 # bytes lag 15 CIFs behind per re-acquisition
 out["ok"] = bool(frames >= a.repeats * (a.frames - 2) and out["fibs_crc_ok"] >= 12 * (frames - 2 * a.repeats)
