@@ -119,6 +119,65 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def host_cores():
+    """One logical CPU per PHYSICAL core of this process's affinity mask (both sockets), from the kernel's topology files: the workers of the CPU
+    baselines are pinned to these.  Returns (cpus [int], dict for the JSON line)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    seen, cpus, packages = set(), [], set()
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                sib = fh.read().strip()
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as fh:
+                pkg = fh.read().strip()
+        except OSError:
+            sib, pkg = str(c), "0"
+        key = (pkg, sib)
+        if key in seen:
+            continue
+        seen.add(key)
+        packages.add(pkg)
+        cpus.append(c)
+    return cpus, {"physical_cores_in_affinity_mask": len(cpus), "logical_cpus_in_affinity_mask": len(allowed), "sockets": len(packages),
+                  "host_logical_cpus": os.cpu_count()}
+
+
+def run_pinned(cpus, work):
+    """work(i) on one thread per entry of cpus, each pinned to its CPU (sched_setaffinity(0) binds the CALLING thread on Linux), all released
+    together; the work is ONE GIL-free C call per thread.  Returns (results, seconds from release to the last thread's end)."""
+    import threading
+    n = len(cpus)
+    res, errs = [None] * n, []
+    ready, go = threading.Barrier(n + 1), threading.Event()
+
+    def body(i):
+        try:
+            try:
+                os.sched_setaffinity(0, {cpus[i]})
+            except (AttributeError, OSError):
+                pass
+            ready.wait()
+            go.wait()
+            res[i] = work(i)
+        except Exception as ex:                                      # noqa: BLE001 -- reported by the caller
+            errs.append(ex)
+    ths = [threading.Thread(target=body, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    ready.wait()
+    t0 = time.perf_counter()
+    go.set()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    return res, dt
+
+
 def cpu_baseline(seconds_target=12.0):
     """oracle (C port of the reference algorithm) on the host cores; bounded sample; returns dict for the JSON line"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -138,17 +197,12 @@ def cpu_baseline(seconds_target=12.0):
     n1 = 64
     O.demod_frames_timing(frames, n1, -1.3e-4, m)
     dt1 = time.perf_counter() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))                          # cores this process may actually use
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))                                    # bounded sample: at most 64 worker threads
+    cpus, topo = host_cores()                                         # one worker per physical core of the affinity mask, pinned (both sockets)
+    cores = len(cpus)
 
     def run(per_thread):
-        t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(cores) as ex:                      # one GIL-free C call per thread
-            list(ex.map(lambda i: O.demod_frames_timing(frames, per_thread, -1.3e-4, m), range(cores)))
-        return time.perf_counter() - t0
+        _, dt_ = run_pinned(cpus, lambda i: O.demod_frames_timing(frames, per_thread, -1.3e-4, m))
+        return dt_
 
     probe = run(8)                                                    # calibrate: oversubscribed hosts scale badly
     per_thread = int(max(8, min(8 * seconds_target / probe, 4 * seconds_target / (dt1 / n1))))
@@ -163,11 +217,13 @@ def cpu_baseline(seconds_target=12.0):
                     break
     except OSError:
         pass
-    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-            "host_logical_cpus": os.cpu_count(), "calibration": cpu_calibration(),
-            "single_thread_value": n1 / dt1,
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "threads": cores, "kind": "port", "cpu_model": cpu_model,
+            "topology": topo, "calibration": cpu_calibration(),
+            "single_thread_value": n1 / dt1, "scaling_efficiency": (done / dt) / (cores * (n1 / dt1)),
+            "scaling_note": "value / (cores x single-thread value); the single thread runs alone at its boost clock, all cores together at the all-core "
+                            "clock and share the memory system (4 frames = 6 MB of input per worker stay in cache; the soft bits are written)",
             "sample": f"{done} frame demods (PLL+CP-phase+76xFFT2048+DQPSK+demap) cycling 4 distinct synthetic frames, "
-                      f"{cores} host threads x {per_thread} frames, oracle/dab_oracle_ofdm.c dab_demod_frame "
+                      f"{cores} pinned worker threads (one per physical core) x {per_thread} frames, oracle/dab_oracle_ofdm.c dab_demod_frame "
                       f"(FFTW absent -> oracle's own radix-4/8 FFT), {dt:.1f} s wall"}
 
 
@@ -613,16 +669,11 @@ def cpu_baseline_full(sample, seconds_target=14.0):
     t0 = time.perf_counter()
     r1 = O.receive_frames(per[0], SLICE_SAMPLES, SLICE_LEAD, warm, subs)
     dt1 = (time.perf_counter() - t0) / warm
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cpus, topo = host_cores()
+    cores = len(cpus)
+
     def run(per_thread):
-        t0_ = time.perf_counter()
-        with cf.ThreadPoolExecutor(cores) as ex:
-            r_ = list(ex.map(lambda i: O.receive_frames(per[i % ne], SLICE_SAMPLES, SLICE_LEAD, per_thread, subs), range(cores)))
-        return r_, time.perf_counter() - t0_
+        return run_pinned(cpus, lambda i: O.receive_frames(per[i % ne], SLICE_SAMPLES, SLICE_LEAD, per_thread, subs))
 
     _, probe = run(warm + 2)                                                        # calibrate: all cores busy scale far from linearly on some hosts
     per_thread = int(max(warm + 2, min(4096, (warm + 2) * seconds_target / probe)))
@@ -634,11 +685,12 @@ def cpu_baseline_full(sample, seconds_target=14.0):
         cifs = [(4 * j + c - 15) % period for c in range(4)]
         ok &= bool(np.array_equal(r["msc"], sample["payload"][e][cifs].reshape(4, -1)))
     done = per_thread * cores
-    return {"value": done / dt, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_value": 1.0 / dt1,
+    return {"value": done / dt, "unit": "frames/s", "cores": cores, "threads": cores, "kind": "port", "single_thread_value": 1.0 / dt1,
+            "scaling_efficiency": (done / dt) / (cores * (1.0 / dt1)), "topology": topo,
             "decoded_bytes_equal_transmitted": ok, "calibration": cpu_calibration(),
             "sample": f"{done} frames through oracle/dab_oracle_chain.c dab_receive_frames (coarse + fine sync, PLL + CP phase + 76 x FFT2048 + DQPSK + demap, "
                       f"fine-frequency update, 4 FIB groups, 18 sub-channels x 4 CIFs: CIF de-interleaver + K=7 Viterbi + descrambler), "
-                      f"{cores} host threads x {per_thread} frames of the receivers the GPU decoded (incl. {warm} settling frames each), {dt:.1f} s wall"}
+                      f"{cores} pinned worker threads (one per physical core) x {per_thread} frames of the receivers the GPU decoded (incl. {warm} settling frames each), {dt:.1f} s wall"}
 
 
 def dry_run(args, rank, world):
@@ -872,6 +924,45 @@ def main():
             line["stage_ms_one_at_a_time"] = {("ofdm_demod" if args.aligned else "sync_and_demod_one_call"): t_d, "fic_viterbi": t_f, "msc_viterbi_incl_deinterleave": t_m}
             if not args.aligned:
                 line["stage_ms_one_at_a_time"]["ofdm_sync_alone"] = pipe.timed(pipe.sync_only, 6)
+        if args.workload == "demod" and world == 1 and not args.dry_run:
+            # What the fraction means.  The roofline the path is PRICED against is HBM -- traffic = 0.99 x algorithmic bytes, nothing is
+            # re-read -- and `frac` stays the north-star figure against 8 TB/s.  What LIMITS the kernel at that fraction is VALU issue at the clock the
+            # power manager grants: 752 VALU instructions per thread and symbol under the bit-exact contract (the reference's per-sample Chebyshev PLL and
+            # two correctly rounded quotients per carrier), ~79 % of the issue slots at ~1.75 GHz (profiles/r05/counters_v5.json, pmc_*_v5.csv).
+            line["roofline"]["limiter"] = "valu_issue@power"
+            line["roofline"]["limiter_evidence"] = ("HBM traffic 0.99 x algorithmic (no wasted bytes); 752 VALU instructions per thread and symbol = ~79 % of issue "
+                                                    "slots at the ~1.75 GHz the power manager sustains; min launch 349.8 us = 0.66 of 8 TB/s shows what the clock costs "
+                                                    "(profiles/r05/counters_v5.json, profiles/r06/)")
+            # the launch-granularity share: the same kernel on 4096 frames per launch (1024 frames = 1024 workgroups of a whole frame = ONE round on
+            # 256 CUs x 4: the tail of the round is idle time the figure above includes)
+            try:
+                F4 = 4 * units
+                big_iq = iq_f.repeat(4, 1, 1).contiguous()
+                big_bits = torch.empty((F4, 230400), dtype=torch.int8, device=device)
+                big_freq = d_freq.repeat(4).contiguous()
+                big_corr = torch.empty((F4, 76, 2), dtype=torch.float32, device=device)
+                big_total = torch.empty(F4, dtype=torch.float32, device=device)
+                big_fine = torch.zeros(F4, dtype=torch.float32, device=device)
+
+                def big_launch():
+                    ctx.ofdm_demod_phase_frames(big_iq, fmt_f32, F4, big_bits, freq_offset=big_freq, cp_corr=big_corr, symbols_per_block=args.spb,
+                                                beta=0.9, total_phase=big_total, fine_freq=big_fine)
+                for _ in range(8):
+                    big_launch()
+                torch.cuda.synchronize()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(10):
+                    big_launch()
+                g1.record(); torch.cuda.synchronize()
+                big_ms = g0.elapsed_time(g1) / 10
+                line["roofline"]["frac_4096_frames_per_launch"] = ALGO_BYTES_PER_FRAME * F4 / (big_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                line["roofline"]["kernel_ms_4096_frames_per_launch"] = big_ms
+                assert torch.equal(big_bits[:units], d_bits) and torch.equal(big_bits[3 * units:], d_bits), "the 4096-frame launch must give the same soft bits"
+                del big_iq, big_bits, big_freq, big_corr, big_total, big_fine
+            except Exception as ex:                                   # (memory: 6.4 GB more; never costs the line)
+                line["roofline"]["frac_4096_frames_per_launch"] = None
+                line["roofline"]["frac_4096_error"] = str(ex)[-200:]
         # PMC-derived HBM traffic per launch, when a profiles/ summary of this round exists (see profiles/README.md)
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
