@@ -18,8 +18,16 @@ int dabgpu_check_hip(hipError_t e, const char* what) {
     return DABGPU_ERR_HIP;
 }
 
+// the capture status of the stream an entry point launches on, asked ONCE per entry point and thread (every entry point binds its context's device
+// first: that is where the memo is dropped) instead of at each of the ~10 scratch look-ups of a decode call
+namespace {
+struct capture_memo { hipStream_t stream; bool valid, capturing; };
+thread_local capture_memo tl_capture = {nullptr, false, false};
+}  // namespace
+
 int dabgpu_bind_device(const dabgpu_ctx* c) {
     if (!c) { dabgpu_set_error("null context"); return DABGPU_ERR_INVALID_ARG; }
+    tl_capture.valid = false;
     return dabgpu_check_hip(hipSetDevice(c->device), "hipSetDevice");
 }
 
@@ -584,9 +592,13 @@ int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out, hipStream_
     if ((size_t)slot >= c->scratch.size()) { c->scratch.resize(slot + 1, nullptr); c->scratch_bytes.resize(slot + 1, 0); }
     bool capturing = false;
     if (user_given) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(user, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) { capturing = true; c->captured_once = true; }
-        else (void)hipGetLastError();
+        if (!tl_capture.valid || tl_capture.stream != user) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool is = hipStreamIsCapturing(user, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+            if (!is) (void)hipGetLastError();
+            tl_capture = {user, true, is};
+        }
+        if (tl_capture.capturing) { capturing = true; c->captured_once = true; }
     }
     if (c->scratch_bytes[slot] < bytes) {
         if (capturing) {

@@ -800,8 +800,27 @@ extern "C" int dabgpu_frame_session_push_frame(dabgpu_frame_session* s, const in
 }
 
 int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64_t* gen_out, int8_t** d_frame_bits, dabgpu_frame_session::slot** slot_out) {
-    std::lock_guard<std::mutex> lock(s->mu);
     DABGPU_BIND(s->ctx);
+    int st;
+    {   // the slot's previous frame (R frames ago) is waited for OUTSIDE the session's lock: the decode thread's commit and every decoder's fetch of
+        // this receiver (and, through the batcher, of the others) take that lock.  Reservations come from one thread (the header's contract),
+        // so next_reserve cannot move while this one waits
+        hipEvent_t done = nullptr;
+        uint64_t gen0;
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            gen0 = s->next_reserve;
+            dabgpu_frame_session::slot& sl0 = s->slots[gen0 % dabgpu_frame_session::R];
+            if (sl0.pending) done = sl0.done;
+        }
+        if (done) {
+            if ((st = dabgpu_check_hip(hipEventSynchronize(done), "hipEventSynchronize(session)"))) return st;
+            std::lock_guard<std::mutex> lock(s->mu);
+            dabgpu_frame_session::slot& sl0 = s->slots[gen0 % dabgpu_frame_session::R];
+            if (s->next_reserve == gen0 && sl0.done == done) sl0.pending = false;
+        }
+    }
+    std::lock_guard<std::mutex> lock(s->mu);
     const uint64_t gen = s->next_reserve;
     // the commits (decode enqueued) may lag the reservations by a few frames (dabgpu_receiver_submit_demod / _submit_decode on two threads), but the
     // result slot and the history slot of `gen` must be free: R - 1 frames at most may be reserved and not yet waited for
@@ -810,8 +829,7 @@ int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64
         return DABGPU_ERR_NOT_READY;
     }
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
-    int st;
-    if (sl.pending) {
+    if (sl.pending) {                                                  // (only if the wait above raced with a commit of that slot: cannot happen with one reserving thread)
         if ((st = dabgpu_check_hip(hipEventSynchronize(sl.done), "hipEventSynchronize(session)"))) return st;
         sl.pending = false;
     }
@@ -841,6 +859,10 @@ int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t read
     dabgpu_ctx* c = s->ctx;
     DABGPU_BIND(c);
     if (gen != s->next_gen) { dabgpu_set_error("session_commit: generation %llu was not the one reserved", (unsigned long long)gen); return DABGPU_ERR_INVALID_ARG; }
+    if (gen >= s->next_reserve) {                                       // (a decode submitted before its demodulation: the slot's ready event is stale or was never recorded)
+        dabgpu_set_error("session_commit: generation %llu has not been reserved (dabgpu_receiver_submit_demod comes first)", (unsigned long long)gen);
+        return DABGPU_ERR_NOT_READY;
+    }
     hipStream_t q = c->stream;
     dabgpu_frame_session::slot& sl = s->slots[gen % dabgpu_frame_session::R];
     int st;
@@ -858,6 +880,13 @@ int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t read
     sl.gen = gen;
     s->next_gen = gen + 1;
     return DABGPU_OK;
+}
+
+// a reservation whose producer failed before anything of the frame was enqueued for the decoder: give the generation back (only the NEWEST
+// reservation can be returned, and only while it has not been committed)
+void dabgpu_session_unreserve(dabgpu_frame_session* s, uint64_t gen) {
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (gen + 1 == s->next_reserve && gen >= s->next_gen) s->next_reserve = gen;
 }
 
 int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out) {

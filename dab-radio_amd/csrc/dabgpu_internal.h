@@ -216,6 +216,7 @@ int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64
 // still makes to the slot's pinned buffers on its own stream, beside the decode) and records the slot's done event
 int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule,
                           hipEvent_t producer_done = nullptr);
+void dabgpu_session_unreserve(dabgpu_frame_session* s, uint64_t gen);
 // result slot of a generation, waited for (DABGPU_ERR_NOT_READY: gone or never pushed); call with s->mu held
 int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out);
 

@@ -190,18 +190,32 @@ extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state*
 
 // Stream A's share of a frame: upload, demodulation into the session's history slot, fine-frequency update, the copies the host reads.  The slot's
 // ev_ready fires when the soft bits are in the history slot, ev_copied when the host copies are made.
+static int submit_demod_reserved(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t gen, int8_t* d_bits, dabgpu_frame_session::slot* sl);
+
 static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation, dabgpu_frame_session::slot** slot_out) {
-    const size_t frame_samples = (size_t)rx->geom[6], n_fft = (size_t)rx->geom[3], n_sym = (size_t)rx->geom[0], frame_bits = (size_t)rx->geom[8];
+    const size_t frame_samples = (size_t)rx->geom[6];
     if (frame_sample + frame_samples > rx->stage_cap) { dabgpu_set_error("receiver_submit_frame: the frame lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
+    DABGPU_BIND(rx->ctx);
+    uint64_t gen = 0;
+    int8_t* d_bits = nullptr;
+    dabgpu_frame_session::slot* sl = nullptr;
+    int st = dabgpu_session_reserve(rx->ses, rx->a, &gen, &d_bits, &sl);
+    if (st) return st;
+    // a failure behind the reservation gives the generation back: the session would otherwise refuse every later commit ("not the one reserved")
+    // and the receiver were wedged for good
+    if ((st = submit_demod_reserved(rx, frame_sample, beta, want_views, gen, d_bits, sl))) { dabgpu_session_unreserve(rx->ses, gen); return st; }
+    if (generation) *generation = gen;
+    if (slot_out) *slot_out = sl;
+    return DABGPU_OK;
+}
+
+static int submit_demod_reserved(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t /*gen*/, int8_t* d_bits, dabgpu_frame_session::slot* sl) {
+    const size_t frame_samples = (size_t)rx->geom[6], n_fft = (size_t)rx->geom[3], n_sym = (size_t)rx->geom[0], frame_bits = (size_t)rx->geom[8];
     dabgpu_ctx* c = rx->ctx;
     DABGPU_BIND(c);
     hipStream_t a = rx->a;
     int st;
-    uint64_t gen = 0;
-    int8_t* d_bits = nullptr;
-    dabgpu_frame_session::slot* sl = nullptr;
-    if ((st = dabgpu_session_reserve(rx->ses, a, &gen, &d_bits, &sl))) return st;
     const size_t fft_bytes = (n_sym + 1) * n_fft * 2 * sizeof(float), dq_bytes = (n_sym - 1) * (size_t)rx->geom[5] * 2 * sizeof(float);
     const bool want_dq = want_views && rx->mode == 1;
     if (want_views) {
@@ -250,8 +264,6 @@ static int submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, in
         CK(hipEventSynchronize(rx->stage_free[rx->cur]));
         rx->stage_pending[rx->cur] = false;
     }
-    if (generation) *generation = gen;
-    if (slot_out) *slot_out = sl;
     return DABGPU_OK;
 }
 

@@ -60,7 +60,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     m_ring.assign(params.nb_null_period, {0.0f, 0.0f});
     m_corr.assign(params.nb_null_period + params.nb_symbol_period, {0.0f, 0.0f});
     m_frame_bits.assign((params.nb_frame_symbols - 1) * params.nb_data_carriers * 2, 0);
-    m_bits_ptr = m_frame_bits.data();
+    m_bits_ptr.store(m_frame_bits.data());
     m_bits_len = m_frame_bits.size();
     m_frame_fft.assign((params.nb_frame_symbols + 1) * params.nb_fft, {0.0f, 0.0f});
     m_frame_dqpsk.assign((params.nb_frame_symbols - 1) * params.nb_fft, {0.0f, 0.0f});
@@ -83,10 +83,10 @@ OFDM_Demod::~OFDM_Demod() {
     if (m_decode_thread.joinable()) m_decode_thread.join();
     dabgpu_frame_batcher::remove_producer(this);
     dabgpu_receiver_destroy(m_rx);
-    if (m_profile && m_total_frames_read > 0) {
-        const double n = (double)m_total_frames_read;
+    if (m_profile && m_total_frames_read.load() > 0) {
+        const double n = (double)m_total_frames_read.load();
         std::fprintf(stderr, "OFDM_Demod profile, us per frame over %d frames: reader { wait for the synchroniser %.1f, wait for a slot %.1f, submit %.1f } "
-                             "delivery { wait for the frame %.1f, batcher %.1f, observers %.1f }\n", m_total_frames_read, m_t_sync_wait / n,
+                             "delivery { wait for the frame %.1f, batcher %.1f, observers %.1f }\n", m_total_frames_read.load(), m_t_sync_wait / n,
                      m_t_slot_wait / n, m_t_submit / n, m_t_frame_wait / n, m_t_batcher / n, m_t_observers / n);
     }
 }
@@ -303,23 +303,33 @@ void OFDM_Demod::SubmitFrame() {
     }
     const double t1 = m_profile ? now_us() : 0.0;
     // what the decoders of this process listen to NOW -- asked after the wait for a slot: an observer that created a decoder while this thread
-    // waited is heard one frame earlier.  (Frames already submitted keep their layout; the decoders decode those call by call.)
+    // waited is heard one frame earlier.  The list in force when a frame's DECODE is enqueued applies (the decode thread may be up to 4 frames
+    // behind this one: those frames, demodulated already, are decoded with the new list too -- every result slot records the list it was decoded
+    // with, and a decoder only picks up what was decoded for it, dabgpu_frame_session_fetch_cif).
     if (m_mode == 1) {
         std::vector<dabgpu_subchannel> subs;
         bool fic = false;
         const uint64_t version = dabgpu_frame_batcher::subscription(subs, fic);
         if (version != m_subs_version) {
-            const int rc = dabgpu_receiver_set_subchannels(m_rx, subs.data(), (int)subs.size(), fic ? 1 : 0);
-            if (rc != DABGPU_OK) fail("dabgpu_receiver_set_subchannels", rc);
+            int rc = dabgpu_receiver_set_subchannels(m_rx, subs.data(), (int)subs.size(), fic ? 1 : 0);
+            if (rc != DABGPU_OK) {
+                // a list the session cannot take (more code words than its scratch may grow to, ...): the stream goes on, the frames are not decoded
+                // with it and the decoders work call by call -- as they do for every frame submitted before they existed
+                std::fprintf(stderr, "OFDM_Demod: the frame session refused the decoders' sub-channel list (%s -- %s): decoding call by call\n", dabgpu_strerror(rc),
+                             dabgpu_last_error());
+                rc = dabgpu_receiver_set_subchannels(m_rx, nullptr, 0, 0);
+                if (rc != DABGPU_OK) fail("dabgpu_receiver_set_subchannels", rc);
+            }
             m_subs_version = version;
         }
     }
     RethrowDeliveryError();
     uint64_t gen = 0;
+    const bool fetch_debug = m_fetch_debug.load(std::memory_order_relaxed);
     const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
     // this thread enqueues the frame's upload, demodulation and fine-frequency update; the decode thread waits for the demodulation and enqueues the
     // decode (dabgpu_receiver_submit_demod / _submit_decode: no stream waits for another on the device, and half the runtime calls leave this thread)
-    const int rc = dabgpu_receiver_submit_demod(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, m_fetch_debug ? 1 : 0, &gen);
+    const int rc = dabgpu_receiver_submit_demod(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, fetch_debug ? 1 : 0, &gen);
     if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_demod", rc);
     float* stage = nullptr;
     (void)dabgpu_receiver_stage(m_rx, &stage, nullptr);
@@ -327,7 +337,7 @@ void OFDM_Demod::SubmitFrame() {
     if (m_profile) { m_t_slot_wait += t1 - t0; m_t_submit += now_us() - t1; }
     {
         std::lock_guard<std::mutex> lock(m_mu);
-        m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, m_fetch_debug, m_mode == 1});
+        m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, fetch_debug, m_mode == 1});
         m_frames_in_flight++;
         m_frames_submitted++;
         m_to_decode.push_back(gen);
@@ -384,7 +394,7 @@ void OFDM_Demod::DeliveryThread() {
                 m_fine_time_offset = it.offset;
                 break;
             case Item::RESET:
-                m_total_frames_desync++;
+                m_total_frames_desync.fetch_add(1, std::memory_order_relaxed);
                 m_freq_coarse = 0.0f;
                 m_freq_fine = 0.0f;
                 m_fine_time_offset = 0;
@@ -402,9 +412,8 @@ void OFDM_Demod::DeliveryThread() {
                 if (rc != DABGPU_OK) fail("dabgpu_receiver_wait_frame", rc);
                 const double t1 = m_profile ? now_us() : 0.0;
                 m_freq_fine = fr.freq_fine;
-                m_total_frames_read++;
-                m_bits_ptr = fr.bits;
-                m_bits_len = fr.n_bits;
+                m_total_frames_read.fetch_add(1, std::memory_order_relaxed);
+                m_bits_ptr.store(fr.bits, std::memory_order_release);          // (fr.n_bits == m_bits_len: the frame length of the mode)
                 if (it.views) {
                     std::memcpy(static_cast<void*>(m_frame_fft.data()), fr.fft, m_frame_fft.size() * sizeof(m_frame_fft[0]));
                     if (m_mode == 1) std::memcpy(static_cast<void*>(m_frame_dqpsk.data()), fr.dqpsk, (m_params.nb_frame_symbols - 1) * m_params.nb_data_carriers * sizeof(m_frame_dqpsk[0]));

@@ -24,6 +24,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <complex>
 #include <condition_variable>
 #include <deque>
@@ -85,23 +86,30 @@ public:
     State GetState() const { return m_state; }
     auto& GetConfig() { return m_cfg; }
     const auto& GetConfig() const { return m_cfg; }
+    // The getters may be called from any thread (a GUI polls them, src/.../render_ofdm_demod.cpp): every value is published by the delivery
+    // thread as ONE atomic word, so none can be read torn; inside an On_OFDM_Frame observer they are that frame's values.  After the last
+    // Process() call they are final once Synchronize() (or the destructor) has returned: frames are delivered from the delivery thread.
     float GetSignalAverage() const { return m_signal_l1_average; }
-    float GetFineFrequencyOffset() const { return m_freq_fine; }
-    float GetCoarseFrequencyOffset() const { return m_freq_coarse; }
-    float GetNetFrequencyOffset() const { return m_freq_fine + m_freq_coarse; }
-    int GetFineTimeOffset() const { return m_fine_time_offset; }
-    int GetTotalFramesRead() const { return m_total_frames_read; }
-    int GetTotalFramesDesync() const { return m_total_frames_desync; }
-    tcb::span<const std::complex<float>> GetFrameFFT() const { return m_frame_fft; }
-    tcb::span<const std::complex<float>> GetFrameDataVec() const { return m_frame_dqpsk; }
-    tcb::span<const viterbi_bit_t> GetFrameDataBits() const { return {m_bits_ptr, m_bits_len}; }
+    float GetFineFrequencyOffset() const { return m_freq_fine.load(std::memory_order_relaxed); }
+    float GetCoarseFrequencyOffset() const { return m_freq_coarse.load(std::memory_order_relaxed); }
+    float GetNetFrequencyOffset() const { return m_freq_fine.load(std::memory_order_relaxed) + m_freq_coarse.load(std::memory_order_relaxed); }
+    int GetFineTimeOffset() const { return m_fine_time_offset.load(std::memory_order_relaxed); }
+    int GetTotalFramesRead() const { return m_total_frames_read.load(std::memory_order_relaxed); }
+    int GetTotalFramesDesync() const { return m_total_frames_desync.load(std::memory_order_relaxed); }
+    // GUI views (FFT of all 77 symbols, per-carrier DQPSK vectors): the reference fills them for every frame (ofdm_demodulator.cpp:701-709,734); here
+    // they cost two extra device-to-host copies per frame (2.2 MB), so they are fetched from the first call of either getter on -- a viewer linked
+    // unchanged sees zeros for the frames before its first poll and the frame's data afterwards.  EnableDebugBuffers(true) before Process() gives the
+    // reference's behaviour from the first frame; EnableDebugBuffers(false) stops the copies until a getter is called again.
+    tcb::span<const std::complex<float>> GetFrameFFT() const { m_fetch_debug.store(true, std::memory_order_relaxed); return m_frame_fft; }
+    tcb::span<const std::complex<float>> GetFrameDataVec() const { m_fetch_debug.store(true, std::memory_order_relaxed); return m_frame_dqpsk; }
+    // the newest delivered frame's soft bits: a view into one of the receiver's 8 result slots -- valid until 7 more frames have been submitted (the
+    // reference's view is overwritten by the NEXT frame, ofdm_demodulator.cpp:627-638: callers copy, app_ofdm_blocks.h:32-35); the length never changes
+    tcb::span<const viterbi_bit_t> GetFrameDataBits() const { return {m_bits_ptr.load(std::memory_order_acquire), m_bits_len}; }
     tcb::span<const float> GetImpulseResponse() const { return m_impulse_response; }
     tcb::span<const float> GetCoarseFrequencyResponse() const { return m_frequency_response; }
     tcb::span<const std::complex<float>> GetCorrelationTimeBuffer() const { return m_corr; }
     auto& On_OFDM_Frame() { return m_on_frame; }
-    // GUI buffers (FFT of all 77 symbols, per-carrier DQPSK vectors) cost two extra device->host copies per frame;
-    // off by default, switch on before Process() when a viewer reads GetFrameFFT()/GetFrameDataVec()
-    void EnableDebugBuffers(bool enable) { m_fetch_debug = enable; }
+    void EnableDebugBuffers(bool enable) { m_fetch_debug.store(enable, std::memory_order_relaxed); }
 
 private:
     size_t FindNullPowerDip(tcb::span<const std::complex<float>> buf);
@@ -127,7 +135,7 @@ private:
     bool m_null_start_found = false;
     bool m_null_end_found = false;
     float m_signal_l1_average = 0.0f;
-    bool m_fetch_debug = false;
+    mutable std::atomic<bool> m_fetch_debug{false};    // set by GetFrameFFT() / GetFrameDataVec() / EnableDebugBuffers
     // null search ring (nb_null_period), NULL+PRS correlation window
     std::vector<std::complex<float>> m_ring;
     size_t m_ring_index = 0, m_ring_length = 0;
@@ -142,13 +150,13 @@ private:
     uint64_t m_subs_version = ~0ull;         // batcher subscription the receiver was last given
     int m_depth = 3;
     // ---- published by the delivery thread, in submission order ----
-    int m_total_frames_read = 0;
-    int m_total_frames_desync = 0;
-    float m_freq_coarse = 0.0f;
-    float m_freq_fine = 0.0f;
-    int m_fine_time_offset = 0;
-    const viterbi_bit_t* m_bits_ptr = nullptr;
-    size_t m_bits_len = 0;
+    std::atomic<int> m_total_frames_read{0};
+    std::atomic<int> m_total_frames_desync{0};
+    std::atomic<float> m_freq_coarse{0.0f};
+    std::atomic<float> m_freq_fine{0.0f};
+    std::atomic<int> m_fine_time_offset{0};
+    std::atomic<const viterbi_bit_t*> m_bits_ptr{nullptr};
+    size_t m_bits_len = 0;                                   // (set once in the constructor: the frame length of the mode)
     std::vector<viterbi_bit_t> m_frame_bits;                 // what GetFrameDataBits() shows before the first frame
     std::vector<std::complex<float>> m_frame_fft;
     std::vector<std::complex<float>> m_frame_dqpsk;

@@ -174,8 +174,9 @@ def test_behind_the_msc_viterbi_kernel(ctx, oracle):
                 got[si].append(aus)
     for si in range(len(subs)):
         # (10 frames = 40 CIFs; a super frame whose fire code a channel error hits is skipped by the acquisition -- seen with DAB_FUZZ_OFFSET=12:
-        # two instead of three super frames in the window; what matters is that every one that came out is the transmitted one, in order)
-        assert len(got[si]) >= 2
+        # two instead of three super frames in the window; what matters is that every one that came out is the transmitted one, in order).
+        # The committed seed delivers all three: a wrongly dropped super frame must not pass there
+        assert len(got[si]) >= (2 if int(os.environ.get("DAB_FUZZ_OFFSET", "0") or 0) else 3)
         # logical frame t leaves the time de-interleaver at CIF t + 15; frames 0..3 were not fed, so the first super frame the
         # DAB+ stage can acquire starts at logical frame 5 (index 1) -- or a later one when a channel error sits in its fire code
         def same(a, b):
