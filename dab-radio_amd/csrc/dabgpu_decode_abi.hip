@@ -696,11 +696,19 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
     return DABGPU_OK;
 }
 
+int dabgpu_frame_session_create_store(dabgpu_frame_session** out, dabgpu_ctx* ctx) {
+    dabgpu_frame_session* s = new dabgpu_frame_session();
+    s->ctx = ctx;
+    s->owns_ctx = false;
+    *out = s;
+    return DABGPU_OK;
+}
+
 extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
     if (!s) return;
     if (s->ctx) {
         (void)hipSetDevice(s->ctx->device);
-        (void)hipStreamSynchronize(s->ctx->stream);
+        if (s->owns_ctx) (void)hipStreamSynchronize(s->ctx->stream);
     }
     for (auto& sl : s->slots) {
         if (sl.h_block) (void)hipHostFree(sl.h_block);
@@ -714,7 +722,7 @@ extern "C" void dabgpu_frame_session_destroy(dabgpu_frame_session* s) {
     }
     if (s->d_hist) (void)hipFree(s->d_hist);
     if (s->d_block) (void)hipFree(s->d_block);
-    if (s->ctx) dabgpu_destroy(s->ctx);
+    if (s->ctx && s->owns_ctx) dabgpu_destroy(s->ctx);
     delete s;
 }
 

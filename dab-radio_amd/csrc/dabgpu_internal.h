@@ -182,6 +182,7 @@ extern "C" hipError_t dabgpu_launch_msc_build(dabgpu_cw_desc* d_descs, const int
 struct dabgpu_frame_session {
     static constexpr int H = 8, R = 8;
     dabgpu_ctx* ctx = nullptr;
+    bool owns_ctx = true;                           // false: a result store of a receiver-bank member (receiver_bank.hip): no history, no stream of its own
     int8_t* d_hist = nullptr;                       // [H][230400]
     // one device block per session, one pinned block per result slot: [4][96] FIB bytes | [4] FIC results | [4][n_sub] MSC results |
     // [4][cif_out] sub-channel bytes -- a frame's results reach the host in ONE copy (they were four; each is an operation on the stream
@@ -217,6 +218,8 @@ int dabgpu_session_reserve(dabgpu_frame_session* s, hipStream_t producer, uint64
 int dabgpu_session_commit(dabgpu_frame_session* s, uint64_t gen, hipEvent_t ready, size_t bits_bytes, int decode, int decode_fic, int tie_rule,
                           hipEvent_t producer_done = nullptr);
 void dabgpu_session_unreserve(dabgpu_frame_session* s, uint64_t gen);
+// a session that only STORES results (slots filled by the receiver bank); ctx is borrowed
+int dabgpu_frame_session_create_store(dabgpu_frame_session** out, dabgpu_ctx* ctx);
 // result slot of a generation, waited for (DABGPU_ERR_NOT_READY: gone or never pushed); call with s->mu held
 int dabgpu_session_slot(dabgpu_frame_session* s, uint64_t gen, dabgpu_frame_session::slot** out);
 

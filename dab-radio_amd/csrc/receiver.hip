@@ -19,6 +19,7 @@
 
 #include "dabgpu.h"
 #include "dabgpu_internal.h"
+#include "receiver_bank.h"
 
 namespace {
 constexpr int STAGES = 3;
@@ -58,12 +59,23 @@ struct dabgpu_receiver {
     unsigned char* h_rec = nullptr;          // laid out like d_rec
     hipEvent_t sync_done = nullptr; bool sync_pending = false; bool sync_coarse = false;
     std::atomic<int> decode_fic{0};          // (written by set_subchannels, read where the decode is submitted: possibly another thread)
+    // a BANKED receiver (receiver_bank.hip): the staging buffers above are its own, everything else is the bank's; submit_* post jobs
+    dabgpu_rx_member* member = nullptr;
+    int device = 0;
+    std::atomic<int> bank_tie{0};            // core model of the two-call form (dabgpu_receiver_submit_demod / _submit_decode)
 };
 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
 
 extern "C" void dabgpu_receiver_destroy(dabgpu_receiver* rx) {
     if (!rx) return;
+    if (rx->member) {
+        dabgpu_rx_bank_leave(rx->member);                            // (waits for the member's jobs: nothing reads the staging buffers afterwards)
+        (void)hipSetDevice(rx->device);
+        for (int k = 0; k < STAGES; k++) if (rx->h_stage[k]) (void)hipHostFree(rx->h_stage[k]);
+        delete rx;
+        return;
+    }
     if (rx->ctx) {
         (void)hipSetDevice(rx->ctx->device);
         if (rx->a) (void)hipStreamSynchronize(rx->a);
@@ -127,11 +139,40 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     return DABGPU_OK;
 }
 
-extern "C" dabgpu_frame_session* dabgpu_receiver_session(dabgpu_receiver* rx) { return rx ? rx->ses : nullptr; }
+extern "C" int dabgpu_receiver_create_banked(dabgpu_receiver** out, int device) {
+    if (!out) { dabgpu_set_error("receiver_create_banked: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int geom[9];
+    (void)dabgpu_get_ofdm_params(1, geom);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); dabgpu_set_error("hipGetDeviceCount found no device"); return DABGPU_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { dabgpu_set_error("device %d out of range (%d devices)", device, n); return DABGPU_ERR_INVALID_ARG; }
+    int st = dabgpu_check_hip(hipSetDevice(device), "hipSetDevice");
+    if (st) return st;
+    dabgpu_receiver* rx = new dabgpu_receiver();
+    rx->mode = 1;
+    rx->device = device;
+    memcpy(rx->geom, geom, sizeof(geom));
+    const size_t n_fft = (size_t)geom[3], frame_samples = (size_t)geom[6];
+    rx->stage_cap = (size_t)geom[2] + (n_fft - (size_t)geom[4]) + frame_samples;
+    for (int k = 0; k < STAGES && !st; k++)
+        st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_stage[k], rx->stage_cap * 2 * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver stage)");
+    if (!st) st = dabgpu_rx_bank_join(device, rx->h_stage, &rx->member);
+    if (st) {
+        for (int k = 0; k < STAGES; k++) if (rx->h_stage[k]) (void)hipHostFree(rx->h_stage[k]);
+        delete rx;
+        return st;
+    }
+    *out = rx;
+    return DABGPU_OK;
+}
+
+extern "C" dabgpu_frame_session* dabgpu_receiver_session(dabgpu_receiver* rx) { return !rx ? nullptr : (rx->member ? dabgpu_rx_bank_session(rx->member) : rx->ses); }
 
 extern "C" int dabgpu_receiver_set_subchannels(dabgpu_receiver* rx, const dabgpu_subchannel* subs, int n, int decode_fic) {
     if (!rx) { dabgpu_set_error("receiver_set_subchannels: null receiver"); return DABGPU_ERR_INVALID_ARG; }
     if (rx->mode != 1 && (n > 0 || decode_fic)) { dabgpu_set_error("receiver_set_subchannels: the DAB layer above the soft bits exists for transmission mode I only"); return DABGPU_ERR_UNSUPPORTED; }
+    if (rx->member) return dabgpu_rx_bank_set_subchannels(rx->member, subs, n, decode_fic);
     const int st = dabgpu_frame_session_set_subchannels(rx->ses, subs, n);
     if (st) return st;
     rx->decode_fic.store(decode_fic ? 1 : 0);
@@ -147,6 +188,7 @@ extern "C" int dabgpu_receiver_stage(dabgpu_receiver* rx, float** h_stage, size_
 
 extern "C" int dabgpu_receiver_reset(dabgpu_receiver* rx) {
     if (!rx) { dabgpu_set_error("receiver_reset: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) return dabgpu_rx_bank_reset(rx->member);
     DABGPU_BIND(rx->ctx);
     // :277-289 coarse = fine = 0, no coarse offset found -- behind everything already enqueued (a frame in flight keeps its offsets)
     return dabgpu_check_hip(hipMemsetAsync(rx->d_state, 0, sizeof(dabgpu_sync_state), rx->a), "hipMemsetAsync(receiver state)");
@@ -156,6 +198,7 @@ extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_syn
     if (!rx || !cfg) { dabgpu_set_error("receiver_submit_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
     const size_t n_fft = (size_t)rx->geom[3];
     if (prs_sample + n_fft > rx->stage_cap) { dabgpu_set_error("receiver_submit_sync: the PRS slot lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) return dabgpu_rx_bank_post_sync(rx->member, cfg, rx->cur, prs_sample);
     if (rx->sync_pending) { dabgpu_set_error("receiver_submit_sync: the previous record has not been collected (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
     dabgpu_ctx* c = rx->ctx;
     DABGPU_BIND(c);
@@ -175,6 +218,7 @@ extern "C" int dabgpu_receiver_submit_sync(dabgpu_receiver* rx, const dabgpu_syn
 
 extern "C" int dabgpu_receiver_wait_sync(dabgpu_receiver* rx, dabgpu_sync_state* out, float* h_impulse, float* h_freq_response) {
     if (!rx || !out) { dabgpu_set_error("receiver_wait_sync: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) return dabgpu_rx_bank_wait_sync(rx->member, out, h_impulse, h_freq_response);
     if (!rx->sync_pending) { dabgpu_set_error("receiver_wait_sync: no synchronisation was submitted"); return DABGPU_ERR_NOT_READY; }
     DABGPU_BIND(rx->ctx);
     int st;
@@ -267,10 +311,22 @@ static int submit_demod_reserved(dabgpu_receiver* rx, size_t frame_sample, float
     return DABGPU_OK;
 }
 
+// banked: post the frame, move on to the next staging buffer (waiting until the bank has uploaded what it still holds)
+static int submit_banked(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie_rule, uint64_t* generation) {
+    const size_t frame_samples = (size_t)rx->geom[6];
+    if (frame_sample + frame_samples > rx->stage_cap) { dabgpu_set_error("receiver_submit_frame: the frame lies outside the staging buffer"); return DABGPU_ERR_INVALID_ARG; }
+    if (dabgpu_rx_bank_sync_pending(rx->member)) { dabgpu_set_error("receiver_submit_frame: collect the synchroniser's record first (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
+    int st = dabgpu_rx_bank_post_frame(rx->member, rx->cur, frame_sample, beta, want_views, tie_rule, generation);
+    if (st) return st;
+    rx->cur = (rx->cur + 1) % STAGES;
+    return dabgpu_rx_bank_wait_stage(rx->member, rx->cur);
+}
+
 // one call, one thread: the decode is enqueued behind the demodulation with device-side waits (stream B waits for ev_ready, and for ev_copied before
 // the slot's done event)
 extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, int tie_rule, uint64_t* generation) {
     if (!rx) { dabgpu_set_error("receiver_submit_frame: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) return submit_banked(rx, frame_sample, beta, want_views, tie_rule, generation);
     uint64_t gen = 0;
     dabgpu_frame_session::slot* sl = nullptr;
     int st = submit_demod(rx, frame_sample, beta, want_views, &gen, &sl);
@@ -289,11 +345,14 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
 // hardware queue, and a queue whose head waits for another queue's event holds back the other receiver's work behind it.
 extern "C" int dabgpu_receiver_submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation) {
     if (!rx) { dabgpu_set_error("receiver_submit_demod: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    // (banked: the frame's decode belongs to the tick that demodulates it, with the core model given at creation time's default: see submit_decode)
+    if (rx->member) return submit_banked(rx, frame_sample, beta, want_views, rx->bank_tie, generation);
     return submit_demod(rx, frame_sample, beta, want_views, generation, nullptr);
 }
 
 extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t generation, int tie_rule) {
     if (!rx) { dabgpu_set_error("receiver_submit_decode: null receiver"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) { rx->bank_tie = tie_rule ? 1 : 0; return DABGPU_OK; }      // (the tick decoded it; the core model of later frames follows this argument)
     dabgpu_frame_session* s = rx->ses;
     DABGPU_BIND(s->ctx);
     dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];
@@ -308,6 +367,7 @@ extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t gener
 
 extern "C" int dabgpu_receiver_wait_frame(dabgpu_receiver* rx, uint64_t generation, dabgpu_receiver_frame* out) {
     if (!rx || !out) { dabgpu_set_error("receiver_wait_frame: null argument"); return DABGPU_ERR_INVALID_ARG; }
+    if (rx->member) return dabgpu_rx_bank_wait_frame(rx->member, generation, out);
     dabgpu_frame_session* s = rx->ses;
     DABGPU_BIND(s->ctx);
     dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];

@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "dabgpu_viterbi_decode_depunctured_host_sync", "dabgpu_stream_bank_process_ring_retained",
     "dabgpu_ofdm_tune", "dabgpu_ofdm_tuned_symbols_per_block", "dabgpu_ofdm_sync_demod_frames",
     "dabgpu_multiplex_mapping",
-    "dabgpu_receiver_create", "dabgpu_receiver_destroy", "dabgpu_receiver_session", "dabgpu_receiver_set_subchannels", "dabgpu_receiver_stage",
+    "dabgpu_receiver_create", "dabgpu_receiver_create_banked", "dabgpu_receiver_destroy", "dabgpu_receiver_session", "dabgpu_receiver_set_subchannels", "dabgpu_receiver_stage",
     "dabgpu_receiver_reset", "dabgpu_receiver_submit_sync", "dabgpu_receiver_wait_sync", "dabgpu_receiver_submit_frame", "dabgpu_receiver_wait_frame",
     "dabgpu_receiver_submit_demod", "dabgpu_receiver_submit_decode",
     "dabgpu_ingest_create", "dabgpu_ingest_destroy", "dabgpu_ingest_acquire", "dabgpu_ingest_submit", "dabgpu_ingest_wait", "dabgpu_ingest_consumed",

@@ -2,6 +2,7 @@
 #include "./ofdm_demodulator.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -40,7 +41,25 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     const char* dev = std::getenv("DABGPU_DEVICE");
     int st;
     if (m_mode == 1) {
-        st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+        // Several receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
+        // one synchroniser launch, one demodulation launch and one decode over all of them.  DABGPU_MIRROR_BANK=1: every mode I receiver on the
+        // library's own tables joins it; 0: none; unset: every receiver but the first one alive (a lone receiver keeps its private pipeline).
+        static std::atomic<int> live{0};
+        const char* bank_env = std::getenv("DABGPU_MIRROR_BANK");
+        const int others = live.fetch_add(1);
+        m_counted = true;
+        bool banked = bank_env ? std::atoi(bank_env) != 0 : others > 0;
+        if (banked) {
+            std::vector<float> prs(2 * params.nb_fft);
+            std::vector<int> map(params.nb_data_carriers);
+            banked = dabgpu_get_prs_fft_ref(1, prs.data()) == DABGPU_OK && dabgpu_get_carrier_mapper(1, map.data()) == DABGPU_OK &&
+                     std::memcmp(prs.data(), prs_fft_ref.data(), prs.size() * sizeof(float)) == 0 &&
+                     std::memcmp(map.data(), carrier_mapper.data(), map.size() * sizeof(int)) == 0;
+        }
+        m_live = &live;
+        if (banked) st = dabgpu_receiver_create_banked(&m_rx, dev ? std::atoi(dev) : 0);
+        else st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+        if (st != DABGPU_OK) live.fetch_sub(1);
     } else {
         // modes II-IV run on the library's built-in tables of that mode: a caller-supplied table must be that table
         std::vector<float> prs(2 * params.nb_fft);
@@ -83,6 +102,7 @@ OFDM_Demod::~OFDM_Demod() {
     if (m_decode_thread.joinable()) m_decode_thread.join();
     dabgpu_frame_batcher::remove_producer(this);
     dabgpu_receiver_destroy(m_rx);
+    if (m_counted && m_live) m_live->fetch_sub(1);
     if (m_profile && m_total_frames_read.load() > 0) {
         const double n = (double)m_total_frames_read.load();
         std::fprintf(stderr, "OFDM_Demod profile, us per frame over %d frames: reader { wait for the synchroniser %.1f, wait for a slot %.1f, submit %.1f } "

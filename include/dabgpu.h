@@ -533,6 +533,17 @@ int dabgpu_frame_session_fetch_cif(dabgpu_frame_session *s, uint64_t generation,
  * Threads: submit_* / stage / reset / set_subchannels / wait_sync from ONE thread (the reader); wait_frame from one other (or the same).
  * At most 7 frames may be submitted and not yet collected with wait_frame (the result slots are a ring of 8).
  */
+/*
+ * BANKED receivers (ABI 4): dabgpu_receiver_create_banked makes a mode I receiver on the library's own tables that is a member of the device's
+ * RECEIVER BANK.  Its interface is the one below, unchanged; its submit_* calls post the work, and one thread per device issues what all members
+ * have posted since its last round as ONE synchroniser launch, ONE demodulation launch over a compact batch of the posted frames and ONE FIC + MSC
+ * decode over the members' history rings (at most one job per member and round, in posting order: frame k's fine-frequency update still
+ * precedes frame k + 1's synchroniser).  N OFDM_Demod objects of a process then cost ~6 runtime calls per frame and member + ~15 per round
+ * instead of ~20 per frame on three streams each (csrc/receiver_bank.hip).  Outputs are those of the private pipeline, bit for bit.
+ * The sub-channel list (dabgpu_receiver_set_subchannels) is the BANK's: the members report one list (the decoders' subscription is process-wide in
+ * the classes above); it applies to the rounds enqueued after the call.  dabgpu_receiver_submit_decode is accepted and does nothing but note the
+ * core model for the frames submitted next (a round decodes what it demodulates).  Up to 64 members per device.
+ */
 typedef struct dabgpu_receiver dabgpu_receiver;
 typedef struct {
     uint64_t generation;
@@ -545,6 +556,7 @@ typedef struct {
 } dabgpu_receiver_frame;
 /* h_prs_fft_ref / h_carrier_mapper as for dabgpu_create (mode I; NULL = built-in tables; must be NULL in modes II-IV) */
 int dabgpu_receiver_create(dabgpu_receiver **out, int device, int transmission_mode, const float *h_prs_fft_ref, const int *h_carrier_mapper);
+int dabgpu_receiver_create_banked(dabgpu_receiver **out, int device);
 void dabgpu_receiver_destroy(dabgpu_receiver *rx);
 dabgpu_frame_session *dabgpu_receiver_session(dabgpu_receiver *rx);      /* owned by the receiver */
 /* what is decoded for the frames submitted from now on (mode I; n <= 64) */

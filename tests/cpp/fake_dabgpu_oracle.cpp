@@ -245,6 +245,7 @@ int dabgpu_receiver_create(dabgpu_receiver** out, int, int mode, const float*, c
     *out = rx;
     return DABGPU_OK;
 }
+int dabgpu_receiver_create_banked(dabgpu_receiver** out, int device) { return dabgpu_receiver_create(out, device, 1, nullptr, nullptr); }   // (no streams to share here)
 void dabgpu_receiver_destroy(dabgpu_receiver* rx) { if (!rx) return; dabgpu_frame_session_destroy(rx->ses); dabgpu_destroy(rx->ctx); delete rx; }
 dabgpu_frame_session* dabgpu_receiver_session(dabgpu_receiver* rx) { return rx ? rx->ses : nullptr; }
 int dabgpu_receiver_set_subchannels(dabgpu_receiver* rx, const dabgpu_subchannel* subs, int n, int decode_fic) {

@@ -153,10 +153,54 @@ def test_two_receivers_with_reader_radio_and_worker_threads_on_the_device(oracle
         args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=env, timeout=600)
-    assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-2000:])
-    out = json.loads(res.stdout.strip().splitlines()[-1])
-    assert out["ok"] and out["receivers"] == 2
-    for r in out["per_receiver"]:
-        assert r["frames"] >= 7 and r["fib_bytes"] >= 30 * 12 * (r["frames"] - 2) and r["cifs_with_output"] >= 2 * (4 * r["frames"] - 15) and r["threaded_equals_serial"]
-    assert out["per_receiver"][0]["digest"] != out["per_receiver"][1]["digest"]
+    env.pop("DABGPU_MIRROR_BANK", None)
+    digests = {}
+    # private pipelines only / every receiver a member of the receiver bank (csrc/receiver_bank.hip: one synchroniser launch, one demodulation launch
+    # and one decode for what both posted) / the default (the second receiver joins the bank, the first keeps its pipeline): the same bytes
+    for bank in ("0", "1", None):
+        e = dict(env) if bank is None else dict(env, DABGPU_MIRROR_BANK=bank)
+        res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=e, timeout=600)
+        assert res.returncode == 0, (bank, res.stdout[-2000:], res.stderr[-2000:])
+        out = json.loads(res.stdout.strip().splitlines()[-1])
+        assert out["ok"] and out["receivers"] == 2, bank
+        for r in out["per_receiver"]:
+            assert r["frames"] >= 7 and r["fib_bytes"] >= 30 * 12 * (r["frames"] - 2) and r["cifs_with_output"] >= 2 * (4 * r["frames"] - 15) and r["threaded_equals_serial"], bank
+        assert out["per_receiver"][0]["digest"] != out["per_receiver"][1]["digest"]
+        digests[bank] = [(r["digest"], r["frames"], r["fib_bytes"], r["cifs_with_output"]) for r in out["per_receiver"]]
+    assert digests["1"] == digests["0"] and digests[None] == digests["0"], digests
+
+
+def test_eight_banked_receivers_equal_eight_private_ones(oracle, tmp_path):
+    """eight receivers of one process, reader + radio + worker threads each, every one on its own capture (carrier offset, timing, payload): all of
+    them members of the receiver bank against all of them on private pipelines -- digest of FIBs + sub-channel bytes, frames and counters equal,
+    receiver by receiver; and the serial phase of the driver (one receiver at a time: rounds of one job) equals the threaded one (full rounds)"""
+    import json
+    import stream_model as SM
+    driver = os.path.join(ROOT, "tests", "cpp", "mirror_threads_driver")
+    if not os.path.exists(driver):
+        import __graft_entry__ as g
+        g.build()
+    subs = [oracle.subchannel(0, 48, eep_level=2, eep_type=0), oracle.subchannel(100, 58, is_uep=True, uep_index=29), oracle.subchannel(300, 42, eep_level=1, eep_type=1)]
+    paths = []
+    for k in range(8):
+        stream, _ = SM.make_ensemble_stream(oracle, 8, subs[:2] + [subs[2]], seed=1200 + k, cfo=(-2.2e-3 + 0.6e-3 * k), timing_pad=137 * k + 11, noise=2.0)
+        p = tmp_path / f"rx{k}.c32"
+        stream.tofile(p)
+        paths.append(str(p))
+    args = [driver, "65536"]
+    for s in subs:
+        if s.is_uep:
+            continue                                   # (the driver's command line takes EEP sub-channels; the UEP one above still shapes the multiplex)
+        args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    digests = {}
+    for bank in ("0", "1"):
+        res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=dict(env, DABGPU_MIRROR_BANK=bank), timeout=900)
+        assert res.returncode == 0, (bank, res.stdout[-2000:], res.stderr[-2000:])
+        out = json.loads(res.stdout.strip().splitlines()[-1])
+        assert out["ok"] and out["receivers"] == 8, bank
+        assert all(r["threaded_equals_serial"] and r["frames"] >= 6 for r in out["per_receiver"]), bank
+        digests[bank] = [(r["digest"], r["frames"], r["fib_bytes"], r["cifs_with_output"]) for r in out["per_receiver"]]
+    assert digests["1"] == digests["0"]
+    assert len({d[0] for d in digests["0"]}) == 8

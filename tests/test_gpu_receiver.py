@@ -43,10 +43,13 @@ def _api(dabgpu):
     return L
 
 
+@pytest.mark.parametrize("form", ["private", "banked"])
 @pytest.mark.parametrize("calls", ["submit_frame", "submit_demod_then_decode"])
-def test_receiver_pipeline_equals_the_oracle_composition(oracle, calls):
+def test_receiver_pipeline_equals_the_oracle_composition(oracle, calls, form):
     """calls: dabgpu_receiver_submit_frame (one call: the decode waits for the demodulation on the device), or dabgpu_receiver_submit_demod followed -- here
-    two frames LATER, as another thread would -- by dabgpu_receiver_submit_decode (the host waits; no stream waits for another): the same bytes"""
+    two frames LATER, as another thread would -- by dabgpu_receiver_submit_decode (the host waits; no stream waits for another): the same bytes.
+    form: a receiver with its own pipeline, or a member of the device's receiver bank (dabgpu_receiver_create_banked: the calls post jobs, a bank
+    thread issues them in rounds -- here rounds of one job): the same interface, the same bytes"""
     import dabgpu
     import stream_model as SM
     O = oracle
@@ -57,7 +60,11 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle, calls):
     stream, truth = SM.make_ensemble_stream(O, n_frames, subs_o, seed=41, cfo=cfo, timing_pad=0, noise=2.0, amplitude=1.0)
     NULL, FRAME = O.NB_NULL_PERIOD, O.NB_FRAME_SAMPLES
     rx = C.c_void_p()
-    ck(L.dabgpu_receiver_create(C.byref(rx), 0, 1, None, None), "dabgpu_receiver_create")
+    if form == "banked":
+        L.dabgpu_receiver_create_banked.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        ck(L.dabgpu_receiver_create_banked(C.byref(rx), 0), "dabgpu_receiver_create_banked")
+    else:
+        ck(L.dabgpu_receiver_create(C.byref(rx), 0, 1, None, None), "dabgpu_receiver_create")
     try:
         dsubs = (dabgpu.SubChannel * 2)(*[dabgpu.SubChannel(s.start_address, s.length, s.is_uep, s.uep_prot_index, s.eep_prot_level, s.eep_type) for s in subs_o])
         ck(L.dabgpu_receiver_set_subchannels(rx, dsubs, 2, 1), "dabgpu_receiver_set_subchannels")
@@ -180,7 +187,11 @@ def test_receivers_come_and_go_without_leaking_device_memory():
     free = []
     for k in range(60):
         rx = C.c_void_p()
-        dabgpu.check(L.dabgpu_receiver_create(C.byref(rx), 0, 1 + (k % 4 if k % 7 == 0 else 0), None, None), "dabgpu_receiver_create")
+        if k % 3 == 1:                                  # every third one a member of the receiver bank (its slot, result store and events come and go)
+            L.dabgpu_receiver_create_banked.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+            dabgpu.check(L.dabgpu_receiver_create_banked(C.byref(rx), 0), "dabgpu_receiver_create_banked")
+        else:
+            dabgpu.check(L.dabgpu_receiver_create(C.byref(rx), 0, 1 + (k % 4 if k % 7 == 0 else 0), None, None), "dabgpu_receiver_create")
         dabgpu.check(L.dabgpu_receiver_submit_sync(rx, C.byref(cfg), 100), "dabgpu_receiver_submit_sync")
         rec = dabgpu.SyncState()
         dabgpu.check(L.dabgpu_receiver_wait_sync(rx, C.byref(rec), None, None), "dabgpu_receiver_wait_sync")
