@@ -62,7 +62,6 @@ struct dabgpu_receiver {
     // a BANKED receiver (receiver_bank.hip): the staging buffers above are its own, everything else is the bank's; submit_* post jobs
     dabgpu_rx_member* member = nullptr;
     int device = 0;
-    std::atomic<int> bank_tie{0};            // core model of the two-call form (dabgpu_receiver_submit_demod / _submit_decode)
 };
 
 #define CK(call) do { st = dabgpu_check_hip((call), #call); if (st) return st; } while (0)
@@ -345,14 +344,16 @@ extern "C" int dabgpu_receiver_submit_frame(dabgpu_receiver* rx, size_t frame_sa
 // hardware queue, and a queue whose head waits for another queue's event holds back the other receiver's work behind it.
 extern "C" int dabgpu_receiver_submit_demod(dabgpu_receiver* rx, size_t frame_sample, float beta, int want_views, uint64_t* generation) {
     if (!rx) { dabgpu_set_error("receiver_submit_demod: null receiver"); return DABGPU_ERR_INVALID_ARG; }
-    // (banked: the frame's decode belongs to the tick that demodulates it, with the core model given at creation time's default: see submit_decode)
-    if (rx->member) return submit_banked(rx, frame_sample, beta, want_views, rx->bank_tie, generation);
+    if (rx->member) {   // a round decodes what it demodulates, with the core model the frame was posted with: dabgpu_receiver_submit_frame carries it
+        dabgpu_set_error("receiver_submit_demod: a banked receiver takes dabgpu_receiver_submit_frame (one call, with the core model)");
+        return DABGPU_ERR_UNSUPPORTED;
+    }
     return submit_demod(rx, frame_sample, beta, want_views, generation, nullptr);
 }
 
 extern "C" int dabgpu_receiver_submit_decode(dabgpu_receiver* rx, uint64_t generation, int tie_rule) {
     if (!rx) { dabgpu_set_error("receiver_submit_decode: null receiver"); return DABGPU_ERR_INVALID_ARG; }
-    if (rx->member) { rx->bank_tie = tie_rule ? 1 : 0; return DABGPU_OK; }      // (the tick decoded it; the core model of later frames follows this argument)
+    if (rx->member) { dabgpu_set_error("receiver_submit_decode: a banked receiver takes dabgpu_receiver_submit_frame"); return DABGPU_ERR_UNSUPPORTED; }
     dabgpu_frame_session* s = rx->ses;
     DABGPU_BIND(s->ctx);
     dabgpu_frame_session::slot* sl = &s->slots[generation % dabgpu_frame_session::R];

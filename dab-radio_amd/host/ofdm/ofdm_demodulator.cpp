@@ -57,6 +57,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
                      std::memcmp(map.data(), carrier_mapper.data(), map.size() * sizeof(int)) == 0;
         }
         m_live = &live;
+        m_banked = banked;
         if (banked) st = dabgpu_receiver_create_banked(&m_rx, dev ? std::atoi(dev) : 0);
         else st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
         if (st != DABGPU_OK) live.fetch_sub(1);
@@ -349,8 +350,10 @@ void OFDM_Demod::SubmitFrame() {
     const size_t frame_sample = (size_t)((int)m_params.nb_null_period + m_reader_time_offset);
     // this thread enqueues the frame's upload, demodulation and fine-frequency update; the decode thread waits for the demodulation and enqueues the
     // decode (dabgpu_receiver_submit_demod / _submit_decode: no stream waits for another on the device, and half the runtime calls leave this thread)
-    const int rc = dabgpu_receiver_submit_demod(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, fetch_debug ? 1 : 0, &gen);
-    if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_demod", rc);
+    // (a member of the receiver bank posts the frame in one call: the bank's round demodulates and decodes it)
+    const int rc = m_banked ? dabgpu_receiver_submit_frame(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, fetch_debug ? 1 : 0, dabgpu_tie_rule_from_env(), &gen)
+                            : dabgpu_receiver_submit_demod(m_rx, frame_sample, m_cfg.sync.fine_freq_update_beta, fetch_debug ? 1 : 0, &gen);
+    if (rc != DABGPU_OK) fail(m_banked ? "dabgpu_receiver_submit_frame" : "dabgpu_receiver_submit_demod", rc);
     float* stage = nullptr;
     (void)dabgpu_receiver_stage(m_rx, &stage, nullptr);
     m_stage = reinterpret_cast<std::complex<float>*>(stage);
@@ -360,7 +363,8 @@ void OFDM_Demod::SubmitFrame() {
         m_items.push_back(Item{Item::FRAME, 0.0f, 0.0f, 0, gen, fetch_debug, m_mode == 1});
         m_frames_in_flight++;
         m_frames_submitted++;
-        m_to_decode.push_back(gen);
+        if (m_banked) m_decodes_submitted = gen + 1;            // (nothing is left for the decode thread)
+        else m_to_decode.push_back(gen);
     }
     m_cv_items.notify_one();
     m_cv_decode.notify_one();

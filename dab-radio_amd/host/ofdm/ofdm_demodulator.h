@@ -131,6 +131,7 @@ private:
     const OFDM_Params m_params;
     int m_mode = 0;                          // transmission mode 1..4 matching m_params
     dabgpu_receiver* m_rx = nullptr;
+    bool m_banked = false;                   // a member of the device's receiver bank (csrc/receiver_bank.hip)
     bool m_counted = false;                  // this object is in the count of live mode I receivers (the receiver bank's AUTO rule)
     std::atomic<int>* m_live = nullptr;
     // ---- reader side ----

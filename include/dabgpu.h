@@ -541,8 +541,8 @@ int dabgpu_frame_session_fetch_cif(dabgpu_frame_session *s, uint64_t generation,
  * precedes frame k + 1's synchroniser).  N OFDM_Demod objects of a process then cost ~6 runtime calls per frame and member + ~15 per round
  * instead of ~20 per frame on three streams each (csrc/receiver_bank.hip).  Outputs are those of the private pipeline, bit for bit.
  * The sub-channel list (dabgpu_receiver_set_subchannels) is the BANK's: the members report one list (the decoders' subscription is process-wide in
- * the classes above); it applies to the rounds enqueued after the call.  dabgpu_receiver_submit_decode is accepted and does nothing but note the
- * core model for the frames submitted next (a round decodes what it demodulates).  Up to 64 members per device.
+ * the classes above); it applies to the rounds enqueued after the call.  A round decodes what it demodulates: frames are posted with dabgpu_receiver_submit_frame (which carries the
+ * core model); the two-call form dabgpu_receiver_submit_demod / _submit_decode returns DABGPU_ERR_UNSUPPORTED.  Up to 64 members per device.
  */
 typedef struct dabgpu_receiver dabgpu_receiver;
 typedef struct {

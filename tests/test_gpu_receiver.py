@@ -55,6 +55,16 @@ def test_receiver_pipeline_equals_the_oracle_composition(oracle, calls, form):
     O = oracle
     L = _api(dabgpu)
     ck = lambda st, what: dabgpu.check(st, what)               # noqa: E731
+    if form == "banked" and calls != "submit_frame":
+        # a round of the bank decodes what it demodulates: the two-call form is refused, with a message
+        L.dabgpu_receiver_create_banked.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        rx = C.c_void_p()
+        ck(L.dabgpu_receiver_create_banked(C.byref(rx), 0), "dabgpu_receiver_create_banked")
+        try:
+            assert L.dabgpu_receiver_submit_demod(rx, 2656, 0.9, 0, None) == 5 and L.dabgpu_receiver_submit_decode(rx, 0, 0) == 5        # DABGPU_ERR_UNSUPPORTED
+        finally:
+            L.dabgpu_receiver_destroy(rx)
+        return
     subs_o = [O.subchannel(0, 48, eep_level=2, eep_type=0), O.subchannel(100, 58, is_uep=True, uep_index=29)]
     n_frames, cfo, toff, lead = 7, 1.9e-3, -63, 30000
     stream, truth = SM.make_ensemble_stream(O, n_frames, subs_o, seed=41, cfo=cfo, timing_pad=0, noise=2.0, amplitude=1.0)
