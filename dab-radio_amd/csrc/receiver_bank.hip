@@ -14,8 +14,11 @@
 // k + 1's synchroniser) and every output are those of the private pipeline: the same kernels run on the same inputs
 // (tests/test_gpu_cpp_mirror.py, tests/test_gpu_receiver.py run both forms).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
@@ -102,8 +105,10 @@ struct rx_bank_tick {
     int n_ens = 0;                              // member slots covered by the decode
     bool decoded = false, fic = false;
     std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
+    int8_t* h_bits = nullptr; size_t h_bits_cap = 0;  // pinned: the soft bits of the round's frames, compact (ONE device-to-host copy per round)
     int status = DABGPU_OK;
-    bool busy = false;                          // enqueued, not yet handed out by the completer
+    bool busy = false;                          // enqueued, not yet handed out by the completers
+    bool sync_handed = false;                   // the synchronisers' records of the round are with their members
 };
 
 struct dabgpu_rx_bank {
@@ -117,7 +122,9 @@ struct dabgpu_rx_bank {
     uint8_t* d_out = nullptr; size_t d_out_cap = 0;
     rx_bank_tick ticks[TICKS];
     uint64_t n_ticks = 0;                       // ticks enqueued
-    uint64_t n_handed = 0;                      // ticks handed out by the completer
+    uint64_t n_handed = 0;                      // ticks whose frames were handed out (and that are free again)
+    uint64_t n_sync_handed = 0;                 // ticks whose synchroniser records were handed out
+    float* h_prs = nullptr;                     // pinned [MAXM][NFFT] c32: the members copy their PRS slot here when they post (ONE upload per round)
     dabgpu_rx_member* members[MAXM] = {nullptr};
     // the decoders' subscription (process-wide in the classes above: dabgpu_frame_batcher)
     std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0; bool fic = false;
@@ -125,11 +132,17 @@ struct dabgpu_rx_bank {
     std::condition_variable cv_jobs, cv_done, cv_ticks;
     std::deque<rx_bank_job> jobs;
     bool stop = false;
-    std::thread worker, completer;
+    std::thread worker, completer, sync_completer;
     int refs = 0;
+    // DABGPU_BANK_PROFILE=1: what the rounds looked like, printed at shutdown
+    bool profile = false;
+    int gather_us = 40;                         // DABGPU_BANK_GATHER_US
+    uint64_t p_sync_jobs = 0, p_frame_jobs = 0, p_ticks_with_frames = 0;
+    double p_enqueue_us = 0, p_wait_sync_us = 0, p_wait_frames_us = 0, p_handout_us = 0, p_worker_idle_us = 0;
 };
 
 namespace {
+double bank_now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 std::mutex g_banks_mu;
 dabgpu_rx_bank* g_banks[16] = {nullptr};
 
@@ -162,9 +175,10 @@ int bank_alloc(dabgpu_rx_bank* b) {
     BK(hipMalloc((void**)&b->d_frq, (size_t)MAXM * NFFT * sizeof(float)));
     BK(hipMalloc((void**)&b->d_corr, (size_t)MAXM * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float)));
     BK(hipMalloc((void**)&b->d_freq, (size_t)MAXM * sizeof(float)));
-    BK(hipMalloc((void**)&b->d_fine, (size_t)MAXM * sizeof(float)));
-    BK(hipMalloc((void**)&b->d_total, (size_t)MAXM * sizeof(float)));
+    BK(hipMalloc((void**)&b->d_fine, (size_t)2 * MAXM * sizeof(float)));            // [fine after the update | total phase]: one copy back per round
+    b->d_total = b->d_fine + MAXM;
     BK(hipMalloc((void**)&b->d_tab, (size_t)TICKS * sizeof(tick_table)));
+    BK(hipHostMalloc((void**)&b->h_prs, (size_t)MAXM * NFFT * 2 * sizeof(float), hipHostMallocDefault));
     for (auto& t : b->ticks) {
         BK(hipHostMalloc((void**)&t.h_tab, sizeof(tick_table), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_states, (size_t)MAXM * sizeof(dabgpu_sync_state), hipHostMallocDefault));
@@ -200,8 +214,10 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     BK(hipMemcpyAsync(d_tab, t.h_tab, sizeof(tick_table), hipMemcpyHostToDevice, a));
     // ---- synchronisers ----
     if (nS) {
-        for (const auto& j : t.sync_jobs)
-            BK(hipMemcpyAsync(b->d_prs + (size_t)j.m->slot * NFFT * 2, j.m->h_stage[j.stage] + 2 * j.sample, NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
+        int lo = MAXM, up = -1;
+        for (const auto& j : t.sync_jobs) { lo = j.m->slot < lo ? j.m->slot : lo; up = j.m->slot > up ? j.m->slot : up; }
+        // (the members copied their PRS slots into the bank's pinned array when they posted: one upload of the range that holds this round's)
+        BK(hipMemcpyAsync(b->d_prs + (size_t)lo * NFFT * 2, b->h_prs + (size_t)lo * NFFT * 2, (size_t)(up - lo + 1) * NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
         const dabgpu_sync_cfg& cfg = t.sync_jobs[0].cfg;
         const bool coarse = cfg.is_coarse_freq_correction != 0;
         const float *d_prs_ref, *d_time_ref;
@@ -247,14 +263,15 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
         bank_scatter_kernel<<<dim3(8, (unsigned)nF), 256, 0, a>>>(b->d_bits, b->d_hist, d_tab, b->d_fine, b->d_states);
         BK(hipGetLastError());
         BK(hipEventRecord(t.ev_demod, a));
-        for (int j = 0; j < nF; j++) {
-            const rx_bank_job& f = t.frame_jobs[(size_t)j];
-            dabgpu_frame_session::slot& sl = f.m->ses->slots[f.gen % dabgpu_frame_session::R];
-            if (!sl.h_bits) BK(hipHostMalloc((void**)&sl.h_bits, FRAME_BITS, hipHostMallocDefault));
-            BK(hipMemcpyAsync(sl.h_bits, b->d_bits + (size_t)j * FRAME_BITS, FRAME_BITS, hipMemcpyDeviceToHost, a));
+        if (t.h_bits_cap < (size_t)nF * FRAME_BITS) {
+            if (t.h_bits) (void)hipHostFree(t.h_bits);
+            t.h_bits = nullptr; t.h_bits_cap = 0;
+            const size_t cap = (size_t)(nF < 8 ? 8 : nF) * FRAME_BITS;
+            BK(hipHostMalloc((void**)&t.h_bits, cap, hipHostMallocDefault));
+            t.h_bits_cap = cap;
         }
-        BK(hipMemcpyAsync(t.h_scal, b->d_fine, (size_t)nF * sizeof(float), hipMemcpyDeviceToHost, a));
-        BK(hipMemcpyAsync(t.h_scal + MAXM, b->d_total, (size_t)nF * sizeof(float), hipMemcpyDeviceToHost, a));
+        BK(hipMemcpyAsync(t.h_bits, b->d_bits, (size_t)nF * FRAME_BITS, hipMemcpyDeviceToHost, a));
+        BK(hipMemcpyAsync(t.h_scal, b->d_fine, (size_t)(MAXM + nF) * sizeof(float), hipMemcpyDeviceToHost, a));      // fine[0..nF) ... total[0..nF)
         BK(hipEventRecord(t.ev_copied, a));
         // ---- decode (stream B) ----
         const size_t n_sub = t.subs.size();
@@ -296,8 +313,14 @@ void worker_main(dabgpu_rx_bank* b) {
     (void)hipSetDevice(b->device);
     for (;;) {
         std::unique_lock<std::mutex> lock(b->mu);
+        const double ti0 = b->profile ? bank_now_us() : 0.0;
         b->cv_jobs.wait(lock, [b] { return b->stop || !b->jobs.empty(); });
+        if (b->profile) b->p_worker_idle_us += bank_now_us() - ti0;
         if (b->stop && b->jobs.empty()) return;
+        // several members: give the others a moment to post as well (a round costs ~25 runtime calls whatever it carries; the calls, not the
+        // device, are what a process can issue only so many of per second) -- at most `gather_us`, and not at all for a lone member
+        if (b->refs > 1 && b->gather_us > 0 && (int)b->jobs.size() < b->refs)
+            b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), [b] { return b->stop || (int)b->jobs.size() >= b->refs; });
         const uint64_t tick_no = b->n_ticks;
         rx_bank_tick& t = b->ticks[tick_no % TICKS];
         b->cv_ticks.wait(lock, [&] { return !t.busy; });                  // (the completer hands ticks out in order: at most TICKS are under way)
@@ -327,7 +350,9 @@ void worker_main(dabgpu_rx_bank* b) {
             const int e = dabgpu_check_hip(hipMemsetAsync(b->d_states + r.m->slot, 0, sizeof(dabgpu_sync_state), b->a), "hipMemsetAsync(bank reset)");
             if (e && !st) st = e;
         }
+        const double te0 = b->profile ? bank_now_us() : 0.0;
         if (!st) st = enqueue_tick(b, t, tick_no);
+        if (b->profile) { b->p_enqueue_us += bank_now_us() - te0; b->p_sync_jobs += t.sync_jobs.size(); b->p_frame_jobs += t.frame_jobs.size(); b->p_ticks_with_frames += t.frame_jobs.empty() ? 0 : 1; }
         lock.lock();
         t.status = st;
         for (const auto& j : t.sync_jobs) j.m->sync_state = 2;
@@ -338,38 +363,55 @@ void worker_main(dabgpu_rx_bank* b) {
     }
 }
 
-// hands the ticks out in order: waits for the device, copies every job's results to its member, wakes the members
+// The synchronisers' records, round by round: the readers wait for them (they cannot finish buffering the frame before), so they do not queue
+// behind the decode of the same or an earlier round
+void sync_completer_main(dabgpu_rx_bank* b) {
+    (void)hipSetDevice(b->device);
+    for (;;) {
+        std::unique_lock<std::mutex> lock(b->mu);
+        b->cv_done.wait(lock, [b] { return (b->stop && b->n_sync_handed == b->n_ticks) || (b->n_sync_handed < b->n_ticks && b->ticks[b->n_sync_handed % TICKS].status != -1); });
+        if (b->n_sync_handed == b->n_ticks) return;
+        rx_bank_tick& t = b->ticks[b->n_sync_handed % TICKS];
+        lock.unlock();
+        int st = t.status;
+        const double tc0 = b->profile ? bank_now_us() : 0.0;
+        if (!st && !t.sync_jobs.empty()) st = dabgpu_check_hip(hipEventSynchronize(t.ev_sync), "hipEventSynchronize(bank sync)");
+        if (b->profile) b->p_wait_sync_us += bank_now_us() - tc0;
+        lock.lock();
+        for (const auto& j : t.sync_jobs) {
+            dabgpu_rx_member* m = j.m;
+            m->sync_status = st;
+            if (!st) {
+                m->sync_rec = t.h_states[m->slot];
+                m->sync_coarse = j.cfg.is_coarse_freq_correction != 0;
+                m->sync_imp.assign(t.h_imp + (size_t)m->slot * NFFT, t.h_imp + (size_t)(m->slot + 1) * NFFT);
+                if (m->sync_coarse) m->sync_frq.assign(t.h_frq + (size_t)m->slot * NFFT, t.h_frq + (size_t)(m->slot + 1) * NFFT);
+            }
+            m->sync_state = 3;
+            m->jobs_in_flight--;
+        }
+        t.sync_handed = true;
+        b->n_sync_handed++;
+        lock.unlock();
+        b->cv_done.notify_all();
+    }
+}
+
+// The frames, round by round: waits for the device, copies every frame's results to its member's result store, wakes the members, frees the round
 void completer_main(dabgpu_rx_bank* b) {
     (void)hipSetDevice(b->device);
     for (;;) {
         std::unique_lock<std::mutex> lock(b->mu);
-        b->cv_done.wait(lock, [b] { return (b->stop && b->n_handed == b->n_ticks) || (b->n_handed < b->n_ticks && b->ticks[b->n_handed % TICKS].busy && b->ticks[b->n_handed % TICKS].status != -1); });
+        b->cv_done.wait(lock, [b] { return (b->stop && b->n_handed == b->n_ticks) || (b->n_handed < b->n_ticks && b->ticks[b->n_handed % TICKS].status != -1); });
         if (b->n_handed == b->n_ticks) return;
         rx_bank_tick& t = b->ticks[b->n_handed % TICKS];
         lock.unlock();
         int st = t.status;
-        // the synchronisers' records first: the readers wait for them
-        if (!st && !t.sync_jobs.empty()) st = dabgpu_check_hip(hipEventSynchronize(t.ev_sync), "hipEventSynchronize(bank sync)");
-        if (!t.sync_jobs.empty()) {
-            lock.lock();
-            for (const auto& j : t.sync_jobs) {
-                dabgpu_rx_member* m = j.m;
-                m->sync_status = st;
-                if (!st) {
-                    m->sync_rec = t.h_states[m->slot];
-                    m->sync_coarse = j.cfg.is_coarse_freq_correction != 0;
-                    m->sync_imp.assign(t.h_imp + (size_t)m->slot * NFFT, t.h_imp + (size_t)(m->slot + 1) * NFFT);
-                    if (m->sync_coarse) m->sync_frq.assign(t.h_frq + (size_t)m->slot * NFFT, t.h_frq + (size_t)(m->slot + 1) * NFFT);
-                }
-                m->sync_state = 3;
-                m->jobs_in_flight--;
-            }
-            lock.unlock();
-            b->cv_done.notify_all();
-        }
+        const double tc0 = b->profile ? bank_now_us() : 0.0;
         if (!t.frame_jobs.empty()) {
             if (!st) st = dabgpu_check_hip(hipEventSynchronize(t.ev_copied), "hipEventSynchronize(bank copies)");
             if (!st) st = dabgpu_check_hip(hipEventSynchronize(t.ev_done), "hipEventSynchronize(bank decode)");
+            if (b->profile) b->p_wait_frames_us += bank_now_us() - tc0;
             const size_t n_sub = t.subs.size();
             const out_ptrs o = out_layout(t.h_out, (size_t)t.n_ens, n_sub, t.cif_out);
             for (size_t j = 0; j < t.frame_jobs.size(); j++) {
@@ -399,6 +441,9 @@ void completer_main(dabgpu_rx_bank* b) {
                         sl.fic = t.fic; sl.subs = t.subs; sl.sub_off = t.sub_off; sl.sub_n = t.sub_n; sl.cif_out = t.cif_out;
                     }
                 }
+                // (the member's slots are plain host memory here: the round's page-locked buffers were the copies' targets)
+                if (!sl.h_bits && hipHostMalloc((void**)&sl.h_bits, FRAME_BITS, hipHostMallocDefault) != hipSuccess) { if (!st) { st = DABGPU_ERR_HIP; dabgpu_set_error("bank: hipHostMalloc(bits)"); } }
+                if (sl.h_bits && !st) memcpy(sl.h_bits, t.h_bits + j * FRAME_BITS, FRAME_BITS);
                 if (!sl.h_aux && hipHostMalloc((void**)&sl.h_aux, 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) { if (!st) { st = DABGPU_ERR_HIP; dabgpu_set_error("bank: hipHostMalloc(aux)"); } }
                 if (sl.h_aux) { sl.h_aux[0] = t.h_scal[j]; sl.h_aux[1] = t.h_scal[MAXM + j]; }
                 sl.pending = false;
@@ -411,9 +456,13 @@ void completer_main(dabgpu_rx_bank* b) {
                 f.m->jobs_in_flight--;
             }
             lock.unlock();
+            b->cv_done.notify_all();
         }
         lock.lock();
+        b->cv_done.wait(lock, [&] { return t.sync_handed; });
+        if (b->profile) b->p_handout_us += bank_now_us() - tc0;
         t.busy = false;
+        t.sync_handed = false;
         t.status = -1;
         b->n_handed++;
         lock.unlock();
@@ -426,10 +475,11 @@ void bank_free(dabgpu_rx_bank* b) {
     (void)hipSetDevice(b->device);
     if (b->a) (void)hipStreamSynchronize(b->a);
     if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
-    void* dev[] = {b->d_prs, b->d_iq, b->d_bits, b->d_hist, b->d_states, b->d_imp, b->d_frq, b->d_corr, b->d_freq, b->d_fine, b->d_total, b->d_tab, b->d_out};
+    void* dev[] = {b->d_prs, b->d_iq, b->d_bits, b->d_hist, b->d_states, b->d_imp, b->d_frq, b->d_corr, b->d_freq, b->d_fine, b->d_tab, b->d_out};
+    if (b->h_prs) (void)hipHostFree(b->h_prs);
     for (void* p : dev) if (p) (void)hipFree(p);
     for (auto& t : b->ticks) {
-        void* host[] = {t.h_tab, t.h_states, t.h_imp, t.h_frq, t.h_scal, t.h_out};
+        void* host[] = {t.h_tab, t.h_states, t.h_imp, t.h_frq, t.h_scal, t.h_out, t.h_bits};
         for (void* p : host) if (p) (void)hipHostFree(p);
         hipEvent_t evs[] = {t.ev_sync, t.ev_demod, t.ev_copied, t.ev_done};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -451,6 +501,8 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
         b = new dabgpu_rx_bank();
         for (auto& t : b->ticks) t.status = -1;
         b->device = device;
+        if (const char* e = std::getenv("DABGPU_BANK_PROFILE")) b->profile = std::atoi(e) != 0;
+        if (const char* e = std::getenv("DABGPU_BANK_GATHER_US")) b->gather_us = std::atoi(e);
         st = dabgpu_create(&b->ctx, device, nullptr, nullptr);
         if (!st) {
             int least = 0, greatest = 0;
@@ -461,6 +513,7 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
         if (st) { bank_free(b); return st; }
         b->worker = std::thread(worker_main, b);
         b->completer = std::thread(completer_main, b);
+        b->sync_completer = std::thread(sync_completer_main, b);
         g_banks[device] = b;
         static bool registered = false;                                    // (the HIP runtime registered its own teardown earlier: this one runs before it)
         if (!registered) { registered = true; std::atexit(dabgpu_rx_bank_shutdown); }
@@ -543,6 +596,11 @@ int dabgpu_rx_bank_post_sync(dabgpu_rx_member* m, const dabgpu_sync_cfg* cfg, in
     {
         std::lock_guard<std::mutex> lock(b->mu);
         if (m->sync_state != 0) { dabgpu_set_error("receiver_submit_sync: the previous record has not been collected (dabgpu_receiver_wait_sync)"); return DABGPU_ERR_INVALID_ARG; }
+    }
+    // the member's row of the bank's pinned PRS array is its own until the record has come back (one synchroniser at a time per member)
+    memcpy(b->h_prs + (size_t)m->slot * NFFT * 2, m->h_stage[stage] + 2 * prs_sample, NFFT * 2 * sizeof(float));
+    {
+        std::lock_guard<std::mutex> lock(b->mu);
         rx_bank_job j{}; j.kind = rx_bank_job::SYNC; j.m = m; j.stage = stage; j.sample = prs_sample; j.cfg = *cfg;
         b->jobs.push_back(j);
         m->sync_state = 1;
@@ -628,6 +686,12 @@ void dabgpu_rx_bank_shutdown(void) {
         b->cv_jobs.notify_all(); b->cv_done.notify_all();
         if (b->worker.joinable()) b->worker.join();
         if (b->completer.joinable()) b->completer.join();
+        if (b->sync_completer.joinable()) b->sync_completer.join();
+        if (b->profile && b->n_ticks)
+            fprintf(stderr, "receiver bank (device %d): %llu rounds, %llu with frames; %.2f frames and %.2f synchronisers per round; per round us: enqueue %.1f, completer { wait sync %.1f, "
+                            "wait frames %.1f, whole hand-out %.1f }; worker idle %.1f\n", b->device, (unsigned long long)b->n_ticks, (unsigned long long)b->p_ticks_with_frames,
+                    (double)b->p_frame_jobs / (double)b->n_ticks, (double)b->p_sync_jobs / (double)b->n_ticks, b->p_enqueue_us / (double)b->n_ticks, b->p_wait_sync_us / (double)b->n_ticks,
+                    b->p_wait_frames_us / (double)b->n_ticks, b->p_handout_us / (double)b->n_ticks, b->p_worker_idle_us / (double)b->n_ticks);
         bank_free(b);
         b = nullptr;
     }

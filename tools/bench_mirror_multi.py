@@ -50,7 +50,7 @@ with tempfile.TemporaryDirectory() as d:
         if res.returncode != 0:
             print(res.stderr[-2000:], file=sys.stderr); sys.exit(res.returncode)
         run = json.loads(res.stdout.strip().splitlines()[-1])
-        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]        # DABGPU_MIRROR_PROFILE=1
+        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1
         if prof:
             run["profile"] = prof
         out["runs"].append(run)
