@@ -90,6 +90,7 @@ struct dabgpu_rx_member {
     uint64_t done_gen = 0;                      // generations < done_gen have their results in the session's slots
     int frame_status = DABGPU_OK;
     int jobs_in_flight = 0;
+    double last_post_us = -1e18;                // when the member posted last (the worker's gathering rule)
     // views (display buffers), allocated at first use
     float* d_fft = nullptr; float* d_dq = nullptr;
 };
@@ -136,7 +137,7 @@ struct dabgpu_rx_bank {
     int refs = 0;
     // DABGPU_BANK_PROFILE=1: what the rounds looked like, printed at shutdown
     bool profile = false;
-    int gather_us = 40;                         // DABGPU_BANK_GATHER_US
+    int gather_us = 150;                        // DABGPU_BANK_GATHER_US
     uint64_t p_sync_jobs = 0, p_frame_jobs = 0, p_ticks_with_frames = 0;
     double p_enqueue_us = 0, p_wait_sync_us = 0, p_wait_frames_us = 0, p_handout_us = 0, p_worker_idle_us = 0;
 };
@@ -212,24 +213,9 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     t.n_ens = hi + 1;
     tick_table* d_tab = b->d_tab + (tick_no % TICKS);
     BK(hipMemcpyAsync(d_tab, t.h_tab, sizeof(tick_table), hipMemcpyHostToDevice, a));
-    // ---- synchronisers ----
-    if (nS) {
-        int lo = MAXM, up = -1;
-        for (const auto& j : t.sync_jobs) { lo = j.m->slot < lo ? j.m->slot : lo; up = j.m->slot > up ? j.m->slot : up; }
-        // (the members copied their PRS slots into the bank's pinned array when they posted: one upload of the range that holds this round's)
-        BK(hipMemcpyAsync(b->d_prs + (size_t)lo * NFFT * 2, b->h_prs + (size_t)lo * NFFT * 2, (size_t)(up - lo + 1) * NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
-        const dabgpu_sync_cfg& cfg = t.sync_jobs[0].cfg;
-        const bool coarse = cfg.is_coarse_freq_correction != 0;
-        const float *d_prs_ref, *d_time_ref;
-        if ((st = dabgpu_mode_sync_tables(c, 1, &d_prs_ref, &d_time_ref))) return st;
-        BK(dabgpu_launch_sync(b->d_prs, NFFT, t.n_ens, &cfg, b->d_states, b->d_imp, coarse ? b->d_frq : nullptr, c->d_tw, d_prs_ref, d_time_ref, d_tab->sync_active, 1, a));
-        BK(hipMemcpyAsync(t.h_states, b->d_states, (size_t)t.n_ens * sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
-        BK(hipMemcpyAsync(t.h_imp, b->d_imp, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
-        if (coarse) BK(hipMemcpyAsync(t.h_frq, b->d_frq, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
-    }
-    BK(hipEventRecord(t.ev_sync, a));
     // ---- frames ----
     t.decoded = false;
+    bool frames_enqueued = false;
     if (nF) {
         for (int j = 0; j < nF; j++) {
             const rx_bank_job& f = t.frame_jobs[(size_t)j];
@@ -263,16 +249,7 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
         bank_scatter_kernel<<<dim3(8, (unsigned)nF), 256, 0, a>>>(b->d_bits, b->d_hist, d_tab, b->d_fine, b->d_states);
         BK(hipGetLastError());
         BK(hipEventRecord(t.ev_demod, a));
-        if (t.h_bits_cap < (size_t)nF * FRAME_BITS) {
-            if (t.h_bits) (void)hipHostFree(t.h_bits);
-            t.h_bits = nullptr; t.h_bits_cap = 0;
-            const size_t cap = (size_t)(nF < 8 ? 8 : nF) * FRAME_BITS;
-            BK(hipHostMalloc((void**)&t.h_bits, cap, hipHostMallocDefault));
-            t.h_bits_cap = cap;
-        }
-        BK(hipMemcpyAsync(t.h_bits, b->d_bits, (size_t)nF * FRAME_BITS, hipMemcpyDeviceToHost, a));
-        BK(hipMemcpyAsync(t.h_scal, b->d_fine, (size_t)(MAXM + nF) * sizeof(float), hipMemcpyDeviceToHost, a));      // fine[0..nF) ... total[0..nF)
-        BK(hipEventRecord(t.ev_copied, a));
+        frames_enqueued = true;
         // ---- decode (stream B) ----
         const size_t n_sub = t.subs.size();
         if (t.fic || n_sub) {
@@ -305,6 +282,34 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
             t.decoded = true;
         }
     }
+    // ---- synchronisers: behind the frames' fine-frequency updates, in front of the bulky copies back ----
+    if (nS) {
+        int lo = MAXM, up = -1;
+        for (const auto& j : t.sync_jobs) { lo = j.m->slot < lo ? j.m->slot : lo; up = j.m->slot > up ? j.m->slot : up; }
+        // (the members copied their PRS slots into the bank's pinned array when they posted: one upload of the range that holds this round's)
+        BK(hipMemcpyAsync(b->d_prs + (size_t)lo * NFFT * 2, b->h_prs + (size_t)lo * NFFT * 2, (size_t)(up - lo + 1) * NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
+        const dabgpu_sync_cfg& cfg = t.sync_jobs[0].cfg;
+        const bool coarse = cfg.is_coarse_freq_correction != 0;
+        const float *d_prs_ref, *d_time_ref;
+        if ((st = dabgpu_mode_sync_tables(c, 1, &d_prs_ref, &d_time_ref))) return st;
+        BK(dabgpu_launch_sync(b->d_prs, NFFT, t.n_ens, &cfg, b->d_states, b->d_imp, coarse ? b->d_frq : nullptr, c->d_tw, d_prs_ref, d_time_ref, d_tab->sync_active, 1, a));
+        BK(hipMemcpyAsync(t.h_states, b->d_states, (size_t)t.n_ens * sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
+        BK(hipMemcpyAsync(t.h_imp, b->d_imp, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
+        if (coarse) BK(hipMemcpyAsync(t.h_frq, b->d_frq, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
+    }
+    BK(hipEventRecord(t.ev_sync, a));
+    if (frames_enqueued) {
+        if (t.h_bits_cap < (size_t)nF * FRAME_BITS) {
+            if (t.h_bits) (void)hipHostFree(t.h_bits);
+            t.h_bits = nullptr; t.h_bits_cap = 0;
+            const size_t cap = (size_t)(nF < 8 ? 8 : nF) * FRAME_BITS;
+            BK(hipHostMalloc((void**)&t.h_bits, cap, hipHostMallocDefault));
+            t.h_bits_cap = cap;
+        }
+        BK(hipMemcpyAsync(t.h_bits, b->d_bits, (size_t)nF * FRAME_BITS, hipMemcpyDeviceToHost, a));
+        BK(hipMemcpyAsync(t.h_scal, b->d_fine, (size_t)(MAXM + nF) * sizeof(float), hipMemcpyDeviceToHost, a));      // fine[0..nF) ... total[0..nF)
+        BK(hipEventRecord(t.ev_copied, a));
+    }
     BK(hipEventRecord(t.ev_done, q));
     return DABGPU_OK;
 }
@@ -319,23 +324,36 @@ void worker_main(dabgpu_rx_bank* b) {
         if (b->stop && b->jobs.empty()) return;
         // several members: give the others a moment to post as well (a round costs ~25 runtime calls whatever it carries; the calls, not the
         // device, are what a process can issue only so many of per second) -- at most `gather_us`, and not at all for a lone member
-        if (b->refs > 1 && b->gather_us > 0 && (int)b->jobs.size() < b->refs)
-            b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), [b] { return b->stop || (int)b->jobs.size() >= b->refs; });
+        if (b->refs > 1 && b->gather_us > 0) {
+            const double t_first = bank_now_us();
+            auto all_in = [b, t_first] {                                   // every member that posted in the last few ms has a job in the queue again
+                if (b->stop) return true;
+                bool in_queue[MAXM] = {false};
+                for (const auto& j : b->jobs) in_queue[j.m->slot] = true;
+                for (int k = 0; k < MAXM; k++) {
+                    const dabgpu_rx_member* m = b->members[k];
+                    if (m && !in_queue[k] && t_first - m->last_post_us < 4000.0) return false;
+                }
+                return true;
+            };
+            if (!all_in()) b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), all_in);
+        }
         const uint64_t tick_no = b->n_ticks;
         rx_bank_tick& t = b->ticks[tick_no % TICKS];
         b->cv_ticks.wait(lock, [&] { return !t.busy; });                  // (the completer hands ticks out in order: at most TICKS are under way)
         t.sync_jobs.clear(); t.frame_jobs.clear();
-        bool taken[MAXM] = {false};
+        int taken[MAXM] = {0};                                             // 0 nothing yet, 1 its frame is in (its next synchroniser may follow), 2 closed
         std::vector<rx_bank_job> resets;
-        // at most one job per member, in posting order (a member's frame k precedes its synchroniser k + 1: they must not share a tick, the
-        // synchroniser reads the fine-frequency word the frame's update writes); synchronisers / frames with another configuration wait a tick
+        // Per member, in posting order: its oldest job, and -- when that is a frame -- the synchroniser of the NEXT frame as well: a round runs its
+        // frames first (upload, demodulation, fine-frequency update) and its synchronisers behind them on the same stream, so the synchroniser still
+        // reads the fine-frequency word the frame's update wrote.  Synchronisers / frames with another configuration wait a round.
         for (auto it = b->jobs.begin(); it != b->jobs.end();) {
             const int slot = it->m->slot;
-            bool take = !taken[slot];
+            bool take = taken[slot] == 0 || (taken[slot] == 1 && it->kind == rx_bank_job::SYNC);
             if (take && it->kind == rx_bank_job::SYNC && !t.sync_jobs.empty() && memcmp(&t.sync_jobs[0].cfg, &it->cfg, sizeof(dabgpu_sync_cfg)) != 0) take = false;
             if (take && it->kind == rx_bank_job::FRAME && !t.frame_jobs.empty() && (t.frame_jobs[0].beta != it->beta || t.frame_jobs[0].tie != it->tie)) take = false;
-            taken[slot] = true;                                            // (a job left behind blocks the member's later ones: order)
-            if (!take) { ++it; continue; }
+            if (!take) { taken[slot] = 2; ++it; continue; }                // (a job left behind blocks the member's later ones: order)
+            taken[slot] = (it->kind == rx_bank_job::FRAME && taken[slot] == 0) ? 1 : 2;
             if (it->kind == rx_bank_job::SYNC) t.sync_jobs.push_back(*it);
             else if (it->kind == rx_bank_job::FRAME) t.frame_jobs.push_back(*it);
             else resets.push_back(*it);
@@ -605,6 +623,7 @@ int dabgpu_rx_bank_post_sync(dabgpu_rx_member* m, const dabgpu_sync_cfg* cfg, in
         b->jobs.push_back(j);
         m->sync_state = 1;
         m->jobs_in_flight++;
+        m->last_post_us = bank_now_us();
     }
     b->cv_jobs.notify_one();
     return DABGPU_OK;
@@ -638,6 +657,7 @@ int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sampl
         b->jobs.push_back(j);
         m->stage_state[stage] = 1;
         m->jobs_in_flight++;
+        m->last_post_us = bank_now_us();
         if (generation) *generation = j.gen;
     }
     b->cv_jobs.notify_one();
