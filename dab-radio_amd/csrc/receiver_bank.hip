@@ -116,6 +116,10 @@ struct dabgpu_rx_bank {
     int device = 0;
     dabgpu_ctx* ctx = nullptr;                  // tables; its stream = stream B (decode), its scratch = the decoder's
     hipStream_t a = nullptr;
+    static constexpr int NUP = 3;               // upload streams: the frames of a round cross PCIe on several DMA engines at once
+    hipStream_t up[NUP] = {nullptr, nullptr, nullptr};
+    hipEvent_t up_ev[NUP] = {nullptr, nullptr, nullptr};
+    hipEvent_t up_gate = nullptr;               // the batch buffer is free again (the previous round's demodulation has read it)
     float* d_prs = nullptr; float* d_iq = nullptr; int8_t* d_bits = nullptr; int8_t* d_hist = nullptr;
     dabgpu_sync_state* d_states = nullptr; float* d_imp = nullptr; float* d_frq = nullptr;
     float* d_corr = nullptr; float* d_freq = nullptr; float* d_fine = nullptr; float* d_total = nullptr;
@@ -137,7 +141,7 @@ struct dabgpu_rx_bank {
     int refs = 0;
     // DABGPU_BANK_PROFILE=1: what the rounds looked like, printed at shutdown
     bool profile = false;
-    int gather_us = 150;                        // DABGPU_BANK_GATHER_US
+    int gather_us = 1000;                        // DABGPU_BANK_GATHER_US
     uint64_t p_sync_jobs = 0, p_frame_jobs = 0, p_ticks_with_frames = 0;
     double p_enqueue_us = 0, p_wait_sync_us = 0, p_wait_frames_us = 0, p_handout_us = 0, p_worker_idle_us = 0;
 };
@@ -180,6 +184,11 @@ int bank_alloc(dabgpu_rx_bank* b) {
     b->d_total = b->d_fine + MAXM;
     BK(hipMalloc((void**)&b->d_tab, (size_t)TICKS * sizeof(tick_table)));
     BK(hipHostMalloc((void**)&b->h_prs, (size_t)MAXM * NFFT * 2 * sizeof(float), hipHostMallocDefault));
+    for (int k = 0; k < dabgpu_rx_bank::NUP; k++) {
+        BK(hipStreamCreateWithFlags(&b->up[k], hipStreamNonBlocking));
+        BK(hipEventCreateWithFlags(&b->up_ev[k], hipEventDisableTiming));
+    }
+    BK(hipEventCreateWithFlags(&b->up_gate, hipEventDisableTiming));
     for (auto& t : b->ticks) {
         BK(hipHostMalloc((void**)&t.h_tab, sizeof(tick_table), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_states, (size_t)MAXM * sizeof(dabgpu_sync_state), hipHostMallocDefault));
@@ -217,11 +226,17 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     t.decoded = false;
     bool frames_enqueued = false;
     if (nF) {
+        // the uploads: 1.5 MB per frame, spread over NUP streams (DMA engines); they may start once the previous round's demodulation has read the
+        // batch buffer (up_gate), the demodulation waits for all of them
+        const int n_up = nF < dabgpu_rx_bank::NUP ? nF : dabgpu_rx_bank::NUP;
+        if (tick_no > 0) for (int k = 0; k < n_up; k++) BK(hipStreamWaitEvent(b->up[k], b->up_gate, 0));
         for (int j = 0; j < nF; j++) {
             const rx_bank_job& f = t.frame_jobs[(size_t)j];
-            BK(hipMemcpyAsync(b->d_iq + (size_t)j * FRAME_SAMPLES * 2, f.m->h_stage[f.stage] + 2 * f.sample, FRAME_SAMPLES * 2 * sizeof(float), hipMemcpyHostToDevice, a));
-            BK(hipEventRecord(f.m->stage_ev[f.stage], a));
+            hipStream_t u = b->up[j % n_up];
+            BK(hipMemcpyAsync(b->d_iq + (size_t)j * FRAME_SAMPLES * 2, f.m->h_stage[f.stage] + 2 * f.sample, FRAME_SAMPLES * 2 * sizeof(float), hipMemcpyHostToDevice, u));
+            BK(hipEventRecord(f.m->stage_ev[f.stage], u));
         }
+        for (int k = 0; k < n_up; k++) { BK(hipEventRecord(b->up_ev[k], b->up[k])); BK(hipStreamWaitEvent(a, b->up_ev[k], 0)); }
         bank_gather_kernel<<<1, 64, 0, a>>>(b->d_states, d_tab, nF, b->d_freq, b->d_fine);
         BK(hipGetLastError());
         const float beta = t.frame_jobs[0].beta;
@@ -243,6 +258,7 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
             BK(hipMemcpyAsync(sl.h_fft, m->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
             BK(hipMemcpyAsync(sl.h_dq, m->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
         }
+        BK(hipEventRecord(b->up_gate, a));                                 // (everything that reads the batch buffer has been enqueued)
         // the ring slot frame g + 4 of a member goes to is read by the decode of its frame g (5 frames = 16 CIFs + the frame's own 4): a member has
         // one frame per tick at most, so the decode of tick T - 4 is the youngest that may still read what this tick overwrites
         if (tick_no >= 4) BK(hipStreamWaitEvent(a, b->ticks[(tick_no - 4) % TICKS].ev_done, 0));
@@ -503,6 +519,9 @@ void bank_free(dabgpu_rx_bank* b) {
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     }
     if (b->a) (void)hipStreamDestroy(b->a);
+    for (hipStream_t u : b->up) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); }
+    for (hipEvent_t e : b->up_ev) if (e) (void)hipEventDestroy(e);
+    if (b->up_gate) (void)hipEventDestroy(b->up_gate);
     if (b->ctx) dabgpu_destroy(b->ctx);
     delete b;
 }
