@@ -564,7 +564,10 @@ extern "C" int dabgpu_msc_stream_create(dabgpu_ctx* c, const dabgpu_subchannel* 
     int st = dabgpu_check_hip(hipMalloc((void**)&s->d_ring, (size_t)16 * s->n_bits), "hipMalloc(ring)");
     if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&s->h_ring, (size_t)16 * s->n_bits, hipHostMallocDefault), "hipHostMalloc(ring)");
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_logical, (size_t)s->n_bits), "hipMalloc(logical)");
-    if (!st) st = dabgpu_check_hip(hipMemset(s->d_ring, 0, (size_t)16 * s->n_bits), "hipMemset(ring)");
+    // on the context's own stream and waited for: hipMemset runs on the NULL stream, with which a hipStreamNonBlocking stream does not synchronise -- a
+    // ring uploaded right after creation (MSC_Decoder creates its stream on its first call-by-call decode) was overwritten by the late zeros
+    if (!st) st = dabgpu_check_hip(hipMemsetAsync(s->d_ring, 0, (size_t)16 * s->n_bits, c->stream), "hipMemsetAsync(ring)");
+    if (!st) st = dabgpu_check_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(ring)");
     if (st) { dabgpu_msc_stream_destroy(s); return st; }
     dabgpu_cw_desc& D = s->proto;
     D = dabgpu_cw_desc{};
@@ -683,7 +686,8 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
     dabgpu_frame_session* s = new dabgpu_frame_session();
     int st = dabgpu_create(&s->ctx, device, nullptr, nullptr);
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&s->d_hist, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMalloc(session history)");
-    if (!st) st = dabgpu_check_hip(hipMemset(s->d_hist, 0, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS), "hipMemset(session history)");
+    if (!st) st = dabgpu_check_hip(hipMemsetAsync(s->d_hist, 0, (size_t)dabgpu_frame_session::H * DABGPU_NB_FRAME_BITS, s->ctx->stream), "hipMemsetAsync(session history)");
+    if (!st) st = dabgpu_check_hip(hipStreamSynchronize(s->ctx->stream), "hipStreamSynchronize(session history)");      // (not the NULL stream: see dabgpu_msc_stream_create)
     if (!st) st = session_layout(s, 0, 0);
     for (auto& sl : s->slots) {
         if (!st) st = slot_block(s, sl);

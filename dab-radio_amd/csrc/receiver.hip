@@ -124,7 +124,7 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_iq, frame_samples * 2 * sizeof(float)), "hipMalloc(receiver)");
     const size_t rec_bytes = REC_HEAD + 2 * n_fft * sizeof(float);
     if (!st) st = dabgpu_check_hip(hipMalloc(&rx->d_rec, rec_bytes), "hipMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipMemset(rx->d_rec, 0, rec_bytes), "hipMemset(receiver)");
+    if (!st) st = dabgpu_check_hip(hipMemsetAsync(rx->d_rec, 0, rec_bytes, rx->a), "hipMemsetAsync(receiver)");      // (on stream A: ordered before its first synchroniser)
     if (!st) {
         rx->d_state = static_cast<dabgpu_sync_state*>(rx->d_rec);
         rx->d_small = reinterpret_cast<float*>(static_cast<unsigned char*>(rx->d_rec) + REC_SMALL);

@@ -173,9 +173,9 @@ int bank_alloc(dabgpu_rx_bank* b) {
     BK(hipMalloc((void**)&b->d_iq, (size_t)MAXM * FRAME_SAMPLES * 2 * sizeof(float)));
     BK(hipMalloc((void**)&b->d_bits, (size_t)MAXM * FRAME_BITS));
     BK(hipMalloc((void**)&b->d_hist, (size_t)MAXM * H * FRAME_BITS));
-    BK(hipMemset(b->d_hist, 0, (size_t)MAXM * H * FRAME_BITS));
+    BK(hipMemsetAsync(b->d_hist, 0, (size_t)MAXM * H * FRAME_BITS, b->a));          // (stream A, not the NULL stream; join() synchronises it)
     BK(hipMalloc((void**)&b->d_states, (size_t)MAXM * sizeof(dabgpu_sync_state)));
-    BK(hipMemset(b->d_states, 0, (size_t)MAXM * sizeof(dabgpu_sync_state)));
+    BK(hipMemsetAsync(b->d_states, 0, (size_t)MAXM * sizeof(dabgpu_sync_state), b->a));
     BK(hipMalloc((void**)&b->d_imp, (size_t)MAXM * NFFT * sizeof(float)));
     BK(hipMalloc((void**)&b->d_frq, (size_t)MAXM * NFFT * sizeof(float)));
     BK(hipMalloc((void**)&b->d_corr, (size_t)MAXM * DABGPU_NB_FRAME_SYMBOLS * 2 * sizeof(float)));

@@ -1,6 +1,7 @@
 // dab/msc/msc_decoder.cpp -- reference: src/dab/msc/msc_decoder.cpp:26-154
 #include "./msc_decoder.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -44,6 +45,7 @@ MSC_Decoder::MSC_Decoder(const Subchannel subchannel)
     }
     m_batch->ring.resize((size_t)16 * (size_t)subchannel.length * 64);
     m_decoded_bytes.resize((size_t)subchannel.length * 8);                              // :30
+    if (const char* e = std::getenv("DABGPU_MSC_EAGER")) if (std::atoi(e)) EnsureStream();   // development: the device objects at construction, as before round 6
     dabgpu_frame_batcher::add_subchannel(m_batch->sc);
 }
 

@@ -180,6 +180,10 @@ int main(int argc, char** argv) {
     for (size_t r = 0; r < R; r++) {
         const bool same = serial[r].fibs == threaded[r].fibs && serial[r].msc == threaded[r].msc && serial[r].frames == threaded[r].frames;
         ok = ok && same && serial[r].frames > 0;
+        if (!same) if (const char* d = std::getenv("DABGPU_DRIVER_DUMP")) {      // development: what differs
+            auto dump = [&](const char* name, const std::vector<uint8_t>& v) { std::ofstream f(std::string(d) + "/" + name + std::to_string(r) + ".bin", std::ios::binary); f.write((const char*)v.data(), (std::streamsize)v.size()); };
+            dump("serial_fibs_", serial[r].fibs); dump("serial_msc_", serial[r].msc); dump("threaded_fibs_", threaded[r].fibs); dump("threaded_msc_", threaded[r].msc);
+        }
         std::printf("%s{\"frames\": %d, \"fib_bytes\": %zu, \"msc_bytes\": %zu, \"cifs_with_output\": %d, \"digest\": \"%016llx\", \"threaded_equals_serial\": %s}", r ? ", " : "",
                     serial[r].frames, serial[r].fibs.size(), serial[r].msc.size(), serial[r].cifs_out, (unsigned long long)fnv(serial[r].msc, fnv(serial[r].fibs)), same ? "true" : "false");
     }

@@ -1,4 +1,4 @@
-import os, sys, subprocess, json
+import os, sys, subprocess, json, numpy as np
 ROOT='/root/repo'
 sys.path.insert(0, ROOT+'/tests'); sys.path.insert(0, ROOT+'/oracle')
 import oracle as O, stream_model as SM
@@ -14,6 +14,20 @@ for s in subs:
     if s.is_uep: continue
     args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
 env=dict(os.environ); env['LD_LIBRARY_PATH']=ROOT+'/dab-radio_amd:/opt/rocm/lib:'+env.get('LD_LIBRARY_PATH','')
-for bank in ("0","1","1"):
-    res=subprocess.run(args+['--']+paths, capture_output=True, text=True, env=dict(env, DABGPU_MIRROR_BANK=bank, DABGPU_BANK_PROFILE="1"), timeout=600)
-    print(bank, res.returncode, res.stdout[-3000:], res.stderr[-1500:])
+mode = sys.argv[1] if len(sys.argv)>1 else "1"
+extra = dict(a.split("=") for a in sys.argv[2:])
+bad=0
+for trial in range(12):
+    d='/tmp/bk8/dump%d'%trial; os.makedirs(d, exist_ok=True)
+    res=subprocess.run(args+['--']+paths, capture_output=True, text=True, env=dict(env, DABGPU_MIRROR_BANK=mode, DABGPU_DRIVER_DUMP=d, **extra), timeout=600)
+    out=json.loads(res.stdout.strip().splitlines()[-1])
+    flags=[r["threaded_equals_serial"] for r in out["per_receiver"]]
+    if not all(flags):
+        bad+=1
+        for r,f in enumerate(flags):
+            if f: continue
+            for kind,rec in (("fibs",30),("msc",1)):
+                a=np.fromfile(f'{d}/serial_{kind}_{r}.bin',np.uint8); b=np.fromfile(f'{d}/threaded_{kind}_{r}.bin',np.uint8)
+                n=min(a.size,b.size); diff=np.nonzero(a[:n]!=b[:n])[0]
+                print("trial",trial,"rx",r,kind,"sizes",a.size,b.size,"first diffs",diff[:8], "n diff", diff.size, "last", diff[-3:] if diff.size else None)
+print("mode",mode,extra,"bad trials",bad,"of 12")
