@@ -588,6 +588,7 @@ void dabgpu_rx_bank_leave(dabgpu_rx_member* m) {
         std::unique_lock<std::mutex> lock(b->mu);
         b->cv_done.wait(lock, [m] { return m->jobs_in_flight == 0; });
         b->members[m->slot] = nullptr;
+        b->refs--;
     }
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : m->stage_ev) if (e) (void)hipEventDestroy(e);
