@@ -41,14 +41,18 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     const char* dev = std::getenv("DABGPU_DEVICE");
     int st;
     if (m_mode == 1) {
-        // Several receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
-        // one synchroniser launch, one demodulation launch and one decode over all of them.  DABGPU_MIRROR_BANK=1: every mode I receiver on the
-        // library's own tables joins it; 0: none; unset: every receiver but the first one alive (a lone receiver keeps its private pipeline).
+        // Many receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
+        // one demodulation launch, one synchroniser launch and one decode over all of them.  Measured (tools/bench_mirror_multi.py):
+        // up to four receivers are faster on pipelines of their own, from about eight on the bank is (7.3 against 4.6 k frames/s at 8, 5.8 against
+        // 2.4 k at 32).  DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
+        // DABGPU_MIRROR_BANK_FROM - 1 (default 4) others are alive at its construction -- the first four keep private pipelines.
         static std::atomic<int> live{0};
         const char* bank_env = std::getenv("DABGPU_MIRROR_BANK");
+        const char* from_env = std::getenv("DABGPU_MIRROR_BANK_FROM");
+        const int from = from_env ? std::max(1, std::atoi(from_env)) : 5;
         const int others = live.fetch_add(1);
         m_counted = true;
-        bool banked = bank_env ? std::atoi(bank_env) != 0 : others > 0;
+        bool banked = bank_env ? std::atoi(bank_env) != 0 : others >= from - 1;
         if (banked) {
             std::vector<float> prs(2 * params.nb_fft);
             std::vector<int> map(params.nb_data_carriers);

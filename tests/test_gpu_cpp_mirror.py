@@ -156,9 +156,11 @@ def test_two_receivers_with_reader_radio_and_worker_threads_on_the_device(oracle
     env.pop("DABGPU_MIRROR_BANK", None)
     digests = {}
     # private pipelines only / every receiver a member of the receiver bank (csrc/receiver_bank.hip: one synchroniser launch, one demodulation launch
-    # and one decode for what both posted) / the default (the second receiver joins the bank, the first keeps its pipeline): the same bytes
+    # and one decode for what both posted) / a mix (the second receiver joins the bank, the first keeps its pipeline): the same bytes
+    env.pop("DABGPU_MIRROR_BANK_FROM", None)
     for bank in ("0", "1", None):
-        e = dict(env) if bank is None else dict(env, DABGPU_MIRROR_BANK=bank)
+        # (None: the AUTO rule with its threshold lowered to the second receiver -- one private pipeline and one bank member side by side)
+        e = dict(env, DABGPU_MIRROR_BANK_FROM="2") if bank is None else dict(env, DABGPU_MIRROR_BANK=bank)
         res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=e, timeout=600)
         assert res.returncode == 0, (bank, res.stdout[-2000:], res.stderr[-2000:])
         out = json.loads(res.stdout.strip().splitlines()[-1])
