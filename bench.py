@@ -350,7 +350,8 @@ class Pipeline:
         # two stored transmission frames that repeat (8 CIFs of changing payload, time interleaved): decoded bytes then prove WHICH
         # ring slots / ages / frames in flight they came from (tools/dabsynth.py)
         # mux_layout: the multiplex every ensemble carries (tools/dabsynth.py: canonical_layout() = 18 x 48 CU EEP 3-A by default, mixed_layout())
-        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs, noise=0.0 if synced else noise, layout=mux_layout)
+        self.iq, self.mux = dabsynth.ensemble_iq(E, min(n_distinct, E), seed, device, mapper, prs, noise=0.0 if synced else noise, layout=mux_layout,
+                                                 fig=True)      # (the FIBs carry the ensembles' FIGs: tools/dabfig.py)
         if synced:
             self.slices, self.cfo, self.toff = dabsynth.ensemble_slices(self.iq, self.mux.n, seed + 2, SLICE_LEAD, SLICE_SAMPLES, noise=noise)
             del self.iq

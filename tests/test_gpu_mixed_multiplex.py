@@ -37,7 +37,7 @@ def received(ctx, oracle):
     prs, mapper, _ = dabgpu.host_tables()
     layout = dabsynth.mixed_layout()
     dabsynth.check_layout(layout, dabgpu)
-    iq, mux = dabsynth.ensemble_iq(E, E, 31, dev, mapper, prs, noise=0.09, period=4 * n_frames, layout=layout)
+    iq, mux = dabsynth.ensemble_iq(E, E, 31, dev, mapper, prs, noise=0.09, period=4 * n_frames, layout=layout, fig=True)
     fmt = dabgpu.IQ_FORMATS.index("raw_f32l")
     hist = {lay: torch.zeros((E, H, dabgpu.NB_FRAME_BITS), dtype=torch.int8, device=dev) for lay in (0, 1)}
     for j in range(n_frames):

@@ -239,6 +239,28 @@ class Carousel:
         return None
 
 
+def repeating_frames(desc, nf):
+    """[nf][4][3][30] FIB data for a transmission that REPEATS every nf frames (tools/dabsynth.py::Multiplex): every frame opens with FIG 0/0, the
+    sub-channel organisation, the service lists and then -- as far as 12 FIBs per frame hold them -- FIG 0/9, programme types and labels are dealt out
+    over the nf frames, so that after one repetition a receiver has seen every group.  Returns (frames, number of groups that did not fit)."""
+    car = Carousel(desc)
+    mci = [g for wave in car.intro for g in wave]
+    groups = [g for g in mci if g[1][0] == 1] + [g for g in mci if g[1][0] != 1] + car.si      # organisation, then services, then SI
+    per_frame = [[fig_0_0(desc, 4 * f)] for f in range(nf)]
+    for k, g in enumerate(groups):
+        per_frame[k % nf].append(g)
+    out = np.zeros((nf, 4, 3, FIB_DATA_BYTES), np.uint8)
+    dropped = 0
+    for f in range(nf):
+        pos = 0
+        for k in range(12):
+            data, used = pack_fib(per_frame[f][pos:])
+            pos += used
+            out[f, k // 3, k % 3] = np.frombuffer(data, np.uint8)
+        dropped += len(per_frame[f]) - pos                     # (only trailing SI groups can be left over: the MCI comes first)
+    return out, dropped
+
+
 def expected_database(desc):
     """what the reference's database must hold once every group has been seen: a canonical text, line for line what
     tests/cpp/ref_callers_driver.cpp dumps from DAB_Database (sorted)"""

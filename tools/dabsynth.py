@@ -237,11 +237,14 @@ class Multiplex:
     in flight in the wrong order, decode to another CIF's payload or to garbage -- with one repeated frame they would not show).
     Decoded CIF r (counted from the first frame) carries payload[(r - 15) mod period]; frame j carries fibs[j mod (period / 4)]."""
 
-    def __init__(self, n, seed, device, period=8, superframes=False, rs_errors=0, layout=None):
+    def __init__(self, n, seed, device, period=8, superframes=False, rs_errors=0, layout=None, fig=False):
         """superframes: every sub-channel carries DAB+ audio super frames (5 logical frames each; period must be a multiple of 20 CIFs so
         that the stored frames repeat whole super frames) drawn from 32 generated ones, each RS codeword with rs_errors damaged symbols
         -- the payload the DAB+ outer code downstream of the channel decoder has real work on.
-        layout: the multiplex (canonical_layout() by default, mixed_layout(), ...): capacity units no sub-channel occupies carry random bits"""
+        layout: the multiplex (canonical_layout() by default, mixed_layout(), ...): capacity units no sub-channel occupies carry random bits
+        fig: the FIBs carry the ensemble's Fast Information Groups (tools/dabfig.py: FIG 0/0 with the CIF count, 0/1 sub-channel organisation, 0/2
+        services, 0/9, 0/17, labels -- a carousel over the stored frames) instead of random bytes: what the reference's FIG_Processor /
+        DAB_Database_Updater can build its database from (tests/test_reference_callers_run.py does that on the single-receiver capture)"""
         assert period % 4 == 0 and period >= 4
         assert not superframes or period % 20 == 0
         self.layout = layout if layout is not None else canonical_layout()
@@ -252,6 +255,13 @@ class Multiplex:
         self.n, self.period, self.n_frames = n, period, period // 4
         nf = self.n_frames
         fib_data = torch.randint(0, 256, (n, nf, 4, 3, 30), generator=g, device=device, dtype=torch.uint8)
+        if fig:
+            import dabfig
+            lay = self.layout
+            self.fig_descriptions = [dabfig.describe(lay, seed=seed + e, eid=0xE000 | ((37 * seed + e) & 0xFFF)) for e in range(n)]
+            packed = [dabfig.repeating_frames(d, nf) for d in self.fig_descriptions]
+            self.fig_groups_dropped = sum(p[1] for p in packed)       # labels that did not fit into nf x 12 FIBs (the MCI always does from nf = 2 on)
+            fib_data = torch.from_numpy(np.stack([p[0] for p in packed])).to(device)
         self.fibs = torch.cat([fib_data, crc16(fib_data)], dim=-1).reshape(n, nf, 4, 96)
         pr96 = torch.from_numpy(prbs_bytes(96)).to(device)
         fic_mother = conv_encode(bytes_to_bits(self.fibs ^ pr96))
@@ -312,11 +322,11 @@ class Multiplex:
         return torch.cat([p[:, (cif_index - 15) % self.period] for p in self.payloads], dim=1)
 
 
-def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8, superframes=False, rs_errors=0, layout=None):
+def ensemble_iq(n_ensembles, n_distinct, seed, device, mapper, prs, noise=0.05, period=8, superframes=False, rs_errors=0, layout=None, fig=False):
     """IQ of n_ensembles ensembles built from n_distinct (<= 64) seeded multiplexes: ensemble e carries
     multiplex e % n_distinct; every ensemble gets its own noise realisation.  Returns (iq [period / 4][E][196608] complex64 -- the
     period / 4 transmission frames that repeat -- and the Multiplex)."""
-    mux = Multiplex(n_distinct, seed, device, period, superframes=superframes, rs_errors=rs_errors, layout=layout)
+    mux = Multiplex(n_distinct, seed, device, period, superframes=superframes, rs_errors=rs_errors, layout=layout, fig=fig)
     nf = mux.n_frames
     iq = torch.empty((nf, n_ensembles, NB_FRAME_SAMPLES), dtype=torch.complex64, device=device)
     g = torch.Generator(device=device)

@@ -13,7 +13,7 @@ cp $S/hbm_traffic.json $D/hbm_traffic_$TAG.json
 cp $S/hbm_traffic.json profiles/hbm_traffic.json
 for f in counters kernel_stats_decode4096 kernel_stats_synced4096 kernel_stats_chain4096; do for e in json csv; do [ -f gpurun_out/${f}_$TAG.$e ] && cp gpurun_out/${f}_$TAG.$e $D/; done; done
 for f in bench_n1 bench_decode bench_decode_4096 bench_decode_4096_natural bench_full bench_ingest bench_mirror bench_stream bench_stream_1024x4 bench_stream_retained bench_io bench_fic \
-         bench_cpp_host bench_dabplus bench_chain bench_chain_profiled bench_sync; do
+         bench_cpp_host bench_dabplus bench_chain bench_chain_profiled bench_sync bench_mirror_multi_bank0 bench_mirror_multi_bank1 bench_mirror_multi_auto soak_mirror; do
   [ -s gpurun_out/${f}_$TAG.json ] && cp gpurun_out/${f}_$TAG.json $D/
 done
 ls $D | grep "_$TAG" | wc -l
