@@ -141,8 +141,35 @@ def host_cores():
         seen.add(key)
         packages.add(pkg)
         cpus.append(c)
-    return cpus, {"physical_cores_in_affinity_mask": len(cpus), "logical_cpus_in_affinity_mask": len(allowed), "sockets": len(packages),
-                  "host_logical_cpus": os.cpu_count()}
+    topo = {"physical_cores_in_affinity_mask": len(cpus), "logical_cpus_in_affinity_mask": len(allowed), "sockets": len(packages),
+            "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": None}
+    # a container may see every CPU of the host and still be allowed only N CPUs' worth of time (cgroup v2 cpu.max / v1 cfs quota): more runnable
+    # threads than that are throttled, they do not run.  The workers are then N physical cores, not all of them (the GPU boxes of this pool: 256
+    # logical CPUs visible, quota 16)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+                q = float(fh.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                period = float(fh.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        topo["cgroup_cpu_quota"] = quota
+        n = max(1, int(quota))
+        if n < len(cpus):
+            step = len(cpus) / n                                      # spread over the mask (both sockets), one worker per chosen core
+            cpus = [cpus[int(k * step)] for k in range(n)]
+    topo["workers"] = len(cpus)
+    return cpus, topo
 
 
 def run_pinned(cpus, work):
@@ -220,8 +247,9 @@ def cpu_baseline(seconds_target=12.0):
     return {"value": done / dt, "unit": "frames/s", "cores": cores, "threads": cores, "kind": "port", "cpu_model": cpu_model,
             "topology": topo, "calibration": cpu_calibration(),
             "single_thread_value": n1 / dt1, "scaling_efficiency": (done / dt) / (cores * (n1 / dt1)),
-            "scaling_note": "value / (cores x single-thread value); the single thread runs alone at its boost clock, all cores together at the all-core "
-                            "clock and share the memory system (4 frames = 6 MB of input per worker stay in cache; the soft bits are written)",
+            "scaling_note": "value / (cores x single-thread value); cores = the physical cores of the affinity mask, or the container's CPU quota when that is "
+                            "smaller (topology.cgroup_cpu_quota: more runnable threads than the quota are throttled); the single thread runs alone at its boost "
+                            "clock, the workers together at the all-core clock",
             "sample": f"{done} frame demods (PLL+CP-phase+76xFFT2048+DQPSK+demap) cycling 4 distinct synthetic frames, "
                       f"{cores} pinned worker threads (one per physical core) x {per_thread} frames, oracle/dab_oracle_ofdm.c dab_demod_frame "
                       f"(FFTW absent -> oracle's own radix-4/8 FFT), {dt:.1f} s wall"}
@@ -948,6 +976,8 @@ def main():
                 def big_launch():
                     ctx.ofdm_demod_phase_frames(big_iq, fmt_f32, F4, big_bits, freq_offset=big_freq, cp_corr=big_corr, symbols_per_block=args.spb,
                                                 beta=0.9, total_phase=big_total, fine_freq=big_fine)
+                if args.spb == 0:
+                    ctx.ofdm_tune(big_iq, fmt_f32, F4, big_bits, with_phase_tail=True)       # (the library's record for THIS call shape, as for the 1024-frame one)
                 for _ in range(8):
                     big_launch()
                 torch.cuda.synchronize()

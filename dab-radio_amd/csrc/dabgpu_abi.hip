@@ -2,6 +2,7 @@
 // argument checking, launches).  No CPU compute path exists here: every compute entry point needs
 // a gfx950 device and fails with DABGPU_ERR_NO_DEVICE otherwise.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,6 +25,12 @@ namespace {
 struct capture_memo { hipStream_t stream; bool valid, capturing; };
 thread_local capture_memo tl_capture = {nullptr, false, false};
 }  // namespace
+
+unsigned dabgpu_wait_event_flags(bool bank_default_block) {
+    static const int mode = [] { const char* e = getenv("DABGPU_EVENT_WAIT"); return !e ? 0 : (strcmp(e, "block") == 0 ? 1 : 2); }();
+    const bool block = mode == 1 || (mode == 0 && bank_default_block);
+    return hipEventDisableTiming | (block ? hipEventBlockingSync : 0u);
+}
 
 int dabgpu_bind_device(const dabgpu_ctx* c) {
     if (!c) { dabgpu_set_error("null context"); return DABGPU_ERR_INVALID_ARG; }

@@ -691,9 +691,9 @@ extern "C" int dabgpu_frame_session_create(dabgpu_frame_session** out, int devic
     if (!st) st = session_layout(s, 0, 0);
     for (auto& sl : s->slots) {
         if (!st) st = slot_block(s, sl);
-        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate(session)");
-        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming), "hipEventCreate(session)");
-        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming), "hipEventCreate(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.done, dabgpu_wait_event_flags(false)), "hipEventCreate(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_ready, dabgpu_wait_event_flags(false)), "hipEventCreate(session)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&sl.ev_copied, dabgpu_wait_event_flags(false)), "hipEventCreate(session)");
     }
     if (st) { dabgpu_frame_session_destroy(s); return st; }
     *out = s;

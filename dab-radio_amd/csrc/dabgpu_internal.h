@@ -63,6 +63,10 @@ int dabgpu_check_hip(hipError_t e, const char* what);
 // thread of a one-process multi-GPU host starts on device 0) -- checked: a failed hipSetDevice is the call's status.
 int dabgpu_bind_device(const dabgpu_ctx* c);
 #define DABGPU_BIND(ctx) do { const int dabgpu_bind_st_ = dabgpu_bind_device(ctx); if (dabgpu_bind_st_) return dabgpu_bind_st_; } while (0)
+// flags of the events host threads wait on (receiver pipeline, frame session, receiver bank): DABGPU_EVENT_WAIT=block makes hipEventSynchronize SLEEP
+// instead of spinning -- threads that wait for the device then cost no CPU (a container's CPU quota is shared by every waiting thread of a many-receiver
+// process), at ~20-50 us more wake-up latency; =spin is the runtime's default.  Unset: `bank_default` for the receiver bank's events, spin elsewhere.
+unsigned dabgpu_wait_event_flags(bool bank_default_block);
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out);
 // the same from a capturable entry point launching on `user` (HIP graphs: see the definition)
 int dabgpu_scratch(dabgpu_ctx* c, int slot, size_t bytes, void** out, hipStream_t user);

@@ -118,7 +118,7 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     rx->stage_cap = (size_t)geom[2] + (n_fft - (size_t)geom[4]) + frame_samples;
     for (int k = 0; k < STAGES && !st; k++) {
         st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_stage[k], rx->stage_cap * 2 * sizeof(float), hipHostMallocDefault), "hipHostMalloc(receiver stage)");
-        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->stage_free[k], hipEventDisableTiming), "hipEventCreate(receiver)");
+        if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->stage_free[k], dabgpu_wait_event_flags(false)), "hipEventCreate(receiver)");
     }
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_prs, n_fft * 2 * sizeof(float)), "hipMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_iq, frame_samples * 2 * sizeof(float)), "hipMalloc(receiver)");
@@ -132,7 +132,7 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     }
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_corr, n_sym * 2 * sizeof(float)), "hipMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_rec, rec_bytes, hipHostMallocDefault), "hipHostMalloc(receiver)");
-    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, hipEventDisableTiming), "hipEventCreate(receiver)");
+    if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, dabgpu_wait_event_flags(false)), "hipEventCreate(receiver)");
     if (st) { dabgpu_receiver_destroy(rx); return st; }
     *out = rx;
     return DABGPU_OK;

@@ -186,19 +186,19 @@ int bank_alloc(dabgpu_rx_bank* b) {
     BK(hipHostMalloc((void**)&b->h_prs, (size_t)MAXM * NFFT * 2 * sizeof(float), hipHostMallocDefault));
     for (int k = 0; k < dabgpu_rx_bank::NUP; k++) {
         BK(hipStreamCreateWithFlags(&b->up[k], hipStreamNonBlocking));
-        BK(hipEventCreateWithFlags(&b->up_ev[k], hipEventDisableTiming));
+        BK(hipEventCreateWithFlags(&b->up_ev[k], dabgpu_wait_event_flags(true)));
     }
-    BK(hipEventCreateWithFlags(&b->up_gate, hipEventDisableTiming));
+    BK(hipEventCreateWithFlags(&b->up_gate, dabgpu_wait_event_flags(true)));
     for (auto& t : b->ticks) {
         BK(hipHostMalloc((void**)&t.h_tab, sizeof(tick_table), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_states, (size_t)MAXM * sizeof(dabgpu_sync_state), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_imp, (size_t)MAXM * NFFT * sizeof(float), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_frq, (size_t)MAXM * NFFT * sizeof(float), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_scal, (size_t)2 * MAXM * sizeof(float), hipHostMallocDefault));
-        BK(hipEventCreateWithFlags(&t.ev_sync, hipEventDisableTiming));
-        BK(hipEventCreateWithFlags(&t.ev_demod, hipEventDisableTiming));
-        BK(hipEventCreateWithFlags(&t.ev_copied, hipEventDisableTiming));
-        BK(hipEventCreateWithFlags(&t.ev_done, hipEventDisableTiming));
+        BK(hipEventCreateWithFlags(&t.ev_sync, dabgpu_wait_event_flags(true)));
+        BK(hipEventCreateWithFlags(&t.ev_demod, dabgpu_wait_event_flags(true)));
+        BK(hipEventCreateWithFlags(&t.ev_copied, dabgpu_wait_event_flags(true)));
+        BK(hipEventCreateWithFlags(&t.ev_done, dabgpu_wait_event_flags(true)));
     }
     return DABGPU_OK;
 }
@@ -560,7 +560,7 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
     m->bank = b;
     m->h_stage = h_stage;
     st = dabgpu_frame_session_create_store(&m->ses, b->ctx);
-    for (int k = 0; k < 3 && !st; k++) st = dabgpu_check_hip(hipEventCreateWithFlags(&m->stage_ev[k], hipEventDisableTiming), "hipEventCreate(bank member)");
+    for (int k = 0; k < 3 && !st; k++) st = dabgpu_check_hip(hipEventCreateWithFlags(&m->stage_ev[k], dabgpu_wait_event_flags(true)), "hipEventCreate(bank member)");
     if (!st) {
         std::lock_guard<std::mutex> lock(b->mu);
         for (int k = 0; k < MAXM && m->slot < 0; k++) if (!b->members[k]) { b->members[k] = m; m->slot = k; }
