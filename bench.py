@@ -963,8 +963,11 @@ def main():
                                                     "slots at the ~1.75 GHz the power manager sustains; min launch 349.8 us = 0.66 of 8 TB/s shows what the clock costs "
                                                     "(profiles/r05/counters_v5.json, profiles/r06/)")
             # the launch-granularity share: the same kernel on 4096 frames per launch (1024 frames = 1024 workgroups of a whole frame = ONE round on
-            # 256 CUs x 4: the tail of the round is idle time the figure above includes)
+            # 256 CUs x 4: the tail of the round is idle time the figure above includes).  Not under --no-extras: the profile passes (rocprofv3 kernel
+            # stats, PMC) of that command must see launches of ONE shape only
             try:
+                if args.no_extras:
+                    raise RuntimeError("skipped (--no-extras)")
                 F4 = 4 * units
                 big_iq = iq_f.repeat(4, 1, 1).contiguous()
                 big_bits = torch.empty((F4, 230400), dtype=torch.int8, device=device)
