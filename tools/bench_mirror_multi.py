@@ -45,11 +45,27 @@ with tempfile.TemporaryDirectory() as d:
         args0 += [str(48 * s), "48", "2", "0"]
     env = dict(os.environ, DABGPU_DRIVER_BENCH="1")
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    import resource
+
+    def cgroup_stat():
+        try:
+            return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat").read().splitlines())}
+        except (OSError, ValueError):
+            return {}
     for r in a.receivers:
+        ru0, cg0 = resource.getrusage(resource.RUSAGE_CHILDREN), cgroup_stat()
         res = subprocess.run(args0 + ["--"] + paths[:r], capture_output=True, text=True, env=env, timeout=900)
+        ru1, cg1 = resource.getrusage(resource.RUSAGE_CHILDREN), cgroup_stat()
         if res.returncode != 0:
             print(res.stderr[-2000:], file=sys.stderr); sys.exit(res.returncode)
         run = json.loads(res.stdout.strip().splitlines()[-1])
+        # what the process cost the host: CPU seconds of the whole child (start-up included) and how long the container's CPU quota throttled it
+        cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
+        run["host_cpu_seconds"] = round(cpu_s, 3)
+        run["host_cpu_ms_per_frame"] = round(1e3 * cpu_s / max(1, run["frames"]), 3)
+        if cg0 and cg1:
+            run["cgroup_throttled_ms"] = round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1)
+            run["cgroup_periods_throttled"] = cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0)
         prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1
         if prof:
             run["profile"] = prof
