@@ -90,6 +90,7 @@ struct dabgpu_rx_member {
     uint64_t done_gen = 0;                      // generations < done_gen have their results in the session's slots
     int frame_status = DABGPU_OK;
     int jobs_in_flight = 0;
+    std::condition_variable cv;                 // the member's own threads wait here (on bank->mu): a hand-out wakes the members it concerns, not all of them
     double last_post_us = -1e18;                // when the member posted last (the worker's gathering rule)
     // views (display buffers), allocated at first use
     float* d_fft = nullptr; float* d_dq = nullptr;
@@ -390,10 +391,10 @@ void worker_main(dabgpu_rx_bank* b) {
         lock.lock();
         t.status = st;
         for (const auto& j : t.sync_jobs) j.m->sync_state = 2;
-        for (const auto& j : t.frame_jobs) j.m->stage_state[j.stage] = 2;
-        for (const auto& r : resets) r.m->jobs_in_flight--;
+        for (const auto& j : t.frame_jobs) { j.m->stage_state[j.stage] = 2; j.m->cv.notify_all(); }
+        for (const auto& r : resets) { r.m->jobs_in_flight--; r.m->cv.notify_all(); }
         lock.unlock();
-        b->cv_done.notify_all();
+        b->cv_done.notify_all();                                           // (the two completers)
     }
 }
 
@@ -423,6 +424,7 @@ void sync_completer_main(dabgpu_rx_bank* b) {
             }
             m->sync_state = 3;
             m->jobs_in_flight--;
+            m->cv.notify_all();
         }
         t.sync_handed = true;
         b->n_sync_handed++;
@@ -488,6 +490,7 @@ void completer_main(dabgpu_rx_bank* b) {
                 f.m->frame_status = st ? st : f.m->frame_status;
                 f.m->done_gen = f.gen + 1;
                 f.m->jobs_in_flight--;
+                f.m->cv.notify_all();
             }
             lock.unlock();
             b->cv_done.notify_all();
@@ -586,7 +589,7 @@ void dabgpu_rx_bank_leave(dabgpu_rx_member* m) {
     dabgpu_rx_bank* b = m->bank;
     {
         std::unique_lock<std::mutex> lock(b->mu);
-        b->cv_done.wait(lock, [m] { return m->jobs_in_flight == 0; });
+        m->cv.wait(lock, [m] { return m->jobs_in_flight == 0; });
         b->members[m->slot] = nullptr;
         b->refs--;
     }
@@ -655,7 +658,7 @@ int dabgpu_rx_bank_wait_sync(dabgpu_rx_member* m, dabgpu_sync_state* out, float*
     dabgpu_rx_bank* b = m->bank;
     std::unique_lock<std::mutex> lock(b->mu);
     if (m->sync_state == 0) { dabgpu_set_error("receiver_wait_sync: no synchronisation was submitted"); return DABGPU_ERR_NOT_READY; }
-    b->cv_done.wait(lock, [m] { return m->sync_state == 3; });
+    m->cv.wait(lock, [m] { return m->sync_state == 3; });
     m->sync_state = 0;
     if (m->sync_status) { dabgpu_set_error("receiver bank: the tick that carried the synchroniser failed"); return m->sync_status; }
     *out = m->sync_rec;
@@ -690,7 +693,7 @@ int dabgpu_rx_bank_wait_stage(dabgpu_rx_member* m, int stage) {
     {
         std::unique_lock<std::mutex> lock(b->mu);
         if (m->stage_state[stage] == 0) return DABGPU_OK;
-        b->cv_done.wait(lock, [&] { return m->stage_state[stage] == 2; });
+        m->cv.wait(lock, [&] { return m->stage_state[stage] == 2; });
     }
     (void)hipSetDevice(b->device);
     const int st = dabgpu_check_hip(hipEventSynchronize(m->stage_ev[stage]), "hipEventSynchronize(bank stage)");
@@ -703,7 +706,7 @@ int dabgpu_rx_bank_wait_frame(dabgpu_rx_member* m, uint64_t generation, dabgpu_r
     {
         std::unique_lock<std::mutex> lock(b->mu);
         if (generation >= m->next_gen) { dabgpu_set_error("receiver_wait_frame: generation %llu was never submitted", (unsigned long long)generation); return DABGPU_ERR_NOT_READY; }
-        b->cv_done.wait(lock, [&] { return m->done_gen > generation; });
+        m->cv.wait(lock, [&] { return m->done_gen > generation; });
         if (m->frame_status) { dabgpu_set_error("receiver bank: the tick that carried the frame failed"); return m->frame_status; }
     }
     dabgpu_frame_session::slot& sl = m->ses->slots[generation % dabgpu_frame_session::R];
