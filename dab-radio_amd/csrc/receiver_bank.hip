@@ -349,7 +349,9 @@ void worker_main(dabgpu_rx_bank* b) {
                 for (const auto& j : b->jobs) in_queue[j.m->slot] = true;
                 for (int k = 0; k < MAXM; k++) {
                     const dabgpu_rx_member* m = b->members[k];
-                    if (m && !in_queue[k] && t_first - m->last_post_us < 4000.0) return false;
+                    // a member with a job under way is waiting for THIS thread's rounds and will not post before they are handed out: only the ones
+                    // that are buffering on their own (nothing in flight) and posted recently are worth waiting for
+                    if (m && !in_queue[k] && m->jobs_in_flight == 0 && t_first - m->last_post_us < 4000.0) return false;
                 }
                 return true;
             };
