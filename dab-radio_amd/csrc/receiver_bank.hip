@@ -14,6 +14,7 @@
 // k + 1's synchroniser) and every output are those of the private pipeline: the same kernels run on the same inputs
 // (tests/test_gpu_cpp_mirror.py, tests/test_gpu_receiver.py run both forms).
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <string.h>
 #include <time.h>
@@ -40,6 +41,7 @@ struct tick_table {
     int32_t newest[MAXM];           // decode: ring slot of the frame of this tick, -1 = no frame
     int32_t slot_of[MAXM];          // batch entry j -> member slot
     int32_t ring_of[MAXM];          // batch entry j -> history ring slot (generation % H)
+    const float* iq_of[MAXM];       // batch entry j -> where its member uploaded the frame's samples
 };
 
 __global__ void bank_gather_kernel(const dabgpu_sync_state* __restrict__ st, const tick_table* __restrict__ tab, int n, float* __restrict__ freq, float* __restrict__ fine) {
@@ -49,6 +51,14 @@ __global__ void bank_gather_kernel(const dabgpu_sync_state* __restrict__ st, con
         freq[j] = s.freq_coarse + s.freq_fine;                       // ofdm_demodulator.cpp:672
         fine[j] = s.freq_fine;
     }
+}
+// the samples of batch entry j, from the buffer its member uploaded them to, into the compact batch the demodulation kernel reads
+__global__ void bank_gather_iq_kernel(float* __restrict__ batch, const tick_table* __restrict__ tab) {
+    const int j = (int)blockIdx.y;
+    const uint4* src = reinterpret_cast<const uint4*>(tab->iq_of[j]);
+    uint4* dst = reinterpret_cast<uint4*>(batch + (size_t)j * FRAME_SAMPLES * 2);
+    constexpr size_t N = FRAME_SAMPLES * 2 * sizeof(float) / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 // soft bits of batch entry j -> its member's ring slot; the updated fine-frequency word -> the member's device record
 __global__ void bank_scatter_kernel(const int8_t* __restrict__ bits, int8_t* __restrict__ hist, const tick_table* __restrict__ tab, const float* __restrict__ fine,
@@ -71,6 +81,7 @@ struct rx_bank_job {
     uint64_t gen;
     int want_views, tie;
     dabgpu_sync_cfg cfg;
+    const float* d_iq;              // FRAME: the member's upload buffer that holds the samples
 };
 
 struct dabgpu_rx_member {
@@ -84,7 +95,8 @@ struct dabgpu_rx_member {
     bool sync_coarse = false;
     dabgpu_sync_state sync_rec;
     std::vector<float> sync_imp, sync_frq;
-    int stage_state[3] = {0, 0, 0};             // 0 free, 1 posted (the frame job that reads it is queued), 2 its upload is enqueued (stage_ev recorded)
+    float* d_iq = nullptr;                      // [2][frame]: the member uploads frame g to half g % 2 when it posts it (see dabgpu_rx_bank_post_frame)
+    int stage_state[3] = {0, 0, 0};             // 0 free, 2 a frame was posted from it: its upload is enqueued (stage_ev recorded)
     hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};
     uint64_t next_gen = 0;                      // next generation to post
     uint64_t done_gen = 0;                      // generations < done_gen have their results in the session's slots
@@ -107,7 +119,6 @@ struct rx_bank_tick {
     int n_ens = 0;                              // member slots covered by the decode
     bool decoded = false, fic = false;
     std::vector<dabgpu_subchannel> subs; std::vector<uint32_t> sub_off, sub_n; uint32_t cif_out = 0;
-    int8_t* h_bits = nullptr; size_t h_bits_cap = 0;  // pinned: the soft bits of the round's frames, compact (ONE device-to-host copy per round)
     int status = DABGPU_OK;
     bool busy = false;                          // enqueued, not yet handed out by the completers
     bool sync_handed = false;                   // the synchronisers' records of the round are with their members
@@ -117,10 +128,9 @@ struct dabgpu_rx_bank {
     int device = 0;
     dabgpu_ctx* ctx = nullptr;                  // tables; its stream = stream B (decode), its scratch = the decoder's
     hipStream_t a = nullptr;
-    static constexpr int NUP = 3;               // upload streams: the frames of a round cross PCIe on several DMA engines at once
+    static constexpr int NUP = 3;               // upload streams (member slot % NUP): frames cross PCIe on several DMA engines at once
     hipStream_t up[NUP] = {nullptr, nullptr, nullptr};
     hipEvent_t up_ev[NUP] = {nullptr, nullptr, nullptr};
-    hipEvent_t up_gate = nullptr;               // the batch buffer is free again (the previous round's demodulation has read it)
     float* d_prs = nullptr; float* d_iq = nullptr; int8_t* d_bits = nullptr; int8_t* d_hist = nullptr;
     dabgpu_sync_state* d_states = nullptr; float* d_imp = nullptr; float* d_frq = nullptr;
     float* d_corr = nullptr; float* d_freq = nullptr; float* d_fine = nullptr; float* d_total = nullptr;
@@ -143,6 +153,7 @@ struct dabgpu_rx_bank {
     // DABGPU_BANK_PROFILE=1: what the rounds looked like, printed at shutdown
     bool profile = false;
     int gather_us = 1000;                        // DABGPU_BANK_GATHER_US
+    int max_rounds = 2;                          // DABGPU_BANK_ROUNDS: rounds enqueued and not yet handed out
     uint64_t p_sync_jobs = 0, p_frame_jobs = 0, p_ticks_with_frames = 0;
     double p_enqueue_us = 0, p_wait_sync_us = 0, p_wait_frames_us = 0, p_handout_us = 0, p_worker_idle_us = 0;
 };
@@ -189,7 +200,6 @@ int bank_alloc(dabgpu_rx_bank* b) {
         BK(hipStreamCreateWithFlags(&b->up[k], hipStreamNonBlocking));
         BK(hipEventCreateWithFlags(&b->up_ev[k], dabgpu_wait_event_flags(true)));
     }
-    BK(hipEventCreateWithFlags(&b->up_gate, dabgpu_wait_event_flags(true)));
     for (auto& t : b->ticks) {
         BK(hipHostMalloc((void**)&t.h_tab, sizeof(tick_table), hipHostMallocDefault));
         BK(hipHostMalloc((void**)&t.h_states, (size_t)MAXM * sizeof(dabgpu_sync_state), hipHostMallocDefault));
@@ -212,11 +222,11 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     tick_table& tab = *t.h_tab;
     const int nS = (int)t.sync_jobs.size(), nF = (int)t.frame_jobs.size();
     int hi = -1;
-    for (int k = 0; k < MAXM; k++) { tab.sync_active[k] = 0; tab.newest[k] = -1; tab.slot_of[k] = 0; tab.ring_of[k] = 0; }
+    for (int k = 0; k < MAXM; k++) { tab.sync_active[k] = 0; tab.newest[k] = -1; tab.slot_of[k] = 0; tab.ring_of[k] = 0; tab.iq_of[k] = nullptr; }
     for (const auto& j : t.sync_jobs) { tab.sync_active[j.m->slot] = 1; if (j.m->slot > hi) hi = j.m->slot; }
     for (int j = 0; j < nF; j++) {
         const rx_bank_job& f = t.frame_jobs[(size_t)j];
-        tab.slot_of[j] = f.m->slot; tab.ring_of[j] = (int)(f.gen % H);
+        tab.slot_of[j] = f.m->slot; tab.ring_of[j] = (int)(f.gen % H); tab.iq_of[j] = f.d_iq;
         tab.newest[f.m->slot] = (int)(f.gen % H);
         if (f.m->slot > hi) hi = f.m->slot;
     }
@@ -227,17 +237,14 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     t.decoded = false;
     bool frames_enqueued = false;
     if (nF) {
-        // the uploads: 1.5 MB per frame, spread over NUP streams (DMA engines); they may start once the previous round's demodulation has read the
-        // batch buffer (up_gate), the demodulation waits for all of them
-        const int n_up = nF < dabgpu_rx_bank::NUP ? nF : dabgpu_rx_bank::NUP;
-        if (tick_no > 0) for (int k = 0; k < n_up; k++) BK(hipStreamWaitEvent(b->up[k], b->up_gate, 0));
-        for (int j = 0; j < nF; j++) {
-            const rx_bank_job& f = t.frame_jobs[(size_t)j];
-            hipStream_t u = b->up[j % n_up];
-            BK(hipMemcpyAsync(b->d_iq + (size_t)j * FRAME_SAMPLES * 2, f.m->h_stage[f.stage] + 2 * f.sample, FRAME_SAMPLES * 2 * sizeof(float), hipMemcpyHostToDevice, u));
-            BK(hipEventRecord(f.m->stage_ev[f.stage], u));
-        }
-        for (int k = 0; k < n_up; k++) { BK(hipEventRecord(b->up_ev[k], b->up[k])); BK(hipStreamWaitEvent(a, b->up_ev[k], 0)); }
+        // the uploads -- 1.5 MB per frame -- were enqueued by the members when they posted (on upload stream slot % NUP, BEFORE the job entered the queue):
+        // an event recorded now on each of those streams lies behind them.  They crossed PCIe while the previous round ran and this one waited to be
+        // formed; the round copies them (device to device, ~1 us each) into the compact batch the demodulation kernel reads.
+        bool used[dabgpu_rx_bank::NUP] = {false, false, false};
+        for (const auto& f : t.frame_jobs) used[f.m->slot % dabgpu_rx_bank::NUP] = true;
+        for (int k = 0; k < dabgpu_rx_bank::NUP; k++) if (used[k]) { BK(hipEventRecord(b->up_ev[k], b->up[k])); BK(hipStreamWaitEvent(a, b->up_ev[k], 0)); }
+        bank_gather_iq_kernel<<<dim3(16, (unsigned)nF), 256, 0, a>>>(b->d_iq, d_tab);
+        BK(hipGetLastError());
         bank_gather_kernel<<<1, 64, 0, a>>>(b->d_states, d_tab, nF, b->d_freq, b->d_fine);
         BK(hipGetLastError());
         const float beta = t.frame_jobs[0].beta;
@@ -259,7 +266,6 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
             BK(hipMemcpyAsync(sl.h_fft, m->d_fft, fft_bytes, hipMemcpyDeviceToHost, a));
             BK(hipMemcpyAsync(sl.h_dq, m->d_dq, dq_bytes, hipMemcpyDeviceToHost, a));
         }
-        BK(hipEventRecord(b->up_gate, a));                                 // (everything that reads the batch buffer has been enqueued)
         // the ring slot frame g + 4 of a member goes to is read by the decode of its frame g (5 frames = 16 CIFs + the frame's own 4): a member has
         // one frame per tick at most, so the decode of tick T - 4 is the youngest that may still read what this tick overwrites
         if (tick_no >= 4) BK(hipStreamWaitEvent(a, b->ticks[(tick_no - 4) % TICKS].ev_done, 0));
@@ -316,14 +322,12 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
     }
     BK(hipEventRecord(t.ev_sync, a));
     if (frames_enqueued) {
-        if (t.h_bits_cap < (size_t)nF * FRAME_BITS) {
-            if (t.h_bits) (void)hipHostFree(t.h_bits);
-            t.h_bits = nullptr; t.h_bits_cap = 0;
-            const size_t cap = (size_t)(nF < 8 ? 8 : nF) * FRAME_BITS;
-            BK(hipHostMalloc((void**)&t.h_bits, cap, hipHostMallocDefault));
-            t.h_bits_cap = cap;
+        // the soft bits go straight to the page-locked buffer of the member's result slot (one copy per frame: what the delivery thread hands to the
+        // observers is that buffer -- a compact copy per round plus a 230 KB memcpy per frame on the completer thread capped the bank at ~15 k frames/s)
+        for (int j = 0; j < nF; j++) {
+            const rx_bank_job& f = t.frame_jobs[(size_t)j];
+            BK(hipMemcpyAsync(f.m->ses->slots[f.gen % dabgpu_frame_session::R].h_bits, b->d_bits + (size_t)j * FRAME_BITS, FRAME_BITS, hipMemcpyDeviceToHost, a));
         }
-        BK(hipMemcpyAsync(t.h_bits, b->d_bits, (size_t)nF * FRAME_BITS, hipMemcpyDeviceToHost, a));
         BK(hipMemcpyAsync(t.h_scal, b->d_fine, (size_t)(MAXM + nF) * sizeof(float), hipMemcpyDeviceToHost, a));      // fine[0..nF) ... total[0..nF)
         BK(hipEventRecord(t.ev_copied, a));
     }
@@ -332,12 +336,13 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
 }
 
 void worker_main(dabgpu_rx_bank* b) {
+    pthread_setname_np(pthread_self(), "dabgpu-bank");
     (void)hipSetDevice(b->device);
     for (;;) {
         std::unique_lock<std::mutex> lock(b->mu);
         const double ti0 = b->profile ? bank_now_us() : 0.0;
         b->cv_jobs.wait(lock, [b] { return b->stop || !b->jobs.empty(); });
-        if (b->profile) b->p_worker_idle_us += bank_now_us() - ti0;
+        if (b->profile && b->n_ticks) b->p_worker_idle_us += bank_now_us() - ti0;       // (not the wait for the very first job: the members are still being constructed)
         if (b->stop && b->jobs.empty()) return;
         // several members: give the others a moment to post as well (a round costs ~25 runtime calls whatever it carries; the calls, not the
         // device, are what a process can issue only so many of per second) -- at most `gather_us`, and not at all for a lone member
@@ -357,6 +362,11 @@ void worker_main(dabgpu_rx_bank* b) {
             };
             if (!all_in()) b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), all_in);
         }
+        // Rounds are not enqueued ahead of the device: a round takes what is queued when it is formed, and with a deep queue of rounds under way every
+        // job that arrives meanwhile becomes a small round of its own at the END of that queue -- many small rounds, each paying the fixed costs, each
+        // member waiting for all of them (measured at 32 members: 4 frames per round, 8 rounds deep, 3 ms from posting a synchroniser to its record).
+        // At most `max_rounds` are under way; what arrives while they run forms the next one, whose size so follows the load (group commit).
+        b->cv_ticks.wait(lock, [b] { return b->n_ticks - b->n_handed < (uint64_t)b->max_rounds; });
         const uint64_t tick_no = b->n_ticks;
         rx_bank_tick& t = b->ticks[tick_no % TICKS];
         b->cv_ticks.wait(lock, [&] { return !t.busy; });                  // (the completer hands ticks out in order: at most TICKS are under way)
@@ -393,7 +403,6 @@ void worker_main(dabgpu_rx_bank* b) {
         lock.lock();
         t.status = st;
         for (const auto& j : t.sync_jobs) j.m->sync_state = 2;
-        for (const auto& j : t.frame_jobs) { j.m->stage_state[j.stage] = 2; j.m->cv.notify_all(); }
         for (const auto& r : resets) { r.m->jobs_in_flight--; r.m->cv.notify_all(); }
         lock.unlock();
         b->cv_done.notify_all();                                           // (the two completers)
@@ -403,6 +412,7 @@ void worker_main(dabgpu_rx_bank* b) {
 // The synchronisers' records, round by round: the readers wait for them (they cannot finish buffering the frame before), so they do not queue
 // behind the decode of the same or an earlier round
 void sync_completer_main(dabgpu_rx_bank* b) {
+    pthread_setname_np(pthread_self(), "dabgpu-bk-sync");
     (void)hipSetDevice(b->device);
     for (;;) {
         std::unique_lock<std::mutex> lock(b->mu);
@@ -437,6 +447,7 @@ void sync_completer_main(dabgpu_rx_bank* b) {
 
 // The frames, round by round: waits for the device, copies every frame's results to its member's result store, wakes the members, frees the round
 void completer_main(dabgpu_rx_bank* b) {
+    pthread_setname_np(pthread_self(), "dabgpu-bk-frm");
     (void)hipSetDevice(b->device);
     for (;;) {
         std::unique_lock<std::mutex> lock(b->mu);
@@ -479,9 +490,7 @@ void completer_main(dabgpu_rx_bank* b) {
                         sl.fic = t.fic; sl.subs = t.subs; sl.sub_off = t.sub_off; sl.sub_n = t.sub_n; sl.cif_out = t.cif_out;
                     }
                 }
-                // (the member's slots are plain host memory here: the round's page-locked buffers were the copies' targets)
-                if (!sl.h_bits && hipHostMalloc((void**)&sl.h_bits, FRAME_BITS, hipHostMallocDefault) != hipSuccess) { if (!st) { st = DABGPU_ERR_HIP; dabgpu_set_error("bank: hipHostMalloc(bits)"); } }
-                if (sl.h_bits && !st) memcpy(sl.h_bits, t.h_bits + j * FRAME_BITS, FRAME_BITS);
+                // (sl.h_bits: the round's device-to-host copy wrote it, enqueue_tick)
                 if (!sl.h_aux && hipHostMalloc((void**)&sl.h_aux, 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) { if (!st) { st = DABGPU_ERR_HIP; dabgpu_set_error("bank: hipHostMalloc(aux)"); } }
                 if (sl.h_aux) { sl.h_aux[0] = t.h_scal[j]; sl.h_aux[1] = t.h_scal[MAXM + j]; }
                 sl.pending = false;
@@ -518,7 +527,7 @@ void bank_free(dabgpu_rx_bank* b) {
     if (b->h_prs) (void)hipHostFree(b->h_prs);
     for (void* p : dev) if (p) (void)hipFree(p);
     for (auto& t : b->ticks) {
-        void* host[] = {t.h_tab, t.h_states, t.h_imp, t.h_frq, t.h_scal, t.h_out, t.h_bits};
+        void* host[] = {t.h_tab, t.h_states, t.h_imp, t.h_frq, t.h_scal, t.h_out};
         for (void* p : host) if (p) (void)hipHostFree(p);
         hipEvent_t evs[] = {t.ev_sync, t.ev_demod, t.ev_copied, t.ev_done};
         for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -526,7 +535,6 @@ void bank_free(dabgpu_rx_bank* b) {
     if (b->a) (void)hipStreamDestroy(b->a);
     for (hipStream_t u : b->up) if (u) { (void)hipStreamSynchronize(u); (void)hipStreamDestroy(u); }
     for (hipEvent_t e : b->up_ev) if (e) (void)hipEventDestroy(e);
-    if (b->up_gate) (void)hipEventDestroy(b->up_gate);
     if (b->ctx) dabgpu_destroy(b->ctx);
     delete b;
 }
@@ -545,6 +553,7 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
         b->device = device;
         if (const char* e = std::getenv("DABGPU_BANK_PROFILE")) b->profile = std::atoi(e) != 0;
         if (const char* e = std::getenv("DABGPU_BANK_GATHER_US")) b->gather_us = std::atoi(e);
+        if (const char* e = std::getenv("DABGPU_BANK_ROUNDS")) b->max_rounds = std::min(TICKS, std::max(1, std::atoi(e)));
         st = dabgpu_create(&b->ctx, device, nullptr, nullptr);
         if (!st) {
             int least = 0, greatest = 0;
@@ -566,6 +575,10 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
     m->h_stage = h_stage;
     st = dabgpu_frame_session_create_store(&m->ses, b->ctx);
     for (int k = 0; k < 3 && !st; k++) st = dabgpu_check_hip(hipEventCreateWithFlags(&m->stage_ev[k], dabgpu_wait_event_flags(true)), "hipEventCreate(bank member)");
+    if (!st) st = dabgpu_check_hip(hipMalloc((void**)&m->d_iq, (size_t)2 * FRAME_SAMPLES * 2 * sizeof(float)), "hipMalloc(bank member samples)");
+    // the rounds copy a frame's soft bits straight into the result slot's page-locked buffer (the session frees them)
+    for (int k = 0; k < dabgpu_frame_session::R && !st; k++)
+        st = dabgpu_check_hip(hipHostMalloc((void**)&m->ses->slots[k].h_bits, FRAME_BITS, hipHostMallocDefault), "hipHostMalloc(bank member soft bits)");
     if (!st) {
         std::lock_guard<std::mutex> lock(b->mu);
         for (int k = 0; k < MAXM && m->slot < 0; k++) if (!b->members[k]) { b->members[k] = m; m->slot = k; }
@@ -578,6 +591,7 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
     if (st) {
         if (m->slot >= 0) { std::lock_guard<std::mutex> lock(b->mu); b->members[m->slot] = nullptr; b->refs--; }
         for (hipEvent_t e : m->stage_ev) if (e) (void)hipEventDestroy(e);
+        if (m->d_iq) (void)hipFree(m->d_iq);
         if (m->ses) dabgpu_frame_session_destroy(m->ses);
         delete m;
         return st;
@@ -597,6 +611,7 @@ void dabgpu_rx_bank_leave(dabgpu_rx_member* m) {
     }
     (void)hipSetDevice(b->device);
     for (hipEvent_t e : m->stage_ev) if (e) (void)hipEventDestroy(e);
+    if (m->d_iq) (void)hipFree(m->d_iq);
     if (m->d_fft) (void)hipFree(m->d_fft);
     if (m->d_dq) (void)hipFree(m->d_dq);
     dabgpu_frame_session_destroy(m->ses);
@@ -671,19 +686,35 @@ int dabgpu_rx_bank_wait_sync(dabgpu_rx_member* m, dabgpu_sync_state* out, float*
 
 int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sample, float beta, int want_views, int tie, uint64_t* generation) {
     dabgpu_rx_bank* b = m->bank;
+    uint64_t gen;
     {
         std::lock_guard<std::mutex> lock(b->mu);
         if (m->next_gen >= m->done_gen + (uint64_t)(dabgpu_frame_session::R - 1)) {
             dabgpu_set_error("receiver_submit_frame: %d frames submitted and not yet collected (at most %d)", (int)(m->next_gen - m->done_gen), dabgpu_frame_session::R - 1);
             return DABGPU_ERR_NOT_READY;
         }
+        gen = m->next_gen;                                                 // (only the member's own thread posts)
+    }
+    // The member uploads its frame itself, now: the samples cross PCIe while the rounds under way run, not inside the round that demodulates them
+    // (32 frames of a round are 1 ms of PCIe in front of the round's synchronisers otherwise).  Half gen % 2 of the member's device buffer: frame g - 2,
+    // which used it, was read by the gather of its round, and that round lies on stream A in front of the synchroniser whose record this frame
+    // was cut with (a member's jobs run in posting order; the synchroniser of frame g is posted after frame g - 1).
+    (void)hipSetDevice(b->device);
+    float* d = m->d_iq + (size_t)(gen % 2) * FRAME_SAMPLES * 2;
+    hipStream_t u = b->up[m->slot % dabgpu_rx_bank::NUP];
+    int st = dabgpu_check_hip(hipMemcpyAsync(d, m->h_stage[stage] + 2 * frame_sample, FRAME_SAMPLES * 2 * sizeof(float), hipMemcpyHostToDevice, u), "hipMemcpyAsync(bank frame)");
+    if (!st) st = dabgpu_check_hip(hipEventRecord(m->stage_ev[stage], u), "hipEventRecord(bank stage)");
+    if (st) return st;
+    {
+        std::lock_guard<std::mutex> lock(b->mu);
         rx_bank_job j{}; j.kind = rx_bank_job::FRAME; j.m = m; j.stage = stage; j.sample = frame_sample; j.beta = beta; j.want_views = want_views; j.tie = tie;
-        j.gen = m->next_gen++;
-        b->jobs.push_back(j);
-        m->stage_state[stage] = 1;
+        j.gen = gen; j.d_iq = d;
+        m->next_gen = gen + 1;
+        b->jobs.push_back(j);                                              // (after the copy was enqueued: the round's event on that stream lies behind it)
+        m->stage_state[stage] = 2;
         m->jobs_in_flight++;
         m->last_post_us = bank_now_us();
-        if (generation) *generation = j.gen;
+        if (generation) *generation = gen;
     }
     b->cv_jobs.notify_one();
     return DABGPU_OK;
@@ -693,9 +724,8 @@ int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sampl
 int dabgpu_rx_bank_wait_stage(dabgpu_rx_member* m, int stage) {
     dabgpu_rx_bank* b = m->bank;
     {
-        std::unique_lock<std::mutex> lock(b->mu);
+        std::lock_guard<std::mutex> lock(b->mu);
         if (m->stage_state[stage] == 0) return DABGPU_OK;
-        m->cv.wait(lock, [&] { return m->stage_state[stage] == 2; });
     }
     (void)hipSetDevice(b->device);
     const int st = dabgpu_check_hip(hipEventSynchronize(m->stage_ev[stage]), "hipEventSynchronize(bank stage)");

@@ -11,6 +11,8 @@
 #include <stdexcept>
 #include <string>
 
+#include <pthread.h>
+
 #include "dabgpu.h"
 #include "dab/dabgpu_frame_batcher.h"
 #include "dab/dabgpu_shared_context.h"
@@ -376,6 +378,7 @@ void OFDM_Demod::SubmitFrame() {
 
 // the generations in submission order: wait (on the host) until the frame is demodulated, enqueue its decode
 void OFDM_Demod::DecodeThread() {
+    pthread_setname_np(pthread_self(), "dabgpu-decode");
     for (;;) {
         uint64_t gen;
         {
@@ -402,6 +405,7 @@ void OFDM_Demod::DecodeThread() {
 
 // :581-639 the coordinator's role: everything a frame publishes, in submission order
 void OFDM_Demod::DeliveryThread() {
+    pthread_setname_np(pthread_self(), "dabgpu-deliver");
     for (;;) {
         Item it;
         {

@@ -538,8 +538,10 @@ int dabgpu_frame_session_fetch_cif(dabgpu_frame_session *s, uint64_t generation,
  * RECEIVER BANK.  Its interface is the one below, unchanged; its submit_* calls post the work, and one thread per device issues what all members
  * have posted since its last round as ONE synchroniser launch, ONE demodulation launch over a compact batch of the posted frames and ONE FIC + MSC
  * decode over the members' history rings (at most one job per member and round, in posting order: frame k's fine-frequency update still
- * precedes frame k + 1's synchroniser).  N OFDM_Demod objects of a process then cost ~6 runtime calls per frame and member + ~15 per round
- * instead of ~20 per frame on three streams each (csrc/receiver_bank.hip).  Outputs are those of the private pipeline, bit for bit.
+ * precedes frame k + 1's synchroniser).  A member uploads its frame itself when it posts it (the samples cross PCIe while earlier rounds run); at most
+ * two rounds are under way (DABGPU_BANK_ROUNDS), what is posted meanwhile forms the next one -- its size follows the load.  N OFDM_Demod objects of a
+ * process then cost ~4 runtime calls per frame and member + ~15 per round instead of ~20 per frame on three streams each (csrc/receiver_bank.hip;
+ * DESIGN.md 4.11b).  Outputs are those of the private pipeline, bit for bit.
  * The sub-channel list (dabgpu_receiver_set_subchannels) is the BANK's: the members report one list (the decoders' subscription is process-wide in
  * the classes above); it applies to the rounds enqueued after the call.  A round decodes what it demodulates: frames are posted with dabgpu_receiver_submit_frame (which carries the
  * core model); the two-call form dabgpu_receiver_submit_demod / _submit_decode returns DABGPU_ERR_UNSUPPORTED.  Up to 64 members per device.

@@ -17,7 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <dirent.h>
 #include <fstream>
+#include <map>
+#include <pthread.h>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -95,6 +98,26 @@ struct FrameQueue {
     void finish() { { std::lock_guard<std::mutex> g(mu); done = true; } cv.notify_all(); }
 };
 
+// development (DABGPU_DRIVER_CPU=1, timing mode): CPU time of every thread of the process by thread name, read from /proc while all of them are alive
+void print_cpu_by_thread_name(size_t frames) {
+    std::map<std::string, std::pair<double, int>> by_name;
+    if (DIR* d = opendir("/proc/self/task")) {
+        while (dirent* e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            const std::string base = std::string("/proc/self/task/") + e->d_name;
+            std::ifstream fc(base + "/comm"), fs(base + "/schedstat");
+            std::string name; std::getline(fc, name);
+            double ns = 0.0; fs >> ns;
+            by_name[name].first += ns; by_name[name].second++;
+        }
+        closedir(d);
+    }
+    std::fprintf(stderr, "CPU by thread name, us per frame over %zu frames:", frames);
+    double total = 0.0;
+    for (const auto& kv : by_name) { std::fprintf(stderr, " %s[%d] %.1f,", kv.first.c_str(), kv.second.second, kv.second.first / 1e3 / (double)frames); total += kv.second.first; }
+    std::fprintf(stderr, " total %.1f\n", total / 1e3 / (double)frames);
+}
+
 void feed(OFDM_Demod& demod, const std::vector<std::complex<float>>& iq, size_t block) {
     for (size_t k = 0; k < iq.size(); k += block)
         demod.Process(tcb::span<const std::complex<float>>(iq.data() + k, std::min(block, iq.size() - k)));
@@ -137,7 +160,8 @@ int main(int argc, char** argv) {
     // ---- phase 2: all receivers at once; reader thread + radio thread (+ two decode workers) per receiver ----
     std::vector<Output> threaded(R);
     // start line: every receiver's objects exist (18 decoders = 18 device contexts each) before the first block is fed / the clock starts
-    std::mutex start_mu; std::condition_variable start_cv; size_t ready = 0;
+    std::mutex start_mu; std::condition_variable start_cv; size_t ready = 0, finished = 0;
+    const bool cpu_report = bench && std::getenv("DABGPU_DRIVER_CPU") != nullptr;
     auto t_start = std::chrono::steady_clock::now();
     auto start_line = [&] {
         std::unique_lock<std::mutex> lk(start_mu);
@@ -150,17 +174,28 @@ int main(int argc, char** argv) {
         for (size_t r = 0; r < R; r++) queues.push_back(std::make_unique<FrameQueue>());
         for (size_t r = 0; r < R; r++) {
             threads.emplace_back([&, r] {                                   // radio thread: owns the decoders of receiver r
+                pthread_setname_np(pthread_self(), "drv-radio");
                 Radio radio(subs, &threaded[r]);
                 start_line();
                 std::vector<viterbi_bit_t> bits;
                 while (queues[r]->pop(bits)) radio.frame(bits, !bench);
             });
             threads.emplace_back([&, r] {                                   // reader thread: owns the demodulator of receiver r
+                pthread_setname_np(pthread_self(), "drv-reader");
                 auto demod = Create_OFDM_Demodulator(1);
                 demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { queues[r]->push(bits); });
                 start_line();
                 feed(*demod, iq[r], block);
                 demod->Synchronize();
+                if (cpu_report) {                                           // every thread of every receiver is still alive at this line
+                    std::unique_lock<std::mutex> lk(start_mu);
+                    if (++finished == R) {
+                        size_t frames = 0;
+                        for (size_t k = 0; k < R; k++) frames += (size_t)threaded[k].frames;
+                        print_cpu_by_thread_name(frames);
+                        start_cv.notify_all();
+                    } else start_cv.wait(lk, [&] { return finished == R; });
+                }
                 queues[r]->finish();
             });
         }

@@ -66,7 +66,7 @@ with tempfile.TemporaryDirectory() as d:
         if cg0 and cg1:
             run["cgroup_throttled_ms"] = round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1)
             run["cgroup_periods_throttled"] = cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0)
-        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1
+        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank") or ln.startswith("CPU by thread name")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1 / DABGPU_DRIVER_CPU=1
         if prof:
             run["profile"] = prof
         out["runs"].append(run)
