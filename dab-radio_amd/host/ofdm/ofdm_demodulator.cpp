@@ -45,13 +45,13 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     if (m_mode == 1) {
         // Many receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
         // one demodulation launch, one synchroniser launch and one decode over all of them.  Measured (tools/bench_mirror_multi.py):
-        // up to four receivers are faster on pipelines of their own, from about eight on the bank is (7.3 against 4.6 k frames/s at 8, 5.8 against
-        // 2.4 k at 32).  DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
-        // DABGPU_MIRROR_BANK_FROM - 1 (default 4) others are alive at its construction -- the first four keep private pipelines.
+        // one or two receivers are faster on pipelines of their own, at four the two are level, from eight on the bank is faster (32: 7.7-10.6 k frames/s
+        // against 2.2-2.5 k).  DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
+        // DABGPU_MIRROR_BANK_FROM - 1 (default 2) others are alive at its construction -- the first two keep private pipelines.
         static std::atomic<int> live{0};
         const char* bank_env = std::getenv("DABGPU_MIRROR_BANK");
         const char* from_env = std::getenv("DABGPU_MIRROR_BANK_FROM");
-        const int from = from_env ? std::max(1, std::atoi(from_env)) : 5;
+        const int from = from_env ? std::max(1, std::atoi(from_env)) : 3;
         const int others = live.fetch_add(1);
         m_counted = true;
         bool banked = bank_env ? std::atoi(bank_env) != 0 : others >= from - 1;
