@@ -64,8 +64,13 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
         }
         m_live = &live;
         m_banked = banked;
-        if (banked) st = dabgpu_receiver_create_banked(&m_rx, dev ? std::atoi(dev) : 0);
-        else st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
+        st = DABGPU_OK;
+        if (banked) {
+            st = dabgpu_receiver_create_banked(&m_rx, dev ? std::atoi(dev) : 0);
+            // (a full bank -- 64 members per device -- is no reason to fail when nobody asked for the bank: the receiver gets a pipeline of its own)
+            if (st != DABGPU_OK && !bank_env) { m_banked = banked = false; m_rx = nullptr; }
+        }
+        if (!banked) st = dabgpu_receiver_create(&m_rx, dev ? std::atoi(dev) : 0, 1, reinterpret_cast<const float*>(prs_fft_ref.data()), carrier_mapper.data());
         if (st != DABGPU_OK) live.fetch_sub(1);
     } else {
         // modes II-IV run on the library's built-in tables of that mode: a caller-supplied table must be that table
