@@ -196,13 +196,21 @@ def test_eight_banked_receivers_equal_eight_private_ones(oracle, tmp_path):
         args += [str(s.start_address), str(s.length), str(s.eep_prot_level), str(s.eep_type)]
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    for k in ("DABGPU_MIRROR_BANK", "DABGPU_MIRROR_BANK_FROM", "DABGPU_BANK_ROUNDS", "DABGPU_BANK_GATHER_US"):
+        env.pop(k, None)
     digests = {}
-    for bank in ("0", "1"):
-        res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=dict(env, DABGPU_MIRROR_BANK=bank), timeout=900)
+    # private pipelines / the bank as it comes (at most two rounds under way) / one round at a time, no gathering window (every round carries whatever
+    # is queued: up to eight frames) / eight rounds deep (rounds of one or two frames) / the classes' own rule (two private pipelines, six members)
+    cases = {"0": {"DABGPU_MIRROR_BANK": "0"}, "1": {"DABGPU_MIRROR_BANK": "1"},
+             "one round": {"DABGPU_MIRROR_BANK": "1", "DABGPU_BANK_ROUNDS": "1", "DABGPU_BANK_GATHER_US": "0"},
+             "eight rounds": {"DABGPU_MIRROR_BANK": "1", "DABGPU_BANK_ROUNDS": "8"}, "auto": {}}
+    for bank, extra in cases.items():
+        res = subprocess.run(args + ["--"] + paths, capture_output=True, text=True, env=dict(env, **extra), timeout=900)
         assert res.returncode == 0, (bank, res.stdout[-2000:], res.stderr[-2000:])
         out = json.loads(res.stdout.strip().splitlines()[-1])
         assert out["ok"] and out["receivers"] == 8, bank
         assert all(r["threaded_equals_serial"] and r["frames"] >= 6 for r in out["per_receiver"]), bank
         digests[bank] = [(r["digest"], r["frames"], r["fib_bytes"], r["cifs_with_output"]) for r in out["per_receiver"]]
-    assert digests["1"] == digests["0"]
+    for bank in cases:
+        assert digests[bank] == digests["0"], bank
     assert len({d[0] for d in digests["0"]}) == 8
