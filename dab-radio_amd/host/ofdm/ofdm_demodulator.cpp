@@ -142,35 +142,59 @@ void OFDM_Demod::Synchronize() {
 // :235-275
 void OFDM_Demod::Process(tcb::span<const std::complex<float>> buf) {
     RethrowDeliveryError();
-    // A record still outstanding from the previous block is collected first.  If the impulse-peak test failed, the samples that were
-    // buffered behind the PRS slot meanwhile -- the rest of that block -- go through the NULL search they would have gone through
-    // (:529-532 Reset, then FindNullPowerDip on the remainder of the block, with that block's signal average)
-    CollectPendingSync();
     UpdateSignalAverage(buf);
+    // A synchroniser submitted in an earlier block is NOT waited for here: the reader buffers on until the earliest sample at which the frame can end
+    // (Run) and collects the record there -- the device's answer travels while the rest of the frame is copied.  Should the impulse-peak test fail, the
+    // samples buffered behind the PRS slot go through the NULL search they would have gone through (:529-532 Reset, then FindNullPowerDip ...), each
+    // with the signal average of the Process() call that delivered it: the calls' boundaries inside the staging buffer are noted for that.
+    // (one stretch per call, never merged: FindNullPowerDip's windows are aligned to the span it is handed, :291-347)
+    if (m_sync_pending) m_spec_segments.push_back(Segment{m_stage_length, m_signal_l1_average});
     Run(buf);
 }
 
+// blocking: Synchronize(), Reset()
 void OFDM_Demod::CollectPendingSync() {
-    // (a loop: the replay can find the next NULL symbol inside the remainder and submit the next synchronisation; in the serial machine that
-    // one ran -- and, if it failed too, the search went on -- inside the same block, with the same signal average: it is resolved here, before
-    // the next block's average is taken, and never by Run()'s rewind, whose position would refer to a buffer that is gone)
-    while (m_sync_pending) {
-        const size_t buffered = m_stage_length;
-        if (ResolveSync()) return;
-        const std::vector<std::complex<float>> rest(m_stage + m_corr.size(), m_stage + buffered);
-        Run(rest);
+    if (!m_sync_pending) return;
+    const size_t buffered = m_stage_length;
+    if (!ResolveSync()) ReplayAfterFailedSync(buffered);
+}
+
+// The impulse-peak test of the synchroniser submitted last failed (ResolveSync has reset the reader: one more desync): the serial machine knew that
+// when the PRS slot was complete and went on searching from the next sample -- do that now with what was buffered meanwhile, serially (a
+// synchroniser submitted on the way is waited for at once), every stretch under the signal average of the call that delivered it.
+void OFDM_Demod::ReplayAfterFailedSync(size_t buffered) {
+    const size_t head = m_corr.size();
+    const std::vector<std::complex<float>> rest(m_stage + head, m_stage + buffered);
+    const std::vector<Segment> segments = std::move(m_spec_segments);
+    m_spec_segments.clear();
+    const float average_now = m_signal_l1_average;
+    m_replaying = true;
+    for (size_t k = 0; k < segments.size(); k++) {
+        const size_t begin = std::min(segments[k].start, buffered) - head, end = std::min(k + 1 < segments.size() ? segments[k + 1].start : buffered, buffered) - head;
+        if (end <= begin) continue;
+        m_signal_l1_average = segments[k].average;
+        Run(tcb::span<const std::complex<float>>(rest.data() + begin, end - begin));
     }
+    m_signal_l1_average = average_now;
+    m_replaying = false;
 }
 
 void OFDM_Demod::Run(tcb::span<const std::complex<float>> buf) {
     size_t pos = 0;
+    // where this span's samples behind a PRS slot begin: in the span, and in the staging buffer (a record outstanding from an earlier call: 0 / what was
+    // buffered before this call)
+    size_t spec_pos = 0, spec_stage = m_stage_length;
     while (pos < buf.size()) {
         auto rest = buf.subspan(pos);
         switch (m_state) {
         case FINDING_NULL_POWER_DIP: pos += FindNullPowerDip(rest); break;
         case READING_NULL_AND_PRS:
             pos += ReadNullPRS(rest);
-            if (m_state == RUNNING_COARSE_FREQ_SYNC) { SubmitSync(); m_spec_pos = pos; }
+            if (m_state == RUNNING_COARSE_FREQ_SYNC) {
+                SubmitSync();
+                spec_pos = pos; spec_stage = m_stage_length;
+                if (m_replaying) (void)ResolveSync();               // (a replay is serial: false = the reader was reset again, the search goes on)
+            }
             break;
         case RUNNING_COARSE_FREQ_SYNC:
         case RUNNING_FINE_TIME_SYNC: {
@@ -182,7 +206,12 @@ void OFDM_Demod::Run(tcb::span<const std::complex<float>> buf) {
             std::copy_n(rest.begin(), take, m_stage + m_stage_length);
             m_stage_length += take;
             pos += take;
-            if (m_stage_length == earliest_end && !ResolveSync()) { m_stage_length = 0; pos = m_spec_pos; }       // back to the sample after the PRS slot
+            if (m_stage_length == earliest_end && !ResolveSync()) {
+                // what earlier calls delivered is replayed call by call; this span's own samples are gone through again from where they began behind
+                // the PRS slot, as ONE span (the serial machine never saw them split at the point where this reader happened to stop buffering)
+                ReplayAfterFailedSync(spec_stage);
+                pos = spec_pos;
+            }
             break;
         }
         case READING_SYMBOLS: pos += ReadSymbols(rest); break;
@@ -279,6 +308,7 @@ void OFDM_Demod::SubmitSync() {
     std::copy(m_corr.begin(), m_corr.end(), m_stage);
     m_stage_length = m_corr.size();
     m_state = RUNNING_FINE_TIME_SYNC;
+    m_spec_segments.assign(1, Segment{m_stage_length, m_signal_l1_average});
     const int rc = dabgpu_receiver_submit_sync(m_rx, &cfg, m_params.nb_null_period);
     if (rc != DABGPU_OK) fail("dabgpu_receiver_submit_sync", rc);
     m_sync_pending = true;

@@ -118,6 +118,7 @@ private:
     void Run(tcb::span<const std::complex<float>> buf);
     void SubmitSync();
     void CollectPendingSync();
+    void ReplayAfterFailedSync(size_t buffered);
     bool ResolveSync();
     void SubmitFrame();
     void ResetReader();
@@ -148,7 +149,10 @@ private:
     std::complex<float>* m_stage = nullptr;
     size_t m_stage_length = 0, m_stage_capacity = 0, m_frame_end = 0;
     bool m_sync_pending = false;             // the synchroniser's record has not been collected yet
-    size_t m_spec_pos = 0;                   // Run(): position in the span from which samples were buffered past the PRS slot
+    // while the record is outstanding: where each Process() call's samples begin in the staging buffer and the signal average in force for them
+    struct Segment { size_t start; float average; };
+    std::vector<Segment> m_spec_segments;
+    bool m_replaying = false;                // ReplayAfterFailedSync is running the serial machine over what was buffered
     int m_reader_time_offset = 0;
     uint64_t m_subs_version = ~0ull;         // batcher subscription the receiver was last given
     int m_depth = 3;
