@@ -27,5 +27,18 @@ assert L.dabgpu_receiver_create(C.byref(rx[0]), 0, 1, None, None) == 0
 out["after_one_receiver_MB"] = round(rss_mb(), 1)
 assert L.dabgpu_receiver_create(C.byref(rx[1]), 0, 1, None, None) == 0
 out["after_two_receivers_MB"] = round(rss_mb(), 1)
+# members of the receiver bank (dabgpu_receiver_create_banked): no streams or contexts of their own -- the first one pays for the bank
+L.dabgpu_receiver_create_banked.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+bk = [C.c_void_p() for _ in range(9)]
+assert L.dabgpu_receiver_create_banked(C.byref(bk[0]), 0) == 0
+out["after_first_banked_receiver_MB"] = round(rss_mb(), 1)
+for k in range(1, 9):
+    assert L.dabgpu_receiver_create_banked(C.byref(bk[k]), 0) == 0
+out["after_nine_banked_receivers_MB"] = round(rss_mb(), 1)
+out["per_further_banked_receiver_MB"] = round((out["after_nine_banked_receivers_MB"] - out["after_first_banked_receiver_MB"]) / 8.0, 1)
+free = C.c_size_t(); total = C.c_size_t()
+hip = C.CDLL("libamdhip64.so")
+hip.hipMemGetInfo(C.byref(free), C.byref(total))
+out["device_used_MB_at_end"] = round((total.value - free.value) / 2**20, 1)
 out["what"] = __doc__.split("\n\n")[0]
 print(json.dumps(out))
