@@ -59,4 +59,5 @@ def pytest_sessionstart(session):
                 seed = int(seed) + k * 1000003
             return plain(seed, *a, **kw)
 
+        shifted.plain = plain                      # (tests/fig_ensemble.py regenerates a FIXTURE's capture: it takes the shift out for that)
         np.random.default_rng = shifted
