@@ -133,6 +133,13 @@ extern "C" int dabgpu_receiver_create(dabgpu_receiver** out, int device, int mod
     if (!st) st = dabgpu_check_hip(hipMalloc((void**)&rx->d_corr, n_sym * 2 * sizeof(float)), "hipMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&rx->h_rec, rec_bytes, hipHostMallocDefault), "hipHostMalloc(receiver)");
     if (!st) st = dabgpu_check_hip(hipEventCreateWithFlags(&rx->sync_done, dabgpu_wait_event_flags(false)), "hipEventCreate(receiver)");
+    // the result slots' page-locked soft-bit and scalar buffers now, not at the first frame that uses each slot (eight allocations of ~1 ms in the first eight frames
+    // of a stream otherwise; the session frees them)
+    for (int k = 0; k < dabgpu_frame_session::R && !st; k++) {
+        dabgpu_frame_session::slot& sl = rx->ses->slots[k];
+        st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_aux, REC_HEAD, hipHostMallocDefault), "hipHostMalloc(receiver slot)");
+        if (!st) st = dabgpu_check_hip(hipHostMalloc((void**)&sl.h_bits, DABGPU_NB_FRAME_BITS, hipHostMallocDefault), "hipHostMalloc(receiver slot)");
+    }
     if (st) { dabgpu_receiver_destroy(rx); return st; }
     *out = rx;
     return DABGPU_OK;

@@ -16,7 +16,7 @@ import numpy as np
 
 
 
-def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, variants=("frame_batcher_one_thread", "call_by_call_one_thread",
+def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, repeats=1, variants=("frame_batcher_one_thread", "call_by_call_one_thread",
                                                                               "frame_batcher_decode_threads", "call_by_call_decode_threads")):
     """the harness on a generated capture file; returns the JSON dict (None when the harness binary has not been built)"""
     import dabsynth
@@ -46,13 +46,20 @@ def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, variants=("
             batch, nt = table[name]
             env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(nt), DABGPU_MIRROR_BATCH=batch)
             env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-            res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
-            if res.returncode != 0:
-                raise RuntimeError("mirror_harness failed: " + res.stderr[-2000:])
-            runs[name] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
-            prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]            # DABGPU_MIRROR_PROFILE=1
-            if prof:
-                runs[name]["profile"] = prof[-1]
+            tries = []
+            for _ in range(max(1, repeats)):                                              # (a run is 0.15-0.2 s: the median of `repeats` processes is reported, all are listed)
+                res = subprocess.run(args, capture_output=True, text=True, env=env, timeout=600)
+                if res.returncode != 0:
+                    raise RuntimeError("mirror_harness failed: " + res.stderr[-2000:])
+                r = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+                prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile")]        # DABGPU_MIRROR_PROFILE=1
+                if prof:
+                    r["profile"] = prof[-1]
+                tries.append(r)
+            tries.sort(key=lambda r: r["frames_per_s"])
+            runs[name] = dict(tries[len(tries) // 2])
+            if len(tries) > 1:
+                runs[name]["frames_per_s_of_every_run"] = [t["frames_per_s"] for t in tries]
     out = dict(runs["frame_batcher_one_thread"])
     out["what"] = ("tests/cpp/mirror_harness: the C++ classes with the reference's signatures driven like basic_radio_app drives the reference's -- a capture file "
                    "read in 65536-sample blocks -> OFDM_Demod::Process -> On_OFDM_Frame observers -> 4 x FIC_Decoder::DecodeFIBGroup + 4 x %d x MSC_Decoder::DecodeCIF per "
