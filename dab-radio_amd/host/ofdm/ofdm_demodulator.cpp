@@ -45,7 +45,7 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     if (m_mode == 1) {
         // Many receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
         // one demodulation launch, one synchroniser launch and one decode over all of them.  Measured (tools/bench_mirror_multi.py):
-        // one or two receivers are faster on pipelines of their own, at four the two are level, from eight on the bank is faster (32: 7.7-10.6 k frames/s
+        // one or two receivers are faster on pipelines of their own, at four the two are level, from eight on the bank is faster (32: 6.0-10.6 k frames/s
         // against 2.2-2.5 k).  DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
         // DABGPU_MIRROR_BANK_FROM - 1 (default 2) others are alive at its construction -- the first two keep private pipelines.
         static std::atomic<int> live{0};
