@@ -506,6 +506,11 @@ void completer_main(dabgpu_rx_bank* b) {
             lock.unlock();
             b->cv_done.notify_all();
         }
+        // The upload streams are never waited for on the host while something is in flight on them (the members' stage events have long fired when they are
+        // looked at), and the HIP runtime releases a queue's finished commands only when somebody does: without this, every frame left a copy command and
+        // 1.5 markers behind (2.4 KB of heap per frame, pinned and device memory of their signals: tools/exp/leakhist.c, profiles/r06/ab_notes.md).  Every 32nd
+        // round, on this thread (not the worker's): a wait for the few uploads in flight.
+        if ((b->n_handed & 31) == 31) for (int k = 0; k < dabgpu_rx_bank::NUP; k++) (void)hipStreamSynchronize(b->up[k]);
         lock.lock();
         b->cv_done.wait(lock, [&] { return t.sync_handed; });
         if (b->profile) b->p_handout_us += bank_now_us() - tc0;

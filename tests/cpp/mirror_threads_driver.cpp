@@ -18,6 +18,8 @@
 #include <cstring>
 #include <deque>
 #include <dirent.h>
+#include <dlfcn.h>
+#include <malloc.h>
 #include <fstream>
 #include <map>
 #include <pthread.h>
@@ -34,7 +36,7 @@
 
 namespace {
 
-struct Output { std::vector<uint8_t> fibs, msc; int frames = 0; int cifs_out = 0; };
+struct Output { std::vector<uint8_t> fibs, msc; int frames = 0; int cifs_out = 0; bool keep = true; size_t n_fib_bytes = 0, n_msc_bytes = 0; };   // keep = false (timing mode): count, do not collect
 
 uint64_t fnv(const std::vector<uint8_t>& v, uint64_t h = 0xCBF29CE484222325ull) { for (uint8_t b : v) { h ^= b; h *= 0x100000001B3ull; } return h; }
 
@@ -56,7 +58,7 @@ struct Radio {
     Output* out;
     Radio(const std::vector<Subchannel>& subs, Output* o) : fic((size_t)dab.nb_fib_cif_bits, (size_t)dab.nb_fibs_per_cif), out(o) {
         for (const auto& s : subs) msc.push_back(std::make_unique<MSC_Decoder>(s));
-        fic.OnFIB().Attach([this](tcb::span<const uint8_t> fib) { out->fibs.insert(out->fibs.end(), fib.begin(), fib.end()); });
+        fic.OnFIB().Attach([this](tcb::span<const uint8_t> fib) { out->n_fib_bytes += fib.size(); if (out->keep) out->fibs.insert(out->fibs.end(), fib.begin(), fib.end()); });
     }
     void frame(const std::vector<viterbi_bit_t>& bits, bool workers) {
         out->frames++;
@@ -72,7 +74,7 @@ struct Radio {
             };
             if (workers && msc.size() > 1) { std::thread a(work, 0, 2), b(work, 1, 2); a.join(); b.join(); }
             else work(0, 1);
-            for (auto& g : got) { if (!g.empty()) out->cifs_out++; out->msc.insert(out->msc.end(), g.begin(), g.end()); }
+            for (auto& g : got) { if (!g.empty()) out->cifs_out++; out->n_msc_bytes += g.size(); if (out->keep) out->msc.insert(out->msc.end(), g.begin(), g.end()); }
         }
     }
 };
@@ -116,6 +118,31 @@ void print_cpu_by_thread_name(size_t frames) {
     double total = 0.0;
     for (const auto& kv : by_name) { std::fprintf(stderr, " %s[%d] %.1f,", kv.first.c_str(), kv.second.second, kv.second.first / 1e3 / (double)frames); total += kv.second.first; }
     std::fprintf(stderr, " total %.1f\n", total / 1e3 / (double)frames);
+}
+
+// development (DABGPU_DRIVER_LOOPS=n, timing mode): resident set of the process and used device memory (when the HIP runtime is in the process)
+std::string memory_sample(int loop) {
+    double rss_mb = 0.0;
+    { std::ifstream f("/proc/self/status"); std::string ln; while (std::getline(f, ln)) if (ln.rfind("VmRSS:", 0) == 0) rss_mb = std::atof(ln.c_str() + 6) / 1024.0; }
+    double dev_mb = -1.0;
+    using mem_fn = int (*)(size_t*, size_t*);
+    if (auto fn = reinterpret_cast<mem_fn>(dlsym(RTLD_DEFAULT, "hipMemGetInfo"))) { size_t fr = 0, tot = 0; if (fn(&fr, &tot) == 0) dev_mb = (double)(tot - fr) / 1048576.0; }
+    // where the resident set lives: the C heap's live bytes (mallinfo2: arenas + mmapped blocks), anonymous pages as a whole, shared / device-mapped pages
+    double anon_mb = 0.0, shmem_mb = 0.0, file_mb = 0.0;
+    { std::ifstream f("/proc/self/status"); std::string ln;
+      while (std::getline(f, ln)) {
+          if (ln.rfind("RssAnon:", 0) == 0) anon_mb = std::atof(ln.c_str() + 8) / 1024.0;
+          if (ln.rfind("RssShmem:", 0) == 0) shmem_mb = std::atof(ln.c_str() + 9) / 1024.0;
+          if (ln.rfind("RssFile:", 0) == 0) file_mb = std::atof(ln.c_str() + 8) / 1024.0;
+      } }
+    using dump_fn = void (*)(const char*);                   // tools/exp/leakhist.c preloaded: live heap blocks by size
+    if (auto fn = reinterpret_cast<dump_fn>(dlsym(RTLD_DEFAULT, "leakhist_dump"))) fn(("loop " + std::to_string(loop)).c_str());
+    const struct mallinfo2 mi = mallinfo2();
+    char buf[400];
+    std::snprintf(buf, sizeof(buf), "{\"loop\": %d, \"host_rss_MB\": %.1f, \"rss_anon_MB\": %.1f, \"rss_shmem_MB\": %.1f, \"rss_file_MB\": %.1f, \"heap_in_use_MB\": %.1f, "
+                  "\"heap_arenas_MB\": %.1f, \"device_used_MB\": %.1f}", loop, rss_mb, anon_mb, shmem_mb, file_mb, (double)(mi.uordblks + mi.hblkhd) / 1048576.0,
+                  (double)(mi.arena + mi.hblkhd) / 1048576.0, dev_mb);
+    return buf;
 }
 
 void feed(OFDM_Demod& demod, const std::vector<std::complex<float>>& iq, size_t block) {
@@ -162,6 +189,8 @@ int main(int argc, char** argv) {
     // start line: every receiver's objects exist (18 decoders = 18 device contexts each) before the first block is fed / the clock starts
     std::mutex start_mu; std::condition_variable start_cv; size_t ready = 0, finished = 0;
     const bool cpu_report = bench && std::getenv("DABGPU_DRIVER_CPU") != nullptr;
+    const int loops = bench && std::getenv("DABGPU_DRIVER_LOOPS") ? std::max(1, std::atoi(std::getenv("DABGPU_DRIVER_LOOPS"))) : 1;
+    std::string memory_samples;
     auto t_start = std::chrono::steady_clock::now();
     auto start_line = [&] {
         std::unique_lock<std::mutex> lk(start_mu);
@@ -175,6 +204,7 @@ int main(int argc, char** argv) {
         for (size_t r = 0; r < R; r++) {
             threads.emplace_back([&, r] {                                   // radio thread: owns the decoders of receiver r
                 pthread_setname_np(pthread_self(), "drv-radio");
+                threaded[r].keep = !bench;
                 Radio radio(subs, &threaded[r]);
                 start_line();
                 std::vector<viterbi_bit_t> bits;
@@ -185,7 +215,14 @@ int main(int argc, char** argv) {
                 auto demod = Create_OFDM_Demodulator(1);
                 demod->On_OFDM_Frame().Attach([&](tcb::span<const viterbi_bit_t> bits) { queues[r]->push(bits); });
                 start_line();
-                feed(*demod, iq[r], block);
+                // (DABGPU_DRIVER_LOOPS: the capture again and again -- every wrap breaks the framing: loss of lock, reset, re-acquisition with frames in flight)
+                for (int loop = 0; loop < loops; loop++) {
+                    feed(*demod, iq[r], block);
+                    if (r == 0 && loops > 1 && (loop == 0 || loop == loops / 4 || loop == loops / 2 || loop == loops - 1)) {
+                        std::lock_guard<std::mutex> lk(start_mu);
+                        memory_samples += (memory_samples.empty() ? "" : ", ") + memory_sample(loop);
+                    }
+                }
                 demod->Synchronize();
                 if (cpu_report) {                                           // every thread of every receiver is still alive at this line
                     std::unique_lock<std::mutex> lk(start_mu);
@@ -205,9 +242,10 @@ int main(int argc, char** argv) {
     if (bench) {
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         size_t frames = 0, bytes = 0;
-        for (size_t r = 0; r < R; r++) { frames += (size_t)threaded[r].frames; bytes += threaded[r].msc.size() + threaded[r].fibs.size(); }
+        for (size_t r = 0; r < R; r++) { frames += (size_t)threaded[r].frames; bytes += threaded[r].n_msc_bytes + threaded[r].n_fib_bytes; }
         std::printf("{\"receivers\": %zu, \"sub_channels\": %zu, \"frames\": %zu, \"seconds\": %.4f, \"frames_per_s\": %.1f, \"x_realtime_per_receiver\": %.1f, "
-                    "\"decoded_bytes\": %zu}\n", R, subs.size(), frames, sec, frames / sec, frames / sec / (double)R / (2.048e6 / 196608.0), bytes);
+                    "\"decoded_bytes\": %zu, \"loops\": %d, \"memory\": [%s]}\n", R, subs.size(), frames, sec, frames / sec, frames / sec / (double)R / (2.048e6 / 196608.0), bytes,
+                    loops, memory_samples.c_str());
         return frames > 0 ? 0 : 1;
     }
     bool ok = true;

@@ -4,7 +4,12 @@ thread (OFDM_Demod::Process from memory, 65536-sample blocks), the demodulator's
 queue -- the reference app's OFDM / radio thread pair (examples/basic_radio_app.cpp:404-419) -- and calls FIC_Decoder + 18 MSC_Decoders.
 Whole-process frames/s and real-time factor per receiver.
 
-    python tools/bench_mirror_multi.py [--receivers 1 2 4 8] [--frames 300]
+Every receiver reads its capture (--frames transmission frames) --loops times back to back: 2000 frames per receiver by default, so that the start of
+a stream (decoders decode call by call until the time de-interleaver's 16 CIFs are theirs, every MSC_Decoder then creates and drops a device stream of its
+own; page-locked buffers are touched for the first time) is a few per cent of the run -- with 300 frames per receiver it was half of it and the figures were
+about half the steady state's.  The wrap breaks nothing in these captures (they begin with the end of their last frame), so every loop delivers --frames frames.
+
+    python tools/bench_mirror_multi.py [--receivers 1 2 4 8] [--frames 100] [--loops 20]
 """
 import argparse, json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +18,8 @@ import numpy as np, torch, dabgpu, dabsynth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--receivers", type=int, nargs="+", default=[1, 2, 4, 8])
-ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--frames", type=int, default=100)
+ap.add_argument("--loops", type=int, default=20)
 ap.add_argument("--subchannels", type=int, default=18)
 ap.add_argument("--only-write", default=None, help="write the IQ files rx<k>.c32 into this directory and stop (tools/timeline_multi.sh)")
 a = ap.parse_args()
@@ -43,7 +49,9 @@ with tempfile.TemporaryDirectory() as d:
     args0 = [driver, "65536"]
     for s in range(a.subchannels):
         args0 += [str(48 * s), "48", "2", "0"]
-    env = dict(os.environ, DABGPU_DRIVER_BENCH="1")
+    env = dict(os.environ, DABGPU_DRIVER_BENCH="1", DABGPU_DRIVER_LOOPS=str(a.loops))
+    if os.environ.get("DABGPU_DRIVER_PRELOAD"):                      # development: tools/exp/leakhist.c
+        env["LD_PRELOAD"] = os.environ["DABGPU_DRIVER_PRELOAD"]
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     import resource
 
@@ -66,7 +74,7 @@ with tempfile.TemporaryDirectory() as d:
         if cg0 and cg1:
             run["cgroup_throttled_ms"] = round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e3, 1)
             run["cgroup_periods_throttled"] = cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0)
-        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank") or ln.startswith("CPU by thread name")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1 / DABGPU_DRIVER_CPU=1
+        prof = [ln for ln in res.stderr.splitlines() if ln.startswith("OFDM_Demod profile") or ln.startswith("receiver bank") or ln.startswith("LEAKHIST") or ln.startswith("CPU by thread name")]        # DABGPU_MIRROR_PROFILE=1 / DABGPU_BANK_PROFILE=1 / DABGPU_DRIVER_CPU=1
         if prof:
             run["profile"] = prof
         out["runs"].append(run)
