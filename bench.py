@@ -1020,7 +1020,7 @@ def main():
                 # ONE receiver behind the drop-in classes (the path basic_radio would call): the C++ harness as a child process, ~4 s
                 try:
                     import bench_mirror
-                    line["extra"]["one_receiver"] = bench_mirror.run_mirror(torch, dabgpu, frames=600, repeats=3, variants=("frame_batcher_one_thread",))
+                    line["extra"]["one_receiver"] = bench_mirror.run_mirror(torch, dabgpu, frames=200, loops=10, repeats=3, variants=("frame_batcher_one_thread",))
                 except Exception as ex:                                    # the harness is test plumbing: its absence must not cost the bench line
                     line["extra"]["one_receiver"] = {"error": str(ex)[-300:]}
             if not args.no_chain:

@@ -16,7 +16,7 @@ import numpy as np
 
 
 
-def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, repeats=1, variants=("frame_batcher_one_thread", "call_by_call_one_thread",
+def run_mirror(torch, dabgpu, frames=200, loops=10, subchannels=18, threads=9, repeats=1, variants=("frame_batcher_one_thread", "call_by_call_one_thread",
                                                                               "frame_batcher_decode_threads", "call_by_call_decode_threads")):
     """the harness on a generated capture file; returns the JSON dict (None when the harness binary has not been built)"""
     import dabsynth
@@ -44,7 +44,8 @@ def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, repeats=1, 
         runs = {}
         for name in variants:
             batch, nt = table[name]
-            env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(nt), DABGPU_MIRROR_BATCH=batch)
+            # (the capture `loops` times back to back: 2000 frames by default -- a 600-frame run was a third start-up)
+            env = dict(os.environ, DABGPU_HARNESS_BENCH="1", DABGPU_HARNESS_THREADS=str(nt), DABGPU_MIRROR_BATCH=batch, DABGPU_HARNESS_LOOPS=str(loops))
             env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
             tries = []
             for _ in range(max(1, repeats)):                                              # (a run is 0.15-0.2 s: the median of `repeats` processes is reported, all are listed)
@@ -76,9 +77,10 @@ def run_mirror(torch, dabgpu, frames=600, subchannels=18, threads=9, repeats=1, 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--loops", type=int, default=10)
     ap.add_argument("--threads", type=int, default=9, help="decode threads of the second run")
     ap.add_argument("--subchannels", type=int, default=18)
     a = ap.parse_args()
     import torch, dabgpu
-    print(json.dumps(run_mirror(torch, dabgpu, a.frames, a.subchannels, a.threads)))
+    print(json.dumps(run_mirror(torch, dabgpu, frames=a.frames, loops=a.loops, subchannels=a.subchannels, threads=a.threads)))
