@@ -155,8 +155,8 @@ int main(int argc, char** argv) {
     size_t max_block = block;
     for (long v : schedule) max_block = std::max(max_block, (size_t)std::labs(v));
     std::vector<std::complex<float>> buf(max_block);
-    // DABGPU_HARNESS_LOOPS = n (timing mode): the capture n times back to back -- the start of a stream (decoders decoding call by call until the time
-    // de-interleaver's 16 CIFs are theirs, first touch of every page-locked buffer) is then a small part of the run
+    // DABGPU_HARNESS_LOOPS = n (timing mode): the capture n times back to back -- the start of a stream (first launches, first-use allocations,
+    // first touch of every page-locked buffer, the decoders' 16-CIF run-in) is then a small part of the run
     const int loops = g_bench && std::getenv("DABGPU_HARNESS_LOOPS") ? std::max(1, std::atoi(std::getenv("DABGPU_HARNESS_LOOPS"))) : 1;
     const double t_run = now_us();
     size_t call = 0;

@@ -5,8 +5,7 @@ queue -- the reference app's OFDM / radio thread pair (examples/basic_radio_app.
 Whole-process frames/s and real-time factor per receiver.
 
 Every receiver reads its capture (--frames transmission frames) --loops times back to back: 2000 frames per receiver by default, so that the start of
-a stream (decoders decode call by call until the time de-interleaver's 16 CIFs are theirs, every MSC_Decoder then creates and drops a device stream of its
-own; page-locked buffers are touched for the first time) is a few per cent of the run -- with 300 frames per receiver it was half of it and the figures were
+a stream (first launches, first-use allocations, first touch of the page-locked buffers, the decoders' 16-CIF run-in: 0.1-0.2 s per process) is a few per cent of the run -- with 300 frames per receiver it was half of it and the figures were
 about half the steady state's.  The wrap breaks nothing in these captures (they begin with the end of their last frame), so every loop delivers --frames frames.
 
     python tools/bench_mirror_multi.py [--receivers 1 2 4 8] [--frames 100] [--loops 20]
