@@ -104,6 +104,8 @@ struct dabgpu_rx_member {
     int jobs_in_flight = 0;
     std::condition_variable cv;                 // the member's own threads wait here (on bank->mu): a hand-out wakes the members it concerns, not all of them
     double last_post_us = -1e18;                // when the member posted last (the worker's gathering rule)
+    double last_record_us = -1e18;              // when a synchroniser's record was handed to the member last, and whether it has posted a frame since
+    bool posted_since_record = true;
     // views (display buffers), allocated at first use
     float* d_fft = nullptr; float* d_dq = nullptr;
 };
@@ -273,7 +275,25 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
         BK(hipGetLastError());
         BK(hipEventRecord(t.ev_demod, a));
         frames_enqueued = true;
-        // ---- decode (stream B) ----
+    }
+    // ---- synchronisers: behind the frames' fine-frequency updates, in front of the decode's launches and the bulky copies back ----
+    if (nS) {
+        int lo = MAXM, up = -1;
+        for (const auto& j : t.sync_jobs) { lo = j.m->slot < lo ? j.m->slot : lo; up = j.m->slot > up ? j.m->slot : up; }
+        // (the members copied their PRS slots into the bank's pinned array when they posted: one upload of the range that holds this round's)
+        BK(hipMemcpyAsync(b->d_prs + (size_t)lo * NFFT * 2, b->h_prs + (size_t)lo * NFFT * 2, (size_t)(up - lo + 1) * NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
+        const dabgpu_sync_cfg& cfg = t.sync_jobs[0].cfg;
+        const bool coarse = cfg.is_coarse_freq_correction != 0;
+        const float *d_prs_ref, *d_time_ref;
+        if ((st = dabgpu_mode_sync_tables(c, 1, &d_prs_ref, &d_time_ref))) return st;
+        BK(dabgpu_launch_sync(b->d_prs, NFFT, t.n_ens, &cfg, b->d_states, b->d_imp, coarse ? b->d_frq : nullptr, c->d_tw, d_prs_ref, d_time_ref, d_tab->sync_active, 1, a));
+        BK(hipMemcpyAsync(t.h_states, b->d_states, (size_t)t.n_ens * sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
+        BK(hipMemcpyAsync(t.h_imp, b->d_imp, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
+        if (coarse) BK(hipMemcpyAsync(t.h_frq, b->d_frq, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
+    }
+    BK(hipEventRecord(t.ev_sync, a));
+    // ---- decode (stream B): enqueued behind the synchronisers -- its ~8 runtime calls used to sit in front of the synchroniser launch every reader waits for ----
+    if (frames_enqueued) {
         const size_t n_sub = t.subs.size();
         if (t.fic || n_sub) {
             const size_t need = out_bytes((size_t)t.n_ens, n_sub, t.cif_out);
@@ -305,22 +325,6 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
             t.decoded = true;
         }
     }
-    // ---- synchronisers: behind the frames' fine-frequency updates, in front of the bulky copies back ----
-    if (nS) {
-        int lo = MAXM, up = -1;
-        for (const auto& j : t.sync_jobs) { lo = j.m->slot < lo ? j.m->slot : lo; up = j.m->slot > up ? j.m->slot : up; }
-        // (the members copied their PRS slots into the bank's pinned array when they posted: one upload of the range that holds this round's)
-        BK(hipMemcpyAsync(b->d_prs + (size_t)lo * NFFT * 2, b->h_prs + (size_t)lo * NFFT * 2, (size_t)(up - lo + 1) * NFFT * 2 * sizeof(float), hipMemcpyHostToDevice, a));
-        const dabgpu_sync_cfg& cfg = t.sync_jobs[0].cfg;
-        const bool coarse = cfg.is_coarse_freq_correction != 0;
-        const float *d_prs_ref, *d_time_ref;
-        if ((st = dabgpu_mode_sync_tables(c, 1, &d_prs_ref, &d_time_ref))) return st;
-        BK(dabgpu_launch_sync(b->d_prs, NFFT, t.n_ens, &cfg, b->d_states, b->d_imp, coarse ? b->d_frq : nullptr, c->d_tw, d_prs_ref, d_time_ref, d_tab->sync_active, 1, a));
-        BK(hipMemcpyAsync(t.h_states, b->d_states, (size_t)t.n_ens * sizeof(dabgpu_sync_state), hipMemcpyDeviceToHost, a));
-        BK(hipMemcpyAsync(t.h_imp, b->d_imp, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
-        if (coarse) BK(hipMemcpyAsync(t.h_frq, b->d_frq, (size_t)t.n_ens * NFFT * sizeof(float), hipMemcpyDeviceToHost, a));
-    }
-    BK(hipEventRecord(t.ev_sync, a));
     if (frames_enqueued) {
         // the soft bits go straight to the page-locked buffer of the member's result slot (one copy per frame: what the delivery thread hands to the
         // observers is that buffer -- a compact copy per round plus a 230 KB memcpy per frame on the completer thread capped the bank at ~15 k frames/s)
@@ -357,6 +361,9 @@ void worker_main(dabgpu_rx_bank* b) {
                     // a member with a job under way is waiting for THIS thread's rounds and will not post before they are handed out: only the ones
                     // that are buffering on their own (nothing in flight) and posted recently are worth waiting for
                     if (m && !in_queue[k] && m->jobs_in_flight == 0 && t_first - m->last_post_us < 4000.0) return false;
+                    // ... and the ones that have just been handed a synchroniser's record: their frame follows within a few hundred us (what is left of
+                    // it to buffer, the post), whatever of theirs is still being decoded -- a round formed before they arrive carries half the members
+                    if (m && !in_queue[k] && !m->posted_since_record && t_first - m->last_record_us < 700.0) return false;
                 }
                 return true;
             };
@@ -436,6 +443,7 @@ void sync_completer_main(dabgpu_rx_bank* b) {
             }
             m->sync_state = 3;
             m->jobs_in_flight--;
+            if (!st && m->sync_rec.sync_valid) { m->last_record_us = bank_now_us(); m->posted_since_record = false; }
             m->cv.notify_all();
         }
         t.sync_handed = true;
@@ -719,6 +727,7 @@ int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sampl
         m->stage_state[stage] = 2;
         m->jobs_in_flight++;
         m->last_post_us = bank_now_us();
+        m->posted_since_record = true;
         if (generation) *generation = gen;
     }
     b->cv_jobs.notify_one();
