@@ -45,14 +45,16 @@ OFDM_Demod::OFDM_Demod(const OFDM_Params& params, const tcb::span<const std::com
     if (m_mode == 1) {
         // Many receivers in one process share ONE pair of device streams (the receiver bank, csrc/receiver_bank.hip): what they post is issued as
         // one demodulation launch, one synchroniser launch and one decode over all of them.  Measured in the steady state (tools/bench_mirror_multi.py, 2000
-        // frames per receiver): up to four receivers are faster on pipelines of their own (9-11 k frames/s in total at 2-4), at eight the two
-        // are level, from sixteen on the bank is faster (12-17 k against 3-5 k) -- and a member costs 6 MB of host memory where a pipeline costs 230.
-        // DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
-        // DABGPU_MIRROR_BANK_FROM - 1 (default 4) others are alive at its construction -- the first four keep private pipelines.
+        // frames per receiver): up to four receivers are faster on pipelines of their own (9-11 k frames/s in total at 2-4 against 5-8 k), at
+        // eight the bank is level or ahead, from sixteen on it is 2.5-5 x faster (12-17 k against 3-5 k) -- and a member costs 6 MB of host memory where a
+        // pipeline costs 230.  DABGPU_MIRROR_BANK=1: every mode I receiver on the library's own tables joins the bank; 0: none; unset: a receiver joins when
+        // DABGPU_MIRROR_BANK_FROM - 1 (default 1) others are alive at its construction -- the first receiver of a process keeps a pipeline of its own (one
+        // receiver is the common case and the fastest on it), every further one is a member: 7 k frames/s at 2-4 receivers instead of 9-11 k (a live signal
+        // needs 10.4 per receiver), 9-13 k at 8-32 instead of 7.5-12 k with four private pipelines beside the bank, and 230 MB less host memory for each.
         static std::atomic<int> live{0};
         const char* bank_env = std::getenv("DABGPU_MIRROR_BANK");
         const char* from_env = std::getenv("DABGPU_MIRROR_BANK_FROM");
-        const int from = from_env ? std::max(1, std::atoi(from_env)) : 5;
+        const int from = from_env ? std::max(1, std::atoi(from_env)) : 2;
         const int others = live.fetch_add(1);
         m_counted = true;
         bool banked = bank_env ? std::atoi(bank_env) != 0 : others >= from - 1;

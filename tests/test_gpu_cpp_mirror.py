@@ -200,7 +200,7 @@ def test_eight_banked_receivers_equal_eight_private_ones(oracle, tmp_path):
         env.pop(k, None)
     digests = {}
     # private pipelines / the bank as it comes (at most two rounds under way) / one round at a time, no gathering window (every round carries whatever
-    # is queued: up to eight frames) / eight rounds deep (rounds of one or two frames) / the classes' own rule (four private pipelines, four members)
+    # is queued: up to eight frames) / eight rounds deep (rounds of one or two frames) / the classes' own rule (one private pipeline, seven members)
     cases = {"0": {"DABGPU_MIRROR_BANK": "0"}, "1": {"DABGPU_MIRROR_BANK": "1"},
              "one round": {"DABGPU_MIRROR_BANK": "1", "DABGPU_BANK_ROUNDS": "1", "DABGPU_BANK_GATHER_US": "0"},
              "eight rounds": {"DABGPU_MIRROR_BANK": "1", "DABGPU_BANK_ROUNDS": "8"}, "auto": {}}

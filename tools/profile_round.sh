@@ -25,7 +25,7 @@ python3 tools/bench_chain.py --ensembles 4096 > $OUT/bench_chain_$TAG.json 2> $O
 python3 bench.py --workload full --no-cpu-baseline > $OUT/bench_full_$TAG.json 2> $OUT/bench_full_$TAG.err
 python3 tools/bench_decode.py --ensembles 4096 --steps 6 > $OUT/bench_decode_4096_$TAG.json 2> $OUT/bench_decode_4096_$TAG.err
 python3 tools/bench_mirror.py > $OUT/bench_mirror_$TAG.json 2> $OUT/bench_mirror_$TAG.err
-# several receivers in one process: private pipelines, all in the receiver bank, and the classes' AUTO rule (the fifth and later ones banked)
+# several receivers in one process: private pipelines, all in the receiver bank, and the classes' AUTO rule (the second and later ones banked)
 for B in 0 1; do DABGPU_BANK_PROFILE=1 DABGPU_MIRROR_BANK=$B python3 tools/bench_mirror_multi.py --receivers 1 2 4 8 16 32 > $OUT/bench_mirror_multi_bank${B}_$TAG.json 2> $OUT/bench_mirror_multi_bank${B}_$TAG.err; done
 DABGPU_BANK_PROFILE=1 python3 tools/bench_mirror_multi.py --receivers 2 4 8 16 32 > $OUT/bench_mirror_multi_auto_$TAG.json 2> $OUT/bench_mirror_multi_auto_$TAG.err
 python3 tools/soak_mirror.py --frames 300 --repeats 40 > $OUT/soak_mirror_$TAG.json 2> $OUT/soak_mirror_$TAG.err
