@@ -3,6 +3,8 @@ subchannel_protection_tables.h:21-139) against the golden plans generated from t
 (tests/golden/reference_vectors.npz:subchannel_plans, generator tests/golden/make_golden.py): all 64 UEP rows and the EEP grid.
 CPU half: dabgpu_subchannel_plan is host-only.  GPU half: one logical frame of every profile is encoded by the oracle, pushed through
 the history ring and decoded by the kernels -- a typo in any row changes the puncturing schedule and garbles the bytes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -70,7 +72,9 @@ def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
             cif[start * 64:(start + length) * 64] = soft
             hist[e, :, 9216:] = np.tile(cif, 4)
             exp_bytes, exp_err = oracle.msc_decode_logical(sc, soft)
-            assert np.array_equal(exp_bytes, payload), "oracle cannot decode its own encoding?"
+            # (a property of the committed seed's noise: under DAB_FUZZ_OFFSET a weak profile may keep a residual error -- the parity below is against the oracle)
+            if not os.environ.get("DAB_FUZZ_OFFSET"):
+                assert np.array_equal(exp_bytes, payload), "oracle cannot decode its own encoding?"
         d_hist = torch.from_numpy(hist).cuda()
         d_out = torch.zeros((n_ens, 4, nb), dtype=torch.uint8, device="cuda")
         d_res = torch.zeros((n_ens * 4, 16), dtype=torch.uint8, device="cuda")
@@ -82,6 +86,6 @@ def test_every_profile_decodes_on_the_gpu(golden, oracle, mapping):
             soft = hist[e, 0, 9216 + start * 64: 9216 + (start + length) * 64]
             exp_bytes, exp_err = oracle.msc_decode_logical(sc, soft)
             for c in range(4):
-                assert np.array_equal(out[e, c], payloads[e]), (length, is_uep, idx, lvl, tb, e, c)
+                assert np.array_equal(out[e, c], exp_bytes), (length, is_uep, idx, lvl, tb, e, c)
                 assert int(res[e, c]["path_error"]) == exp_err and int(res[e, c]["n_out_bytes"]) == nb
     assert n_done == len(golden["subchannel_plans"]) - 1
