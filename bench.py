@@ -1023,6 +1023,19 @@ def main():
                     line["extra"]["one_receiver"] = bench_mirror.run_mirror(torch, dabgpu, frames=200, loops=10, repeats=3, variants=("frame_batcher_one_thread",))
                 except Exception as ex:                                    # the harness is test plumbing: its absence must not cost the bench line
                     line["extra"]["one_receiver"] = {"error": str(ex)[-300:]}
+                # EIGHT receivers of one process behind the classes (reader + delivery + radio thread each, 2000 frames per receiver): every one on a pipeline
+                # of its own, every one a member of the receiver bank, and the classes' own rule (the first private, the others members) -- ~15 s
+                try:
+                    import bench_mirror_multi
+                    mm = bench_mirror_multi.run_multi(torch, dabgpu, receivers=(8,), frames=100, loops=20, modes=("0", "1", None))
+                    if mm is not None:
+                        line["extra"]["eight_receivers"] = {
+                            "what": mm["what"], "frames_per_receiver": 2000,
+                            "frames_per_s": {("private_pipelines" if r["bank"] == "0" else ("receiver_bank" if r["bank"] == "1" else "classes_own_rule")): r["frames_per_s"] for r in mm["runs"]},
+                            "host_cpu_ms_per_frame": {("private_pipelines" if r["bank"] == "0" else ("receiver_bank" if r["bank"] == "1" else "classes_own_rule")): r["host_cpu_ms_per_frame"] for r in mm["runs"]},
+                            "memory_of_the_bank_run": [r["memory"] for r in mm["runs"] if r["bank"] == "1"][0]}
+                except Exception as ex:
+                    line["extra"]["eight_receivers"] = {"error": str(ex)[-300:]}
             if not args.no_chain:
                 import bench_chain
                 line["extra"]["chain"] = bench_chain.run_chain(ctx, dabgpu, torch, device, args.extra_ensembles, args.distinct,
