@@ -348,9 +348,24 @@ void worker_main(dabgpu_rx_bank* b) {
         b->cv_jobs.wait(lock, [b] { return b->stop || !b->jobs.empty(); });
         if (b->profile && b->n_ticks) b->p_worker_idle_us += bank_now_us() - ti0;       // (not the wait for the very first job: the members are still being constructed)
         if (b->stop && b->jobs.empty()) return;
-        // several members: give the others a moment to post as well (a round costs ~25 runtime calls whatever it carries; the calls, not the
-        // device, are what a process can issue only so many of per second) -- at most `gather_us`, and not at all for a lone member
-        if (b->refs > 1 && b->gather_us > 0) {
+        if (b->gather_us > 0) {
+            // (1) A frame was posted a moment ago and the synchroniser of the NEXT frame is not in the queue yet: the reader posts it as soon as it has read the
+            // NULL symbol and the PRS that follow (tens of us, when the samples are there) -- a round formed in between carries the frame alone and the
+            // synchroniser waits for the round after it (a third of the rounds of two members carried a synchroniser only).  At most 150 us after the post.
+            auto follows = [b] {
+                if (b->stop) return true;
+                bool frame_q[MAXM] = {false}, sync_q[MAXM] = {false};
+                for (const auto& j : b->jobs) { if (j.kind == rx_bank_job::SYNC) sync_q[j.m->slot] = true; else if (j.kind == rx_bank_job::FRAME) frame_q[j.m->slot] = true; }
+                const double now = bank_now_us();
+                for (int k = 0; k < MAXM; k++) {
+                    const dabgpu_rx_member* m = b->members[k];
+                    if (m && frame_q[k] && !sync_q[k] && m->sync_state == 0 && now - m->last_post_us < 150.0) return false;
+                }
+                return true;
+            };
+            for (int spin = 0; spin < 4 && !follows(); spin++) b->cv_jobs.wait_for(lock, std::chrono::microseconds(50), follows);
+            // (2) several members: give the others a moment to post as well (a round costs ~25 runtime calls whatever it carries; the calls, not the
+            // device, are what a process can issue only so many of per second) -- at most `gather_us`, and not at all for a lone member
             const double t_first = bank_now_us();
             auto all_in = [b, t_first] {                                   // every member that posted in the last few ms has a job in the queue again
                 if (b->stop) return true;
@@ -367,7 +382,7 @@ void worker_main(dabgpu_rx_bank* b) {
                 }
                 return true;
             };
-            if (!all_in()) b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), all_in);
+            if (b->refs > 1 && !all_in()) b->cv_jobs.wait_for(lock, std::chrono::microseconds(b->gather_us), all_in);
         }
         // Rounds are not enqueued ahead of the device: a round takes what is queued when it is formed, and with a deep queue of rounds under way every
         // job that arrives meanwhile becomes a small round of its own at the END of that queue -- many small rounds, each paying the fixed costs, each

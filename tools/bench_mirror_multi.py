@@ -61,7 +61,8 @@ def run_multi(torch, dabgpu, receivers=(1, 2, 4, 8), frames=100, loops=20, subch
                 env["DABGPU_MIRROR_BANK"] = str(mode)
             if os.environ.get("DABGPU_DRIVER_PRELOAD"):                      # development: tools/exp/leakhist.c
                 env["LD_PRELOAD"] = os.environ["DABGPU_DRIVER_PRELOAD"]
-            env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "dab-radio_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+            # (DABGPU_LIBDIR: development -- another build of libdabgpu.so for a same-box A/B)
+            env["LD_LIBRARY_PATH"] = os.environ.get("DABGPU_LIBDIR", os.path.join(ROOT, "dab-radio_amd")) + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
             for r in receivers:
                 ru0, cg0 = resource.getrusage(resource.RUSAGE_CHILDREN), cgroup_stat()
                 res = subprocess.run(args0 + ["--"] + paths[:r], capture_output=True, text=True, env=env, timeout=900)
