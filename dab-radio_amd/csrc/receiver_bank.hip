@@ -82,6 +82,7 @@ struct rx_bank_job {
     int want_views, tie;
     dabgpu_sync_cfg cfg;
     const float* d_iq;              // FRAME: the member's upload buffer that holds the samples
+    int up;                         // FRAME: the upload stream the member's copy went to
 };
 
 struct dabgpu_rx_member {
@@ -133,6 +134,9 @@ struct dabgpu_rx_bank {
     static constexpr int NUP = 3;               // upload streams (member slot % NUP): frames cross PCIe on several DMA engines at once
     hipStream_t up[NUP] = {nullptr, nullptr, nullptr};
     hipEvent_t up_ev[NUP] = {nullptr, nullptr, nullptr};
+    int n_up = 0;                                // DABGPU_BANK_UPLOADS: how many of them are used; 0 = one up to 12 members, all of them beyond (measured: a round of
+                                                 // 8 members waits on ONE event instead of three -- 12.0-13.9 k frames/s against 9.5-11.3 k -- and 32 members' uploads
+                                                 // overlap on three DMA engines -- 17.2-18.5 k against 13.9-14.6 k on one)
     float* d_prs = nullptr; float* d_iq = nullptr; int8_t* d_bits = nullptr; int8_t* d_hist = nullptr;
     dabgpu_sync_state* d_states = nullptr; float* d_imp = nullptr; float* d_frq = nullptr;
     float* d_corr = nullptr; float* d_freq = nullptr; float* d_fine = nullptr; float* d_total = nullptr;
@@ -243,7 +247,7 @@ int enqueue_tick(dabgpu_rx_bank* b, rx_bank_tick& t, uint64_t tick_no) {
         // an event recorded now on each of those streams lies behind them.  They crossed PCIe while the previous round ran and this one waited to be
         // formed; the round copies them (device to device, ~1 us each) into the compact batch the demodulation kernel reads.
         bool used[dabgpu_rx_bank::NUP] = {false, false, false};
-        for (const auto& f : t.frame_jobs) used[f.m->slot % dabgpu_rx_bank::NUP] = true;
+        for (const auto& f : t.frame_jobs) used[f.up] = true;
         for (int k = 0; k < dabgpu_rx_bank::NUP; k++) if (used[k]) { BK(hipEventRecord(b->up_ev[k], b->up[k])); BK(hipStreamWaitEvent(a, b->up_ev[k], 0)); }
         bank_gather_iq_kernel<<<dim3(16, (unsigned)nF), 256, 0, a>>>(b->d_iq, d_tab);
         BK(hipGetLastError());
@@ -581,6 +585,7 @@ int dabgpu_rx_bank_join(int device, float* const* h_stage, dabgpu_rx_member** ou
         b->device = device;
         if (const char* e = std::getenv("DABGPU_BANK_PROFILE")) b->profile = std::atoi(e) != 0;
         if (const char* e = std::getenv("DABGPU_BANK_GATHER_US")) b->gather_us = std::atoi(e);
+        if (const char* e = std::getenv("DABGPU_BANK_UPLOADS")) b->n_up = std::min((int)dabgpu_rx_bank::NUP, std::max(0, std::atoi(e)));
         if (const char* e = std::getenv("DABGPU_BANK_ROUNDS")) b->max_rounds = std::min(TICKS, std::max(1, std::atoi(e)));
         st = dabgpu_create(&b->ctx, device, nullptr, nullptr);
         if (!st) {
@@ -715,6 +720,7 @@ int dabgpu_rx_bank_wait_sync(dabgpu_rx_member* m, dabgpu_sync_state* out, float*
 int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sample, float beta, int want_views, int tie, uint64_t* generation) {
     dabgpu_rx_bank* b = m->bank;
     uint64_t gen;
+    int n_up;
     {
         std::lock_guard<std::mutex> lock(b->mu);
         if (m->next_gen >= m->done_gen + (uint64_t)(dabgpu_frame_session::R - 1)) {
@@ -722,6 +728,7 @@ int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sampl
             return DABGPU_ERR_NOT_READY;
         }
         gen = m->next_gen;                                                 // (only the member's own thread posts)
+        n_up = b->n_up > 0 ? b->n_up : (b->refs <= 12 ? 1 : (int)dabgpu_rx_bank::NUP);
     }
     // The member uploads its frame itself, now: the samples cross PCIe while the rounds under way run, not inside the round that demodulates them
     // (32 frames of a round are 1 ms of PCIe in front of the round's synchronisers otherwise).  Half gen % 2 of the member's device buffer: frame g - 2,
@@ -729,14 +736,15 @@ int dabgpu_rx_bank_post_frame(dabgpu_rx_member* m, int stage, size_t frame_sampl
     // was cut with (a member's jobs run in posting order; the synchroniser of frame g is posted after frame g - 1).
     (void)hipSetDevice(b->device);
     float* d = m->d_iq + (size_t)(gen % 2) * FRAME_SAMPLES * 2;
-    hipStream_t u = b->up[m->slot % dabgpu_rx_bank::NUP];
+    const int up_k = m->slot % n_up;
+    hipStream_t u = b->up[up_k];
     int st = dabgpu_check_hip(hipMemcpyAsync(d, m->h_stage[stage] + 2 * frame_sample, FRAME_SAMPLES * 2 * sizeof(float), hipMemcpyHostToDevice, u), "hipMemcpyAsync(bank frame)");
     if (!st) st = dabgpu_check_hip(hipEventRecord(m->stage_ev[stage], u), "hipEventRecord(bank stage)");
     if (st) return st;
     {
         std::lock_guard<std::mutex> lock(b->mu);
         rx_bank_job j{}; j.kind = rx_bank_job::FRAME; j.m = m; j.stage = stage; j.sample = frame_sample; j.beta = beta; j.want_views = want_views; j.tie = tie;
-        j.gen = gen; j.d_iq = d;
+        j.gen = gen; j.d_iq = d; j.up = up_k;
         m->next_gen = gen + 1;
         b->jobs.push_back(j);                                              // (after the copy was enqueued: the round's event on that stream lies behind it)
         m->stage_state[stage] = 2;
