@@ -218,7 +218,7 @@ int main(int argc, char** argv) {
                 // (DABGPU_DRIVER_LOOPS: the capture again and again -- every wrap breaks the framing: loss of lock, reset, re-acquisition with frames in flight)
                 for (int loop = 0; loop < loops; loop++) {
                     feed(*demod, iq[r], block);
-                    if (r == 0 && loops > 1 && (loop == 0 || loop == loops / 4 || loop == loops / 2 || loop == loops - 1)) {
+                    if (r == 0 && loops > 1 && (loop == 0 || loop == loops - 1 || (loops >= 8 && loop % (loops / 8) == 0) || (loops < 8 && (loop == loops / 4 || loop == loops / 2)))) {
                         std::lock_guard<std::mutex> lk(start_mu);
                         memory_samples += (memory_samples.empty() ? "" : ", ") + memory_sample(loop);
                     }
